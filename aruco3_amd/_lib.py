@@ -1,0 +1,304 @@
+"""ctypes binding of libaruco3_hip.so (the C ABI of include/aruco3_hip.h).
+
+There is no CPU implementation behind this module: if the shared library is missing, or
+no MI355X is visible, every entry point raises.  Build with `python __graft_entry__.py`
+(or `make -C aruco3_amd/csrc`).
+"""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libaruco3_hip.so"
+
+OK, ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_INTERNAL, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
+FMT_RGB8, FMT_RGBA8, FMT_L8 = 0, 1, 2
+MEM_HOST, MEM_DEVICE = 0, 1
+STAGE_THRESHOLD, STAGE_CONTOUR, STAGE_DECODE = 0, 1, 2
+
+# every symbol include/aruco3_hip.h declares
+SYMBOLS = [
+    "a3_abi_version", "a3_default_config", "a3_create", "a3_destroy", "a3_last_error", "a3_set_stream", "a3_set_pool_limits",
+    "a3_get_tau", "a3_set_debug_taps", "a3_detect_batch", "a3_get_stats", "a3_download_grey", "a3_download_thresholded",
+    "a3_candidate_count", "a3_download_candidates", "a3_download_homographies", "a3_estimate_pose", "a3_estimate_pose_normalized",
+    "a3_find_nearest", "a3_calculate_tau", "a3_set_profiling", "a3_get_profile", "a3_selftest_ieee",
+]
+
+
+class A3Error(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"aruco3_hip error {code}: {message}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("threshold_window", C.c_uint32),
+        ("contour_simplification_epsilon", C.c_double),
+        ("min_side_length_factor", C.c_float),
+        ("min_corner_separation_factor", C.c_float),
+        ("homography_sample_size", C.c_uint32),
+        ("filter_high_bit_errors", C.c_uint8),
+    ]
+
+
+class MarkerRec(C.Structure):
+    _fields_ = [
+        ("frame", C.c_uint32),
+        ("id", C.c_uint32),
+        ("code", C.c_uint64),
+        ("corners", C.c_uint32 * 8),
+        ("hamming_distance", C.c_uint8),
+        ("rotation", C.c_uint8),
+        ("candidate_index", C.c_uint16),
+    ]
+
+
+MARKER_DTYPE = np.dtype([("frame", "<u4"), ("id", "<u4"), ("code", "<u8"), ("corners", "<u4", (8,)), ("hamming_distance", "u1"),
+                         ("rotation", "u1"), ("candidate_index", "<u2")], align=True)
+assert MARKER_DTYPE.itemsize == C.sizeof(MarkerRec) == 56
+
+
+class PoseRec(C.Structure):
+    _fields_ = [("error", C.c_float), ("rotation", C.c_float * 9), ("translation", C.c_float * 3)]
+
+
+class Intrinsics(C.Structure):
+    _fields_ = [("image_width", C.c_uint32), ("image_height", C.c_uint32), ("focal_x", C.c_float), ("focal_y", C.c_float),
+                ("principal_x", C.c_float), ("principal_y", C.c_float)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("darts", C.c_uint64), ("contours_traced", C.c_uint64), ("contours_materialised", C.c_uint64),
+                ("candidates_pre", C.c_uint64), ("candidates", C.c_uint64), ("markers", C.c_uint64),
+                ("resolve_iterations", C.c_uint32), ("jump_rounds", C.c_uint32), ("chunks", C.c_uint32), ("reserved", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+
+
+_lib = None
+
+
+def load():
+    """dlopen the library and declare the prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(f"{LIB_PATH} is missing: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()'). "
+                          "aruco3_amd has no CPU fallback.")
+    L = C.CDLL(str(LIB_PATH))
+    vp, u8p, u32p, u64p, f32p, f64p = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.POINTER(C.c_double)
+    L.a3_abi_version.restype = C.c_int
+    L.a3_default_config.restype = None
+    L.a3_default_config.argtypes = [C.POINTER(Config)]
+    L.a3_create.restype = C.c_int
+    L.a3_create.argtypes = [C.c_int, C.POINTER(Config), u64p, C.c_size_t, C.c_uint8, C.c_uint8, C.POINTER(vp)]
+    L.a3_destroy.restype = None
+    L.a3_destroy.argtypes = [vp]
+    L.a3_last_error.restype = C.c_char_p
+    L.a3_last_error.argtypes = [vp]
+    L.a3_set_stream.restype = C.c_int
+    L.a3_set_stream.argtypes = [vp, vp]
+    L.a3_set_pool_limits.restype = C.c_int
+    L.a3_set_pool_limits.argtypes = [vp, C.c_uint64, C.c_uint64]
+    L.a3_get_tau.restype = C.c_int
+    L.a3_get_tau.argtypes = [vp, u8p]
+    L.a3_set_debug_taps.restype = C.c_int
+    L.a3_set_debug_taps.argtypes = [vp, C.c_int]
+    L.a3_detect_batch.restype = C.c_int
+    L.a3_detect_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_size_t, C.c_size_t, C.c_uint32, vp, C.c_size_t, u32p,
+                                  C.POINTER(C.c_size_t)]
+    L.a3_get_stats.restype = C.c_int
+    L.a3_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.a3_download_grey.restype = C.c_int
+    L.a3_download_grey.argtypes = [vp, C.c_uint32, u8p]
+    L.a3_download_thresholded.restype = C.c_int
+    L.a3_download_thresholded.argtypes = [vp, C.c_uint32, u8p]
+    L.a3_candidate_count.restype = C.c_int
+    L.a3_candidate_count.argtypes = [vp, C.c_uint32, u32p, u32p]
+    L.a3_download_candidates.restype = C.c_int
+    L.a3_download_candidates.argtypes = [vp, C.c_uint32, C.c_int, u32p, C.c_size_t]
+    L.a3_download_homographies.restype = C.c_int
+    L.a3_download_homographies.argtypes = [vp, C.c_uint32, u8p, u8p, u64p, C.POINTER(C.c_int32), C.c_size_t]
+    L.a3_estimate_pose.restype = C.c_int
+    L.a3_estimate_pose.argtypes = [vp, u32p, C.c_size_t, C.c_float, C.POINTER(Intrinsics), C.c_uint32, C.c_uint32, C.POINTER(PoseRec)]
+    L.a3_estimate_pose_normalized.restype = C.c_int
+    L.a3_estimate_pose_normalized.argtypes = [vp, f32p, C.c_size_t, C.c_float, C.POINTER(PoseRec)]
+    L.a3_find_nearest.restype = C.c_int
+    L.a3_find_nearest.argtypes = [vp, u64p, C.c_size_t, u32p, u8p]
+    L.a3_calculate_tau.restype = C.c_int
+    L.a3_calculate_tau.argtypes = [C.c_int, u64p, C.c_size_t, u8p]
+    L.a3_set_profiling.restype = C.c_int
+    L.a3_set_profiling.argtypes = [vp, C.c_int]
+    L.a3_get_profile.restype = C.c_int
+    L.a3_get_profile.argtypes = [vp, C.c_int, f64p, u64p, C.c_int]
+    L.a3_selftest_ieee.restype = C.c_int
+    L.a3_selftest_ieee.argtypes = [vp, f64p, f64p, C.c_size_t, f64p, f64p, f32p, f32p]
+    _lib = L
+    return L
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def check(rc, ctx=None):
+    if rc != OK:
+        raise A3Error(rc, load().a3_last_error(ctx).decode("utf-8", "replace"))
+
+
+def default_config() -> Config:
+    cfg = Config()
+    load().a3_default_config(C.byref(cfg))
+    return cfg
+
+
+class Context:
+    """Owns one a3_ctx (one device, one stream)."""
+
+    def __init__(self, config: Config, codes: np.ndarray, num_bits: int, tau: int, device: int = 0):
+        L = load()
+        self._codes = np.ascontiguousarray(codes, dtype=np.uint64)
+        h = C.c_void_p()
+        rc = L.a3_create(device, C.byref(config), _p(self._codes, C.c_uint64), self._codes.size, num_bits, tau, C.byref(h))
+        check(rc, None)
+        self.handle = h
+        self.device = device
+        self.sample = int(config.homography_sample_size)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            load().a3_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def tau(self) -> int:
+        t = C.c_uint8()
+        check(load().a3_get_tau(self.handle, C.byref(t)), self.handle)
+        return int(t.value)
+
+    def set_stream(self, stream_ptr: int):
+        check(load().a3_set_stream(self.handle, C.c_void_p(stream_ptr)), self.handle)
+
+    def set_debug_taps(self, on: bool):
+        check(load().a3_set_debug_taps(self.handle, int(on)), self.handle)
+
+    def set_pool_limits(self, max_darts: int = 0, max_points: int = 0):
+        check(load().a3_set_pool_limits(self.handle, max_darts, max_points), self.handle)
+
+    def set_profiling(self, on: bool):
+        check(load().a3_set_profiling(self.handle, int(on)), self.handle)
+
+    def profile(self, stage: int, reset: bool = False):
+        ms, n = C.c_double(), C.c_uint64()
+        check(load().a3_get_profile(self.handle, stage, C.byref(ms), C.byref(n), int(reset)), self.handle)
+        return float(ms.value), int(n.value)
+
+    def stats(self) -> dict:
+        s = Stats()
+        check(load().a3_get_stats(self.handle, C.byref(s)), self.handle)
+        return s.as_dict()
+
+    def detect_batch(self, pixels_ptr: int, memory: int, fmt: int, width: int, height: int, row_stride: int, frame_stride: int, n_frames: int,
+                     out_cap: int = 0):
+        """-> (markers structured array, per-frame counts)"""
+        cap = out_cap or max(64 * n_frames, 64)
+        out = np.zeros(cap, dtype=MARKER_DTYPE)
+        per = np.zeros(max(n_frames, 1), dtype=np.uint32)
+        n = C.c_size_t()
+        rc = load().a3_detect_batch(self.handle, C.c_void_p(pixels_ptr), memory, fmt, width, height, row_stride, frame_stride, n_frames,
+                                    out.ctypes.data_as(C.c_void_p), cap, _p(per, C.c_uint32), C.byref(n))
+        check(rc, self.handle)
+        return out[: n.value], per[:n_frames]
+
+    # ---- Detection.grey / thresholded / candidates / homographies of the last batch ----
+    def download_grey(self, frame: int, w: int, h: int, thresholded: bool = False) -> np.ndarray:
+        out = np.empty((h, w), dtype=np.uint8)
+        fn = load().a3_download_thresholded if thresholded else load().a3_download_grey
+        check(fn(self.handle, frame, _p(out, C.c_uint8)), self.handle)
+        return out
+
+    def candidates(self, frame: int, before_discard: bool = False) -> np.ndarray:
+        a, b = C.c_uint32(), C.c_uint32()
+        check(load().a3_candidate_count(self.handle, frame, C.byref(a), C.byref(b)), self.handle)
+        cnt = a.value if before_discard else b.value
+        out = np.zeros((max(cnt, 1), 4, 2), dtype=np.uint32)
+        check(load().a3_download_candidates(self.handle, frame, int(before_discard), _p(out, C.c_uint32), max(cnt, 1)), self.handle)
+        return out[:cnt]
+
+    def homographies(self, frame: int, with_patches: bool = True):
+        a, b = C.c_uint32(), C.c_uint32()
+        check(load().a3_candidate_count(self.handle, frame, C.byref(a), C.byref(b)), self.handle)
+        cnt, S = b.value, self.sample
+        patches = np.zeros((max(cnt, 1), S, S), dtype=np.uint8)
+        ok = np.zeros(max(cnt, 1), dtype=np.uint8)
+        codes = np.zeros((max(cnt, 1), 4), dtype=np.uint64)
+        dec = np.zeros(max(cnt, 1), dtype=np.int32)
+        check(load().a3_download_homographies(self.handle, frame, _p(patches, C.c_uint8) if with_patches else None, _p(ok, C.c_uint8),
+                                              _p(codes, C.c_uint64), _p(dec, C.c_int32), max(cnt, 1)), self.handle)
+        return patches[:cnt], ok[:cnt], codes[:cnt], dec[:cnt]
+
+    # ---- pose ----
+    def estimate_pose(self, corners: np.ndarray, marker_size_mm: float, image_size=None, intrinsics: Intrinsics = None) -> np.ndarray:
+        c = np.ascontiguousarray(corners, dtype=np.uint32).reshape(-1, 8)
+        out = (PoseRec * (2 * max(c.shape[0], 1)))()
+        iw, ih = image_size if image_size else (1, 1)
+        check(load().a3_estimate_pose(self.handle, _p(c, C.c_uint32), c.shape[0], marker_size_mm, C.byref(intrinsics) if intrinsics else None,
+                                      iw, ih, out), self.handle)
+        return out
+
+    def estimate_pose_normalized(self, points: np.ndarray, marker_size_mm: float):
+        p = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 8)
+        out = (PoseRec * (2 * max(p.shape[0], 1)))()
+        check(load().a3_estimate_pose_normalized(self.handle, _p(p, C.c_float), p.shape[0], marker_size_mm, out), self.handle)
+        return out
+
+    def find_nearest(self, bits: np.ndarray):
+        b = np.ascontiguousarray(bits, dtype=np.uint64)
+        idx = np.zeros(max(b.size, 1), dtype=np.uint32)
+        dist = np.zeros(max(b.size, 1), dtype=np.uint8)
+        check(load().a3_find_nearest(self.handle, _p(b, C.c_uint64), b.size, _p(idx, C.c_uint32), _p(dist, C.c_uint8)), self.handle)
+        return idx[: b.size], dist[: b.size]
+
+    def selftest_ieee(self, a: np.ndarray, b: np.ndarray):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        n = a.size
+        sq, dv = np.zeros(n), np.zeros(n)
+        sqf, dvf = np.zeros(n, dtype=np.float32), np.zeros(n, dtype=np.float32)
+        check(load().a3_selftest_ieee(self.handle, _p(a, C.c_double), _p(b, C.c_double), n, _p(sq, C.c_double), _p(dv, C.c_double),
+                                      _p(sqf, C.c_float), _p(dvf, C.c_float)), self.handle)
+        return sq, dv, sqf, dvf
+
+
+# ---- dictionary helpers used by ARDictionary (device kernels; no host arithmetic) ----
+_dict_ctx = {}
+
+
+def _ctx_for(codes: np.ndarray) -> Context:
+    key = (codes.ctypes.data, codes.size)
+    ctx = _dict_ctx.get(key)
+    if ctx is None:
+        ctx = Context(default_config(), codes, 64, 1)
+        _dict_ctx[key] = ctx
+    return ctx
+
+
+def find_nearest(codes: np.ndarray, bits: np.ndarray):
+    return _ctx_for(codes).find_nearest(bits)
+
+
+def calculate_tau(codes: np.ndarray) -> int:
+    codes = np.ascontiguousarray(codes, dtype=np.uint64)
+    t = C.c_uint8()
+    check(load().a3_calculate_tau(0, _p(codes, C.c_uint64), codes.size, C.byref(t)), None)
+    return int(t.value)

@@ -1,0 +1,633 @@
+// a3_api.hip -- host side of libaruco3_hip.so: context, device pools, the batch pipeline and the C ABI
+// declared in include/aruco3_hip.h.  No CPU fallback of any stage lives here: without a HIP device
+// a3_create fails with A3_ERR_NO_DEVICE.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "a3_common.h"
+
+namespace a3 {
+// k_threshold.hip
+hipError_t launch_grey_threshold(hipStream_t, const uint8_t*, int, size_t, size_t, int, int, uint32_t, uint32_t, uint8_t*, uint8_t*);
+// k_contours.hip
+hipError_t launch_dart_count(hipStream_t, const uint8_t*, int, int, uint32_t, uint32_t, unsigned long long*);
+hipError_t launch_dart_build(hipStream_t, const uint8_t*, int, int, uint32_t, uint32_t, const uint32_t*, uint32_t*, uint32_t*, uint32_t*,
+                             uint8_t*, uint8_t*, uint32_t*, JumpState*, uint32_t);
+hipError_t launch_jump(hipStream_t, const JumpState*, JumpState*, uint32_t, int, DeviceCounters*);
+hipError_t launch_resolve(hipStream_t, const JumpState*, uint32_t, int, const uint32_t*, const uint8_t*, const uint8_t*, uint64_t*, uint64_t*,
+                          DeviceCounters*, unsigned int*, unsigned int*, int);
+hipError_t launch_select_scatter(hipStream_t, const JumpState*, uint32_t, const uint32_t*, const uint64_t*, const uint32_t*, uint32_t, uint32_t,
+                                 uint32_t, double, uint32_t*, ContourRec*, uint32_t*, uint32_t, uint64_t, DeviceCounters*, const uint32_t*,
+                                 uint32_t*);
+hipError_t launch_contour_quads(hipStream_t, const ContourRec*, const DeviceCounters*, uint32_t, const uint32_t*, double, uint32_t, uint32_t,
+                                uint32_t, CandRec*, uint32_t*, unsigned int*);
+// k_decode.hip
+size_t decode_out_bytes();
+hipError_t launch_frame_candidates(hipStream_t, const CandRec*, const uint32_t*, uint32_t, uint32_t, float, uint16_t*, uint16_t*, uint32_t*,
+                                   uint32_t*, unsigned int*);
+hipError_t launch_decode(hipStream_t, const uint8_t*, int, int, uint32_t, const uint16_t*, const uint32_t*, const unsigned int*, uint32_t,
+                         uint32_t, uint32_t, uint32_t, const uint64_t*, uint32_t, uint32_t, int, void*, uint8_t*, int);
+hipError_t launch_compact_markers(hipStream_t, const void*, const uint16_t*, const uint32_t*, uint32_t, uint32_t, uint32_t, a3_marker*,
+                                  uint32_t, uint32_t*, unsigned int*, unsigned int*);
+hipError_t launch_pose(hipStream_t, const uint32_t*, const float*, uint32_t, int, float, float, float, float, float, float, float, a3_pose*);
+hipError_t launch_find_nearest(hipStream_t, const uint64_t*, uint32_t, const uint64_t*, uint32_t, uint32_t*, uint8_t*);
+hipError_t launch_calc_tau(hipStream_t, const uint64_t*, uint32_t, unsigned int*);
+hipError_t launch_selftest(hipStream_t, const double*, const double*, uint32_t, double*, double*, float*, float*);
+}  // namespace a3
+
+using namespace a3;
+
+namespace {
+
+std::string g_create_error;
+
+constexpr uint32_t kMaxCand = 1024;          // quad candidates kept per frame
+constexpr uint32_t kMaxContoursDefault = 1u << 20;
+constexpr uint64_t kMaxDartsDefault = 48ull << 20;
+constexpr uint64_t kMaxPointsDefault = 64ull << 20;
+constexpr uint64_t kHardMaxDarts = 3ull << 30;   // 32-bit dart indices
+constexpr uint64_t kHardMaxPoints = 3ull << 30;
+constexpr int kResolveIters = 12;
+constexpr uint32_t kPatchCap = 32768;        // debug taps: warped patches kept per batch
+
+// grow-only device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct Chunk { uint32_t first, count; uint64_t darts; uint32_t max_frame_darts; };
+
+}  // namespace
+
+struct a3_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    a3_config cfg{};
+    uint8_t num_bits = 0, tau = 0;
+    uint32_t n_codes = 0, mark_size = 0;
+    std::string err;
+
+    uint64_t max_darts = kMaxDartsDefault, max_points = kMaxPointsDefault;
+    uint32_t max_contours = kMaxContoursDefault;
+    bool debug_taps = false;
+    bool profiling = false;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double prof_ms[A3_STAGE_COUNT] = {0, 0, 0};
+    uint64_t prof_n[A3_STAGE_COUNT] = {0, 0, 0};
+    a3_stats stats{};
+
+    // last batch geometry (for the debug downloads)
+    uint32_t W = 0, H = 0, frames = 0;
+
+    DevBuf dict, in, grey, bin, frame_darts, frame_base, frame_cursor, pix_base;
+    DevBuf d_xy, d_info, d_F, d_succ, stA, stB, t_cur, t_next, cyc_slot;
+    DevBuf contours, cyc_start_off, points, counters, scratch_u32;
+    DevBuf cands, cand_count, pre_xy, fin_xy, fin_count, work, outs, patches, markers, per_frame;
+    DevBuf tmp_a, tmp_b, tmp_c, tmp_d;
+    void* pinned = nullptr;
+    size_t pinned_cap = 0;
+};
+
+namespace {
+
+int fail(a3_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof buf, "%s", what);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define A3_HIP(call)                                                        \
+    do {                                                                    \
+        hipError_t e_ = (call);                                             \
+        if (e_ != hipSuccess) return fail(ctx, A3_ERR_HIP, #call, e_);      \
+    } while (0)
+
+int ensure_pinned(a3_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->pinned_cap) return A3_OK;
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    ctx->pinned = nullptr; ctx->pinned_cap = 0;
+    A3_HIP(hipHostMalloc(&ctx->pinned, bytes, hipHostMallocDefault));
+    ctx->pinned_cap = bytes;
+    return A3_OK;
+}
+
+uint32_t mark_size_of(uint8_t num_bits) {  // src/dictionaries.rs:154-156
+    return (uint32_t)((uint8_t)std::ceil(std::sqrt((float)num_bits)) + 2);
+}
+
+int ensure_dart_pool(a3_ctx* ctx, uint64_t darts) {
+    A3_HIP(ctx->d_xy.ensure(darts * 4));
+    A3_HIP(ctx->d_info.ensure(darts));
+    A3_HIP(ctx->d_F.ensure(darts));
+    A3_HIP(ctx->d_succ.ensure(darts * 4));
+    A3_HIP(ctx->stA.ensure(darts * sizeof(JumpState)));
+    A3_HIP(ctx->stB.ensure(darts * sizeof(JumpState)));
+    A3_HIP(ctx->t_cur.ensure(darts * 8));
+    A3_HIP(ctx->t_next.ensure(darts * 8));
+    A3_HIP(ctx->cyc_slot.ensure(darts * 4));
+    return A3_OK;
+}
+
+// the whole pipeline for one batch; `pixels` is a device pointer here
+int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t H, size_t row_stride, size_t frame_stride, uint32_t n,
+              a3_marker* out, size_t out_cap, uint32_t* per_frame_count, size_t* out_n) {
+    hipStream_t st = ctx->stream;
+    const size_t npx = (size_t)W * H;
+    const uint32_t minwh = W < H ? W : H;
+    const uint32_t min_edge_length = (uint32_t)((float)minwh * ctx->cfg.min_side_length_factor);   // src/aruco.rs:55
+    const float min_corner_separation = (float)minwh * ctx->cfg.min_corner_separation_factor;       // src/aruco.rs:56
+    const uint32_t S = ctx->cfg.homography_sample_size;
+
+    A3_HIP(ctx->grey.ensure(npx * n));
+    A3_HIP(ctx->bin.ensure(npx * n));
+    A3_HIP(ctx->frame_darts.ensure((size_t)n * 8));
+    A3_HIP(ctx->cands.ensure((size_t)n * kMaxCand * sizeof(CandRec)));
+    A3_HIP(ctx->cand_count.ensure((size_t)n * 4));
+    A3_HIP(ctx->pre_xy.ensure((size_t)n * kMaxCand * 16));
+    A3_HIP(ctx->fin_xy.ensure((size_t)n * kMaxCand * 16));
+    A3_HIP(ctx->fin_count.ensure((size_t)n * 4));
+    A3_HIP(ctx->work.ensure((size_t)n * kMaxCand * 4));
+    A3_HIP(ctx->outs.ensure((size_t)n * kMaxCand * decode_out_bytes()));
+    A3_HIP(ctx->per_frame.ensure((size_t)n * 4));
+    const uint32_t marker_cap = (uint32_t)std::min<size_t>(std::max<size_t>(out_cap, 1), (size_t)n * kMaxCand);
+    A3_HIP(ctx->markers.ensure((size_t)marker_cap * sizeof(a3_marker)));
+    A3_HIP(ctx->scratch_u32.ensure(64));
+    if (ctx->debug_taps) A3_HIP(ctx->patches.ensure((size_t)kPatchCap * S * S));
+    ctx->W = W; ctx->H = H; ctx->frames = n;
+    ctx->stats = a3_stats{};
+
+    // ---- K1 ----
+    if (ctx->profiling) A3_HIP(hipEventRecord(ctx->ev[0], st));
+    A3_HIP(launch_grey_threshold(st, pixels, fmt, row_stride, frame_stride, (int)W, (int)H, n, ctx->cfg.threshold_window,
+                                 ctx->grey.as<uint8_t>(), ctx->bin.as<uint8_t>()));
+    if (ctx->profiling) A3_HIP(hipEventRecord(ctx->ev[1], st));
+
+    // ---- contour graph size per frame -> chunk plan ----
+    A3_HIP(hipMemsetAsync(ctx->frame_darts.p, 0, (size_t)n * 8, st));
+    A3_HIP(launch_dart_count(st, ctx->bin.as<uint8_t>(), (int)W, (int)H, 0, n, ctx->frame_darts.as<unsigned long long>()));
+    if (int rc = ensure_pinned(ctx, std::max<size_t>((size_t)n * 8, 1 << 16))) return rc;
+    A3_HIP(hipMemcpyAsync(ctx->pinned, ctx->frame_darts.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    A3_HIP(hipStreamSynchronize(st));
+    std::vector<uint64_t> fd((uint64_t*)ctx->pinned, (uint64_t*)ctx->pinned + n);
+    uint64_t biggest = 0;
+    for (uint64_t v : fd) { biggest = std::max(biggest, v); ctx->stats.darts += v; }
+    if (biggest > kHardMaxDarts) return fail(ctx, A3_ERR_CAPACITY, "a frame needs more contour-graph nodes than 32-bit indices allow");
+    if (biggest > ctx->max_darts) ctx->max_darts = biggest;  // one frame must fit; grow the pool
+    std::vector<Chunk> chunks;
+    {
+        Chunk c{0, 0, 0, 0};
+        for (uint32_t f = 0; f < n; f++) {
+            if (c.count && c.darts + fd[f] > ctx->max_darts) { chunks.push_back(c); c = Chunk{f, 0, 0, 0}; }
+            c.count++; c.darts += fd[f]; c.max_frame_darts = (uint32_t)std::max<uint64_t>(c.max_frame_darts, fd[f]);
+        }
+        if (c.count) chunks.push_back(c);
+    }
+    uint32_t max_chunk_frames = 0; uint64_t max_chunk_darts = 0;
+    for (auto& c : chunks) { max_chunk_frames = std::max(max_chunk_frames, c.count); max_chunk_darts = std::max(max_chunk_darts, c.darts); }
+    ctx->stats.chunks = (uint32_t)chunks.size();
+    if (int rc = ensure_dart_pool(ctx, std::max<uint64_t>(max_chunk_darts, 1))) return rc;
+    A3_HIP(ctx->pix_base.ensure((size_t)max_chunk_frames * npx * 4));
+    A3_HIP(ctx->frame_base.ensure((size_t)(max_chunk_frames + 1) * 4 * chunks.size()));
+    A3_HIP(ctx->frame_cursor.ensure((size_t)max_chunk_frames * 4));
+    A3_HIP(ctx->counters.ensure(sizeof(DeviceCounters) * chunks.size()));
+    A3_HIP(ctx->contours.ensure((size_t)ctx->max_contours * sizeof(ContourRec)));
+    A3_HIP(ctx->cyc_start_off.ensure((size_t)ctx->max_contours * 4));
+    A3_HIP(ctx->points.ensure(ctx->max_points * 4));
+
+    A3_HIP(hipMemsetAsync(ctx->counters.p, 0, sizeof(DeviceCounters) * chunks.size(), st));
+    A3_HIP(hipMemsetAsync(ctx->cand_count.p, 0, (size_t)n * 4, st));
+    A3_HIP(hipMemsetAsync(ctx->scratch_u32.p, 0, 64, st));
+    unsigned int* d_work_count = ctx->scratch_u32.as<unsigned int>() + 0;
+    unsigned int* d_marker_total = ctx->scratch_u32.as<unsigned int>() + 1;
+    unsigned int* d_changed_tmp = ctx->scratch_u32.as<unsigned int>() + 2;
+    unsigned int* d_iters = ctx->scratch_u32.as<unsigned int>() + 3;
+    unsigned int* d_err = ctx->scratch_u32.as<unsigned int>() + 4;
+
+    // frame bases of every chunk, uploaded once
+    std::vector<uint32_t> bases;
+    for (auto& c : chunks) {
+        uint32_t acc = 0;
+        for (uint32_t i = 0; i < max_chunk_frames + 1; i++) {
+            bases.push_back(acc);
+            if (i < c.count) acc += (uint32_t)fd[c.first + i];
+        }
+    }
+    // the pinned buffer still holds fd; stage the bases behind it
+    if (int rc = ensure_pinned(ctx, (size_t)n * 8 + bases.size() * 4 + (1 << 16))) return rc;
+    uint32_t* h_bases = reinterpret_cast<uint32_t*>((uint8_t*)ctx->pinned + (size_t)n * 8);
+    memcpy(h_bases, bases.data(), bases.size() * 4);
+    A3_HIP(hipMemcpyAsync(ctx->frame_base.p, h_bases, bases.size() * 4, hipMemcpyHostToDevice, st));
+
+    // ---- contour stage, chunk by chunk ----
+    const uint8_t* d_bin = ctx->bin.as<uint8_t>();
+    int rounds_max = 0;
+    for (size_t ci = 0; ci < chunks.size(); ci++) {
+        const Chunk& c = chunks[ci];
+        DeviceCounters* ctr = ctx->counters.as<DeviceCounters>() + ci;
+        const uint32_t* fb = ctx->frame_base.as<uint32_t>() + ci * (max_chunk_frames + 1);
+        const uint32_t nd = (uint32_t)c.darts;
+        if (nd == 0) continue;
+        A3_HIP(hipMemsetAsync(ctx->frame_cursor.p, 0, (size_t)c.count * 4, st));
+        A3_HIP(launch_dart_build(st, d_bin, (int)W, (int)H, c.first, c.count, fb, ctx->frame_cursor.as<uint32_t>(), ctx->pix_base.as<uint32_t>(),
+                                 ctx->d_xy.as<uint32_t>(), ctx->d_info.as<uint8_t>(), ctx->d_F.as<uint8_t>(), ctx->d_succ.as<uint32_t>(),
+                                 ctx->stA.as<JumpState>(), nd));
+        int rounds = 1;
+        while ((1ull << rounds) < (uint64_t)c.max_frame_darts && rounds < 31) rounds++;
+        rounds += 1;  // the round that observes "nothing moved"
+        rounds_max = std::max(rounds_max, rounds);
+        JumpState* a = ctx->stA.as<JumpState>();
+        JumpState* b = ctx->stB.as<JumpState>();
+        for (int r = 0; r < rounds; r++) { A3_HIP(launch_jump(st, a, b, nd, r, ctr)); std::swap(a, b); }
+        // both buffers are final once converged; the last round always is the observing one, so `a` (last written or skipped) is valid
+        const JumpState* fin = a;
+        A3_HIP(launch_resolve(st, fin, nd, (int)W, ctx->d_xy.as<uint32_t>(), ctx->d_info.as<uint8_t>(), ctx->d_F.as<uint8_t>(),
+                              ctx->t_cur.as<uint64_t>(), ctx->t_next.as<uint64_t>(), ctr, d_changed_tmp, d_iters, kResolveIters));
+        A3_HIP(launch_select_scatter(st, fin, nd, ctx->d_succ.as<uint32_t>(), ctx->t_cur.as<uint64_t>(), fb, c.count, c.first, min_edge_length,
+                                     ctx->cfg.contour_simplification_epsilon, ctx->cyc_slot.as<uint32_t>(), ctx->contours.as<ContourRec>(),
+                                     ctx->cyc_start_off.as<uint32_t>(), ctx->max_contours, ctx->max_points, ctr, ctx->d_xy.as<uint32_t>(),
+                                     ctx->points.as<uint32_t>()));
+        A3_HIP(launch_contour_quads(st, ctx->contours.as<ContourRec>(), ctr, ctx->max_contours, ctx->points.as<uint32_t>(),
+                                    ctx->cfg.contour_simplification_epsilon, min_edge_length, c.first, kMaxCand,
+                                    ctx->cands.as<CandRec>() + (size_t)c.first * kMaxCand, ctx->cand_count.as<uint32_t>() + c.first, d_err));
+    }
+    if (ctx->profiling) A3_HIP(hipEventRecord(ctx->ev[2], st));
+
+    // ---- candidates -> markers, all frames at once ----
+    A3_HIP(launch_frame_candidates(st, ctx->cands.as<CandRec>(), ctx->cand_count.as<uint32_t>(), n, kMaxCand, min_corner_separation,
+                                   ctx->pre_xy.as<uint16_t>(), ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(),
+                                   ctx->work.as<uint32_t>(), d_work_count));
+    A3_HIP(launch_decode(st, ctx->grey.as<uint8_t>(), (int)W, (int)H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), d_work_count,
+                         kMaxCand, S, ctx->mark_size, S, ctx->dict.as<uint64_t>(), ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors,
+                         ctx->outs.p, ctx->debug_taps ? ctx->patches.as<uint8_t>() : nullptr, 2048));
+    A3_HIP(launch_compact_markers(st, ctx->outs.p, ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(), n, 0, kMaxCand,
+                                  ctx->markers.as<a3_marker>(), marker_cap, ctx->per_frame.as<uint32_t>(), d_marker_total, d_err));
+    if (ctx->profiling) A3_HIP(hipEventRecord(ctx->ev[3], st));
+
+    // ---- results ----
+    const size_t ctr_bytes = sizeof(DeviceCounters) * chunks.size();
+    if (int rc = ensure_pinned(ctx, ctr_bytes + 64 + (size_t)n * 4 + (1 << 16))) return rc;
+    uint8_t* hp = (uint8_t*)ctx->pinned;
+    A3_HIP(hipMemcpyAsync(hp, ctx->counters.p, ctr_bytes, hipMemcpyDeviceToHost, st));
+    A3_HIP(hipMemcpyAsync(hp + ctr_bytes, ctx->scratch_u32.p, 64, hipMemcpyDeviceToHost, st));
+    A3_HIP(hipMemcpyAsync(hp + ctr_bytes + 64, ctx->per_frame.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    A3_HIP(hipStreamSynchronize(st));
+    const DeviceCounters* hc = reinterpret_cast<const DeviceCounters*>(hp);
+    const unsigned int* hs = reinterpret_cast<const unsigned int*>(hp + ctr_bytes);
+    unsigned int flags = hs[4];
+    uint64_t need_points = 0; uint32_t need_contours = 0;
+    for (size_t ci = 0; ci < chunks.size(); ci++) {
+        flags |= hc[ci].err_flags;
+        need_points = std::max<uint64_t>(need_points, hc[ci].points);
+        need_contours = std::max(need_contours, hc[ci].contours);
+        ctx->stats.contours_traced += hc[ci].traced;
+        ctx->stats.contours_materialised += hc[ci].contours;
+        for (int r = 0; r < 32; r++) if (hc[ci].jump_changed[r]) ctx->stats.jump_rounds = std::max<uint32_t>(ctx->stats.jump_rounds, r + 1);
+    }
+    ctx->stats.resolve_iterations = hs[3];
+    if (flags & (kErrPointPool | kErrContourTable)) {
+        // grow and let the caller loop re-run the batch
+        if (need_points > ctx->max_points) ctx->max_points = std::min<uint64_t>(kHardMaxPoints, std::max(need_points, ctx->max_points * 2));
+        if (need_contours > ctx->max_contours) ctx->max_contours = std::max(need_contours, ctx->max_contours * 2);
+        return 1;  // retry
+    }
+    if (flags & kErrBrokenEvent) return fail(ctx, A3_ERR_INTERNAL, "contour graph: a start event lies on an open chain");
+    if (flags & kErrResolve) return fail(ctx, A3_ERR_INTERNAL, "contour start resolution did not converge");
+    if (flags & kErrCandTable) return fail(ctx, A3_ERR_CAPACITY, "more candidates / markers than the output tables hold");
+    const uint32_t total = hs[1];
+    if (total > out_cap) return fail(ctx, A3_ERR_CAPACITY, "out_cap is smaller than the number of markers found");
+    const uint32_t* hpf = reinterpret_cast<const uint32_t*>(hp + ctr_bytes + 64);
+    if (per_frame_count) memcpy(per_frame_count, hpf, (size_t)n * 4);
+    if (total) {
+        A3_HIP(hipMemcpyAsync(out, ctx->markers.p, (size_t)total * sizeof(a3_marker), hipMemcpyDeviceToHost, st));
+        A3_HIP(hipStreamSynchronize(st));
+    }
+    *out_n = total;
+    ctx->stats.markers = total;
+    if (ctx->profiling) {
+        float ms;
+        A3_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); ctx->prof_ms[A3_STAGE_THRESHOLD] += ms; ctx->prof_n[A3_STAGE_THRESHOLD]++;
+        A3_HIP(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2])); ctx->prof_ms[A3_STAGE_CONTOUR] += ms; ctx->prof_n[A3_STAGE_CONTOUR]++;
+        A3_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->prof_ms[A3_STAGE_DECODE] += ms; ctx->prof_n[A3_STAGE_DECODE]++;
+    }
+    return A3_OK;
+}
+
+}  // namespace
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" {
+
+int a3_abi_version(void) { return A3_ABI_VERSION; }
+
+void a3_default_config(a3_config* cfg) {  // src/aruco.rs:32-43
+    if (!cfg) return;
+    cfg->threshold_window = 7;
+    cfg->contour_simplification_epsilon = 0.05;
+    cfg->min_side_length_factor = 0.2f;
+    cfg->min_corner_separation_factor = 0.1f;
+    cfg->homography_sample_size = 49;
+    cfg->filter_high_bit_errors = 1;
+}
+
+const char* a3_last_error(const a3_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int a3_calculate_tau(int device, const uint64_t* codes, size_t n_codes, uint8_t* tau) {
+    a3_ctx* ctx = nullptr;
+    if (!codes || !tau) return fail(ctx, A3_ERR_INVALID, "a3_calculate_tau: null argument");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(ctx, A3_ERR_NO_DEVICE, "no HIP device");
+    A3_HIP(hipSetDevice(device));
+    uint64_t* d = nullptr; unsigned int* dt = nullptr;
+    A3_HIP(hipMalloc(&d, std::max<size_t>(n_codes, 1) * 8));
+    A3_HIP(hipMalloc(&dt, 4));
+    unsigned int init = 255, res = 255;
+    A3_HIP(hipMemcpy(d, codes, n_codes * 8, hipMemcpyHostToDevice));
+    A3_HIP(hipMemcpy(dt, &init, 4, hipMemcpyHostToDevice));
+    A3_HIP(launch_calc_tau(nullptr, d, (uint32_t)n_codes, dt));
+    A3_HIP(hipMemcpy(&res, dt, 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d); (void)hipFree(dt);
+    *tau = (uint8_t)res;
+    return A3_OK;
+}
+
+int a3_create(int device, const a3_config* cfg, const uint64_t* codes, size_t n_codes, uint8_t num_bits, uint8_t tau, a3_ctx** out) {
+    a3_ctx* ctx = nullptr;
+    if (!cfg || !out || (!codes && n_codes)) return fail(ctx, A3_ERR_INVALID, "a3_create: null argument");
+    if (cfg->threshold_window == 0) return fail(ctx, A3_ERR_INVALID, "threshold_window must be > 0 (imageproc asserts block_radius > 0)");
+    if (!(cfg->contour_simplification_epsilon > 0.0)) return fail(ctx, A3_ERR_INVALID, "contour_simplification_epsilon must be > 0");
+    if (cfg->homography_sample_size == 0 || cfg->homography_sample_size > 200)
+        return fail(ctx, A3_ERR_INVALID, "homography_sample_size must be in 1..200");
+    if (num_bits == 0 || num_bits > 64) return fail(ctx, A3_ERR_INVALID, "num_bits must be in 1..64");
+    if (n_codes > 0xFFFFFFFFull) return fail(ctx, A3_ERR_INVALID, "dictionary too large");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(ctx, A3_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+    if (device < 0 || device >= count) return fail(ctx, A3_ERR_INVALID, "device index out of range");
+    A3_HIP(hipSetDevice(device));
+    a3_ctx* c = new a3_ctx();
+    c->device = device;
+    c->cfg = *cfg;
+    c->num_bits = num_bits;
+    c->n_codes = (uint32_t)n_codes;
+    c->mark_size = mark_size_of(num_bits);
+    ctx = c;
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; ctx = nullptr; return fail(ctx, A3_ERR_HIP, "hipStreamCreate", e); }
+    c->stream = c->own_stream;
+    for (auto& ev : c->ev) {
+        e = hipEventCreate(&ev);
+        if (e != hipSuccess) { a3_destroy(c); ctx = nullptr; return fail(ctx, A3_ERR_HIP, "hipEventCreate", e); }
+    }
+    e = c->dict.ensure(std::max<size_t>(n_codes, 1) * 8);
+    if (e == hipSuccess && n_codes) e = hipMemcpy(c->dict.p, codes, n_codes * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { a3_destroy(c); ctx = nullptr; return fail(ctx, A3_ERR_HIP, "dictionary upload", e); }
+    if (tau == 0) {  // src/dictionaries.rs:124
+        uint8_t t = 255;
+        int rc = a3_calculate_tau(device, codes, n_codes, &t);
+        if (rc) { a3_destroy(c); return rc; }
+        tau = t;
+    }
+    c->tau = tau;
+    *out = c;
+    return A3_OK;
+}
+
+void a3_destroy(a3_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    DevBuf* bufs[] = {&ctx->dict, &ctx->in, &ctx->grey, &ctx->bin, &ctx->frame_darts, &ctx->frame_base, &ctx->frame_cursor, &ctx->pix_base,
+                      &ctx->d_xy, &ctx->d_info, &ctx->d_F, &ctx->d_succ, &ctx->stA, &ctx->stB, &ctx->t_cur, &ctx->t_next, &ctx->cyc_slot,
+                      &ctx->contours, &ctx->cyc_start_off, &ctx->points, &ctx->counters, &ctx->scratch_u32, &ctx->cands, &ctx->cand_count,
+                      &ctx->pre_xy, &ctx->fin_xy, &ctx->fin_count, &ctx->work, &ctx->outs, &ctx->patches, &ctx->markers, &ctx->per_frame,
+                      &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_d};
+    for (DevBuf* b : bufs) b->release();
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int a3_set_stream(a3_ctx* ctx, void* hip_stream) {
+    if (!ctx) return A3_ERR_INVALID;
+    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return A3_OK;
+}
+
+int a3_set_pool_limits(a3_ctx* ctx, uint64_t max_darts, uint64_t max_points) {
+    if (!ctx) return A3_ERR_INVALID;
+    if (max_darts) ctx->max_darts = std::min<uint64_t>(max_darts, kHardMaxDarts);
+    if (max_points) ctx->max_points = std::min<uint64_t>(max_points, kHardMaxPoints);
+    return A3_OK;
+}
+
+int a3_set_debug_taps(a3_ctx* ctx, int enabled) {
+    if (!ctx) return A3_ERR_INVALID;
+    ctx->debug_taps = enabled != 0;
+    return A3_OK;
+}
+
+int a3_get_tau(const a3_ctx* ctx, uint8_t* tau) {
+    if (!ctx || !tau) return A3_ERR_INVALID;
+    *tau = ctx->tau;
+    return A3_OK;
+}
+
+int a3_detect_batch(a3_ctx* ctx, const void* pixels, int memory, int fmt, uint32_t width, uint32_t height, size_t row_stride,
+                    size_t frame_stride, uint32_t n_frames, a3_marker* out, size_t out_cap, uint32_t* per_frame_count, size_t* out_n) {
+    if (!ctx) return A3_ERR_INVALID;
+    if (!out_n || (!out && out_cap)) return fail(ctx, A3_ERR_INVALID, "a3_detect_batch: null output");
+    *out_n = 0;
+    if (n_frames == 0) return A3_OK;
+    if (!pixels) return fail(ctx, A3_ERR_INVALID, "a3_detect_batch: null pixels");
+    if (fmt != A3_FMT_RGB8 && fmt != A3_FMT_RGBA8 && fmt != A3_FMT_L8) return fail(ctx, A3_ERR_INVALID, "unknown pixel format");
+    if (width == 0 || height == 0) {  // an empty image has no contours
+        if (per_frame_count) memset(per_frame_count, 0, (size_t)n_frames * 4);
+        return A3_OK;
+    }
+    if (width > 65535 || height > 65535 || (uint64_t)width * height >= (1ull << 30))
+        return fail(ctx, A3_ERR_INVALID, "image dimensions above 65535 (or 2^30 pixels) are not supported");
+    const size_t bpp = fmt == A3_FMT_RGB8 ? 3 : (fmt == A3_FMT_RGBA8 ? 4 : 1);
+    if (row_stride == 0) row_stride = (size_t)width * bpp;
+    if (row_stride < (size_t)width * bpp) return fail(ctx, A3_ERR_INVALID, "row_stride smaller than a row");
+    if (frame_stride == 0) frame_stride = row_stride * height;
+    if (frame_stride < row_stride * (height - 1) + (size_t)width * bpp) return fail(ctx, A3_ERR_INVALID, "frame_stride smaller than a frame");
+    A3_HIP(hipSetDevice(ctx->device));
+    const uint8_t* d_pixels = reinterpret_cast<const uint8_t*>(pixels);
+    if (memory == A3_MEM_HOST) {
+        const size_t bytes = frame_stride * (n_frames - 1) + row_stride * (height - 1) + (size_t)width * bpp;
+        A3_HIP(ctx->in.ensure(bytes));
+        A3_HIP(hipMemcpyAsync(ctx->in.p, pixels, bytes, hipMemcpyHostToDevice, ctx->stream));
+        d_pixels = ctx->in.as<uint8_t>();
+    } else if (memory != A3_MEM_DEVICE) return fail(ctx, A3_ERR_INVALID, "memory must be A3_MEM_HOST or A3_MEM_DEVICE");
+    for (int attempt = 0; attempt < 6; attempt++) {
+        const int rc = run_batch(ctx, d_pixels, fmt, width, height, row_stride, frame_stride, n_frames, out, out_cap, per_frame_count, out_n);
+        if (rc != 1) return rc;
+    }
+    return fail(ctx, A3_ERR_CAPACITY, "contour pools kept overflowing");
+}
+
+int a3_get_stats(const a3_ctx* ctx, a3_stats* stats) {
+    if (!ctx || !stats) return A3_ERR_INVALID;
+    *stats = ctx->stats;
+    return A3_OK;
+}
+
+static int download_plane(a3_ctx* ctx, const DevBuf& buf, uint32_t frame, uint8_t* dst) {
+    if (!ctx || !dst) return A3_ERR_INVALID;
+    if (frame >= ctx->frames) return fail(ctx, A3_ERR_INVALID, "frame index outside the last batch");
+    const size_t npx = (size_t)ctx->W * ctx->H;
+    A3_HIP(hipSetDevice(ctx->device));
+    A3_HIP(hipMemcpy(dst, buf.as<uint8_t>() + npx * frame, npx, hipMemcpyDeviceToHost));
+    return A3_OK;
+}
+
+int a3_download_grey(a3_ctx* ctx, uint32_t frame, uint8_t* dst) { return ctx ? download_plane(ctx, ctx->grey, frame, dst) : A3_ERR_INVALID; }
+int a3_download_thresholded(a3_ctx* ctx, uint32_t frame, uint8_t* dst) { return ctx ? download_plane(ctx, ctx->bin, frame, dst) : A3_ERR_INVALID; }
+
+int a3_candidate_count(a3_ctx* ctx, uint32_t frame, uint32_t* n_pre, uint32_t* n_final) {
+    if (!ctx) return A3_ERR_INVALID;
+    if (frame >= ctx->frames) return fail(ctx, A3_ERR_INVALID, "frame index outside the last batch");
+    A3_HIP(hipSetDevice(ctx->device));
+    uint32_t a = 0, b = 0;
+    A3_HIP(hipMemcpy(&a, ctx->cand_count.as<uint32_t>() + frame, 4, hipMemcpyDeviceToHost));
+    A3_HIP(hipMemcpy(&b, ctx->fin_count.as<uint32_t>() + frame, 4, hipMemcpyDeviceToHost));
+    if (n_pre) *n_pre = std::min(a, kMaxCand);
+    if (n_final) *n_final = b;
+    return A3_OK;
+}
+
+int a3_download_candidates(a3_ctx* ctx, uint32_t frame, int before_discard, uint32_t* dst_xy, size_t cap_quads) {
+    if (!ctx || !dst_xy) return A3_ERR_INVALID;
+    uint32_t a = 0, b = 0;
+    if (int rc = a3_candidate_count(ctx, frame, &a, &b)) return rc;
+    const uint32_t cnt = before_discard ? a : b;
+    if (cnt > cap_quads) return fail(ctx, A3_ERR_CAPACITY, "cap_quads too small");
+    std::vector<uint16_t> tmp((size_t)cnt * 8);
+    const DevBuf& src = before_discard ? ctx->pre_xy : ctx->fin_xy;
+    if (cnt) A3_HIP(hipMemcpy(tmp.data(), src.as<uint16_t>() + (size_t)frame * kMaxCand * 8, tmp.size() * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < tmp.size(); i++) dst_xy[i] = tmp[i];
+    return A3_OK;
+}
+
+struct DecodeOutHost { uint64_t code; uint64_t codes[4]; uint32_t id; uint8_t valid, rotation, hamming, hom_ok; int32_t decode_ok; uint32_t pad; };
+
+int a3_download_homographies(a3_ctx* ctx, uint32_t frame, uint8_t* dst, uint8_t* ok, uint64_t* codes4, int32_t* decode_ok, size_t cap) {
+    if (!ctx) return A3_ERR_INVALID;
+    uint32_t b = 0;
+    if (int rc = a3_candidate_count(ctx, frame, nullptr, &b)) return rc;
+    if (b > cap) return fail(ctx, A3_ERR_CAPACITY, "cap too small");
+    if (sizeof(DecodeOutHost) != decode_out_bytes()) return fail(ctx, A3_ERR_INTERNAL, "DecodeOut layout mismatch");
+    std::vector<DecodeOutHost> o(b);
+    if (b) A3_HIP(hipMemcpy(o.data(), (uint8_t*)ctx->outs.p + (size_t)frame * kMaxCand * sizeof(DecodeOutHost), (size_t)b * sizeof(DecodeOutHost),
+                            hipMemcpyDeviceToHost));
+    const uint32_t S = ctx->cfg.homography_sample_size;
+    for (uint32_t k = 0; k < b; k++) {
+        if (ok) ok[k] = o[k].hom_ok;
+        if (decode_ok) decode_ok[k] = o[k].decode_ok;
+        if (codes4) for (int r = 0; r < 4; r++) codes4[4 * k + r] = o[k].codes[r];
+        if (dst) {
+            if (!ctx->debug_taps) return fail(ctx, A3_ERR_INVALID, "patches are only kept after a3_set_debug_taps(ctx, 1)");
+            const size_t slot = (size_t)frame * kMaxCand + k;
+            if (slot >= kPatchCap) return fail(ctx, A3_ERR_CAPACITY, "patch tap holds the first 32768 candidate slots only");
+            A3_HIP(hipMemcpy(dst + (size_t)k * S * S, ctx->patches.as<uint8_t>() + slot * S * S, (size_t)S * S, hipMemcpyDeviceToHost));
+        }
+    }
+    return A3_OK;
+}
+
+static int pose_common(a3_ctx* ctx, const uint32_t* corners, const float* norm, size_t n, int mode, float size_mm, const a3_intrinsics* intr,
+                       uint32_t iw, uint32_t ih, a3_pose* out) {
+    if (!ctx || !out || (!corners && !norm)) return A3_ERR_INVALID;
+    if (n == 0) return A3_OK;
+    A3_HIP(hipSetDevice(ctx->device));
+    const size_t in_bytes = n * 8 * 4;
+    A3_HIP(ctx->tmp_a.ensure(in_bytes));
+    A3_HIP(ctx->tmp_b.ensure(n * 2 * sizeof(a3_pose)));
+    A3_HIP(hipMemcpyAsync(ctx->tmp_a.p, corners ? (const void*)corners : (const void*)norm, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    float fx = 1, fy = 1, cx = 0, cy = 0;
+    if (intr) { fx = intr->focal_x; fy = intr->focal_y; cx = intr->principal_x; cy = intr->principal_y; }
+    A3_HIP(launch_pose(ctx->stream, corners ? ctx->tmp_a.as<uint32_t>() : nullptr, norm ? ctx->tmp_a.as<float>() : nullptr, (uint32_t)n, mode,
+                       size_mm, (float)iw, (float)ih, fx, fy, cx, cy, ctx->tmp_b.as<a3_pose>()));
+    A3_HIP(hipMemcpyAsync(out, ctx->tmp_b.p, n * 2 * sizeof(a3_pose), hipMemcpyDeviceToHost, ctx->stream));
+    A3_HIP(hipStreamSynchronize(ctx->stream));
+    return A3_OK;
+}
+
+int a3_estimate_pose(a3_ctx* ctx, const uint32_t* corners_xy, size_t n, float marker_size_mm, const a3_intrinsics* intr, uint32_t image_width,
+                     uint32_t image_height, a3_pose* out) {
+    if (!corners_xy) return A3_ERR_INVALID;
+    return pose_common(ctx, corners_xy, nullptr, n, intr ? 1 : 0, marker_size_mm, intr, image_width, image_height, out);
+}
+
+int a3_estimate_pose_normalized(a3_ctx* ctx, const float* points_xy, size_t n, float marker_size_mm, a3_pose* out) {
+    if (!points_xy) return A3_ERR_INVALID;
+    return pose_common(ctx, nullptr, points_xy, n, 2, marker_size_mm, nullptr, 1, 1, out);
+}
+
+int a3_find_nearest(a3_ctx* ctx, const uint64_t* bits, size_t n, uint32_t* idx, uint8_t* dist) {
+    if (!ctx || !bits || !idx || !dist) return A3_ERR_INVALID;
+    if (n == 0) return A3_OK;
+    A3_HIP(hipSetDevice(ctx->device));
+    A3_HIP(ctx->tmp_a.ensure(n * 8));
+    A3_HIP(ctx->tmp_c.ensure(n * 4));
+    A3_HIP(ctx->tmp_d.ensure(n));
+    A3_HIP(hipMemcpyAsync(ctx->tmp_a.p, bits, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    A3_HIP(launch_find_nearest(ctx->stream, ctx->dict.as<uint64_t>(), ctx->n_codes, ctx->tmp_a.as<uint64_t>(), (uint32_t)n, ctx->tmp_c.as<uint32_t>(),
+                               ctx->tmp_d.as<uint8_t>()));
+    A3_HIP(hipMemcpyAsync(idx, ctx->tmp_c.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    A3_HIP(hipMemcpyAsync(dist, ctx->tmp_d.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    A3_HIP(hipStreamSynchronize(ctx->stream));
+    return A3_OK;
+}
+
+int a3_set_profiling(a3_ctx* ctx, int enabled) {
+    if (!ctx) return A3_ERR_INVALID;
+    ctx->profiling = enabled != 0;
+    return A3_OK;
+}
+
+int a3_get_profile(a3_ctx* ctx, int stage, double* total_ms, uint64_t* launches, int reset) {
+    if (!ctx || stage < 0 || stage >= A3_STAGE_COUNT) return A3_ERR_INVALID;
+    if (total_ms) *total_ms = ctx->prof_ms[stage];
+    if (launches) *launches = ctx->prof_n[stage];
+    if (reset) { ctx->prof_ms[stage] = 0; ctx->prof_n[stage] = 0; }
+    return A3_OK;
+}
+
+int a3_selftest_ieee(a3_ctx* ctx, const double* a, const double* b, size_t n, double* sqrt_a, double* a_div_b, float* sqrtf_a, float* a_divf_b) {
+    if (!ctx || !a || !b || !sqrt_a || !a_div_b || !sqrtf_a || !a_divf_b) return A3_ERR_INVALID;
+    if (n == 0) return A3_OK;
+    A3_HIP(hipSetDevice(ctx->device));
+    A3_HIP(ctx->tmp_a.ensure(n * 8)); A3_HIP(ctx->tmp_b.ensure(n * 8)); A3_HIP(ctx->tmp_c.ensure(n * 16)); A3_HIP(ctx->tmp_d.ensure(n * 8));
+    A3_HIP(hipMemcpy(ctx->tmp_a.p, a, n * 8, hipMemcpyHostToDevice));
+    A3_HIP(hipMemcpy(ctx->tmp_b.p, b, n * 8, hipMemcpyHostToDevice));
+    double* sq = ctx->tmp_c.as<double>(); double* dv = sq + n;
+    float* sqf = ctx->tmp_d.as<float>(); float* dvf = sqf + n;
+    A3_HIP(launch_selftest(ctx->stream, ctx->tmp_a.as<double>(), ctx->tmp_b.as<double>(), (uint32_t)n, sq, dv, sqf, dvf));
+    A3_HIP(hipStreamSynchronize(ctx->stream));
+    A3_HIP(hipMemcpy(sqrt_a, sq, n * 8, hipMemcpyDeviceToHost));
+    A3_HIP(hipMemcpy(a_div_b, dv, n * 8, hipMemcpyDeviceToHost));
+    A3_HIP(hipMemcpy(sqrtf_a, sqf, n * 4, hipMemcpyDeviceToHost));
+    A3_HIP(hipMemcpy(a_divf_b, dvf, n * 4, hipMemcpyDeviceToHost));
+    return A3_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// a3_common.h -- shared device/host declarations for libaruco3_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/aruco3_hip.h"
+
+namespace a3 {
+
+constexpr int WAVE = 64;
+
+// ---- contour graph ("darts") ------------------------------------------------------------
+// A dart is (pixel, direction of a foreground 8-neighbour).  Directions are numbered
+// clockwise on screen starting at west, the ring order of the border follower the
+// reference calls (imageproc find_contours, src/aruco.rs:64): W NW N NE E SE S SW.
+__device__ __constant__ const int8_t kDX[8] = {-1, -1, 0, 1, 1, 1, 0, -1};
+__device__ __constant__ const int8_t kDY[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+
+constexpr uint32_t kNoKey = 0xFFFFFFFFu;  // "this dart is not a start event"
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+// dart info byte: bits 0-2 = incoming direction, bit 3 = W-event dart, bit 4 = E-event dart,
+// bit 5 = successor missing (chain end; only face cycles of the 8-neighbour graph do this)
+constexpr uint8_t kInfoW = 1u << 3;
+constexpr uint8_t kInfoE = 1u << 4;
+constexpr uint8_t kInfoBroken = 1u << 5;
+
+// state carried by the pointer-doubling rounds (24 bytes per dart, ping-pong)
+struct JumpState {
+    uint64_t key;   // (start-event key << 32) | dart index : minimum over the window
+    uint32_t ptr;   // succ^(2^round)
+    uint32_t off;   // hops from this dart to the first dart holding `key`
+    uint16_t minx, miny, maxx, maxy;  // bounding box over the window
+};
+static_assert(sizeof(JumpState) == 24, "JumpState layout");
+
+// one border that survived the size pruning and gets its points written out
+struct ContourRec {
+    uint32_t frame;
+    uint32_t start_key;   // 2*raster(start pixel) (+1 when started as a hole border): the reference's contour order
+    uint32_t point_base;  // into the point pool
+    uint32_t n;           // number of points
+};
+
+// a quad candidate (contours_to_candidates + enforce_clockwise, src/aruco.rs:124-185)
+struct CandRec {
+    uint32_t start_key;
+    uint16_t xy[8];
+};
+
+struct DeviceCounters {
+    unsigned long long darts;       // per chunk: next free dart
+    unsigned long long points;      // next free point
+    unsigned int contours;          // next free ContourRec
+    unsigned int traced;            // cycles with a start event (stat)
+    unsigned int err_flags;         // bit 0: event dart on a broken chain, bit 1: point pool overflow,
+                                    // bit 2: contour table overflow, bit 3: candidate table overflow
+    unsigned int resolve_changed;   // start resolution: cycles whose start moved in this pass
+    unsigned int jump_changed[32];  // per doubling round: darts whose key changed
+    unsigned int pad[2];
+};
+
+constexpr unsigned kErrBrokenEvent = 1u, kErrPointPool = 2u, kErrContourTable = 4u, kErrCandTable = 8u, kErrResolve = 16u;
+
+}  // namespace a3

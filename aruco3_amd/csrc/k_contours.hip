@@ -1,0 +1,581 @@
+// k_contours.hip -- K2..K4: binary image -> quad candidates, fully data-parallel.
+//
+// Replaces `imageproc::contours::find_contours` + `contours_to_candidates` +
+// `enforce_clockwise_corners` (src/aruco.rs:64-68, 124-185).
+//
+// The reference follows borders one at a time in raster order with a label image
+// (Suzuki-Abe).  Here the same borders come out of a graph formulation with no
+// sequential scan (executable model + proof sketch: tests/dart_model.py):
+//
+//   dart       (pixel p, direction k of a foreground 8-neighbour); only pixels that have a
+//              background / out-of-image 4-neighbour carry darts ("border pixels").
+//   succ       (p,k) -> (p + dir(k'), opposite(k')), k' = next foreground neighbour
+//              counter-clockwise after k.  A bijection: darts fall into cycles, and every
+//              border the reference traces is one cycle, rotated to its start dart.
+//   doubling   log2(longest cycle) rounds of pointer jumping give every dart its cycle's
+//              leader (the dart holding the smallest start-event key), its hop distance to
+//              the leader (=> rank along the border) and the cycle's bounding box.
+//   events     a W-event at pixel q (x>0, west neighbour background) can start a border as
+//              "outer", an E-event (x+1<W, east neighbour background) as "hole"; which event
+//              starts a cycle is the fixpoint of the rule in k_resolve_eval (the reference's
+//              label tests `== 1` / `> 0`, restated on cycles).  Start keys give the
+//              reference's contour order.
+//   pruning    only parity-safe: a border whose bounding-box diagonal^2 is below the
+//              reference's edge test, or whose epsilon = 0.05*len exceeds that diagonal,
+//              can never yield a 4-point candidate (src/aruco.rs:133-158), so its points
+//              are never written.
+//   DP         one wave per surviving border: Douglas-Peucker with a wave arg-max, split
+//              count capped at 3 (exactly 4 points are needed), hull + winding + edge test.
+//
+// Wave-level ballot/scan compaction allocates dart ranges with one atomic per wave.
+#include "a3_common.h"
+
+namespace a3 {
+
+// ---------------------------------------------------------------------------------------
+// neighbourhood masks for 4 consecutive pixels per lane
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t row_dword(const uint8_t* __restrict__ img, int W, int H, int x4, int y, bool aligned) {
+    if (y < 0 || y >= H || x4 >= W) return 0u;
+    const uint8_t* p = img + (size_t)y * W + x4;
+    if (aligned && x4 + 3 < W) return *reinterpret_cast<const uint32_t*>(p);
+    uint32_t d = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) if (x4 + i < W) d |= (uint32_t)p[i] << (8 * i);
+    return d;
+}
+
+// 6-bit occupancy of columns x4-1 .. x4+4 of one row (bit 0 = x4-1)
+__device__ __forceinline__ uint32_t row_bits(const uint8_t* __restrict__ img, int W, int H, int x4, int y, bool aligned, int lane) {
+    uint32_t d = row_dword(img, W, H, x4, y, aligned);
+    uint32_t dl = __shfl_up(d, 1), dr = __shfl_down(d, 1);
+    const bool row_ok = y >= 0 && y < H;
+    if (lane == 0) dl = (row_ok && x4 > 0 && x4 - 1 < W) ? (uint32_t)img[(size_t)y * W + x4 - 1] << 24 : 0u;
+    if (lane == 63) dr = (row_ok && x4 + 4 < W) ? (uint32_t)img[(size_t)y * W + x4 + 4] : 0u;
+    uint32_t m = (dl >> 24) ? 1u : 0u;
+    m |= (d & 0x000000FFu) ? 2u : 0u;
+    m |= (d & 0x0000FF00u) ? 4u : 0u;
+    m |= (d & 0x00FF0000u) ? 8u : 0u;
+    m |= (d & 0xFF000000u) ? 16u : 0u;
+    m |= (dr & 0xFFu) ? 32u : 0u;
+    return m;
+}
+
+// foreground-neighbour mask of pixel i (0..3) of the lane, ring order W NW N NE E SE S SW
+__device__ __forceinline__ uint32_t nb_mask(uint32_t mA, uint32_t mC, uint32_t mB, int i) {
+    const uint32_t a = mA >> i, c = mC >> i, b = mB >> i;
+    return (c & 1u) | ((a & 1u) << 1) | (((a >> 1) & 1u) << 2) | (((a >> 2) & 1u) << 3) | (((c >> 2) & 1u) << 4) |
+           (((b >> 2) & 1u) << 5) | (((b >> 1) & 1u) << 6) | ((b & 1u) << 7);
+}
+
+// a pixel carries darts iff it is foreground, not isolated, and has a background / outside 4-neighbour
+__device__ __forceinline__ bool is_node(uint32_t self_fg, uint32_t F) { return self_fg && F != 0u && (F & 0x55u) != 0x55u; }
+
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_t* total) {
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    *total = __shfl(inc, 63);
+    return inc - v;
+}
+
+// grid: (ceil(W/256), ceil(H/4), frames); block 256 = 4 waves, one image row segment per wave
+__global__ __launch_bounds__(256) void k_dart_count(const uint8_t* __restrict__ bin, int W, int H, uint32_t first_frame, int aligned,
+                                                    unsigned long long* __restrict__ frame_darts) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x4 = (blockIdx.x * 64 + lane) * 4, y = blockIdx.y * 4 + wave;
+    const uint32_t f = blockIdx.z;
+    const uint8_t* img = bin + (size_t)(first_frame + f) * W * H;
+    const uint32_t mA = row_bits(img, W, H, x4, y - 1, aligned, lane);
+    const uint32_t mC = row_bits(img, W, H, x4, y, aligned, lane);
+    const uint32_t mB = row_bits(img, W, H, x4, y + 1, aligned, lane);
+    uint32_t nd = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t F = nb_mask(mA, mC, mB, i);
+        if (is_node((mC >> (i + 1)) & 1u, F)) nd += __popc(F);
+    }
+    uint32_t total;
+    wave_excl_scan(nd, lane, &total);
+    if (lane == 0 && total) atomicAdd(&frame_darts[f], (unsigned long long)total);
+}
+
+// Same traversal; hands every border pixel a contiguous dart range inside its frame's range.
+__global__ __launch_bounds__(256) void k_dart_assign(const uint8_t* __restrict__ bin, int W, int H, uint32_t first_frame, int aligned,
+                                                     const uint32_t* __restrict__ frame_base, uint32_t* __restrict__ frame_cursor,
+                                                     uint32_t* __restrict__ pix_base, uint32_t* __restrict__ d_xy,
+                                                     uint8_t* __restrict__ d_info, uint8_t* __restrict__ d_F) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x4 = (blockIdx.x * 64 + lane) * 4, y = blockIdx.y * 4 + wave;
+    const uint32_t f = blockIdx.z;
+    const uint8_t* img = bin + (size_t)(first_frame + f) * W * H;
+    const uint32_t mA = row_bits(img, W, H, x4, y - 1, aligned, lane);
+    const uint32_t mC = row_bits(img, W, H, x4, y, aligned, lane);
+    const uint32_t mB = row_bits(img, W, H, x4, y + 1, aligned, lane);
+    uint32_t Fm[4], nd = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t F = nb_mask(mA, mC, mB, i);
+        Fm[i] = is_node((mC >> (i + 1)) & 1u, F) ? F : 0u;
+        nd += __popc(Fm[i]);
+    }
+    uint32_t total;
+    const uint32_t excl = wave_excl_scan(nd, lane, &total);
+    uint32_t base = 0;
+    if (lane == 0 && total) base = atomicAdd(&frame_cursor[f], total);
+    base = __shfl(base, 0);
+    if (!nd) return;
+    uint32_t cur = frame_base[f] + base + excl;
+    uint32_t* pb = pix_base + (size_t)f * W * H + (size_t)y * W;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t F = Fm[i];
+        if (!F) continue;
+        const int x = x4 + i;
+        pb[x] = cur;
+        // event darts: first foreground neighbour clockwise from W (resp. E) when that side is background
+        int kW = -1, kE = -1;
+        if (x > 0 && !(F & 1u)) kW = __ffs(F >> 1);  // F>>1 != 0 here; ffs is 1-based -> direction index
+        if (x + 1 < W && !(F & 16u)) {
+            const uint32_t r = ((F >> 5) | (F << 3)) & 0xFFu;  // bit j <-> direction (5 + j) & 7
+            kE = (5 + __ffs(r) - 1) & 7;
+        }
+        const uint32_t xy = (uint32_t)x | ((uint32_t)y << 16);
+        uint32_t m = F;
+        while (m) {
+            const int k = __ffs(m) - 1;
+            m &= m - 1;
+            d_xy[cur] = xy;
+            d_F[cur] = (uint8_t)F;
+            d_info[cur] = (uint8_t)(k | (k == kW ? kInfoW : 0) | (k == kE ? kInfoE : 0));
+            cur++;
+        }
+    }
+}
+
+// successor of every dart + initial doubling state.  grid.y = frame, grid-stride over its darts.
+__global__ __launch_bounds__(256) void k_dart_link(const uint8_t* __restrict__ bin, int W, int H, uint32_t first_frame,
+                                                   const uint32_t* __restrict__ frame_base, const uint32_t* __restrict__ pix_base,
+                                                   const uint32_t* __restrict__ d_xy, uint8_t* __restrict__ d_info,
+                                                   const uint8_t* __restrict__ d_F, uint32_t* __restrict__ d_succ,
+                                                   JumpState* __restrict__ st) {
+    const uint32_t f = blockIdx.y;
+    const uint32_t lo = frame_base[f], hi = frame_base[f + 1];
+    const uint8_t* img = bin + (size_t)(first_frame + f) * W * H;
+    const uint32_t* pb = pix_base + (size_t)f * W * H;
+    for (uint32_t d = lo + blockIdx.x * blockDim.x + threadIdx.x; d < hi; d += gridDim.x * blockDim.x) {
+        const uint32_t xy = d_xy[d];
+        const int x = xy & 0xFFFF, y = xy >> 16;
+        const uint32_t F = d_F[d];
+        uint8_t info = d_info[d];
+        const int k = info & 7;
+        // next foreground neighbour counter-clockwise after k: directions k-1, k-2, ..., k
+        const uint32_t r = ((F >> k) | (F << (8 - k))) & 0xFFu;  // bit j <-> direction (k + j) & 7
+        const int j = 31 - __clz(r);                              // bit 0 (k itself) is always set
+        const int ko = (k + j) & 7;
+        const int nx = x + kDX[ko], ny = y + kDY[ko];
+        // is the target a border pixel (background / outside 4-neighbour)?
+        const bool w0 = nx > 0 ? img[(size_t)ny * W + nx - 1] != 0 : false;
+        const bool e0 = nx + 1 < W ? img[(size_t)ny * W + nx + 1] != 0 : false;
+        const bool n0 = ny > 0 ? img[(size_t)(ny - 1) * W + nx] != 0 : false;
+        const bool s0 = ny + 1 < H ? img[(size_t)(ny + 1) * W + nx] != 0 : false;
+        uint32_t succ;
+        if (w0 && e0 && n0 && s0) {
+            succ = d;  // interior pixel: only face cycles of the 8-neighbour graph walk there
+            info |= kInfoBroken;
+            d_info[d] = info;
+        } else {
+            const uint32_t tb = pb[(size_t)ny * W + nx];
+            const uint32_t tF = d_F[tb];
+            const int kin = (ko + 4) & 7;
+            succ = tb + __popc(tF & ((1u << kin) - 1u));
+        }
+        d_succ[d] = succ;
+        const uint32_t q = (uint32_t)y * (uint32_t)W + (uint32_t)x;
+        const uint32_t ek = (info & kInfoW) ? 2u * q : ((info & kInfoE) ? 2u * q + 1u : kNoKey);
+        JumpState s;
+        s.key = ((uint64_t)ek << 32) | d;
+        s.ptr = succ;
+        s.off = 0;
+        s.minx = s.maxx = (uint16_t)x;
+        s.miny = s.maxy = (uint16_t)y;
+        st[d] = s;
+    }
+}
+
+// one pointer-doubling round: window [d, d + 2^round) -> [d, d + 2^(round+1))
+__global__ __launch_bounds__(256) void k_jump(const JumpState* __restrict__ in, JumpState* __restrict__ out, uint32_t n_darts,
+                                              int round, DeviceCounters* __restrict__ ctr) {
+    // Converged in an earlier round (no key moved): key/off/box of BOTH ping-pong buffers are final, so
+    // later rounds do nothing and the consumers may read either buffer.
+    if (round > 0 && ctr->jump_changed[round - 1] == 0) return;
+    uint32_t changed = 0;
+    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
+        JumpState s = in[d];
+        const JumpState t = in[s.ptr];
+        if (t.key < s.key) {
+            s.key = t.key;
+            s.off = (1u << round) + t.off;
+            changed++;
+        }
+        s.minx = t.minx < s.minx ? t.minx : s.minx; s.miny = t.miny < s.miny ? t.miny : s.miny;
+        s.maxx = t.maxx > s.maxx ? t.maxx : s.maxx; s.maxy = t.maxy > s.maxy ? t.maxy : s.maxy;
+        s.ptr = t.ptr;
+        out[d] = s;
+    }
+    // one counter update per wave
+    for (int o = 32; o > 0; o >>= 1) changed += __shfl_down(changed, o);
+    if ((threadIdx.x & 63) == 0 && changed) atomicAdd(&ctr->jump_changed[round], changed);
+}
+
+// ---------------------------------------------------------------------------------------
+// start resolution
+// ---------------------------------------------------------------------------------------
+constexpr uint64_t kInf64 = ~0ull;
+
+// leaders get their natural start (their own key: the smallest event on the cycle); every other slot is "never"
+__global__ void k_resolve_init(const JumpState* __restrict__ st, uint32_t n_darts, uint64_t* __restrict__ t_cur,
+                               uint64_t* __restrict__ t_next) {
+    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
+        const uint64_t key = st[d].key;
+        const bool natural = (uint32_t)key == d && (uint32_t)(key >> 32) != kNoKey;
+        t_cur[d] = natural ? key : kInf64;
+        t_next[d] = kInf64;
+    }
+}
+
+// Evaluate every start event under the current assignment T (Jacobi step):
+//   Wfires(q)  = every cycle through q has T >= 2q          (reference: label(q) == 1 when the scan arrives)
+//   W-event(q) fires iff Wfires(q); E-event(q) fires iff not (hasW(q) and Wfires(q))
+//                                                           (reference: the `else if`, label(q) > 0)
+// and propose T'(cycle) = min key of its firing events.
+__global__ __launch_bounds__(256) void k_resolve_eval(const JumpState* __restrict__ st, uint32_t n_darts, int W,
+                                                      const uint32_t* __restrict__ d_xy, const uint8_t* __restrict__ d_info,
+                                                      const uint8_t* __restrict__ d_F, const uint64_t* __restrict__ t_cur,
+                                                      uint64_t* __restrict__ t_next, int iter, DeviceCounters* __restrict__ ctr) {
+    if (iter > 0 && ctr->resolve_changed == 0) return;
+    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
+        const uint8_t info = d_info[d];
+        if (!(info & (kInfoW | kInfoE))) continue;
+        // an event dart must sit on an intact cycle, whose leader is its own leader (chains that end on an
+        // interior pixel belong to face cycles of the 8-neighbour graph and never carry events)
+        const uint32_t my_leader = (uint32_t)st[d].key;
+        if ((uint32_t)st[my_leader].key != my_leader) { atomicOr(&ctr->err_flags, kErrBrokenEvent); continue; }
+        const uint32_t xy = d_xy[d];
+        const uint32_t x = xy & 0xFFFF, y = xy >> 16;
+        const uint32_t q = y * (uint32_t)W + x;
+        const uint32_t F = d_F[d];
+        const int k = info & 7;
+        const uint32_t base = d - __popc(F & ((1u << k) - 1u));
+        const int cnt = __popc(F);
+        bool wfires = true;
+        for (int i = 0; i < cnt; i++) {
+            const uint32_t leader = (uint32_t)st[base + i].key;
+            const uint32_t t = (uint32_t)(t_cur[leader] >> 32);
+            if (t < 2u * q) { wfires = false; break; }
+        }
+        const bool has_w = x > 0 && !(F & 1u);
+        uint32_t key = kNoKey;
+        if ((info & kInfoW) && wfires) key = 2u * q;
+        else if ((info & kInfoE) && !(has_w && wfires)) key = 2u * q + 1u;
+        if (key != kNoKey) atomicMin(reinterpret_cast<unsigned long long*>(&t_next[my_leader]),
+                                     (unsigned long long)(((uint64_t)key << 32) | d));
+    }
+}
+
+// adopt T' as T, count the cycles whose start moved, clear T' for the next pass
+__global__ void k_resolve_commit(const JumpState* __restrict__ st, uint32_t n_darts, uint64_t* __restrict__ t_cur,
+                                 uint64_t* __restrict__ t_next, int iter, DeviceCounters* __restrict__ ctr,
+                                 unsigned int* __restrict__ changed_out) {
+    // changed_out is a second counter so that every block sees a stable resolve_changed during this launch
+    if (iter > 0 && ctr->resolve_changed == 0) return;
+    uint32_t changed = 0;
+    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
+        if ((uint32_t)st[d].key != d) continue;
+        const uint64_t a = t_cur[d], b = t_next[d];
+        if (a != b) { changed++; t_cur[d] = b; }
+        t_next[d] = kInf64;
+    }
+    for (int o = 32; o > 0; o >>= 1) changed += __shfl_down(changed, o);
+    if ((threadIdx.x & 63) == 0 && changed) atomicAdd(changed_out, changed);
+}
+
+__global__ void k_resolve_roll(DeviceCounters* __restrict__ ctr, unsigned int* __restrict__ changed_out, unsigned int* iters_done,
+                               int iter, int last) {
+    // single thread: publish this pass's count for the next pass's early-exit test
+    if (iter > 0 && ctr->resolve_changed == 0) return;
+    ctr->resolve_changed = *changed_out;
+    *changed_out = 0;
+    *iters_done = (unsigned int)iter + 1u;
+    if (last && ctr->resolve_changed != 0) atomicOr(&ctr->err_flags, kErrResolve);
+}
+
+// ---------------------------------------------------------------------------------------
+// select the borders worth materialising, then write their points in traversal order
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restrict__ st, uint32_t n_darts, const uint32_t* __restrict__ d_succ,
+                                                      const uint64_t* __restrict__ t_cur, const uint32_t* __restrict__ frame_base,
+                                                      uint32_t n_frames, uint32_t first_frame, uint32_t min_edge_length, double eps_factor,
+                                                      uint32_t* __restrict__ cyc_slot, ContourRec* __restrict__ contours,
+                                                      uint32_t* __restrict__ cyc_start_off, uint32_t max_contours, uint64_t max_points,
+                                                      DeviceCounters* __restrict__ ctr) {
+    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
+        const JumpState s = st[d];
+        if ((uint32_t)s.key != d) continue;  // leaders only
+        uint32_t slot = kNone;
+        const uint64_t t = t_cur[d];
+        if (t != kInf64) {
+            atomicAdd(&ctr->traced, 1u);
+            // the successor's window must have wrapped around to this leader, else this is a chain, not a cycle
+            const uint32_t sl = d_succ[d];
+            if (sl == d || (uint32_t)st[sl].key != d) { atomicOr(&ctr->err_flags, kErrBrokenEvent); cyc_slot[d] = kNone; continue; }
+            const uint32_t n = st[sl].off + 1u;
+            const uint32_t bw = s.maxx - s.minx, bh = s.maxy - s.miny;
+            const uint32_t diag2 = bw * bw + bh * bh;
+            // (1) every edge of a candidate has length^2 >= min_edge_length (src/aruco.rs:149-158) and joins two
+            //     border points, so diag2 must reach it; (2) Douglas-Peucker splits only when a point is further
+            //     than eps = eps_factor*n from a chord, and no point is further than the box diagonal (+1 slack).
+            const double eps = (double)n * eps_factor;
+            const bool can_split = eps < sqrt((double)diag2) + 1.0;
+            if (n >= 4u && diag2 >= min_edge_length && can_split) {
+                const uint32_t c = atomicAdd(&ctr->contours, 1u);
+                const unsigned long long pbase = atomicAdd(&ctr->points, (unsigned long long)n);
+                if (c >= max_contours) atomicOr(&ctr->err_flags, kErrContourTable);
+                else if (pbase + n > max_points) atomicOr(&ctr->err_flags, kErrPointPool);
+                else {
+                    // frame of this dart: binary search in frame_base
+                    uint32_t lo = 0, hi = n_frames;
+                    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (frame_base[mid] <= d) lo = mid; else hi = mid; }
+                    ContourRec r;
+                    r.frame = first_frame + lo;
+                    r.start_key = (uint32_t)(t >> 32);
+                    r.point_base = (uint32_t)pbase;
+                    r.n = n;
+                    contours[c] = r;
+                    cyc_start_off[c] = st[(uint32_t)t].off;
+                    slot = c;
+                }
+            }
+        }
+        cyc_slot[d] = slot;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restrict__ st, uint32_t n_darts, const uint32_t* __restrict__ d_xy,
+                                                        const uint32_t* __restrict__ cyc_slot, const ContourRec* __restrict__ contours,
+                                                        const uint32_t* __restrict__ cyc_start_off, uint32_t* __restrict__ points) {
+    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
+        const JumpState s = st[d];
+        const uint32_t c = cyc_slot[(uint32_t)s.key];
+        if (c == kNone) continue;
+        const ContourRec r = contours[c];
+        const uint32_t so = cyc_start_off[c];
+        // off = hops forward to the leader; position along the border counted from the start dart
+        const uint32_t rank = so >= s.off ? so - s.off : so + r.n - s.off;
+        points[r.point_base + rank] = d_xy[d];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K4: Douglas-Peucker + hull + winding + edge test, one wave per border
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int orient(int px, int py, int qx, int qy, int rx, int ry) {
+    const long long v = (long long)(qy - py) * (rx - qx) - (long long)(qx - px) * (ry - qy);
+    return v == 0 ? 0 : (v > 0 ? 1 : -1);  // 0 collinear, 1 clockwise, -1 counter-clockwise (imageproc naming)
+}
+
+// imageproc::geometry::convex_hull restricted to what the caller needs: the 4 input points in hull order
+// if all four are hull vertices, otherwise false.  Mirrors the Graham scan (start = top-most then left-most,
+// angular insertion sort, pop while the turn is not counter-clockwise).
+__device__ bool hull4(const int* __restrict__ in /*8*/, int* __restrict__ out /*8*/) {
+    int sp = 0;
+    for (int i = 1; i < 4; i++)
+        if (in[2 * i + 1] < in[2 * sp + 1] || (in[2 * i + 1] == in[2 * sp + 1] && in[2 * i] < in[2 * sp])) sp = i;
+    const int sx = in[2 * sp], sy = in[2 * sp + 1];
+    int qx[3], qy[3];
+    {   // swap(0, sp); remove(0)
+        int tx[4], ty[4];
+        for (int i = 0; i < 4; i++) { tx[i] = in[2 * i]; ty[i] = in[2 * i + 1]; }
+        tx[sp] = tx[0]; ty[sp] = ty[0];
+        for (int i = 0; i < 3; i++) { qx[i] = tx[i + 1]; qy[i] = ty[i + 1]; }
+    }
+    for (int i = 1; i < 3; i++) {
+        const int ax = qx[i], ay = qy[i];
+        int j = i;
+        while (j > 0) {
+            const int bx = qx[j - 1], by = qy[j - 1];
+            const int o = orient(sx, sy, ax, ay, bx, by);
+            bool less;
+            if (o == 0) {
+                const long long da = (long long)(ax - sx) * (ax - sx) + (long long)(ay - sy) * (ay - sy);
+                const long long db = (long long)(bx - sx) * (bx - sx) + (long long)(by - sy) * (by - sy);
+                less = da < db;
+            } else less = (o == -1);
+            if (!less) break;
+            qx[j] = bx; qy[j] = by; j--;
+        }
+        qx[j] = ax; qy[j] = ay;
+    }
+    int hx[5], hy[5], sn = 1;
+    hx[0] = sx; hy[0] = sy;
+    for (int i = 0; i < 3; i++) {
+        while (sn > 1 && orient(hx[sn - 2], hy[sn - 2], hx[sn - 1], hy[sn - 1], qx[i], qy[i]) != -1) sn--;
+        hx[sn] = qx[i]; hy[sn] = qy[i]; sn++;
+    }
+    if (sn != 4) return false;
+    for (int i = 0; i < 4; i++) { out[2 * i] = hx[i]; out[2 * i + 1] = hy[i]; }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_contour_quads(const ContourRec* __restrict__ contours, const DeviceCounters* __restrict__ ctr,
+                                                       uint32_t max_contours, const uint32_t* __restrict__ points, double eps_factor,
+                                                       uint32_t min_edge_length, uint32_t first_frame, uint32_t max_cand,
+                                                       CandRec* __restrict__ cands, uint32_t* __restrict__ cand_count,
+                                                       unsigned int* __restrict__ err_flags) {
+    const uint32_t n_contours = min(ctr->contours, max_contours);
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t c = wave_global; c < n_contours; c += n_waves) {
+        const ContourRec r = contours[c];
+        const uint32_t* P = points + r.point_base;
+        const uint32_t n = r.n;
+        const double eps = (double)n * eps_factor;  // c.points.len() as f64 * epsilon, src/aruco.rs:133
+        // work list of chords (a,b); every split adds one kept point, exactly 3 splits are needed
+        uint32_t seg_a[8], seg_b[8];
+        int nseg = 1, splits = 0;
+        uint32_t kept[3];
+        seg_a[0] = 0; seg_b[0] = n - 1;
+        bool reject = false;
+        while (nseg > 0 && !reject) {
+            nseg--;
+            const uint32_t a = seg_a[nseg], b = seg_b[nseg];
+            const uint32_t pa = P[a], pb = P[b];
+            const long long ax = pa & 0xFFFF, ay = pa >> 16, bx = pb & 0xFFFF, by = pb >> 16;
+            const long long la = ay - by, lb = bx - ax, lc = ax * by - bx * ay;
+            unsigned long long best = 0;  // (|num| << 32) | ~index : max picks largest num, then smallest index
+            for (uint32_t i = a + 1 + lane; i <= b; i += 64) {
+                const uint32_t p = P[i];
+                long long num = la * (long long)(p & 0xFFFF) + lb * (long long)(p >> 16) + lc;
+                if (num < 0) num = -num;
+                const unsigned long long cand = ((unsigned long long)num << 32) | (unsigned long long)(~i);
+                if (cand > best) best = cand;
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned long long other = __shfl_xor(best, o);
+                if (other > best) best = other;
+            }
+            const unsigned long long num = best >> 32;
+            if (num == 0) continue;
+            const uint32_t index = ~(uint32_t)best;
+            // d = |a x + b y + c| / sqrt(a^2 + b^2) in f64, compared with `>` (imageproc approximate_polygon_dp)
+            const double dmax = (double)num / sqrt((double)(la * la + lb * lb));
+            if (dmax > eps) {
+                if (splits == 3) { reject = true; break; }
+                kept[splits++] = index;
+                seg_a[nseg] = a; seg_b[nseg] = index; nseg++;
+                seg_a[nseg] = index; seg_b[nseg] = b; nseg++;
+            }
+        }
+        if (reject || splits != 3) continue;  // edges.len() != 4 (after the closed pop)
+        if (lane != 0) continue;
+        // kept indices in increasing order, preceded by point 0 (the last point is popped: closed = true)
+        uint32_t k0 = kept[0], k1 = kept[1], k2 = kept[2], t;
+        if (k0 > k1) { t = k0; k0 = k1; k1 = t; }
+        if (k1 > k2) { t = k1; k1 = k2; k2 = t; }
+        if (k0 > k1) { t = k0; k0 = k1; k1 = t; }
+        const uint32_t idx[4] = {0u, k0, k1, k2};
+        int q[8], hq[8];
+        for (int i = 0; i < 4; i++) { const uint32_t p = P[idx[i]]; q[2 * i] = p & 0xFFFF; q[2 * i + 1] = p >> 16; }
+        if (!hull4(q, hq)) continue;  // convexity, src/aruco.rs:143-147
+        uint32_t cmin = min_edge_length + 1u;  // src/aruco.rs:149-159 (squared length vs unsquared threshold, quirk Q1)
+        for (int i = 0; i < 4; i++) {
+            const int j = (i + 1) & 3;
+            const int dx = hq[2 * i] - hq[2 * j], dy = hq[2 * i + 1] - hq[2 * j + 1];
+            const uint32_t d2 = (uint32_t)(dx * dx + dy * dy);
+            cmin = d2 < cmin ? d2 : cmin;
+        }
+        if (cmin < min_edge_length) continue;
+        // enforce_clockwise_corners, src/aruco.rs:168-185
+        const int dx1 = hq[2] - hq[0], dy1 = hq[3] - hq[1], dx2 = hq[4] - hq[0], dy2 = hq[5] - hq[1];
+        if (dx1 * dy2 - dy1 * dx2 < 0) { int tx = hq[2], ty = hq[3]; hq[2] = hq[6]; hq[3] = hq[7]; hq[6] = tx; hq[7] = ty; }
+        const uint32_t fl = r.frame - first_frame;
+        const uint32_t slot = atomicAdd(&cand_count[fl], 1u);
+        if (slot >= max_cand) { atomicOr(err_flags, kErrCandTable); continue; }
+        CandRec cr;
+        cr.start_key = r.start_key;
+        for (int i = 0; i < 8; i++) cr.xy[i] = (uint16_t)hq[i];
+        cands[(size_t)fl * max_cand + slot] = cr;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------
+static inline int blocks_for(uint64_t n, int per_block, int cap) {
+    uint64_t b = (n + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > (uint64_t)cap) b = cap;
+    return (int)b;
+}
+
+hipError_t launch_dart_count(hipStream_t st, const uint8_t* bin, int W, int H, uint32_t first_frame, uint32_t n_frames,
+                             unsigned long long* frame_darts) {
+    const int aligned = (W % 4 == 0) && ((uintptr_t)bin % 4 == 0);
+    dim3 grid((W + 255) / 256, (H + 3) / 4, n_frames), block(256);
+    hipLaunchKernelGGL(k_dart_count, grid, block, 0, st, bin, W, H, first_frame, aligned, frame_darts);
+    return hipGetLastError();
+}
+
+hipError_t launch_dart_build(hipStream_t st, const uint8_t* bin, int W, int H, uint32_t first_frame, uint32_t n_frames,
+                             const uint32_t* frame_base, uint32_t* frame_cursor, uint32_t* pix_base, uint32_t* d_xy, uint8_t* d_info,
+                             uint8_t* d_F, uint32_t* d_succ, JumpState* st0, uint32_t n_darts) {
+    const int aligned = (W % 4 == 0) && ((uintptr_t)bin % 4 == 0);
+    dim3 grid((W + 255) / 256, (H + 3) / 4, n_frames), block(256);
+    hipLaunchKernelGGL(k_dart_assign, grid, block, 0, st, bin, W, H, first_frame, aligned, frame_base, frame_cursor, pix_base, d_xy, d_info, d_F);
+    const uint32_t per_frame = n_frames ? (n_darts + n_frames - 1) / n_frames : 0;
+    dim3 lgrid(blocks_for(per_frame, 256, 1024), n_frames);
+    hipLaunchKernelGGL(k_dart_link, lgrid, block, 0, st, bin, W, H, first_frame, frame_base, pix_base, d_xy, d_info, d_F, d_succ, st0);
+    return hipGetLastError();
+}
+
+hipError_t launch_jump(hipStream_t st, const JumpState* in, JumpState* out, uint32_t n_darts, int round, DeviceCounters* ctr) {
+    hipLaunchKernelGGL(k_jump, dim3(blocks_for(n_darts, 256, 8192)), dim3(256), 0, st, in, out, n_darts, round, ctr);
+    return hipGetLastError();
+}
+
+hipError_t launch_resolve(hipStream_t st, const JumpState* fin, uint32_t n_darts, int W, const uint32_t* d_xy, const uint8_t* d_info,
+                          const uint8_t* d_F, uint64_t* t_cur, uint64_t* t_next, DeviceCounters* ctr, unsigned int* changed_tmp,
+                          unsigned int* iters_done, int max_iters) {
+    const dim3 grid(blocks_for(n_darts, 256, 4096)), block(256);
+    hipLaunchKernelGGL(k_resolve_init, grid, block, 0, st, fin, n_darts, t_cur, t_next);
+    for (int it = 0; it < max_iters; it++) {
+        hipLaunchKernelGGL(k_resolve_eval, grid, block, 0, st, fin, n_darts, W, d_xy, d_info, d_F, t_cur, t_next, it, ctr);
+        hipLaunchKernelGGL(k_resolve_commit, grid, block, 0, st, fin, n_darts, t_cur, t_next, it, ctr, changed_tmp);
+        hipLaunchKernelGGL(k_resolve_roll, dim3(1), dim3(1), 0, st, ctr, changed_tmp, iters_done, it, it == max_iters - 1);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_select_scatter(hipStream_t st, const JumpState* fin, uint32_t n_darts, const uint32_t* d_succ, const uint64_t* t_cur,
+                                 const uint32_t* frame_base, uint32_t n_frames, uint32_t first_frame, uint32_t min_edge_length,
+                                 double eps_factor, uint32_t* cyc_slot, ContourRec* contours, uint32_t* cyc_start_off, uint32_t max_contours,
+                                 uint64_t max_points, DeviceCounters* ctr, const uint32_t* d_xy, uint32_t* points) {
+    const dim3 grid(blocks_for(n_darts, 256, 4096)), block(256);
+    hipLaunchKernelGGL(k_cycle_select, grid, block, 0, st, fin, n_darts, d_succ, t_cur, frame_base, n_frames, first_frame, min_edge_length,
+                       eps_factor, cyc_slot, contours, cyc_start_off, max_contours, max_points, ctr);
+    hipLaunchKernelGGL(k_scatter_points, grid, block, 0, st, fin, n_darts, d_xy, cyc_slot, contours, cyc_start_off, points);
+    return hipGetLastError();
+}
+
+hipError_t launch_contour_quads(hipStream_t st, const ContourRec* contours, const DeviceCounters* ctr, uint32_t max_contours,
+                                const uint32_t* points, double eps_factor, uint32_t min_edge_length, uint32_t first_frame, uint32_t max_cand,
+                                CandRec* cands, uint32_t* cand_count, unsigned int* err_flags) {
+    hipLaunchKernelGGL(k_contour_quads, dim3(1024), dim3(256), 0, st, contours, ctr, max_contours, points, eps_factor, min_edge_length,
+                       first_frame, max_cand, cands, cand_count, err_flags);
+    return hipGetLastError();
+}
+
+}  // namespace a3

@@ -1,0 +1,752 @@
+// k_decode.hip -- K5..K7: candidate ordering + discard_too_near, homography warp + Otsu +
+// triangle resize + bit decode + dictionary lookup + marker accept, IPPE pose, dictionary utilities.
+//
+// Replaces src/aruco.rs:69-113 (discard_too_near, extract_homographies,
+// homography_to_code_permutations, the find_nearest loop and the accept test),
+// src/dictionaries.rs:129-138,160-196 and src/pose.rs:52-348.
+//
+// Floating point follows the reference operation by operation (f64 for the 8x8 solve and
+// Otsu, f32 elsewhere); the library is built with -ffp-contract=off so that no a*b+c is
+// fused, exactly like the Rust reference and the CPU oracle.
+#include "a3_common.h"
+
+namespace a3 {
+
+// ---------------------------------------------------------------------------------------
+// per frame: order candidates as the reference found them, then discard_too_near
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float perimeter4(const uint16_t* q) {  // src/aruco.rs:328-338
+    float p = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int j = (i + 1) & 3;
+        const float dx = (float)q[2 * i] - (float)q[2 * j];
+        const float dy = (float)q[2 * i + 1] - (float)q[2 * j + 1];
+        p += sqrtf((dx * dx) + (dy * dy));
+    }
+    return p;
+}
+
+// one wave per frame.  cands: unordered CandRec[max_cand] per frame (as k_contour_quads appended them).
+__global__ __launch_bounds__(64) void k_frame_candidates(const CandRec* __restrict__ cands, const uint32_t* __restrict__ cand_count,
+                                                         uint32_t max_cand, float min_distance, uint16_t* __restrict__ pre_xy,
+                                                         uint16_t* __restrict__ fin_xy, uint32_t* __restrict__ fin_count,
+                                                         uint32_t* __restrict__ work, unsigned int* __restrict__ work_count) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t* s_xy = reinterpret_cast<uint16_t*>(smem);                       // max_cand * 8
+    float* s_per = reinterpret_cast<float*>(smem + (size_t)max_cand * 16);    // max_cand
+    uint8_t* s_dead = smem + (size_t)max_cand * 20;                           // max_cand
+    const uint32_t f = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint32_t c = min(cand_count[f], max_cand);
+    const CandRec* src = cands + (size_t)f * max_cand;
+    // rank sort by start key (keys are unique: one border starts per pixel visit)
+    for (uint32_t i = lane; i < c; i += 64) {
+        const uint32_t key = src[i].start_key;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < c; j++) rank += src[j].start_key < key;
+        for (int k = 0; k < 8; k++) s_xy[rank * 8 + k] = src[i].xy[k];
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < c; i += 64) {
+        s_per[i] = perimeter4(&s_xy[i * 8]);
+        s_dead[i] = 0;
+        for (int k = 0; k < 8; k++) pre_xy[((size_t)f * max_cand + i) * 8 + k] = s_xy[i * 8 + k];
+    }
+    __syncthreads();
+    // discard_too_near, src/aruco.rs:187-232: i ascending; for j > i ascending, a close pair kills the smaller
+    // perimeter; once i itself is dead the rest of its row is a no-op.
+    for (uint32_t i = 0; i + 1 < c; i++) {
+        if (s_dead[i]) continue;  // uniform: LDS value
+        const float per_i = s_per[i];
+        bool i_dead = false;
+        for (uint32_t j0 = i + 1; j0 < c && !i_dead; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            bool close_alive = false, bigger = false;
+            if (j < c && !s_dead[j]) {
+                float distance = 0.0f;
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const float dx = (float)s_xy[i * 8 + 2 * p] - (float)s_xy[j * 8 + 2 * p];
+                    const float dy = (float)s_xy[i * 8 + 2 * p + 1] - (float)s_xy[j * 8 + 2 * p + 1];
+                    distance += sqrtf((dx * dx) + (dy * dy));
+                }
+                close_alive = (distance / 4.0f) < min_distance;
+                bigger = close_alive && !(per_i >= s_per[j]);
+            }
+            const unsigned long long m_close = __ballot(close_alive), m_big = __ballot(bigger);
+            unsigned long long kill = m_close;
+            if (m_big) {
+                const int first = __ffsll((long long)m_big) - 1;
+                kill = m_close & ((1ull << first) - 1ull);
+                i_dead = true;
+            }
+            if ((kill >> lane) & 1ull) s_dead[j] = 1;
+        }
+        if (i_dead && lane == 0) s_dead[i] = 1;
+        __syncthreads();
+    }
+    __syncthreads();
+    // survivors, order preserved
+    uint32_t base = 0;
+    for (uint32_t i0 = 0; i0 < c; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const bool alive = i < c && !s_dead[i];
+        const unsigned long long m = __ballot(alive);
+        if (alive) {
+            const uint32_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            for (int k = 0; k < 8; k++) fin_xy[((size_t)f * max_cand + pos) * 8 + k] = s_xy[i * 8 + k];
+        }
+        base += __popcll(m);
+    }
+    if (lane == 0) {
+        fin_count[f] = base;
+        if (base) {
+            const uint32_t w0 = atomicAdd(work_count, base);
+            for (uint32_t k = 0; k < base; k++) work[w0 + k] = f * max_cand + k;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// decode one candidate per workgroup
+// ---------------------------------------------------------------------------------------
+struct DecodeOut {      // one per final candidate slot
+    uint64_t code;
+    uint64_t codes[4];
+    uint32_t id;
+    uint8_t valid, rotation, hamming, hom_ok;
+    int32_t decode_ok;
+    uint32_t pad;
+};
+
+// imageproc Projection::from_control_points: 8x8 system in f64, LU with partial pivoting (nalgebra order of
+// operations), cast to f32, adjugate inverse normalised by its last element.  Single lane.
+__device__ bool solve_projection(const float* from, float S, float* inv_out) {
+    double A[8][8], b[8];
+    const float to[8] = {0.0f, 0.0f, S, 0.0f, S, S, 0.0f, S};
+    for (int i = 0; i < 4; i++) {
+        const double xf = from[2 * i], yf = from[2 * i + 1], x = to[2 * i], y = to[2 * i + 1];
+        A[2 * i][0] = 0.0; A[2 * i][1] = 0.0; A[2 * i][2] = 0.0; A[2 * i][3] = -xf; A[2 * i][4] = -yf; A[2 * i][5] = -1.0;
+        A[2 * i][6] = y * xf; A[2 * i][7] = y * yf;
+        A[2 * i + 1][0] = xf; A[2 * i + 1][1] = yf; A[2 * i + 1][2] = 1.0; A[2 * i + 1][3] = 0.0; A[2 * i + 1][4] = 0.0; A[2 * i + 1][5] = 0.0;
+        A[2 * i + 1][6] = -x * xf; A[2 * i + 1][7] = -x * yf;
+        b[2 * i] = -y; b[2 * i + 1] = x;
+    }
+    int perm_i[8], perm_j[8], np = 0;
+    for (int i = 0; i < 8; i++) {
+        int piv = i; double best = fabs(A[i][i]);
+        for (int r = i + 1; r < 8; r++) { const double v = fabs(A[r][i]); if (v > best) { best = v; piv = r; } }
+        const double diag = A[piv][i];
+        if (diag == 0.0) continue;
+        if (piv != i) {
+            perm_i[np] = i; perm_j[np] = piv; np++;
+            for (int c = 0; c < 8; c++) { const double t = A[i][c]; A[i][c] = A[piv][c]; A[piv][c] = t; }
+        }
+        const double inv_diag = 1.0 / diag;
+        for (int r = i + 1; r < 8; r++) A[r][i] *= inv_diag;
+        for (int c = i + 1; c < 8; c++) {
+            const double pr = -A[i][c];
+            for (int r = i + 1; r < 8; r++) A[r][c] = pr * A[r][i] + A[r][c];
+        }
+    }
+    for (int k = 0; k < np; k++) { const double t = b[perm_i[k]]; b[perm_i[k]] = b[perm_j[k]]; b[perm_j[k]] = t; }
+    for (int i = 0; i < 7; i++) {
+        const double coeff = -b[i];
+        for (int r = i + 1; r < 8; r++) b[r] = coeff * A[r][i] + b[r];
+    }
+    for (int i = 7; i >= 0; i--) {
+        const double diag = A[i][i];
+        if (diag == 0.0) return false;
+        const double coeff = b[i] / diag;
+        b[i] = coeff;
+        const double nc = -coeff;
+        for (int r = 0; r < i; r++) b[r] = nc * A[r][i] + b[r];
+    }
+    float t[9];
+    for (int i = 0; i < 8; i++) t[i] = (float)b[i];
+    t[8] = 1.0f;
+    const float t00 = t[0], t01 = t[1], t02 = t[2], t10 = t[3], t11 = t[4], t12 = t[5], t20 = t[6], t21 = t[7], t22 = t[8];
+    const float m00 = t11 * t22 - t12 * t21;
+    const float m01 = t10 * t22 - t12 * t20;
+    const float m02 = t10 * t21 - t11 * t20;
+    const float det = t00 * m00 - t01 * m01 + t02 * m02;
+    if (fabsf(det) < 1e-10f) return false;
+    const float m10 = t01 * t22 - t02 * t21;
+    const float m11 = t00 * t22 - t02 * t20;
+    const float m12 = t00 * t21 - t01 * t20;
+    const float m20 = t01 * t12 - t02 * t11;
+    const float m21 = t00 * t12 - t02 * t10;
+    const float m22 = t00 * t11 - t01 * t10;
+    const float r[9] = {m00 / det, -m10 / det, m20 / det, -m01 / det, m11 / det, -m21 / det, m02 / det, -m12 / det, m22 / det};
+    for (int i = 0; i < 8; i++) inv_out[i] = r[i] / r[8];
+    inv_out[8] = 1.0f;
+    return true;
+}
+
+__device__ __forceinline__ uint8_t clamp_u8(float x) {
+    if (x < 255.0f) { if (x > 0.0f) return (uint8_t)x; return 0; }
+    return 255;  // also NaN
+}
+
+__device__ __forceinline__ uint32_t sat_u32(float x) {  // Rust `as u32`
+    if (!(x > 0.0f)) return 0u;
+    if (x >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)x;
+}
+
+// imageproc interpolate_bilinear: default (0) outside, the two horizontal lerps truncated to u8 first
+__device__ __forceinline__ uint8_t sample_bilinear(const uint8_t* __restrict__ img, uint32_t w, uint32_t h, float x, float y) {
+    const float left = floorf(x), right = left + 1.0f, top = floorf(y), bottom = top + 1.0f;
+    const float rw = x - left, bw = y - top;
+    if (left < 0.0f || right >= (float)w || top < 0.0f || bottom >= (float)h) return 0;
+    const uint32_t l = sat_u32(left), r = sat_u32(right), t = sat_u32(top), b = sat_u32(bottom);
+    const float tl = img[(size_t)t * w + l], tr = img[(size_t)t * w + r], bl = img[(size_t)b * w + l], br = img[(size_t)b * w + r];
+    const uint8_t tv = clamp_u8((1.0f - rw) * tl + rw * tr);
+    const uint8_t bv = clamp_u8((1.0f - rw) * bl + rw * br);
+    return clamp_u8((1.0f - bw) * (float)tv + bw * (float)bv);
+}
+
+__device__ __forceinline__ float triangle_kernel(float x) { return fabsf(x) < 1.0f ? 1.0f - fabsf(x) : 0.0f; }
+
+// image::imageops::resize weights for output index o (in_len -> out_len), normalised; returns left, sets count
+__device__ uint32_t resize_weights(uint32_t in_len, uint32_t out_len, uint32_t o, float* ws, uint32_t* count) {
+    const float ratio = (float)in_len / (float)out_len;
+    const float sratio = ratio < 1.0f ? 1.0f : ratio;
+    const float src_support = 1.0f * sratio;
+    float input = ((float)o + 0.5f) * ratio;
+    long long left = (long long)floorf(input - src_support);
+    left = left < 0 ? 0 : (left > (long long)in_len - 1 ? (long long)in_len - 1 : left);
+    long long right = (long long)ceilf(input + src_support);
+    right = right < left + 1 ? left + 1 : (right > (long long)in_len ? (long long)in_len : right);
+    input = input - 0.5f;
+    float sum = 0.0f;
+    uint32_t n = 0;
+    for (long long i = left; i < right; i++) {
+        const float w = triangle_kernel(((float)i - input) / sratio);
+        ws[n++] = w;
+        sum += w;
+    }
+    for (uint32_t i = 0; i < n; i++) ws[i] /= sum;
+    *count = n;
+    return (uint32_t)left;
+}
+
+// grid-stride over the work list; block = 256 threads; dynamic LDS:
+//   patch S*S | tmp n*S f32 | wtab n*max_taps f32 | wleft n u32 | wcnt n u32 | bits n*n
+__global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ grey, int W, int H, uint32_t first_frame,
+                                                const uint16_t* __restrict__ fin_xy, const uint32_t* __restrict__ work,
+                                                const unsigned int* __restrict__ work_count, uint32_t max_cand, uint32_t S, uint32_t n,
+                                                uint32_t max_taps, const uint64_t* __restrict__ dict, uint32_t n_codes, uint32_t tau,
+                                                int filter, DecodeOut* __restrict__ outs, uint8_t* __restrict__ patches /*nullable*/) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t* s_patch = smem;
+    size_t o = ((size_t)S * S + 15) & ~(size_t)15;
+    float* s_tmp = reinterpret_cast<float*>(smem + o); o += (size_t)n * S * 4;
+    float* s_w = reinterpret_cast<float*>(smem + o); o += (size_t)n * max_taps * 4;
+    uint32_t* s_left = reinterpret_cast<uint32_t*>(smem + o); o += (size_t)n * 4;
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem + o); o += (size_t)n * 4;
+    uint8_t* s_bits = smem + o;
+    __shared__ uint32_t s_hist[256];
+    __shared__ float s_inv[9];
+    __shared__ int s_ok, s_have;
+    __shared__ uint32_t s_otsu;
+    __shared__ uint64_t s_codes[4];
+    __shared__ unsigned long long s_best[4][4];
+
+    const int tid = threadIdx.x;
+    const uint32_t n_work = *work_count;
+    for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+        const uint32_t slot = work[wi];
+        const uint32_t fl = slot / max_cand;
+        const uint8_t* img = grey + (size_t)(first_frame + fl) * W * H;
+        const uint16_t* q = fin_xy + (size_t)slot * 8;
+        __syncthreads();
+        if (tid == 0) {
+            float from[8];
+            for (int i = 0; i < 8; i++) from[i] = (float)q[i];
+            float inv[9];
+            const bool ok = solve_projection(from, (float)S, inv);
+            for (int i = 0; i < 9; i++) s_inv[i] = inv[i];
+            s_ok = ok;
+        }
+        s_hist[tid] = 0;
+        __syncthreads();
+        const bool ok = s_ok != 0;
+        const uint32_t pw = ok ? S : 1u, ph = pw;
+        // warp_into: integer output coordinates, no centre offset, mapping = the projection's inverse
+        if (ok) {
+            const float t0 = s_inv[0], t1 = s_inv[1], t2 = s_inv[2], t3 = s_inv[3], t4 = s_inv[4], t5 = s_inv[5], t6 = s_inv[6],
+                        t7 = s_inv[7], t8 = s_inv[8];
+            for (uint32_t i = tid; i < S * S; i += 256) {
+                const float fx = (float)(i % S), fy = (float)(i / S);
+                const float d = t6 * fx + t7 * fy + t8;
+                const float px = (t0 * fx + t1 * fy + t2) / d;
+                const float py = (t3 * fx + t4 * fy + t5) / d;
+                const uint8_t v = sample_bilinear(img, (uint32_t)W, (uint32_t)H, px, py);
+                s_patch[i] = v;
+                atomicAdd(&s_hist[v], 1u);
+            }
+        } else if (tid == 0) {  // GrayImage::new(1, 1): one black pixel (quirk Q4)
+            s_patch[0] = 0;
+            s_hist[0] = 1;
+        }
+        __syncthreads();
+        if (patches) {
+            uint8_t* dst = patches + (size_t)slot * S * S;
+            for (uint32_t i = tid; i < S * S; i += 256) dst[i] = ok ? s_patch[i] : 0;
+        }
+        // otsu_level: the reference's sequential scan, literally (f64)
+        if (tid == 0) {
+            const uint32_t total_weight = pw * ph;
+            double total_pixel_sum = 0.0;
+            for (uint32_t t = 0; t < 256; t++) total_pixel_sum = total_pixel_sum + (double)(t * s_hist[t]);
+            double background_pixel_sum = 0.0;
+            uint32_t background_weight = 0;
+            double largest_variance = 0.0;
+            uint32_t best_threshold = 0;
+            for (uint32_t t = 0; t < 256; t++) {
+                background_weight += s_hist[t];
+                if (background_weight == 0) continue;
+                const uint32_t foreground_weight = total_weight - background_weight;
+                if (foreground_weight == 0) break;
+                background_pixel_sum += (double)(t * s_hist[t]);
+                const double foreground_pixel_sum = total_pixel_sum - background_pixel_sum;
+                const double background_mean = background_pixel_sum / (double)background_weight;
+                const double foreground_mean = foreground_pixel_sum / (double)foreground_weight;
+                const double diff = background_mean - foreground_mean;
+                const double mean_diff_squared = diff * diff;
+                const double intra_class_variance = (double)background_weight * (double)foreground_weight * mean_diff_squared;
+                if (intra_class_variance > largest_variance) { largest_variance = intra_class_variance; best_threshold = t; }
+            }
+            s_otsu = best_threshold;
+        }
+        // resize weights (same table for both passes: the patch and the grid are square)
+        if (tid >= 64 && tid < 64 + (int)n) {
+            const uint32_t oi = tid - 64;
+            uint32_t cnt;
+            s_left[oi] = resize_weights(pw, n, oi, s_w + (size_t)oi * max_taps, &cnt);
+            s_cnt[oi] = cnt;
+        }
+        __syncthreads();
+        const uint32_t otsu = s_otsu;
+        for (uint32_t i = tid; i < pw * ph; i += 256) s_patch[i] = s_patch[i] > otsu ? 255 : 0;  // threshold(.., Binary)
+        __syncthreads();
+        if (pw == n) {  // resize() copies when the size already matches
+            for (uint32_t i = tid; i < n * n; i += 256) s_bits[i] = s_patch[i] > 127;
+        } else {
+            for (uint32_t i = tid; i < n * pw; i += 256) {  // vertical pass into f32
+                const uint32_t oy = i / pw, x = i - oy * pw;
+                const float* ws = s_w + (size_t)oy * max_taps;
+                const uint32_t left = s_left[oy], cnt = s_cnt[oy];
+                float t = 0.0f;
+                for (uint32_t k = 0; k < cnt; k++) t += (float)s_patch[(left + k) * pw + x] * ws[k];
+                s_tmp[oy * pw + x] = t;
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < n * n; i += 256) {  // horizontal pass, clamp, round to nearest
+                const uint32_t y = i / n, ox = i - y * n;
+                const float* ws = s_w + (size_t)ox * max_taps;
+                const uint32_t left = s_left[ox], cnt = s_cnt[ox];
+                float t = 0.0f;
+                for (uint32_t k = 0; k < cnt; k++) t += s_tmp[y * pw + left + k] * ws[k];
+                const float c = t < 0.0f ? 0.0f : (t > 255.0f ? 255.0f : t);
+                s_bits[y * n + ox] = (uint8_t)roundf(c) > 127;
+            }
+        }
+        __syncthreads();
+        // border test + 4 rotated codes, src/aruco.rs:287-310
+        if (tid == 0) {
+            int have = 1;
+            const uint32_t end = n ? n - 1 : 0;
+            for (uint32_t i = 0; i < n && have; i++) {
+                if (s_bits[i * n] || s_bits[i * n + end]) have = 0;
+                else if (s_bits[i] || s_bits[end * n + i]) have = 0;
+            }
+            if (have) {
+                for (int r = 0; r < 4; r++) {
+                    // rotation r of the bit matrix read row-major: after r applications of rotate_bit_matrix
+                    // (new[a][b] = old[b][n-1-a]) cell (y,x) comes from the original at
+                    //   r=0 (y,x)  r=1 (x,n-1-y)  r=2 (n-1-y,n-1-x)  r=3 (n-1-x,y)
+                    uint64_t v = 0;
+                    for (uint32_t y = 1; y + 1 < n; y++)
+                        for (uint32_t x = 1; x + 1 < n; x++) {
+                            uint32_t sy, sx;
+                            if (r == 0) { sy = y; sx = x; }
+                            else if (r == 1) { sy = x; sx = n - 1 - y; }
+                            else if (r == 2) { sy = n - 1 - y; sx = n - 1 - x; }
+                            else { sy = n - 1 - x; sx = y; }
+                            if (s_bits[sy * n + sx]) v |= 1;
+                            v = (v << 1) | (v >> 63);
+                        }
+                    v = (v >> 1) | (v << 63);
+                    s_codes[r] = v;
+                }
+            }
+            s_have = have;
+        }
+        __syncthreads();
+        const int have = s_have;
+        // find_nearest for the 4 codes: strict '<' => lowest index among equal distances
+        unsigned long long best[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+        if (have) {
+            const uint64_t c0 = s_codes[0], c1 = s_codes[1], c2 = s_codes[2], c3 = s_codes[3];
+            for (uint32_t i = tid; i < n_codes; i += 256) {
+                const uint64_t c = dict[i];
+                const unsigned long long k0 = ((unsigned long long)__popcll(c ^ c0) << 32) | i;
+                const unsigned long long k1 = ((unsigned long long)__popcll(c ^ c1) << 32) | i;
+                const unsigned long long k2 = ((unsigned long long)__popcll(c ^ c2) << 32) | i;
+                const unsigned long long k3 = ((unsigned long long)__popcll(c ^ c3) << 32) | i;
+                best[0] = k0 < best[0] ? k0 : best[0];
+                best[1] = k1 < best[1] ? k1 : best[1];
+                best[2] = k2 < best[2] ? k2 : best[2];
+                best[3] = k3 < best[3] ? k3 : best[3];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                for (int o2 = 32; o2 > 0; o2 >>= 1) {
+                    const unsigned long long other = __shfl_xor(best[r], o2);
+                    best[r] = other < best[r] ? other : best[r];
+                }
+            if ((tid & 63) == 0)
+                for (int r = 0; r < 4; r++) s_best[tid >> 6][r] = best[r];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            DecodeOut out;
+            out.valid = 0; out.id = 0; out.code = 0; out.rotation = 0; out.hamming = 0; out.pad = 0;
+            out.hom_ok = ok; out.decode_ok = have;
+            for (int r = 0; r < 4; r++) out.codes[r] = have ? s_codes[r] : 0;
+            int found_any = 0;
+            uint32_t min_code_distance = 0x7FFFFFFFu, min_rotation = 0, min_code_id = 0x7FFFFFFFu;
+            uint64_t min_code = 0x7FFFFFFFull;
+            if (have) {
+                for (uint32_t r = 0; r < 4; r++) {
+                    unsigned long long b = s_best[0][r];
+                    for (int w = 1; w < 4; w++) b = s_best[w][r] < b ? s_best[w][r] : b;
+                    // empty dictionary: find_nearest returns (0, 0xFF)
+                    const uint32_t nearest_dist = n_codes ? (uint32_t)(b >> 32) : 0xFFu;
+                    const uint32_t nearest_id = n_codes ? (uint32_t)b : 0u;
+                    if (nearest_dist < min_code_distance) {
+                        min_code = s_codes[r]; min_code_distance = nearest_dist; min_code_id = nearest_id; min_rotation = r; found_any = 1;
+                    }
+                }
+            }
+            if (found_any && (!filter || min_code_distance < tau)) {
+                out.valid = 1; out.id = min_code_id; out.code = min_code; out.rotation = (uint8_t)min_rotation;
+                out.hamming = (uint8_t)min_code_distance;
+            }
+            outs[slot] = out;
+        }
+    }
+}
+
+// gather the accepted markers, frame by frame, candidate order preserved.  Single block.
+__global__ __launch_bounds__(256) void k_compact_markers(const DecodeOut* __restrict__ outs, const uint16_t* __restrict__ fin_xy,
+                                                         const uint32_t* __restrict__ fin_count, uint32_t n_frames, uint32_t first_frame,
+                                                         uint32_t max_cand, a3_marker* __restrict__ markers, uint32_t marker_cap,
+                                                         uint32_t* __restrict__ per_frame, unsigned int* __restrict__ marker_total,
+                                                         unsigned int* __restrict__ err_flags) {
+    __shared__ uint32_t s_scan[256];
+    __shared__ uint32_t s_base;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_base = *marker_total;
+    __syncthreads();
+    for (uint32_t f0 = 0; f0 < n_frames; f0 += 256) {
+        const uint32_t f = f0 + tid;
+        uint32_t cnt = 0;
+        if (f < n_frames) {
+            const uint32_t c = fin_count[f];
+            for (uint32_t k = 0; k < c; k++) cnt += outs[(size_t)f * max_cand + k].valid;
+        }
+        s_scan[tid] = cnt;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const uint32_t v = tid >= o ? s_scan[tid - o] : 0;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        const uint32_t excl = s_scan[tid] - cnt, tile_total = s_scan[255];
+        const uint32_t base = s_base;
+        if (f < n_frames) {
+            per_frame[first_frame + f] = cnt;
+            uint32_t pos = base + excl;
+            const uint32_t c = fin_count[f];
+            for (uint32_t k = 0; k < c; k++) {
+                const DecodeOut o = outs[(size_t)f * max_cand + k];
+                if (!o.valid) continue;
+                if (pos < marker_cap) {
+                    a3_marker m;
+                    m.frame = first_frame + f;
+                    m.id = o.id;
+                    m.code = o.code;
+                    const uint16_t* q = fin_xy + ((size_t)f * max_cand + k) * 8;
+                    for (int i = 0; i < 4; i++) {  // corners.rotate_left(min_rotation), src/aruco.rs:103
+                        const int s = (i + o.rotation) & 3;
+                        m.corners[2 * i] = q[2 * s];
+                        m.corners[2 * i + 1] = q[2 * s + 1];
+                    }
+                    m.hamming_distance = o.hamming;
+                    m.rotation = o.rotation;
+                    m.candidate_index = (uint16_t)k;
+                    markers[pos] = m;
+                } else atomicOr(err_flags, kErrCandTable);
+                pos++;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_base = base + tile_total;
+        __syncthreads();
+    }
+    if (tid == 0) *marker_total = s_base;
+}
+
+// ---------------------------------------------------------------------------------------
+// IPPE pose, one lane per marker (src/pose.rs:52-348; matrices row-major)
+// ---------------------------------------------------------------------------------------
+__device__ void find_rotation_to_z(const float v[3], float rot[9]) {  // src/pose.rs:238-267
+    for (int i = 0; i < 9; i++) rot[i] = 0.0f;
+    const float a = v[0] * v[0], b = v[1] * v[1], c = v[2] * v[2];
+    const float nrm = sqrtf(a + b + c);
+    const float ax = v[0] / nrm, ay = v[1] / nrm, az = v[2] / nrm;
+    if (fabsf(1.0f + az) < 1e-6f) {
+        rot[0] = 1.0f; rot[4] = 1.0f; rot[8] = -1.0f;
+    } else {
+        const float d = 1.0f / (1.0f + az);
+        const float ax2 = ax * ax, ay2 = ay * ay, axay = ax * ay;
+        rot[0] = -ax2 * d + 1.0f; rot[1] = -axay * d;       rot[2] = -ax;
+        rot[3] = -axay * d;       rot[4] = -ay2 * d + 1.0f; rot[5] = -ay;
+        rot[6] = ax;              rot[7] = ay;              rot[8] = 1.0f - (ax2 + ay2) * d;
+    }
+}
+
+__device__ void compute_rotations(const float j[4], float tx, float ty, float r1[9], float r2[9]) {  // src/pose.rs:158-235
+    const float t[3] = {tx, ty, 1.0f};
+    float rz[9], rv[9];
+    find_rotation_to_z(t, rz);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) rv[r * 3 + c] = rz[c * 3 + r];
+#define RV(r, c) rv[((r) - 1) * 3 + ((c) - 1)]
+    const float b00 = RV(1, 1) - tx * RV(3, 1);
+    const float b01 = RV(1, 2) - tx * RV(3, 2);
+    const float b10 = RV(2, 1) - ty * RV(3, 1);
+    const float b11 = RV(2, 2) - ty * RV(3, 2);
+    const float inv_det = 1.0f / (b00 * b11 - b01 * b10);
+    const float binv00 = inv_det * b11, binv01 = -inv_det * b01, binv10 = -inv_det * b10, binv11 = inv_det * b00;
+    const float a00 = binv00 * j[0] + binv01 * j[2];
+    const float a01 = binv00 * j[1] + binv01 * j[3];
+    const float a10 = binv10 * j[0] + binv11 * j[2];
+    const float a11 = binv10 * j[1] + binv11 * j[3];
+    const float ata00 = a00 * a00 + a01 * a01;
+    const float ata01 = a00 * a10 + a01 * a11;
+    const float ata11 = a10 * a10 + a11 * a11;
+    const float gamma = sqrtf(0.5f * (ata00 + ata11 + sqrtf((ata00 - ata11) * (ata00 - ata11) + 4.0f * ata01 * ata01)));
+    const float rt00 = a00 / gamma, rt01 = a01 / gamma, rt10 = a10 / gamma, rt11 = a11 / gamma;
+    const float rt00_2 = rt00 * rt00, rt01_2 = rt01 * rt01, rt10_2 = rt10 * rt10, rt11_2 = rt11 * rt11;
+    const float b0 = sqrtf(-rt00_2 - rt10_2 + 1.0f);
+    float b1 = sqrtf(-rt01_2 - rt11_2 + 1.0f);
+    const float sp = -rt00 * rt01 - rt10 * rt11;
+    if (sp < 0.0f) b1 = -b1;
+    for (int r = 1; r <= 3; r++) {
+        r1[(r - 1) * 3 + 0] = (rt00) * RV(r, 1) + (rt10) * RV(r, 2) + (b0) * RV(r, 3);
+        r1[(r - 1) * 3 + 1] = (rt01) * RV(r, 1) + (rt11) * RV(r, 2) + (b1) * RV(r, 3);
+        r1[(r - 1) * 3 + 2] = (b1 * rt10 - b0 * rt11) * RV(r, 1) + (b0 * rt01 - b1 * rt00) * RV(r, 2) + (rt00 * rt11 - rt01 * rt10) * RV(r, 3);
+        r2[(r - 1) * 3 + 0] = (rt00) * RV(r, 1) + (rt10) * RV(r, 2) + (-b0) * RV(r, 3);
+        r2[(r - 1) * 3 + 1] = (rt01) * RV(r, 1) + (rt11) * RV(r, 2) + (-b1) * RV(r, 3);
+        r2[(r - 1) * 3 + 2] = (b0 * rt11 - b1 * rt10) * RV(r, 1) + (b1 * rt00 - b0 * rt01) * RV(r, 2) + (rt00 * rt11 - rt01 * rt10) * RV(r, 3);
+    }
+#undef RV
+}
+
+__device__ void compute_translation(const float obj[12], const float pts[8], const float rot[9], float t[3]) {  // src/pose.rs:269-335
+    float m11 = 4.0f, m13 = 0.0f, m22 = 4.0f, m23 = 0.0f, m31 = 0.0f, m32 = 0.0f, m33 = 0.0f;
+    float atb0 = 0.0f, atb1 = 0.0f, atb2 = 0.0f;
+    for (int i = 0; i < 4; i++) {
+        const float ox = obj[3 * i], oy = obj[3 * i + 1];
+        const float rx = rot[0] * ox + rot[1] * oy;
+        const float ry = rot[3] * ox + rot[4] * oy;
+        const float rz = rot[6] * ox + rot[7] * oy;
+        const float a2 = -pts[2 * i], b2 = -pts[2 * i + 1];
+        m13 += a2; m23 += b2; m31 += a2; m32 += b2;
+        m33 += a2 * a2 + b2 * b2;
+        const float bx = -a2 * rz - rx;
+        const float by = -b2 * rz - ry;
+        atb0 += bx; atb1 += by;
+        atb2 += a2 * bx + b2 * by;
+    }
+    const float det_a_inv = 1.0f / (m11 * m22 * m33 - m11 * m23 * m32 - m13 * m22 * m31);
+    const float s11 = m22 * m33 - m23 * m32, s12 = m13 * m32, s13 = -m13 * m22;
+    const float s21 = m23 * m31, s22 = m11 * m33 - m13 * m31, s23 = -m11 * m23;
+    const float s31 = -m22 * m31, s32 = -m11 * m32, s33 = m11 * m22;
+    t[0] = det_a_inv * (s11 * atb0 + s12 * atb1 + s13 * atb2);
+    t[1] = det_a_inv * (s21 * atb0 + s22 * atb1 + s23 * atb2);
+    t[2] = det_a_inv * (s31 * atb0 + s32 * atb1 + s33 * atb2);
+}
+
+__device__ float reprojection_error(const a3_pose& p, const float obj[12], const float pts[8]) {  // src/pose.rs:337-348
+    float error = 0.0f;
+    const float* r = p.rotation;
+    for (int i = 0; i < 4; i++) {
+        const float x = obj[3 * i], y = obj[3 * i + 1], z = obj[3 * i + 2];
+        const float px = (r[0] * x + r[1] * y + r[2] * z) + p.translation[0];
+        const float py = (r[3] * x + r[4] * y + r[5] * z) + p.translation[1];
+        const float pz = (r[6] * x + r[7] * y + r[8] * z) + p.translation[2];
+        const float zz = pz > 1e-5f ? pz : 1e-5f;
+        const float dx = (px / zz) - pts[2 * i];
+        const float dy = (py / zz) - pts[2 * i + 1];
+        error += sqrtf(dx * dx + dy * dy);
+    }
+    return error;
+}
+
+__device__ void solve_normalized(const float pts[8], float marker_size_mm, a3_pose* o1, a3_pose* o2) {  // src/pose.rs:64-156
+    const float hw = 0.5f * marker_size_mm;
+    const float obj[12] = {-hw, hw, 0.0f, hw, hw, 0.0f, hw, -hw, 0.0f, -hw, -hw, 0.0f};
+    const float p1x = -pts[0], p1y = -pts[1], p2x = -pts[2], p2y = -pts[3], p3x = -pts[4], p3y = -pts[5], p4x = -pts[6], p4y = -pts[7];
+    const float half_width = marker_size_mm / 2.0f;
+    const float det_inv = -1.0f / (half_width * (p1x * p2y - p2x * p1y - p1x * p4y + p2x * p3y - p3x * p2y + p4x * p1y + p3x * p4y - p4x * p3y));
+    float h[9];
+    h[0] = det_inv * (p1x * p3x * p2y - p2x * p3x * p1y - p1x * p4x * p2y + p2x * p4x * p1y - p1x * p3x * p4y + p1x * p4x * p3y + p2x * p3x * p4y - p2x * p4x * p3y);
+    h[1] = det_inv * (p1x * p2x * p3y - p1x * p3x * p2y - p1x * p2x * p4y + p2x * p4x * p1y + p1x * p3x * p4y - p3x * p4x * p1y - p2x * p4x * p3y + p3x * p4x * p2y);
+    h[2] = det_inv * half_width * (p1x * p2x * p3y - p2x * p3x * p1y - p1x * p2x * p4y + p1x * p4x * p2y - p1x * p4x * p3y + p3x * p4x * p1y + p2x * p3x * p4y - p3x * p4x * p2y);
+    h[3] = det_inv * (p1x * p2y * p3y - p2x * p1y * p3y - p1x * p2y * p4y + p2x * p1y * p4y - p3x * p1y * p4y + p4x * p1y * p3y + p3x * p2y * p4y - p4x * p2y * p3y);
+    h[4] = det_inv * (p2x * p1y * p3y - p3x * p1y * p2y - p1x * p2y * p4y + p4x * p1y * p2y + p1x * p3y * p4y - p4x * p1y * p3y - p2x * p3y * p4y + p3x * p2y * p4y);
+    h[5] = det_inv * half_width * (p1x * p2y * p3y - p3x * p1y * p2y - p2x * p1y * p4y + p4x * p1y * p2y - p1x * p3y * p4y + p3x * p1y * p4y + p2x * p3y * p4y - p4x * p2y * p3y);
+    h[6] = -det_inv * (p1x * p3y - p3x * p1y - p1x * p4y - p2x * p3y + p3x * p2y + p4x * p1y + p2x * p4y - p4x * p2y);
+    h[7] = det_inv * (p1x * p2y - p2x * p1y - p1x * p3y + p3x * p1y + p2x * p4y - p4x * p2y - p3x * p4y + p4x * p3y);
+    h[8] = 1.0f;
+    const float j[4] = {h[0] - h[6] * h[2], h[1] - h[7] * h[2], h[3] - h[6] * h[5], h[4] - h[7] * h[5]};
+    a3_pose a, b;
+    compute_rotations(j, h[2], h[5], a.rotation, b.rotation);
+    compute_translation(obj, pts, a.rotation, a.translation);
+    compute_translation(obj, pts, b.rotation, b.translation);
+    a.error = reprojection_error(a, obj, pts);
+    b.error = reprojection_error(b, obj, pts);
+    if (a.error < b.error) { *o1 = a; *o2 = b; } else { *o1 = b; *o2 = a; }
+}
+
+// mode 0: pts = corners / (w,h) (solve_with_undistorted_points); 1: unproject through intrinsics; 2: already normalised
+__global__ void k_pose(const uint32_t* __restrict__ corners, const float* __restrict__ norm_pts, uint32_t n, int mode, float marker_size_mm,
+                       float iw, float ih, float fx, float fy, float cx, float cy, a3_pose* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float pts[8];
+    for (int k = 0; k < 4; k++) {
+        if (mode == 2) { pts[2 * k] = norm_pts[8 * i + 2 * k]; pts[2 * k + 1] = norm_pts[8 * i + 2 * k + 1]; continue; }
+        const float x = (float)corners[8 * i + 2 * k], y = (float)corners[8 * i + 2 * k + 1];
+        if (mode == 0) { pts[2 * k] = x / iw; pts[2 * k + 1] = y / ih; }            // src/pose.rs:60
+        else { pts[2 * k] = (x - cx) / fx; pts[2 * k + 1] = (y - cy) / fy; }         // src/pinhole.rs:88-93
+    }
+    a3_pose p1, p2;
+    solve_normalized(pts, marker_size_mm, &p1, &p2);
+    out[2 * i] = p1;
+    out[2 * i + 1] = p2;
+}
+
+// ---------------------------------------------------------------------------------------
+// dictionary utilities
+// ---------------------------------------------------------------------------------------
+__global__ void k_find_nearest(const uint64_t* __restrict__ dict, uint32_t n_codes, const uint64_t* __restrict__ bits, uint32_t n,
+                               uint32_t* __restrict__ idx, uint8_t* __restrict__ dist) {
+    // one wave per query
+    const int lane = threadIdx.x & 63;
+    const uint32_t qi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (qi >= n) return;
+    const uint64_t b = bits[qi];
+    unsigned long long best = ~0ull;
+    for (uint32_t i = lane; i < n_codes; i += 64) {
+        const unsigned long long k = ((unsigned long long)__popcll(dict[i] ^ b) << 32) | i;
+        best = k < best ? k : best;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(best, o);
+        best = other < best ? other : best;
+    }
+    if (lane == 0) {
+        idx[qi] = n_codes ? (uint32_t)best : 0u;
+        dist[qi] = n_codes ? (uint8_t)(best >> 32) : 0xFF;
+    }
+}
+
+__global__ void k_calc_tau(const uint64_t* __restrict__ dict, uint32_t n_codes, unsigned int* __restrict__ tau) {
+    unsigned int best = 255;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_codes; i += gridDim.x * blockDim.x) {
+        const uint64_t c = dict[i];
+        for (uint32_t j = i + 1; j < n_codes; j++) {
+            const unsigned int d = __popcll(c ^ dict[j]);
+            best = d < best ? d : best;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { const unsigned int other = __shfl_xor(best, o); best = other < best ? other : best; }
+    if ((threadIdx.x & 63) == 0) atomicMin(tau, best);
+}
+
+__global__ void k_selftest_ieee(const double* __restrict__ a, const double* __restrict__ b, uint32_t n, double* __restrict__ sq,
+                                double* __restrict__ dv, float* __restrict__ sqf, float* __restrict__ dvf) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    sq[i] = sqrt(a[i]);
+    dv[i] = a[i] / b[i];
+    sqf[i] = sqrtf((float)a[i]);
+    dvf[i] = (float)a[i] / (float)b[i];
+}
+
+// ---------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------
+size_t decode_lds_bytes(uint32_t S, uint32_t n, uint32_t max_taps) {
+    size_t o = ((size_t)S * S + 15) & ~(size_t)15;
+    o += (size_t)n * S * 4 + (size_t)n * max_taps * 4 + (size_t)n * 8 + (size_t)n * n;
+    return (o + 15) & ~(size_t)15;
+}
+
+hipError_t launch_frame_candidates(hipStream_t st, const CandRec* cands, const uint32_t* cand_count, uint32_t n_frames, uint32_t max_cand,
+                                   float min_distance, uint16_t* pre_xy, uint16_t* fin_xy, uint32_t* fin_count, uint32_t* work,
+                                   unsigned int* work_count) {
+    const size_t lds = (size_t)max_cand * 21 + 16;
+    hipLaunchKernelGGL(k_frame_candidates, dim3(n_frames), dim3(64), lds, st, cands, cand_count, max_cand, min_distance, pre_xy, fin_xy,
+                       fin_count, work, work_count);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode(hipStream_t st, const uint8_t* grey, int W, int H, uint32_t first_frame, const uint16_t* fin_xy, const uint32_t* work,
+                         const unsigned int* work_count, uint32_t max_cand, uint32_t S, uint32_t n, uint32_t max_taps, const uint64_t* dict,
+                         uint32_t n_codes, uint32_t tau, int filter, void* outs, uint8_t* patches, int grid_blocks) {
+    hipLaunchKernelGGL(k_decode, dim3(grid_blocks), dim3(256), decode_lds_bytes(S, n, max_taps), st, grey, W, H, first_frame, fin_xy, work,
+                       work_count, max_cand, S, n, max_taps, dict, n_codes, tau, filter, reinterpret_cast<DecodeOut*>(outs), patches);
+    return hipGetLastError();
+}
+
+size_t decode_out_bytes() { return sizeof(DecodeOut); }
+
+hipError_t launch_compact_markers(hipStream_t st, const void* outs, const uint16_t* fin_xy, const uint32_t* fin_count, uint32_t n_frames,
+                                  uint32_t first_frame, uint32_t max_cand, a3_marker* markers, uint32_t marker_cap, uint32_t* per_frame,
+                                  unsigned int* marker_total, unsigned int* err_flags) {
+    hipLaunchKernelGGL(k_compact_markers, dim3(1), dim3(256), 0, st, reinterpret_cast<const DecodeOut*>(outs), fin_xy, fin_count, n_frames,
+                       first_frame, max_cand, markers, marker_cap, per_frame, marker_total, err_flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_pose(hipStream_t st, const uint32_t* corners, const float* norm_pts, uint32_t n, int mode, float marker_size_mm, float iw,
+                       float ih, float fx, float fy, float cx, float cy, a3_pose* out) {
+    hipLaunchKernelGGL(k_pose, dim3((n + 63) / 64), dim3(64), 0, st, corners, norm_pts, n, mode, marker_size_mm, iw, ih, fx, fy, cx, cy, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_find_nearest(hipStream_t st, const uint64_t* dict, uint32_t n_codes, const uint64_t* bits, uint32_t n, uint32_t* idx,
+                               uint8_t* dist) {
+    hipLaunchKernelGGL(k_find_nearest, dim3((n * 64 + 255) / 256), dim3(256), 0, st, dict, n_codes, bits, n, idx, dist);
+    return hipGetLastError();
+}
+
+hipError_t launch_calc_tau(hipStream_t st, const uint64_t* dict, uint32_t n_codes, unsigned int* tau) {
+    hipLaunchKernelGGL(k_calc_tau, dim3(64), dim3(256), 0, st, dict, n_codes, tau);
+    return hipGetLastError();
+}
+
+hipError_t launch_selftest(hipStream_t st, const double* a, const double* b, uint32_t n, double* sq, double* dv, float* sqf, float* dvf) {
+    hipLaunchKernelGGL(k_selftest_ieee, dim3((n + 255) / 256), dim3(256), 0, st, a, b, n, sq, dv, sqf, dvf);
+    return hipGetLastError();
+}
+
+}  // namespace a3

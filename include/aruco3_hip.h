@@ -1,0 +1,149 @@
+/*
+ * aruco3_hip.h -- C ABI of libaruco3_hip.so: the MI355X (gfx950) implementation of the
+ * aruco3 detection hot path.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * The reference crate has no FFI seam today: this ABI is placed
+ * INSIDE `Detector::detect` (src/aruco.rs:52-121) and the pose solvers
+ * (src/pose.rs:52-81) so that their public Rust signatures stay unchanged; the Rust-side
+ * binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Threading: one a3_ctx per (device, stream); a context is not re-entrant.
+ * Errors: every entry point returns 0 on success and a negative A3_ERR_* otherwise;
+ * a3_last_error() gives the message.  Nothing unwinds across the boundary.
+ */
+#ifndef ARUCO3_HIP_H
+#define ARUCO3_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define A3_ABI_VERSION 1
+
+enum {
+    A3_OK = 0,
+    A3_ERR_INVALID = -1,    /* bad argument (null pointer, zero size, threshold_window == 0 ...) */
+    A3_ERR_HIP = -2,        /* a HIP runtime call failed */
+    A3_ERR_CAPACITY = -3,   /* caller's output array (or a fixed device pool) is too small */
+    A3_ERR_INTERNAL = -4,   /* an invariant of the contour stage did not hold; results withheld */
+    A3_ERR_NO_DEVICE = -5
+};
+
+/* pixel layouts accepted where the reference takes an image::DynamicImage (src/aruco.rs:52,60) */
+enum { A3_FMT_RGB8 = 0, A3_FMT_RGBA8 = 1, A3_FMT_L8 = 2 };
+/* where `pixels` lives */
+enum { A3_MEM_HOST = 0, A3_MEM_DEVICE = 1 };
+
+/* DetectorConfig, src/aruco.rs:23-43 (same fields, same defaults via a3_default_config) */
+typedef struct a3_config {
+    uint32_t threshold_window;               /* 7 */
+    double   contour_simplification_epsilon; /* 0.05 */
+    float    min_side_length_factor;         /* 0.2 */
+    float    min_corner_separation_factor;   /* 0.1 */
+    uint32_t homography_sample_size;         /* 49 */
+    uint8_t  filter_high_bit_errors;         /* 1 */
+} a3_config;
+
+/* Marker, src/aruco.rs:8-13, plus the frame it belongs to in a batch */
+typedef struct a3_marker {
+    uint32_t frame;
+    uint32_t id;               /* index into the dictionary */
+    uint64_t code;             /* the code as read (uncorrected), src/aruco.rs:10 */
+    uint32_t corners[8];       /* x0,y0 .. x3,y3 after corners.rotate_left(rotation) */
+    uint8_t  hamming_distance;
+    uint8_t  rotation;         /* 0..3, src/aruco.rs:89,103 */
+    uint16_t candidate_index;  /* position in Detection.candidates of that frame */
+} a3_marker;
+
+/* MarkerPose, src/pose.rs:8-12; rotation row-major as Matrix3::new(...) is written */
+typedef struct a3_pose {
+    float error;
+    float rotation[9];
+    float translation[3];
+} a3_pose;
+
+/* CameraIntrinsics, src/pinhole.rs:11-18 */
+typedef struct a3_intrinsics {
+    uint32_t image_width, image_height;
+    float focal_x, focal_y, principal_x, principal_y;
+} a3_intrinsics;
+
+/* per-batch stage counters (the reference prints the rejects in debug builds, src/aruco.rs:163-164) */
+typedef struct a3_stats {
+    uint64_t darts;                 /* contour-graph nodes built */
+    uint64_t contours_traced;       /* borders the reference would have followed (excluding 1-pixel specks) */
+    uint64_t contours_materialised; /* those that survived the parity-safe size pruning */
+    uint64_t candidates_pre;        /* after contours_to_candidates */
+    uint64_t candidates;            /* after discard_too_near */
+    uint64_t markers;
+    uint32_t resolve_iterations;    /* start-resolution passes (1 = no anomaly) */
+    uint32_t jump_rounds;           /* pointer-doubling rounds that did work */
+    uint32_t chunks;                /* sub-batches the frames were split into */
+    uint32_t reserved;
+} a3_stats;
+
+typedef struct a3_ctx a3_ctx;
+
+int  a3_abi_version(void);
+void a3_default_config(a3_config *cfg);
+
+/* Detector { config, dictionary } (src/aruco.rs:46-49).  `codes` is ARDictionary.code_list,
+ * tau == 0 means "compute the minimum pairwise distance" (src/dictionaries.rs:124). */
+int  a3_create(int device, const a3_config *cfg, const uint64_t *codes, size_t n_codes, uint8_t num_bits, uint8_t tau,
+               a3_ctx **out);
+void a3_destroy(a3_ctx *ctx);
+const char *a3_last_error(const a3_ctx *ctx); /* ctx may be NULL: message of the last failed a3_create */
+/* run on the caller's HIP stream (hipStream_t as void*); NULL = the context's own stream */
+int  a3_set_stream(a3_ctx *ctx, void *hip_stream);
+/* total darts / contour points the device pools may hold (0 keeps the default); call before detect */
+int  a3_set_pool_limits(a3_ctx *ctx, uint64_t max_darts, uint64_t max_points);
+int  a3_get_tau(const a3_ctx *ctx, uint8_t *tau);
+/* keep the warped 49x49 patches (Detection.homographies) of the next batches for a3_download_homographies */
+int  a3_set_debug_taps(a3_ctx *ctx, int enabled);
+
+/* Detector::detect over a batch of independent frames (src/aruco.rs:52-121).
+ * pixels: n_frames images, `frame_stride` bytes apart, rows `row_stride` bytes apart.
+ * out: markers of frame 0 first, in the reference's order; per_frame_count[n_frames] optional. */
+int  a3_detect_batch(a3_ctx *ctx, const void *pixels, int memory, int fmt, uint32_t width, uint32_t height,
+                     size_t row_stride, size_t frame_stride, uint32_t n_frames,
+                     a3_marker *out, size_t out_cap, uint32_t *per_frame_count, size_t *out_n);
+int  a3_get_stats(const a3_ctx *ctx, a3_stats *stats);
+
+/* Detection.grey / .candidates / .homographies of the last batch (src/aruco.rs:16-21,115-120),
+ * plus the thresholded image; host destinations. */
+int  a3_download_grey(a3_ctx *ctx, uint32_t frame, uint8_t *dst);
+int  a3_download_thresholded(a3_ctx *ctx, uint32_t frame, uint8_t *dst);
+int  a3_candidate_count(a3_ctx *ctx, uint32_t frame, uint32_t *n_pre, uint32_t *n_final);
+int  a3_download_candidates(a3_ctx *ctx, uint32_t frame, int before_discard, uint32_t *dst_xy, size_t cap_quads);
+int  a3_download_homographies(a3_ctx *ctx, uint32_t frame, uint8_t *dst, uint8_t *ok, uint64_t *codes4, int32_t *decode_ok,
+                              size_t cap);
+
+/* pose::solve_with_undistorted_points (intr == NULL, src/pose.rs:59-62) or
+ * pose::solve_with_intrinsics (src/pose.rs:52-55) for n markers; out holds 2*n poses,
+ * the lower-error one first (src/pose.rs:76-80). */
+int  a3_estimate_pose(a3_ctx *ctx, const uint32_t *corners_xy, size_t n, float marker_size_mm, const a3_intrinsics *intr,
+                      uint32_t image_width, uint32_t image_height, a3_pose *out);
+/* pose::solve_with_normalized_points (src/pose.rs:64-81) */
+int  a3_estimate_pose_normalized(a3_ctx *ctx, const float *points_xy, size_t n, float marker_size_mm, a3_pose *out);
+
+/* ARDictionary::find_nearest for n codes (src/dictionaries.rs:160-196) and calculate_tau (:129-138) */
+int  a3_find_nearest(a3_ctx *ctx, const uint64_t *bits, size_t n, uint32_t *idx, uint8_t *dist);
+int  a3_calculate_tau(int device, const uint64_t *codes, size_t n_codes, uint8_t *tau);
+
+/* measurement: device time spent in a stage, summed over the launches since the last reset */
+enum { A3_STAGE_THRESHOLD = 0, A3_STAGE_CONTOUR = 1, A3_STAGE_DECODE = 2, A3_STAGE_COUNT = 3 };
+int  a3_set_profiling(a3_ctx *ctx, int enabled);
+int  a3_get_profile(a3_ctx *ctx, int stage, double *total_ms, uint64_t *launches, int reset);
+
+/* numerics self-check used by the GPU tests: evaluates the IEEE operations the kernels rely on
+ * (f64 sqrt/div, f32 sqrt/div) for n inputs so that the host can compare them bit for bit */
+int  a3_selftest_ieee(a3_ctx *ctx, const double *a, const double *b, size_t n, double *sqrt_a, double *a_div_b,
+                      float *sqrtf_a, float *a_divf_b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

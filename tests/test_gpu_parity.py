@@ -1,0 +1,261 @@
+"""Parity of the HIP path against the CPU oracle, stage by stage, through the C ABI.  GPU only.
+
+Bit-exact is the bar for everything integer (grey, threshold, candidates, corner order, codes, ids) and also
+for the warped patches (the kernels repeat the oracle's float operations one by one with contraction off);
+pose floats are compared at 1e-4 as BASELINE.json states."""
+import numpy as np
+import pytest
+
+from tests.util import assert_frame_parity, markers_of_hip, markers_of_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from aruco3_amd import _lib
+
+    _lib.load()
+    return _lib
+
+
+def _detector(dicts, name="ARUCO", **cfg):
+    from aruco3_amd.aruco import Detector, DetectorConfig
+
+    return Detector(DetectorConfig(**cfg), dicts.new_from_named_dict(name))
+
+
+def _run(det, frames, populate=True, out_cap=0):
+    ctx = det._context()
+    ctx.set_debug_taps(populate)
+    a = np.ascontiguousarray(frames)
+    if a.ndim == 3:
+        a = a[None] if a.shape[-1] in (3, 4) else a[..., None]
+    if a.ndim == 3:
+        a = a[None]
+    n, h, w, c = a.shape
+    from aruco3_amd import _lib
+
+    fmt = {1: _lib.FMT_L8, 3: _lib.FMT_RGB8, 4: _lib.FMT_RGBA8}[c]
+    markers, per = ctx.detect_batch(a.ctypes.data, _lib.MEM_HOST, fmt, w, h, w * c, h * w * c, n, out_cap)
+    return ctx, markers, per
+
+
+def _check(det, oracle, frames, check_patches=True):
+    d = det.dictionary
+    ctx, markers, per = _run(det, frames)
+    frames = np.asarray(frames)
+    if frames.ndim == 3 and frames.shape[-1] in (3, 4):
+        frames = frames[None]
+    elif frames.ndim == 2:
+        frames = frames[None]
+    pos = 0
+    for f in range(frames.shape[0]):
+        img = frames[f]
+        res = oracle.detect(img, d.code_list, d.num_bits, det._context().tau)
+        h, w = img.shape[:2]
+        assert_frame_parity(ctx, f, img, res, w, h, check_patches)
+        got = markers_of_hip(markers[pos: pos + int(per[f])])
+        pos += int(per[f])
+        assert got == markers_of_oracle(res)
+    assert pos == len(markers)
+    return ctx
+
+
+def test_ieee_ops_are_correctly_rounded(hip, dicts):
+    """f64 sqrt/div (Douglas-Peucker distance, 8x8 solve, Otsu) and f32 sqrt/div must round like the host's."""
+    ctx = _detector(dicts)._context()
+    rng = np.random.default_rng(5)
+    a = np.concatenate([rng.integers(0, 1 << 27, 200000).astype(np.float64), rng.random(100000) * 1e6, [0.0, 1.0, 2.0, 3.0, 1e-300, 1e300]])
+    b = np.concatenate([np.sqrt(rng.integers(1, 1 << 26, 200000).astype(np.float64)), rng.random(100000) * 1e3 + 1e-3, [1.0, 3.0, 7.0, 10.0, 1e300, 1e-300]])
+    sq, dv, sqf, dvf = ctx.selftest_ieee(a, b)
+    assert np.array_equal(sq, np.sqrt(a))
+    assert np.array_equal(dv, a / b)
+    af, bf = a.astype(np.float32), b.astype(np.float32)
+    with np.errstate(over="ignore", under="ignore"):
+        assert np.array_equal(sqf, np.sqrt(af))
+        assert np.array_equal(dvf.view(np.uint32), (af / bf).view(np.uint32))
+
+
+def test_find_nearest_and_tau(hip, dicts, oracle):
+    """src/dictionaries.rs:239-281 through the device kernels"""
+    d = dicts.new_from_named_dict("ARUCO_DEFAULT")
+    assert d.find_nearest(0x1084210) == (0, 0)
+    assert d.find_nearest(0x1084209) == (2, 0)
+    assert d.find_nearest(0b00000001_00001000_01000010_10001001) == (2, 1)
+    assert d.find_nearest(0x1084217) == (1, 0)
+    assert d.try_find_nearest(0b01100001_00001000_01000010_00001001)[0] == 2
+    assert d.try_find_nearest(int("11111111" "0000100" "01000010" "00001001", 2)) is None
+    rng = np.random.default_rng(3)
+    q = rng.integers(0, 1 << 25, 500, dtype=np.uint64)
+    idx, dist = hip.find_nearest(d.code_list, q)
+    for i in range(q.size):
+        assert (int(idx[i]), int(dist[i])) == oracle.find_nearest(d.code_list, int(q[i]))
+    for name in ("ARTAG", "ARTOOLKITPLUS", "ARUCO", "APRILTAG_16H5"):
+        dd = dicts.new_from_named_dict(name)
+        assert hip.calculate_tau(dd.code_list) == oracle.calculate_tau(dd.code_list), name
+    assert dicts.new_from_named_dict("ARTOOLKITPLUS").tau == oracle.calculate_tau(dicts.new_from_named_dict("ARTOOLKITPLUS").code_list)
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (479, 641), (64, 64), (17, 300), (300, 17), (5, 3), (1, 1), (2, 9), (250, 244)])
+@pytest.mark.parametrize("channels", [3, 4, 1])
+def test_threshold_stage_bit_exact(dicts, oracle, shape, channels):
+    """K1 against into_luma8 + adaptive_threshold on noise and on smooth ramps (clipped windows at every border)."""
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1] + channels)
+    h, w = shape
+    noise = rng.integers(0, 256, (h, w, channels), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    ramp = ((xx * 3 + yy * 5) % 256).astype(np.uint8)[..., None].repeat(channels, axis=2)
+    flat = np.full((h, w, channels), 200, np.uint8)
+    det = _detector(dicts)
+    frames = np.stack([noise, ramp, flat])
+    ctx, _, _ = _run(det, frames if channels > 1 else frames[..., 0][..., None], populate=False)
+    for f in range(3):
+        img = frames[f] if channels > 1 else frames[f][..., 0]
+        grey = oracle.to_luma8(img)
+        assert np.array_equal(ctx.download_grey(f, w, h), grey)
+        assert np.array_equal(ctx.download_grey(f, w, h, thresholded=True), oracle.adaptive_threshold(grey, 7))
+
+
+def test_other_threshold_window(dicts, oracle):
+    from aruco3_amd import synth
+
+    frames, _ = synth.config_frames(1, 1)
+    for win in (3, 11):
+        det = _detector(dicts, threshold_window=win)
+        ctx, _, _ = _run(det, frames, populate=False)
+        grey = oracle.to_luma8(frames[0])
+        assert np.array_equal(ctx.download_grey(0, 640, 480, thresholded=True), oracle.adaptive_threshold(grey, win))
+
+
+@pytest.mark.parametrize("config", [1, 2, 4])
+def test_baseline_configs_full_parity(dicts, oracle, config):
+    """BASELINE.json configs 1, 2 (=3 per GPU) and 4 at full resolution, a few frames each: every stage equal."""
+    from aruco3_amd import synth
+
+    spec, name = synth.config_spec(config)
+    frames, truth = synth.config_frames(config, 3)
+    det = _detector(dicts, name)
+    _check(det, oracle, frames)
+    if config in (1, 2):
+        ctx, markers, per = _run(det, frames, populate=False)
+        pos = 0
+        for f in range(len(frames)):
+            ids = sorted(int(m["id"]) for m in markers[pos: pos + int(per[f])])
+            pos += int(per[f])
+            assert ids == sorted(t.id for t in truth[f])  # what was rendered is what is read
+
+
+def test_config5_4k_with_pose(dicts, oracle):
+    """BASELINE.json config 5: 3840x2160, 16 markers, detect + IPPE pose; pose floats within 1e-4 (relative to scale)."""
+    from aruco3_amd import pose, synth
+
+    frames, truth = synth.config_frames(5, 1)
+    det = _detector(dicts, "ARUCO")
+    ctx = _check(det, oracle, frames, check_patches=True)
+    _, markers, per = _run(det, frames, populate=False)
+    assert len(markers) >= 12
+    corners = markers["corners"]
+    got = pose.solve_batch(corners, 40.0, (3840, 2160))
+    for i, m in enumerate(markers):
+        (e1, r1, t1), (e2, r2, t2) = oracle.solve_with_undistorted_points(corners[i], 40.0, (3840, 2160))
+        for (ge, gr, gt), (e, r, t) in zip([(got[i][0].error, got[i][0].rotation, got[i][0].translation),
+                                            (got[i][1].error, got[i][1].rotation, got[i][1].translation)], [(e1, r1, t1), (e2, r2, t2)]):
+            assert np.allclose(gr, r, atol=1e-4, rtol=0)
+            assert np.allclose(gt, t, atol=1e-4 * max(1.0, float(np.abs(t).max())), rtol=0)
+            assert abs(ge - e) <= 1e-4
+
+
+def test_noise_frames_reference_bench_recipe(dicts, oracle):
+    """benches/detect_markers.rs:29-45: uniform random RGB; ~half the pixels are foreground, so this is the
+    contour stage's stress case (giant component, hundreds of thousands of tiny borders, column-0 anomalies)."""
+    from aruco3_amd import synth
+
+    det = _detector(dicts)
+    frames = np.stack([synth.noise_frame(512, 512, 77 + i) for i in range(2)])
+    ctx = _check(det, oracle, frames)
+    st = ctx.stats()
+    assert st["contours_traced"] > 10000
+
+
+def test_structured_binary_layouts(dicts, oracle):
+    """Hand-made layouts that exercise the border follower's corner cases: shapes touching every image edge,
+    one-pixel-wide strokes (points visited twice), nested rings, diagonal chains."""
+    h, w = 96, 128
+    base = np.full((h, w), 210, np.uint8)
+    imgs = []
+    a = base.copy(); a[:, :20] = 20; a[10:40, 0:60] = 20; a[50:90, 100:128] = 20; imgs.append(a)       # left/right edge blocks
+    b = base.copy(); b[0:8, :] = 20; b[h - 8:, :] = 20; b[20:70, 30:100] = 20; b[35:55, 45:85] = 210; imgs.append(b)  # top/bottom + ring
+    c = base.copy()
+    for i in range(60):
+        c[10 + i, 10 + i] = 20; c[10 + i, 100 - i] = 20
+    c[80, 5:120] = 20; imgs.append(c)                                                                  # thin strokes
+    d = np.full((h, w), 30, np.uint8); d[5:90, 5:120] = 220; d[20:70, 20:100] = 30; d[30:60, 30:90] = 220; imgs.append(d)  # dark frame, nested
+    det = _detector(dicts)
+    _check(det, oracle, np.stack(imgs)[..., None])
+
+
+def test_chunked_batches_equal_single(dicts, oracle):
+    """A pool too small for the batch splits it into chunks; results must not change."""
+    from aruco3_amd import synth
+
+    frames, _ = synth.config_frames(1, 6)
+    det = _detector(dicts, "ARUCO_DEFAULT")
+    _, m_all, per_all = _run(det, frames, populate=False)
+    det2 = _detector(dicts, "ARUCO_DEFAULT")
+    det2._context().set_pool_limits(max_darts=12000, max_points=0)
+    ctx2, m_chunk, per_chunk = _run(det2, frames, populate=False)
+    assert ctx2.stats()["chunks"] > 1
+    assert per_all.tolist() == per_chunk.tolist()
+    assert markers_of_hip(m_all) == markers_of_hip(m_chunk)
+    assert m_all["frame"].tolist() == m_chunk["frame"].tolist()
+
+
+def test_error_behaviour(hip, dicts):
+    from aruco3_amd.aruco import Detector, DetectorConfig
+
+    d = dicts.new_from_named_dict("ARUCO")
+    with pytest.raises(hip.A3Error):  # imageproc asserts block_radius > 0
+        Detector(DetectorConfig(threshold_window=0), d)._context()
+    det = Detector(DetectorConfig(), d)
+    img = np.zeros((480, 640, 3), np.uint8)
+    assert det.detect(img).markers == []
+    from aruco3_amd import synth
+
+    frames, _ = synth.config_frames(1, 1)
+    with pytest.raises(hip.A3Error) as e:
+        det._context().detect_batch(frames.ctypes.data, hip.MEM_HOST, hip.FMT_RGB8, 640, 480, 640 * 3, 640 * 480 * 3, 1, out_cap=1)
+    assert e.value.code == hip.ERR_CAPACITY
+
+
+def test_pose_kats_on_device(dicts):
+    """src/pose.rs:514-598 through the pose kernel"""
+    from aruco3_amd import pose
+    from tests.test_oracle_kat import PA_ROT, PB_ROT
+
+    pa, pb = pose.solve_with_undistorted_points([(90, 89), (95, 150), (80, 170), (75, 90)], 17.0, (1000, 1000))
+    assert np.abs(pa.rotation - PA_ROT).sum() < 2e-5 and np.abs(pb.rotation - PB_ROT).sum() < 2e-5
+    assert np.abs(pa.translation - np.array([20.32196265994096, 29.69316666108512, 238.3658341694123])).sum() < 0.0005
+    assert np.abs(pb.translation - np.array([19.85146615649354, 29.20013946746331, 234.3277337340188])).sum() < 0.0005
+    pts = [(-0.090, -0.089), (-0.095, -0.150), (-0.080, -0.170), (-0.075, -0.090)]
+    qa, qb = pose.solve_with_normalized_points(pts, 19.0)
+    sign = np.array([[-1, -1, -1], [-1, -1, -1], [1, 1, 1]])
+    assert np.abs(qa.rotation - PA_ROT * sign).max() <= 1e-5 and np.abs(qb.rotation - PB_ROT * sign).max() <= 1e-5
+    assert np.abs(qa.translation - np.array([-22.712781796404, -33.18648038591866, 266.408873483460])).max() <= 1e-3
+
+
+def test_device_resident_torch_input(dicts, oracle):
+    """Frames already in HBM (torch tensor) through Detector.detect_batch, as bench.py feeds them."""
+    import torch
+
+    from aruco3_amd import synth
+    from aruco3_amd.aruco import Detector, DetectorConfig
+
+    frames, truth = synth.config_frames(1, 2)
+    d = dicts.new_from_named_dict("ARUCO_DEFAULT")
+    det = Detector(DetectorConfig(), d)
+    out = det.detect_batch(torch.from_numpy(frames).cuda())
+    for f in range(2):
+        ref = oracle.detect(frames[f], d.code_list, d.num_bits, d._tau)
+        assert [(m.id, m.code, m.corners, m.hamming_distance) for m in out[f].markers] == [
+            (m["id"], m["code"], m["corners"], m["hamming_distance"]) for m in ref["markers"]]

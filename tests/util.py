@@ -1,0 +1,34 @@
+"""Shared comparison helpers for the parity tests."""
+import numpy as np
+
+
+def markers_of_oracle(res):
+    return [(m["id"], m["code"], tuple(m["corners"]), m["hamming_distance"], m["rotation"]) for m in res["markers"]]
+
+
+def markers_of_hip(arr):
+    out = []
+    for m in arr:
+        c = m["corners"]
+        out.append((int(m["id"]), int(m["code"]), tuple((int(c[2 * i]), int(c[2 * i + 1])) for i in range(4)), int(m["hamming_distance"]),
+                    int(m["rotation"])))
+    return out
+
+
+def assert_frame_parity(ctx, frame_idx, img, res, w, h, check_patches=True):
+    """Every stage the C ABI exposes for one frame of the last batch against the oracle's dict `res`."""
+    grey = ctx.download_grey(frame_idx, w, h)
+    assert np.array_equal(grey, res["grey"]), "grey differs"
+    thr = ctx.download_grey(frame_idx, w, h, thresholded=True)
+    bad = np.argwhere(thr != res["thresholded"])
+    assert bad.size == 0, f"thresholded differs at {bad[:5].tolist()} ({len(bad)} px)"
+    pre = ctx.candidates(frame_idx, before_discard=True)
+    assert pre.tolist() == res["candidates_pre"].tolist(), "candidates before discard_too_near differ"
+    fin = ctx.candidates(frame_idx)
+    assert fin.tolist() == res["candidates"].tolist(), "candidates differ"
+    patches, ok, codes, dec = ctx.homographies(frame_idx, with_patches=check_patches)
+    assert ok.tolist() == res["homography_ok"].tolist()
+    assert dec.tolist() == res["decode_ok"].tolist()
+    assert codes.tolist() == res["codes"].tolist()
+    if check_patches:
+        assert np.array_equal(patches, res["homographies"]), "warped patches differ"
