@@ -86,6 +86,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP/HSA runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64,
+    # and a second copy (from /opt/rocm) initialised in the same process finds no device.  Importing torch first
+    # makes the dynamic linker bind this library's NEEDED libamdhip64.so.7 to the copy torch already loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # a host without PyTorch: the system ROCm runtime is used
+        pass
     if not LIB_PATH.exists():
         raise ImportError(f"{LIB_PATH} is missing: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()'). "
                           "aruco3_amd has no CPU fallback.")
