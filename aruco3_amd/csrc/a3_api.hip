@@ -12,17 +12,18 @@
 
 namespace a3 {
 // k_threshold.hip
-hipError_t launch_grey_threshold(hipStream_t, const uint8_t*, int, size_t, size_t, int, int, uint32_t, uint32_t, uint8_t*, uint8_t*);
+hipError_t launch_grey_threshold(hipStream_t, const uint8_t*, int, size_t, size_t, int, int, uint32_t, uint32_t, uint8_t*, uint64_t*);
 // k_contours.hip
-hipError_t launch_dart_count(hipStream_t, const uint8_t*, int, int, uint32_t, uint32_t, unsigned long long*);
-hipError_t launch_dart_build(hipStream_t, const uint8_t*, int, int, uint32_t, uint32_t, const uint32_t*, uint32_t*, uint32_t*, uint32_t*,
-                             uint8_t*, uint8_t*, uint32_t*, JumpState*, uint32_t);
+hipError_t launch_dart_count(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, unsigned long long*);
+hipError_t launch_dart_build(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, const uint32_t*, uint32_t*, uint32_t*, uint64_t*,
+                             uint32_t*, uint8_t*, uint8_t*, uint32_t*, JumpState*, uint32_t);
 hipError_t launch_jump(hipStream_t, const JumpState*, JumpState*, uint32_t, int, DeviceCounters*);
 hipError_t launch_resolve(hipStream_t, const JumpState*, uint32_t, int, const uint32_t*, const uint8_t*, const uint8_t*, uint64_t*, uint64_t*,
-                          DeviceCounters*, unsigned int*, unsigned int*, int);
+                          DeviceCounters*, int);
 hipError_t launch_select_scatter(hipStream_t, const JumpState*, uint32_t, const uint32_t*, const uint64_t*, const uint32_t*, uint32_t, uint32_t,
-                                 uint32_t, double, uint32_t*, ContourRec*, uint32_t*, uint32_t, uint64_t, DeviceCounters*, const uint32_t*,
-                                 uint32_t*);
+                                 uint32_t, double, double, uint32_t*, ContourRec*, uint32_t*, uint32_t, uint64_t, DeviceCounters*,
+                                 const uint32_t*, uint32_t*);
+hipError_t launch_unpack_bits(hipStream_t, const uint64_t*, int, int, uint8_t*);
 hipError_t launch_contour_quads(hipStream_t, const ContourRec*, const DeviceCounters*, uint32_t, const uint32_t*, double, uint32_t, uint32_t,
                                 uint32_t, CandRec*, uint32_t*, unsigned int*);
 // k_decode.hip
@@ -51,7 +52,7 @@ constexpr uint64_t kMaxDartsDefault = 48ull << 20;
 constexpr uint64_t kMaxPointsDefault = 64ull << 20;
 constexpr uint64_t kHardMaxDarts = 3ull << 30;   // 32-bit dart indices
 constexpr uint64_t kHardMaxPoints = 3ull << 30;
-constexpr int kResolveIters = 12;
+constexpr int kResolveIters = 10;           // <= DeviceCounters::resolve_changed slots
 constexpr uint32_t kPatchCap = 32768;        // debug taps: warped patches kept per batch
 
 // grow-only device buffer
@@ -93,7 +94,7 @@ struct a3_ctx {
     // last batch geometry (for the debug downloads)
     uint32_t W = 0, H = 0, frames = 0;
 
-    DevBuf dict, in, grey, bin, frame_darts, frame_base, frame_cursor, pix_base;
+    DevBuf dict, in, grey, bin, frame_darts, frame_base, frame_cursor, pix_base, node_bits;
     DevBuf d_xy, d_info, d_F, d_succ, stA, stB, t_cur, t_next, cyc_slot;
     DevBuf contours, cyc_start_off, points, counters, scratch_u32;
     DevBuf cands, cand_count, pre_xy, fin_xy, fin_count, work, outs, patches, markers, per_frame;
@@ -155,7 +156,8 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     const uint32_t S = ctx->cfg.homography_sample_size;
 
     A3_HIP(ctx->grey.ensure(npx * n));
-    A3_HIP(ctx->bin.ensure(npx * n));
+    const size_t bits_per_frame = (size_t)words_per_row(W) * 8 * H;   // packed thresholded image
+    A3_HIP(ctx->bin.ensure(bits_per_frame * n));
     A3_HIP(ctx->frame_darts.ensure((size_t)n * 8));
     A3_HIP(ctx->cands.ensure((size_t)n * kMaxCand * sizeof(CandRec)));
     A3_HIP(ctx->cand_count.ensure((size_t)n * 4));
@@ -175,12 +177,12 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     // ---- K1 ----
     if (ctx->profiling) A3_HIP(hipEventRecord(ctx->ev[0], st));
     A3_HIP(launch_grey_threshold(st, pixels, fmt, row_stride, frame_stride, (int)W, (int)H, n, ctx->cfg.threshold_window,
-                                 ctx->grey.as<uint8_t>(), ctx->bin.as<uint8_t>()));
+                                 ctx->grey.as<uint8_t>(), ctx->bin.as<uint64_t>()));
     if (ctx->profiling) A3_HIP(hipEventRecord(ctx->ev[1], st));
 
     // ---- contour graph size per frame -> chunk plan ----
     A3_HIP(hipMemsetAsync(ctx->frame_darts.p, 0, (size_t)n * 8, st));
-    A3_HIP(launch_dart_count(st, ctx->bin.as<uint8_t>(), (int)W, (int)H, 0, n, ctx->frame_darts.as<unsigned long long>()));
+    A3_HIP(launch_dart_count(st, ctx->bin.as<uint64_t>(), (int)W, (int)H, 0, n, ctx->frame_darts.as<unsigned long long>()));
     if (int rc = ensure_pinned(ctx, std::max<size_t>((size_t)n * 8, 1 << 16))) return rc;
     A3_HIP(hipMemcpyAsync(ctx->pinned, ctx->frame_darts.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
     A3_HIP(hipStreamSynchronize(st));
@@ -203,6 +205,7 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     ctx->stats.chunks = (uint32_t)chunks.size();
     if (int rc = ensure_dart_pool(ctx, std::max<uint64_t>(max_chunk_darts, 1))) return rc;
     A3_HIP(ctx->pix_base.ensure((size_t)max_chunk_frames * npx * 4));
+    A3_HIP(ctx->node_bits.ensure((size_t)max_chunk_frames * bits_per_frame));
     A3_HIP(ctx->frame_base.ensure((size_t)(max_chunk_frames + 1) * 4 * chunks.size()));
     A3_HIP(ctx->frame_cursor.ensure((size_t)max_chunk_frames * 4));
     A3_HIP(ctx->counters.ensure(sizeof(DeviceCounters) * chunks.size()));
@@ -215,8 +218,6 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     A3_HIP(hipMemsetAsync(ctx->scratch_u32.p, 0, 64, st));
     unsigned int* d_work_count = ctx->scratch_u32.as<unsigned int>() + 0;
     unsigned int* d_marker_total = ctx->scratch_u32.as<unsigned int>() + 1;
-    unsigned int* d_changed_tmp = ctx->scratch_u32.as<unsigned int>() + 2;
-    unsigned int* d_iters = ctx->scratch_u32.as<unsigned int>() + 3;
     unsigned int* d_err = ctx->scratch_u32.as<unsigned int>() + 4;
 
     // frame bases of every chunk, uploaded once
@@ -235,7 +236,8 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     A3_HIP(hipMemcpyAsync(ctx->frame_base.p, h_bases, bases.size() * 4, hipMemcpyHostToDevice, st));
 
     // ---- contour stage, chunk by chunk ----
-    const uint8_t* d_bin = ctx->bin.as<uint8_t>();
+    const uint64_t* d_bin = ctx->bin.as<uint64_t>();
+    const double image_diag = std::sqrt((double)W * W + (double)H * H);
     int rounds_max = 0;
     for (size_t ci = 0; ci < chunks.size(); ci++) {
         const Chunk& c = chunks[ci];
@@ -245,7 +247,7 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
         if (nd == 0) continue;
         A3_HIP(hipMemsetAsync(ctx->frame_cursor.p, 0, (size_t)c.count * 4, st));
         A3_HIP(launch_dart_build(st, d_bin, (int)W, (int)H, c.first, c.count, fb, ctx->frame_cursor.as<uint32_t>(), ctx->pix_base.as<uint32_t>(),
-                                 ctx->d_xy.as<uint32_t>(), ctx->d_info.as<uint8_t>(), ctx->d_F.as<uint8_t>(), ctx->d_succ.as<uint32_t>(),
+                                 ctx->node_bits.as<uint64_t>(), ctx->d_xy.as<uint32_t>(), ctx->d_info.as<uint8_t>(), ctx->d_F.as<uint8_t>(), ctx->d_succ.as<uint32_t>(),
                                  ctx->stA.as<JumpState>(), nd));
         int rounds = 1;
         while ((1ull << rounds) < (uint64_t)c.max_frame_darts && rounds < 31) rounds++;
@@ -257,9 +259,10 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
         // both buffers are final once converged; the last round always is the observing one, so `a` (last written or skipped) is valid
         const JumpState* fin = a;
         A3_HIP(launch_resolve(st, fin, nd, (int)W, ctx->d_xy.as<uint32_t>(), ctx->d_info.as<uint8_t>(), ctx->d_F.as<uint8_t>(),
-                              ctx->t_cur.as<uint64_t>(), ctx->t_next.as<uint64_t>(), ctr, d_changed_tmp, d_iters, kResolveIters));
+                              ctx->t_cur.as<uint64_t>(), ctx->t_next.as<uint64_t>(), ctr, kResolveIters));
         A3_HIP(launch_select_scatter(st, fin, nd, ctx->d_succ.as<uint32_t>(), ctx->t_cur.as<uint64_t>(), fb, c.count, c.first, min_edge_length,
-                                     ctx->cfg.contour_simplification_epsilon, ctx->cyc_slot.as<uint32_t>(), ctx->contours.as<ContourRec>(),
+                                     ctx->cfg.contour_simplification_epsilon, image_diag, ctx->cyc_slot.as<uint32_t>(),
+                                     ctx->contours.as<ContourRec>(),
                                      ctx->cyc_start_off.as<uint32_t>(), ctx->max_contours, ctx->max_points, ctr, ctx->d_xy.as<uint32_t>(),
                                      ctx->points.as<uint32_t>()));
         A3_HIP(launch_contour_quads(st, ctx->contours.as<ContourRec>(), ctr, ctx->max_contours, ctx->points.as<uint32_t>(),
@@ -298,8 +301,10 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
         ctx->stats.contours_traced += hc[ci].traced;
         ctx->stats.contours_materialised += hc[ci].contours;
         for (int r = 0; r < 32; r++) if (hc[ci].jump_changed[r]) ctx->stats.jump_rounds = std::max<uint32_t>(ctx->stats.jump_rounds, r + 1);
+        uint32_t it = 1;  // pass k+1 ran iff pass k moved something
+        for (int r = 0; r < kResolveIters - 1; r++) if (hc[ci].resolve_changed[r]) it = r + 2;
+        ctx->stats.resolve_iterations = std::max(ctx->stats.resolve_iterations, it);
     }
-    ctx->stats.resolve_iterations = hs[3];
     if (flags & (kErrPointPool | kErrContourTable)) {
         // grow and let the caller loop re-run the batch
         if (need_points > ctx->max_points) ctx->max_points = std::min<uint64_t>(kHardMaxPoints, std::max(need_points, ctx->max_points * 2));
@@ -414,7 +419,7 @@ void a3_destroy(a3_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     DevBuf* bufs[] = {&ctx->dict, &ctx->in, &ctx->grey, &ctx->bin, &ctx->frame_darts, &ctx->frame_base, &ctx->frame_cursor, &ctx->pix_base,
-                      &ctx->d_xy, &ctx->d_info, &ctx->d_F, &ctx->d_succ, &ctx->stA, &ctx->stB, &ctx->t_cur, &ctx->t_next, &ctx->cyc_slot,
+                      &ctx->node_bits, &ctx->d_xy, &ctx->d_info, &ctx->d_F, &ctx->d_succ, &ctx->stA, &ctx->stB, &ctx->t_cur, &ctx->t_next, &ctx->cyc_slot,
                       &ctx->contours, &ctx->cyc_start_off, &ctx->points, &ctx->counters, &ctx->scratch_u32, &ctx->cands, &ctx->cand_count,
                       &ctx->pre_xy, &ctx->fin_xy, &ctx->fin_count, &ctx->work, &ctx->outs, &ctx->patches, &ctx->markers, &ctx->per_frame,
                       &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_d};
@@ -500,7 +505,17 @@ static int download_plane(a3_ctx* ctx, const DevBuf& buf, uint32_t frame, uint8_
 }
 
 int a3_download_grey(a3_ctx* ctx, uint32_t frame, uint8_t* dst) { return ctx ? download_plane(ctx, ctx->grey, frame, dst) : A3_ERR_INVALID; }
-int a3_download_thresholded(a3_ctx* ctx, uint32_t frame, uint8_t* dst) { return ctx ? download_plane(ctx, ctx->bin, frame, dst) : A3_ERR_INVALID; }
+int a3_download_thresholded(a3_ctx* ctx, uint32_t frame, uint8_t* dst) {
+    if (!ctx || !dst) return A3_ERR_INVALID;
+    if (frame >= ctx->frames) return fail(ctx, A3_ERR_INVALID, "frame index outside the last batch");
+    const size_t npx = (size_t)ctx->W * ctx->H, wpf = (size_t)words_per_row(ctx->W) * ctx->H;
+    A3_HIP(hipSetDevice(ctx->device));
+    A3_HIP(ctx->tmp_a.ensure(npx));
+    A3_HIP(launch_unpack_bits(ctx->stream, ctx->bin.as<uint64_t>() + wpf * frame, (int)ctx->W, (int)ctx->H, ctx->tmp_a.as<uint8_t>()));
+    A3_HIP(hipStreamSynchronize(ctx->stream));
+    A3_HIP(hipMemcpy(dst, ctx->tmp_a.p, npx, hipMemcpyDeviceToHost));
+    return A3_OK;
+}
 
 int a3_candidate_count(a3_ctx* ctx, uint32_t frame, uint32_t* n_pre, uint32_t* n_final) {
     if (!ctx) return A3_ERR_INVALID;

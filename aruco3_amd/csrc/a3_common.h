@@ -26,14 +26,26 @@ constexpr uint8_t kInfoW = 1u << 3;
 constexpr uint8_t kInfoE = 1u << 4;
 constexpr uint8_t kInfoBroken = 1u << 5;
 
-// state carried by the pointer-doubling rounds (24 bytes per dart, ping-pong)
-struct JumpState {
+// state carried by the pointer-doubling rounds (16 bytes per dart = one dwordx4, ping-pong)
+struct __attribute__((aligned(16))) JumpState {
     uint64_t key;   // (start-event key << 32) | dart index : minimum over the window
     uint32_t ptr;   // succ^(2^round)
     uint32_t off;   // hops from this dart to the first dart holding `key`
-    uint16_t minx, miny, maxx, maxy;  // bounding box over the window
 };
-static_assert(sizeof(JumpState) == 24, "JumpState layout");
+static_assert(sizeof(JumpState) == 16, "JumpState layout");
+
+// The thresholded image is kept bit-packed: row y of a frame is `words_per_row(W)` little-endian u64 words,
+// bit i of word j is pixel x = 64 j + i (1 = white / foreground); bits past the image width are 0.
+__host__ __device__ inline uint32_t words_per_row(uint32_t W) { return (W + 63u) / 64u; }
+
+// Directions k whose dart (p,k) can lie on a border the reference follows, from the foreground-neighbour mask F
+// of p: neighbour k foreground, neighbour k-1 background (the counter-clockwise sweep is not empty), and for a
+// 4-neighbour direction (k even) neighbour k-2 background as well; every other dart only belongs to a
+// triangular face cycle of the 8-neighbour graph (tests/dart_model.py, rule "pdart").
+__host__ __device__ inline uint32_t pdart_mask(uint32_t F) {
+    const uint32_t rot1 = ((F << 1) | (F >> 7)) & 0xFFu, rot2 = ((F << 2) | (F >> 6)) & 0xFFu;
+    return F & ~rot1 & (0xAAu | ~rot2) & 0xFFu;
+}
 
 // one border that survived the size pruning and gets its points written out
 struct ContourRec {
@@ -56,8 +68,9 @@ struct DeviceCounters {
     unsigned int traced;            // cycles with a start event (stat)
     unsigned int err_flags;         // bit 0: event dart on a broken chain, bit 1: point pool overflow,
                                     // bit 2: contour table overflow, bit 3: candidate table overflow
-    unsigned int resolve_changed;   // start resolution: cycles whose start moved in this pass
-    unsigned int jump_changed[32];  // per doubling round: darts whose key changed
+    unsigned int pad0;
+    unsigned int jump_changed[32];     // per doubling round: darts whose key changed
+    unsigned int resolve_changed[16];  // per start-resolution pass: cycles whose start moved
     unsigned int pad[2];
 };
 

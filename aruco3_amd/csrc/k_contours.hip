@@ -1,153 +1,170 @@
-// k_contours.hip -- K2..K4: binary image -> quad candidates, fully data-parallel.
+// k_contours.hip -- K2..K4: bit-packed binary image -> quad candidates, fully data-parallel.
 //
 // Replaces `imageproc::contours::find_contours` + `contours_to_candidates` +
 // `enforce_clockwise_corners` (src/aruco.rs:64-68, 124-185).
 //
 // The reference follows borders one at a time in raster order with a label image
 // (Suzuki-Abe).  Here the same borders come out of a graph formulation with no
-// sequential scan (executable model + proof sketch: tests/dart_model.py):
+// sequential scan (executable model, checked against the oracle: tests/dart_model.py):
 //
-//   dart       (pixel p, direction k of a foreground 8-neighbour); only pixels that have a
-//              background / out-of-image 4-neighbour carry darts ("border pixels").
+//   dart       (pixel p, direction k of a foreground 8-neighbour) with a non-empty
+//              counter-clockwise sweep (pdart_mask in a3_common.h): the only darts a border
+//              can pass through, about 1.2 per border pixel.
 //   succ       (p,k) -> (p + dir(k'), opposite(k')), k' = next foreground neighbour
-//              counter-clockwise after k.  A bijection: darts fall into cycles, and every
-//              border the reference traces is one cycle, rotated to its start dart.
+//              counter-clockwise after k.  Darts fall into cycles (plus open chains that
+//              belong to no border), and every border the reference traces is one cycle,
+//              rotated to its start dart.
 //   doubling   log2(longest cycle) rounds of pointer jumping give every dart its cycle's
-//              leader (the dart holding the smallest start-event key), its hop distance to
-//              the leader (=> rank along the border) and the cycle's bounding box.
+//              leader (the dart holding the smallest start-event key) and its hop distance
+//              to the leader (=> cycle length and rank along the border).
 //   events     a W-event at pixel q (x>0, west neighbour background) can start a border as
 //              "outer", an E-event (x+1<W, east neighbour background) as "hole"; which event
 //              starts a cycle is the fixpoint of the rule in k_resolve_eval (the reference's
 //              label tests `== 1` / `> 0`, restated on cycles).  Start keys give the
 //              reference's contour order.
-//   pruning    only parity-safe: a border whose bounding-box diagonal^2 is below the
-//              reference's edge test, or whose epsilon = 0.05*len exceeds that diagonal,
-//              can never yield a 4-point candidate (src/aruco.rs:133-158), so its points
-//              are never written.
+//   pruning    only parity-safe (see k_cycle_select): a border too short to hold one
+//              candidate edge, or so long that epsilon = 0.05*len exceeds the image
+//              diagonal, can never yield a 4-point candidate (src/aruco.rs:133-158).
 //   DP         one wave per surviving border: Douglas-Peucker with a wave arg-max, split
 //              count capped at 3 (exactly 4 points are needed), hull + winding + edge test.
 //
-// Wave-level ballot/scan compaction allocates dart ranges with one atomic per wave.
+// Border pixels are found 64 at a time with word-wide bit operations on the packed image;
+// dart ranges are handed out with a block scan and one atomic per workgroup.
 #include "a3_common.h"
 
 namespace a3 {
 
 // ---------------------------------------------------------------------------------------
-// neighbourhood masks for 4 consecutive pixels per lane
+// 64 pixels per lane: neighbour occupancy words in ring order W NW N NE E SE S SW
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t row_dword(const uint8_t* __restrict__ img, int W, int H, int x4, int y, bool aligned) {
-    if (y < 0 || y >= H || x4 >= W) return 0u;
-    const uint8_t* p = img + (size_t)y * W + x4;
-    if (aligned && x4 + 3 < W) return *reinterpret_cast<const uint32_t*>(p);
-    uint32_t d = 0;
+struct Nb8 { uint64_t c; uint64_t n[8]; };
+
+__device__ __forceinline__ uint64_t ldw(const uint64_t* __restrict__ img, int wpr, int H, int j, int y) {
+    return (y >= 0 && y < H && j >= 0 && j < wpr) ? img[(size_t)y * wpr + j] : 0ull;
+}
+
+__device__ __forceinline__ Nb8 load_nb8(const uint64_t* __restrict__ img, int wpr, int H, int j, int y) {
+    Nb8 r;
+    const uint64_t al = ldw(img, wpr, H, j - 1, y - 1), a = ldw(img, wpr, H, j, y - 1), ar = ldw(img, wpr, H, j + 1, y - 1);
+    const uint64_t cl = ldw(img, wpr, H, j - 1, y), c = ldw(img, wpr, H, j, y), cr = ldw(img, wpr, H, j + 1, y);
+    const uint64_t bl = ldw(img, wpr, H, j - 1, y + 1), b = ldw(img, wpr, H, j, y + 1), br = ldw(img, wpr, H, j + 1, y + 1);
+    r.c = c;
+    r.n[0] = (c << 1) | (cl >> 63);   // W : pixel x-1
+    r.n[1] = (a << 1) | (al >> 63);   // NW
+    r.n[2] = a;                       // N
+    r.n[3] = (a >> 1) | (ar << 63);   // NE
+    r.n[4] = (c >> 1) | (cr << 63);   // E
+    r.n[5] = (b >> 1) | (br << 63);   // SE
+    r.n[6] = b;                       // S
+    r.n[7] = (b << 1) | (bl >> 63);   // SW
+    return r;
+}
+
+// per direction: the pixels of this word that own a dart in that direction (pdart_mask, 64 pixels at once)
+__device__ __forceinline__ void pdart_words(const Nb8& nb, uint64_t p[8]) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) if (x4 + i < W) d |= (uint32_t)p[i] << (8 * i);
-    return d;
+    for (int k = 0; k < 8; k++) {
+        uint64_t m = nb.c & nb.n[k] & ~nb.n[(k + 7) & 7];
+        if ((k & 1) == 0) m &= ~nb.n[(k + 6) & 7];
+        p[k] = m;
+    }
 }
 
-// 6-bit occupancy of columns x4-1 .. x4+4 of one row (bit 0 = x4-1)
-__device__ __forceinline__ uint32_t row_bits(const uint8_t* __restrict__ img, int W, int H, int x4, int y, bool aligned, int lane) {
-    uint32_t d = row_dword(img, W, H, x4, y, aligned);
-    uint32_t dl = __shfl_up(d, 1), dr = __shfl_down(d, 1);
-    const bool row_ok = y >= 0 && y < H;
-    if (lane == 0) dl = (row_ok && x4 > 0 && x4 - 1 < W) ? (uint32_t)img[(size_t)y * W + x4 - 1] << 24 : 0u;
-    if (lane == 63) dr = (row_ok && x4 + 4 < W) ? (uint32_t)img[(size_t)y * W + x4 + 4] : 0u;
-    uint32_t m = (dl >> 24) ? 1u : 0u;
-    m |= (d & 0x000000FFu) ? 2u : 0u;
-    m |= (d & 0x0000FF00u) ? 4u : 0u;
-    m |= (d & 0x00FF0000u) ? 8u : 0u;
-    m |= (d & 0xFF000000u) ? 16u : 0u;
-    m |= (dr & 0xFFu) ? 32u : 0u;
-    return m;
-}
-
-// foreground-neighbour mask of pixel i (0..3) of the lane, ring order W NW N NE E SE S SW
-__device__ __forceinline__ uint32_t nb_mask(uint32_t mA, uint32_t mC, uint32_t mB, int i) {
-    const uint32_t a = mA >> i, c = mC >> i, b = mB >> i;
-    return (c & 1u) | ((a & 1u) << 1) | (((a >> 1) & 1u) << 2) | (((a >> 2) & 1u) << 3) | (((c >> 2) & 1u) << 4) |
-           (((b >> 2) & 1u) << 5) | (((b >> 1) & 1u) << 6) | ((b & 1u) << 7);
-}
-
-// a pixel carries darts iff it is foreground, not isolated, and has a background / outside 4-neighbour
-__device__ __forceinline__ bool is_node(uint32_t self_fg, uint32_t F) { return self_fg && F != 0u && (F & 0x55u) != 0x55u; }
-
-__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_t* total) {
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* s_wave, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t inc = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = __shfl_up(inc, o);
+        const uint32_t t = __shfl_up(inc, o);
         if (lane >= o) inc += t;
     }
-    *total = __shfl(inc, 63);
-    return inc - v;
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const uint32_t t = s_wave[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    *total = tot;
+    return base + inc - v;
 }
 
-// grid: (ceil(W/256), ceil(H/4), frames); block 256 = 4 waves, one image row segment per wave
-__global__ __launch_bounds__(256) void k_dart_count(const uint8_t* __restrict__ bin, int W, int H, uint32_t first_frame, int aligned,
+// grid: (ceil(wpr*H/256), frames).  One packed word (64 pixels) per lane.
+__global__ __launch_bounds__(256) void k_dart_count(const uint64_t* __restrict__ bits, int W, int H, uint32_t first_frame,
                                                     unsigned long long* __restrict__ frame_darts) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x4 = (blockIdx.x * 64 + lane) * 4, y = blockIdx.y * 4 + wave;
-    const uint32_t f = blockIdx.z;
-    const uint8_t* img = bin + (size_t)(first_frame + f) * W * H;
-    const uint32_t mA = row_bits(img, W, H, x4, y - 1, aligned, lane);
-    const uint32_t mC = row_bits(img, W, H, x4, y, aligned, lane);
-    const uint32_t mB = row_bits(img, W, H, x4, y + 1, aligned, lane);
+    __shared__ uint32_t s_wave[4];
+    const int wpr = (int)words_per_row((uint32_t)W);
+    const uint32_t wi = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
     uint32_t nd = 0;
+    if (wi < (uint32_t)(wpr * H)) {
+        const int y = wi / wpr, j = wi - y * wpr;
+        const Nb8 nb = load_nb8(bits + (size_t)(first_frame + f) * wpr * H, wpr, H, j, y);
+        if (nb.c) {
+            uint64_t p[8];
+            pdart_words(nb, p);
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t F = nb_mask(mA, mC, mB, i);
-        if (is_node((mC >> (i + 1)) & 1u, F)) nd += __popc(F);
+            for (int k = 0; k < 8; k++) nd += __popcll(p[k]);
+        }
     }
     uint32_t total;
-    wave_excl_scan(nd, lane, &total);
-    if (lane == 0 && total) atomicAdd(&frame_darts[f], (unsigned long long)total);
+    block_excl_scan_256(nd, s_wave, &total);
+    if (threadIdx.x == 0 && total) atomicAdd(&frame_darts[f], (unsigned long long)total);
 }
 
-// Same traversal; hands every border pixel a contiguous dart range inside its frame's range.
-__global__ __launch_bounds__(256) void k_dart_assign(const uint8_t* __restrict__ bin, int W, int H, uint32_t first_frame, int aligned,
+// Same traversal; hands every border pixel a contiguous dart range inside its frame's range and writes
+// the per-dart records.  node_bits: packed "this pixel owns darts" image (same layout as bits).
+__global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict__ bits, int W, int H, uint32_t first_frame,
                                                      const uint32_t* __restrict__ frame_base, uint32_t* __restrict__ frame_cursor,
-                                                     uint32_t* __restrict__ pix_base, uint32_t* __restrict__ d_xy,
-                                                     uint8_t* __restrict__ d_info, uint8_t* __restrict__ d_F) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x4 = (blockIdx.x * 64 + lane) * 4, y = blockIdx.y * 4 + wave;
-    const uint32_t f = blockIdx.z;
-    const uint8_t* img = bin + (size_t)(first_frame + f) * W * H;
-    const uint32_t mA = row_bits(img, W, H, x4, y - 1, aligned, lane);
-    const uint32_t mC = row_bits(img, W, H, x4, y, aligned, lane);
-    const uint32_t mB = row_bits(img, W, H, x4, y + 1, aligned, lane);
-    uint32_t Fm[4], nd = 0;
+                                                     uint32_t* __restrict__ pix_base, uint64_t* __restrict__ node_bits,
+                                                     uint32_t* __restrict__ d_xy, uint8_t* __restrict__ d_info, uint8_t* __restrict__ d_F) {
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_base;
+    const int wpr = (int)words_per_row((uint32_t)W);
+    const uint32_t wi = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    const bool active = wi < (uint32_t)(wpr * H);
+    const int y = active ? wi / wpr : 0, j = active ? wi - y * wpr : 0;
+    Nb8 nb;
+    nb.c = 0;
+    uint64_t p[8];
+    uint64_t nodes = 0;
+    uint32_t nd = 0;
+    if (active) {
+        nb = load_nb8(bits + (size_t)(first_frame + f) * wpr * H, wpr, H, j, y);
+        if (nb.c) {
+            pdart_words(nb, p);
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t F = nb_mask(mA, mC, mB, i);
-        Fm[i] = is_node((mC >> (i + 1)) & 1u, F) ? F : 0u;
-        nd += __popc(Fm[i]);
+            for (int k = 0; k < 8; k++) { nd += __popcll(p[k]); nodes |= p[k]; }
+        }
+        node_bits[(size_t)f * wpr * H + wi] = nodes;
     }
     uint32_t total;
-    const uint32_t excl = wave_excl_scan(nd, lane, &total);
-    uint32_t base = 0;
-    if (lane == 0 && total) base = atomicAdd(&frame_cursor[f], total);
-    base = __shfl(base, 0);
-    if (!nd) return;
-    uint32_t cur = frame_base[f] + base + excl;
+    const uint32_t excl = block_excl_scan_256(nd, s_wave, &total);
+    if (threadIdx.x == 0) s_base = total ? atomicAdd(&frame_cursor[f], total) : 0u;
+    __syncthreads();
+    if (!nodes) return;
+    uint32_t cur = frame_base[f] + s_base + excl;
     uint32_t* pb = pix_base + (size_t)f * W * H + (size_t)y * W;
+    while (nodes) {
+        const int i = __ffsll((long long)nodes) - 1;
+        nodes &= nodes - 1;
+        const int x = 64 * j + i;
+        uint32_t F = 0, P = 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t F = Fm[i];
-        if (!F) continue;
-        const int x = x4 + i;
+        for (int k = 0; k < 8; k++) { F |= (uint32_t)((nb.n[k] >> i) & 1ull) << k; P |= (uint32_t)((p[k] >> i) & 1ull) << k; }
         pb[x] = cur;
         // event darts: first foreground neighbour clockwise from W (resp. E) when that side is background
         int kW = -1, kE = -1;
-        if (x > 0 && !(F & 1u)) kW = __ffs(F >> 1);  // F>>1 != 0 here; ffs is 1-based -> direction index
+        if (x > 0 && !(F & 1u)) kW = __ffs(F >> 1);  // 1-based position in F>>1 == direction index
         if (x + 1 < W && !(F & 16u)) {
-            const uint32_t r = ((F >> 5) | (F << 3)) & 0xFFu;  // bit j <-> direction (5 + j) & 7
+            const uint32_t r = ((F >> 5) | (F << 3)) & 0xFFu;  // bit t <-> direction (5 + t) & 7
             kE = (5 + __ffs(r) - 1) & 7;
         }
         const uint32_t xy = (uint32_t)x | ((uint32_t)y << 16);
-        uint32_t m = F;
-        while (m) {
-            const int k = __ffs(m) - 1;
-            m &= m - 1;
+        while (P) {
+            const int k = __ffs(P) - 1;
+            P &= P - 1;
             d_xy[cur] = xy;
             d_F[cur] = (uint8_t)F;
             d_info[cur] = (uint8_t)(k | (k == kW ? kInfoW : 0) | (k == kE ? kInfoE : 0));
@@ -157,14 +174,15 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint8_t* __restrict__
 }
 
 // successor of every dart + initial doubling state.  grid.y = frame, grid-stride over its darts.
-__global__ __launch_bounds__(256) void k_dart_link(const uint8_t* __restrict__ bin, int W, int H, uint32_t first_frame,
-                                                   const uint32_t* __restrict__ frame_base, const uint32_t* __restrict__ pix_base,
+__global__ __launch_bounds__(256) void k_dart_link(int W, int H, const uint32_t* __restrict__ frame_base,
+                                                   const uint32_t* __restrict__ pix_base, const uint64_t* __restrict__ node_bits,
                                                    const uint32_t* __restrict__ d_xy, uint8_t* __restrict__ d_info,
                                                    const uint8_t* __restrict__ d_F, uint32_t* __restrict__ d_succ,
                                                    JumpState* __restrict__ st) {
     const uint32_t f = blockIdx.y;
     const uint32_t lo = frame_base[f], hi = frame_base[f + 1];
-    const uint8_t* img = bin + (size_t)(first_frame + f) * W * H;
+    const int wpr = (int)words_per_row((uint32_t)W);
+    const uint64_t* nbits = node_bits + (size_t)f * wpr * H;
     const uint32_t* pb = pix_base + (size_t)f * W * H;
     for (uint32_t d = lo + blockIdx.x * blockDim.x + threadIdx.x; d < hi; d += gridDim.x * blockDim.x) {
         const uint32_t xy = d_xy[d];
@@ -173,26 +191,18 @@ __global__ __launch_bounds__(256) void k_dart_link(const uint8_t* __restrict__ b
         uint8_t info = d_info[d];
         const int k = info & 7;
         // next foreground neighbour counter-clockwise after k: directions k-1, k-2, ..., k
-        const uint32_t r = ((F >> k) | (F << (8 - k))) & 0xFFu;  // bit j <-> direction (k + j) & 7
-        const int j = 31 - __clz(r);                              // bit 0 (k itself) is always set
-        const int ko = (k + j) & 7;
+        const uint32_t r = ((F >> k) | (F << (8 - k))) & 0xFFu;  // bit t <-> direction (k + t) & 7
+        const int t = 31 - __clz(r);                              // bit 0 (k itself) is always set
+        const int ko = (k + t) & 7;
         const int nx = x + kDX[ko], ny = y + kDY[ko];
-        // is the target a border pixel (background / outside 4-neighbour)?
-        const bool w0 = nx > 0 ? img[(size_t)ny * W + nx - 1] != 0 : false;
-        const bool e0 = nx + 1 < W ? img[(size_t)ny * W + nx + 1] != 0 : false;
-        const bool n0 = ny > 0 ? img[(size_t)(ny - 1) * W + nx] != 0 : false;
-        const bool s0 = ny + 1 < H ? img[(size_t)(ny + 1) * W + nx] != 0 : false;
-        uint32_t succ;
-        if (w0 && e0 && n0 && s0) {
-            succ = d;  // interior pixel: only face cycles of the 8-neighbour graph walk there
-            info |= kInfoBroken;
-            d_info[d] = info;
-        } else {
+        uint32_t succ = d;  // chain end unless the target dart exists
+        if ((nbits[(size_t)ny * wpr + (nx >> 6)] >> (nx & 63)) & 1ull) {
             const uint32_t tb = pb[(size_t)ny * W + nx];
-            const uint32_t tF = d_F[tb];
+            const uint32_t tP = pdart_mask(d_F[tb]);
             const int kin = (ko + 4) & 7;
-            succ = tb + __popc(tF & ((1u << kin) - 1u));
+            if ((tP >> kin) & 1u) succ = tb + __popc(tP & ((1u << kin) - 1u));
         }
+        if (succ == d) { info |= kInfoBroken; d_info[d] = info; }
         d_succ[d] = succ;
         const uint32_t q = (uint32_t)y * (uint32_t)W + (uint32_t)x;
         const uint32_t ek = (info & kInfoW) ? 2u * q : ((info & kInfoE) ? 2u * q + 1u : kNoKey);
@@ -200,8 +210,6 @@ __global__ __launch_bounds__(256) void k_dart_link(const uint8_t* __restrict__ b
         s.key = ((uint64_t)ek << 32) | d;
         s.ptr = succ;
         s.off = 0;
-        s.minx = s.maxx = (uint16_t)x;
-        s.miny = s.maxy = (uint16_t)y;
         st[d] = s;
     }
 }
@@ -209,8 +217,8 @@ __global__ __launch_bounds__(256) void k_dart_link(const uint8_t* __restrict__ b
 // one pointer-doubling round: window [d, d + 2^round) -> [d, d + 2^(round+1))
 __global__ __launch_bounds__(256) void k_jump(const JumpState* __restrict__ in, JumpState* __restrict__ out, uint32_t n_darts,
                                               int round, DeviceCounters* __restrict__ ctr) {
-    // Converged in an earlier round (no key moved): key/off/box of BOTH ping-pong buffers are final, so
-    // later rounds do nothing and the consumers may read either buffer.
+    // Converged in an earlier round (no key moved): key/off of BOTH ping-pong buffers are final, so later rounds do
+    // nothing and the consumers may read either buffer.
     if (round > 0 && ctr->jump_changed[round - 1] == 0) return;
     uint32_t changed = 0;
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
@@ -221,12 +229,9 @@ __global__ __launch_bounds__(256) void k_jump(const JumpState* __restrict__ in, 
             s.off = (1u << round) + t.off;
             changed++;
         }
-        s.minx = t.minx < s.minx ? t.minx : s.minx; s.miny = t.miny < s.miny ? t.miny : s.miny;
-        s.maxx = t.maxx > s.maxx ? t.maxx : s.maxx; s.maxy = t.maxy > s.maxy ? t.maxy : s.maxy;
         s.ptr = t.ptr;
         out[d] = s;
     }
-    // one counter update per wave
     for (int o = 32; o > 0; o >>= 1) changed += __shfl_down(changed, o);
     if ((threadIdx.x & 63) == 0 && changed) atomicAdd(&ctr->jump_changed[round], changed);
 }
@@ -256,21 +261,20 @@ __global__ __launch_bounds__(256) void k_resolve_eval(const JumpState* __restric
                                                       const uint32_t* __restrict__ d_xy, const uint8_t* __restrict__ d_info,
                                                       const uint8_t* __restrict__ d_F, const uint64_t* __restrict__ t_cur,
                                                       uint64_t* __restrict__ t_next, int iter, DeviceCounters* __restrict__ ctr) {
-    if (iter > 0 && ctr->resolve_changed == 0) return;
+    if (iter > 0 && ctr->resolve_changed[iter - 1] == 0) return;
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
         const uint8_t info = d_info[d];
         if (!(info & (kInfoW | kInfoE))) continue;
-        // an event dart must sit on an intact cycle, whose leader is its own leader (chains that end on an
-        // interior pixel belong to face cycles of the 8-neighbour graph and never carry events)
+        // an event dart must sit on an intact cycle, whose leader is its own leader (open chains never carry events)
         const uint32_t my_leader = (uint32_t)st[d].key;
         if ((uint32_t)st[my_leader].key != my_leader) { atomicOr(&ctr->err_flags, kErrBrokenEvent); continue; }
         const uint32_t xy = d_xy[d];
         const uint32_t x = xy & 0xFFFF, y = xy >> 16;
         const uint32_t q = y * (uint32_t)W + x;
-        const uint32_t F = d_F[d];
+        const uint32_t F = d_F[d], P = pdart_mask(F);
         const int k = info & 7;
-        const uint32_t base = d - __popc(F & ((1u << k) - 1u));
-        const int cnt = __popc(F);
+        const uint32_t base = d - __popc(P & ((1u << k) - 1u));
+        const int cnt = __popc(P);
         bool wfires = true;
         for (int i = 0; i < cnt; i++) {
             const uint32_t leader = (uint32_t)st[base + i].key;
@@ -286,12 +290,10 @@ __global__ __launch_bounds__(256) void k_resolve_eval(const JumpState* __restric
     }
 }
 
-// adopt T' as T, count the cycles whose start moved, clear T' for the next pass
+// adopt T' as T, count the cycles whose start moved (into this pass's slot), clear T' for the next pass
 __global__ void k_resolve_commit(const JumpState* __restrict__ st, uint32_t n_darts, uint64_t* __restrict__ t_cur,
-                                 uint64_t* __restrict__ t_next, int iter, DeviceCounters* __restrict__ ctr,
-                                 unsigned int* __restrict__ changed_out) {
-    // changed_out is a second counter so that every block sees a stable resolve_changed during this launch
-    if (iter > 0 && ctr->resolve_changed == 0) return;
+                                 uint64_t* __restrict__ t_next, int iter, int last, DeviceCounters* __restrict__ ctr) {
+    if (iter > 0 && ctr->resolve_changed[iter - 1] == 0) return;
     uint32_t changed = 0;
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
         if ((uint32_t)st[d].key != d) continue;
@@ -300,17 +302,10 @@ __global__ void k_resolve_commit(const JumpState* __restrict__ st, uint32_t n_da
         t_next[d] = kInf64;
     }
     for (int o = 32; o > 0; o >>= 1) changed += __shfl_down(changed, o);
-    if ((threadIdx.x & 63) == 0 && changed) atomicAdd(changed_out, changed);
-}
-
-__global__ void k_resolve_roll(DeviceCounters* __restrict__ ctr, unsigned int* __restrict__ changed_out, unsigned int* iters_done,
-                               int iter, int last) {
-    // single thread: publish this pass's count for the next pass's early-exit test
-    if (iter > 0 && ctr->resolve_changed == 0) return;
-    ctr->resolve_changed = *changed_out;
-    *changed_out = 0;
-    *iters_done = (unsigned int)iter + 1u;
-    if (last && ctr->resolve_changed != 0) atomicOr(&ctr->err_flags, kErrResolve);
+    if ((threadIdx.x & 63) == 0 && changed) {
+        atomicAdd(&ctr->resolve_changed[iter], changed);
+        if (last) atomicOr(&ctr->err_flags, kErrResolve);  // still moving after the last pass we are willing to run
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -319,7 +314,7 @@ __global__ void k_resolve_roll(DeviceCounters* __restrict__ ctr, unsigned int* _
 __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restrict__ st, uint32_t n_darts, const uint32_t* __restrict__ d_succ,
                                                       const uint64_t* __restrict__ t_cur, const uint32_t* __restrict__ frame_base,
                                                       uint32_t n_frames, uint32_t first_frame, uint32_t min_edge_length, double eps_factor,
-                                                      uint32_t* __restrict__ cyc_slot, ContourRec* __restrict__ contours,
+                                                      double image_diag, uint32_t* __restrict__ cyc_slot, ContourRec* __restrict__ contours,
                                                       uint32_t* __restrict__ cyc_start_off, uint32_t max_contours, uint64_t max_points,
                                                       DeviceCounters* __restrict__ ctr) {
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
@@ -333,21 +328,20 @@ __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restric
             const uint32_t sl = d_succ[d];
             if (sl == d || (uint32_t)st[sl].key != d) { atomicOr(&ctr->err_flags, kErrBrokenEvent); cyc_slot[d] = kNone; continue; }
             const uint32_t n = st[sl].off + 1u;
-            const uint32_t bw = s.maxx - s.minx, bh = s.maxy - s.miny;
-            const uint32_t diag2 = bw * bw + bh * bh;
-            // (1) every edge of a candidate has length^2 >= min_edge_length (src/aruco.rs:149-158) and joins two
-            //     border points, so diag2 must reach it; (2) Douglas-Peucker splits only when a point is further
-            //     than eps = eps_factor*n from a chord, and no point is further than the box diagonal (+1 slack).
+            // Parity-safe pruning (src/aruco.rs:133-158):
+            //  (1) a candidate keeps 4 points whose hull-adjacent pairs are >= sqrt(min_edge_length) apart; two border
+            //      points i < j are at most min(j-i, n-(j-i)) 8-connected steps apart, i.e. dist^2 <= 2*(n/2)^2, so
+            //      n^2 >= 2*min_edge_length is necessary;
+            //  (2) Douglas-Peucker splits only when a point is further than eps = eps_factor*n from a chord, and no two
+            //      pixels are further apart than the image diagonal (+1 slack for rounding).
             const double eps = (double)n * eps_factor;
-            const bool can_split = eps < sqrt((double)diag2) + 1.0;
-            if (n >= 4u && diag2 >= min_edge_length && can_split) {
+            if (n >= 5u && (uint64_t)n * n >= 2ull * min_edge_length && eps < image_diag + 1.0) {
                 const uint32_t c = atomicAdd(&ctr->contours, 1u);
                 const unsigned long long pbase = atomicAdd(&ctr->points, (unsigned long long)n);
                 if (c >= max_contours) atomicOr(&ctr->err_flags, kErrContourTable);
                 else if (pbase + n > max_points) atomicOr(&ctr->err_flags, kErrPointPool);
                 else {
-                    // frame of this dart: binary search in frame_base
-                    uint32_t lo = 0, hi = n_frames;
+                    uint32_t lo = 0, hi = n_frames;  // frame of this dart: binary search in frame_base
                     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (frame_base[mid] <= d) lo = mid; else hi = mid; }
                     ContourRec r;
                     r.frame = first_frame + lo;
@@ -369,7 +363,9 @@ __global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restr
                                                         const uint32_t* __restrict__ cyc_start_off, uint32_t* __restrict__ points) {
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
         const JumpState s = st[d];
-        const uint32_t c = cyc_slot[(uint32_t)s.key];
+        const uint32_t leader = (uint32_t)s.key;
+        if ((uint32_t)st[leader].key != leader) continue;  // open chain: its "leader" slot was never written
+        const uint32_t c = cyc_slot[leader];
         if (c == kNone) continue;
         const ContourRec r = contours[c];
         const uint32_t so = cyc_start_off[c];
@@ -511,6 +507,14 @@ __global__ __launch_bounds__(256) void k_contour_quads(const ContourRec* __restr
     }
 }
 
+// expand the packed thresholded image to 0/255 bytes (debug tap a3_download_thresholded)
+__global__ void k_unpack_bits(const uint64_t* __restrict__ bits, int W, int H, uint8_t* __restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const int wpr = (int)words_per_row((uint32_t)W);
+    out[(size_t)y * W + x] = ((bits[(size_t)y * wpr + (x >> 6)] >> (x & 63)) & 1ull) ? 255 : 0;
+}
+
 // ---------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------
@@ -521,23 +525,22 @@ static inline int blocks_for(uint64_t n, int per_block, int cap) {
     return (int)b;
 }
 
-hipError_t launch_dart_count(hipStream_t st, const uint8_t* bin, int W, int H, uint32_t first_frame, uint32_t n_frames,
+hipError_t launch_dart_count(hipStream_t st, const uint64_t* bits, int W, int H, uint32_t first_frame, uint32_t n_frames,
                              unsigned long long* frame_darts) {
-    const int aligned = (W % 4 == 0) && ((uintptr_t)bin % 4 == 0);
-    dim3 grid((W + 255) / 256, (H + 3) / 4, n_frames), block(256);
-    hipLaunchKernelGGL(k_dart_count, grid, block, 0, st, bin, W, H, first_frame, aligned, frame_darts);
+    const uint32_t words = words_per_row((uint32_t)W) * (uint32_t)H;
+    hipLaunchKernelGGL(k_dart_count, dim3((words + 255) / 256, n_frames), dim3(256), 0, st, bits, W, H, first_frame, frame_darts);
     return hipGetLastError();
 }
 
-hipError_t launch_dart_build(hipStream_t st, const uint8_t* bin, int W, int H, uint32_t first_frame, uint32_t n_frames,
-                             const uint32_t* frame_base, uint32_t* frame_cursor, uint32_t* pix_base, uint32_t* d_xy, uint8_t* d_info,
-                             uint8_t* d_F, uint32_t* d_succ, JumpState* st0, uint32_t n_darts) {
-    const int aligned = (W % 4 == 0) && ((uintptr_t)bin % 4 == 0);
-    dim3 grid((W + 255) / 256, (H + 3) / 4, n_frames), block(256);
-    hipLaunchKernelGGL(k_dart_assign, grid, block, 0, st, bin, W, H, first_frame, aligned, frame_base, frame_cursor, pix_base, d_xy, d_info, d_F);
+hipError_t launch_dart_build(hipStream_t st, const uint64_t* bits, int W, int H, uint32_t first_frame, uint32_t n_frames,
+                             const uint32_t* frame_base, uint32_t* frame_cursor, uint32_t* pix_base, uint64_t* node_bits, uint32_t* d_xy,
+                             uint8_t* d_info, uint8_t* d_F, uint32_t* d_succ, JumpState* st0, uint32_t n_darts) {
+    const uint32_t words = words_per_row((uint32_t)W) * (uint32_t)H;
+    hipLaunchKernelGGL(k_dart_assign, dim3((words + 255) / 256, n_frames), dim3(256), 0, st, bits, W, H, first_frame, frame_base, frame_cursor,
+                       pix_base, node_bits, d_xy, d_info, d_F);
     const uint32_t per_frame = n_frames ? (n_darts + n_frames - 1) / n_frames : 0;
-    dim3 lgrid(blocks_for(per_frame, 256, 1024), n_frames);
-    hipLaunchKernelGGL(k_dart_link, lgrid, block, 0, st, bin, W, H, first_frame, frame_base, pix_base, d_xy, d_info, d_F, d_succ, st0);
+    hipLaunchKernelGGL(k_dart_link, dim3(blocks_for(per_frame, 256, 1024), n_frames), dim3(256), 0, st, W, H, frame_base, pix_base, node_bits,
+                       d_xy, d_info, d_F, d_succ, st0);
     return hipGetLastError();
 }
 
@@ -547,25 +550,23 @@ hipError_t launch_jump(hipStream_t st, const JumpState* in, JumpState* out, uint
 }
 
 hipError_t launch_resolve(hipStream_t st, const JumpState* fin, uint32_t n_darts, int W, const uint32_t* d_xy, const uint8_t* d_info,
-                          const uint8_t* d_F, uint64_t* t_cur, uint64_t* t_next, DeviceCounters* ctr, unsigned int* changed_tmp,
-                          unsigned int* iters_done, int max_iters) {
+                          const uint8_t* d_F, uint64_t* t_cur, uint64_t* t_next, DeviceCounters* ctr, int max_iters) {
     const dim3 grid(blocks_for(n_darts, 256, 4096)), block(256);
     hipLaunchKernelGGL(k_resolve_init, grid, block, 0, st, fin, n_darts, t_cur, t_next);
     for (int it = 0; it < max_iters; it++) {
         hipLaunchKernelGGL(k_resolve_eval, grid, block, 0, st, fin, n_darts, W, d_xy, d_info, d_F, t_cur, t_next, it, ctr);
-        hipLaunchKernelGGL(k_resolve_commit, grid, block, 0, st, fin, n_darts, t_cur, t_next, it, ctr, changed_tmp);
-        hipLaunchKernelGGL(k_resolve_roll, dim3(1), dim3(1), 0, st, ctr, changed_tmp, iters_done, it, it == max_iters - 1);
+        hipLaunchKernelGGL(k_resolve_commit, grid, block, 0, st, fin, n_darts, t_cur, t_next, it, it == max_iters - 1 ? 1 : 0, ctr);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_select_scatter(hipStream_t st, const JumpState* fin, uint32_t n_darts, const uint32_t* d_succ, const uint64_t* t_cur,
                                  const uint32_t* frame_base, uint32_t n_frames, uint32_t first_frame, uint32_t min_edge_length,
-                                 double eps_factor, uint32_t* cyc_slot, ContourRec* contours, uint32_t* cyc_start_off, uint32_t max_contours,
-                                 uint64_t max_points, DeviceCounters* ctr, const uint32_t* d_xy, uint32_t* points) {
+                                 double eps_factor, double image_diag, uint32_t* cyc_slot, ContourRec* contours, uint32_t* cyc_start_off,
+                                 uint32_t max_contours, uint64_t max_points, DeviceCounters* ctr, const uint32_t* d_xy, uint32_t* points) {
     const dim3 grid(blocks_for(n_darts, 256, 4096)), block(256);
     hipLaunchKernelGGL(k_cycle_select, grid, block, 0, st, fin, n_darts, d_succ, t_cur, frame_base, n_frames, first_frame, min_edge_length,
-                       eps_factor, cyc_slot, contours, cyc_start_off, max_contours, max_points, ctr);
+                       eps_factor, image_diag, cyc_slot, contours, cyc_start_off, max_contours, max_points, ctr);
     hipLaunchKernelGGL(k_scatter_points, grid, block, 0, st, fin, n_darts, d_xy, cyc_slot, contours, cyc_start_off, points);
     return hipGetLastError();
 }
@@ -575,6 +576,11 @@ hipError_t launch_contour_quads(hipStream_t st, const ContourRec* contours, cons
                                 CandRec* cands, uint32_t* cand_count, unsigned int* err_flags) {
     hipLaunchKernelGGL(k_contour_quads, dim3(1024), dim3(256), 0, st, contours, ctr, max_contours, points, eps_factor, min_edge_length,
                        first_frame, max_cand, cands, cand_count, err_flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_bits(hipStream_t st, const uint64_t* bits, int W, int H, uint8_t* out) {
+    hipLaunchKernelGGL(k_unpack_bits, dim3((W + 255) / 256, H), dim3(256), 0, st, bits, W, H, out);
     return hipGetLastError();
 }
 

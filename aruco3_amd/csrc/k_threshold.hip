@@ -7,7 +7,8 @@
 //   white iff L >= floor(sum / area) over the window clipped to the image
 //         <=> sum < (L + 1) * area                        (no division)
 //
-// HBM-bound: 3 B read + 1 B grey + 1 B binary per pixel (RGB8).  One 256-thread workgroup
+// HBM-bound: 3 B read + 1 B grey + 1/8 B binary per pixel (RGB8): the thresholded image leaves the kernel
+// bit-packed (a3_common.h: words_per_row), which is all the contour stage reads.  One 256-thread workgroup
 // produces a 240 x 64 tile: 78 rows x 256 columns of pixels are loaded once with 12-byte
 // (4-pixel) lane loads, one wave-instruction per image row segment, converted to grey
 // bytes in LDS; a separable box sum follows -- horizontal 15-tap sums as u16 (24 bytes in,
@@ -70,7 +71,7 @@ __device__ __forceinline__ uint32_t load_grey4(const uint8_t* __restrict__ frame
 
 template <int FMT>
 __global__ __launch_bounds__(256) void k_grey_threshold7(const uint8_t* __restrict__ pixels, size_t row_stride, size_t frame_stride,
-                                                         int W, int H, uint8_t* __restrict__ grey, uint8_t* __restrict__ bin,
+                                                         int W, int H, uint8_t* __restrict__ grey, uint8_t* __restrict__ bits,
                                                          int aligned_in, int aligned_out) {
     __shared__ __attribute__((aligned(16))) uint8_t s_g[T_LH][T_LW];
     __shared__ __attribute__((aligned(16))) uint16_t s_h[T_LH][T_G][8];
@@ -80,7 +81,8 @@ __global__ __launch_bounds__(256) void k_grey_threshold7(const uint8_t* __restri
     const uint32_t f = blockIdx.z;
     const uint8_t* frame = pixels + (size_t)f * frame_stride;
     uint8_t* gout = grey + (size_t)f * W * H;
-    uint8_t* bout = bin + (size_t)f * W * H;
+    const size_t bpr = (size_t)words_per_row((uint32_t)W) * 8;  // bytes per packed row
+    uint8_t* bout = bits + (size_t)f * bpr * H;
 
     // ---- phase A: load + convert; lane l of a wave owns columns 4l..4l+3 of one loaded row ----
     const int lane_c = (tid & 63) * 4;
@@ -160,18 +162,13 @@ __global__ __launch_bounds__(256) void k_grey_threshold7(const uint8_t* __restri
                 const uint64_t gq = *reinterpret_cast<const uint64_t*>(&s_g[rr + T_R][8 + 8 * j]);
                 const uint32_t sums[8] = {acc.x & 0xFFFFu, acc.x >> 16, acc.y & 0xFFFFu, acc.y >> 16,
                                           acc.z & 0xFFFFu, acc.z >> 16, acc.w & 0xFFFFu, acc.w >> 16};
-                uint64_t outq = 0;
+                uint32_t outb = 0;
 #pragma unroll
                 for (int p = 0; p < 8; p++) {
                     uint32_t gv = (uint32_t)(gq >> (8 * p)) & 255u;
-                    if (sums[p] < (gv + 1u) * (ax[p] * ay)) outq |= (uint64_t)255u << (8 * p);
+                    if (sums[p] < (gv + 1u) * (ax[p] * ay)) outb |= 1u << p;   // ax == 0 past the right edge: stays 0
                 }
-                uint8_t* dst = bout + (size_t)y * W + xb;
-                if (aligned_out && xb + 7 < W) *reinterpret_cast<uint64_t*>(dst) = outq;
-                else {
-#pragma unroll
-                    for (int p = 0; p < 8; p++) if (xb + p < W) dst[p] = (uint8_t)(outq >> (8 * p));
-                }
+                bout[(size_t)y * bpr + (xb >> 3)] = (uint8_t)outb;
             }
         }
     }
@@ -189,28 +186,39 @@ __global__ void k_grey_generic(const uint8_t* __restrict__ pixels, size_t row_st
     for (int i = 0; i < 4; i++) if (x4 + i < W) dst[i] = (uint8_t)(g4 >> (8 * i));
 }
 
-__global__ void k_threshold_generic(const uint8_t* __restrict__ grey, int W, int H, int radius, uint8_t* __restrict__ bin) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= W) return;
+// one wave per packed word: 64 consecutive pixels, result gathered with a ballot
+__global__ __launch_bounds__(64) void k_threshold_generic(const uint8_t* __restrict__ grey, int W, int H, int radius, uint64_t* __restrict__ bits) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y;
     const uint8_t* g = grey + (size_t)blockIdx.z * W * H;
-    const int ylo = y > radius ? y - radius : 0, yhi = (long long)y + radius < H - 1 ? y + radius : H - 1;
-    const int xlo = x > radius ? x - radius : 0, xhi = (long long)x + radius < W - 1 ? x + radius : W - 1;
-    unsigned long long sum = 0;
-    for (int yy = ylo; yy <= yhi; yy++)
-        for (int xx = xlo; xx <= xhi; xx++) sum += g[(size_t)yy * W + xx];
-    const unsigned long long area = (unsigned long long)(yhi - ylo + 1) * (unsigned long long)(xhi - xlo + 1);
-    const unsigned long long gv = g[(size_t)y * W + x];
-    bin[(size_t)blockIdx.z * W * H + (size_t)y * W + x] = sum < (gv + 1) * area ? 255 : 0;
+    bool white = false;
+    if (x < W) {
+        const int ylo = y > radius ? y - radius : 0, yhi = (long long)y + radius < H - 1 ? y + radius : H - 1;
+        const int xlo = x > radius ? x - radius : 0, xhi = (long long)x + radius < W - 1 ? x + radius : W - 1;
+        unsigned long long sum = 0;
+        for (int yy = ylo; yy <= yhi; yy++)
+            for (int xx = xlo; xx <= xhi; xx++) sum += g[(size_t)yy * W + xx];
+        const unsigned long long area = (unsigned long long)(yhi - ylo + 1) * (unsigned long long)(xhi - xlo + 1);
+        const unsigned long long gv = g[(size_t)y * W + x];
+        white = sum < (gv + 1) * area;
+    }
+    const unsigned long long m = __ballot(white);
+    const size_t wpr = words_per_row((uint32_t)W);
+    if (threadIdx.x == 0) bits[(size_t)blockIdx.z * wpr * H + (size_t)y * wpr + blockIdx.x] = m;
 }
 
 // ---- host launcher -------------------------------------------------------------------------
 hipError_t launch_grey_threshold(hipStream_t st, const uint8_t* pixels, int fmt, size_t row_stride, size_t frame_stride, int W, int H,
-                                 uint32_t n, uint32_t radius, uint8_t* grey, uint8_t* bin) {
+                                 uint32_t n, uint32_t radius, uint8_t* grey, uint64_t* bits) {
     if (radius == (uint32_t)T_R) {
         const int bpp = fmt == A3_FMT_RGB8 ? 3 : (fmt == A3_FMT_RGBA8 ? 4 : 1);
         const size_t need = bpp == 3 ? 4 : (bpp == 4 ? 16 : 4);
         const int aligned_in = ((uintptr_t)pixels % need == 0) && (row_stride % need == 0) && (frame_stride % need == 0);
-        const int aligned_out = (W % 8 == 0) && ((uintptr_t)grey % 8 == 0) && ((uintptr_t)bin % 8 == 0);
+        const int aligned_out = (W % 4 == 0) && ((uintptr_t)grey % 4 == 0);
+        uint8_t* bin = reinterpret_cast<uint8_t*>(bits);
+        if (W % 64 != 0) {  // packed rows end in padding bits that no tile writes
+            hipError_t e = hipMemsetAsync(bits, 0, (size_t)words_per_row((uint32_t)W) * 8 * H * n, st);
+            if (e != hipSuccess) return e;
+        }
         dim3 grid((W + T_TW - 1) / T_TW, (H + T_TH - 1) / T_TH, n), block(256);
         if (fmt == A3_FMT_RGB8)
             hipLaunchKernelGGL(k_grey_threshold7<A3_FMT_RGB8>, grid, block, 0, st, pixels, row_stride, frame_stride, W, H, grey, bin, aligned_in, aligned_out);
@@ -220,11 +228,11 @@ hipError_t launch_grey_threshold(hipStream_t st, const uint8_t* pixels, int fmt,
             hipLaunchKernelGGL(k_grey_threshold7<A3_FMT_L8>, grid, block, 0, st, pixels, row_stride, frame_stride, W, H, grey, bin, aligned_in, aligned_out);
         return hipGetLastError();
     }
-    dim3 block(64), grid4(((W + 3) / 4 + 63) / 64, H, n), grid1((W + 63) / 64, H, n);
+    dim3 block(64), grid4(((W + 3) / 4 + 63) / 64, H, n), grid1(words_per_row((uint32_t)W), H, n);
     if (fmt == A3_FMT_RGB8) hipLaunchKernelGGL(k_grey_generic<A3_FMT_RGB8>, grid4, block, 0, st, pixels, row_stride, frame_stride, W, H, grey);
     else if (fmt == A3_FMT_RGBA8) hipLaunchKernelGGL(k_grey_generic<A3_FMT_RGBA8>, grid4, block, 0, st, pixels, row_stride, frame_stride, W, H, grey);
     else hipLaunchKernelGGL(k_grey_generic<A3_FMT_L8>, grid4, block, 0, st, pixels, row_stride, frame_stride, W, H, grey);
-    hipLaunchKernelGGL(k_threshold_generic, grid1, block, 0, st, grey, W, H, (int)radius, bin);
+    hipLaunchKernelGGL(k_threshold_generic, grid1, block, 0, st, grey, W, H, (int)radius, bits);
     return hipGetLastError();
 }
 

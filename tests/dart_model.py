@@ -25,6 +25,15 @@ DY = [0, -1, -1, -1, 0, 1, 1, 1]
 INF = 1 << 62
 
 
+def pdart_mask(F: int) -> int:
+    """Directions k whose dart (p,k) can lie on a real border: neighbour k foreground, neighbour k-1 background
+    (the counter-clockwise sweep is not empty) and, for a 4-neighbour direction (k even), neighbour k-2 background
+    too -- otherwise the dart only belongs to a triangular face cycle of the 8-neighbour graph."""
+    rot1 = ((F << 1) | (F >> 7)) & 0xFF
+    rot2 = ((F << 2) | (F >> 6)) & 0xFF
+    return F & ~rot1 & (0xAA | ~rot2) & 0xFF
+
+
 def contours_by_darts(binary: np.ndarray, max_iter: int = 64, node_rule: str = "any8"):
     """-> (list of contours as lists of (x, y), stats dict), same order/rotation as find_contours."""
     h, w = binary.shape
@@ -49,6 +58,8 @@ def contours_by_darts(binary: np.ndarray, max_iter: int = 64, node_rule: str = "
             return False
         if node_rule == "any8":
             return F[y, x] != 0xFF
+        if node_rule == "pdart":
+            return pdart_mask(int(F[y, x])) != 0
         # "border4": at least one background / out-of-image 4-neighbour
         return (F[y, x] & 0b01010101) != 0b01010101
 
@@ -57,8 +68,9 @@ def contours_by_darts(binary: np.ndarray, max_iter: int = 64, node_rule: str = "
     for y in range(h):
         for x in range(w):
             if is_node(x, y):
+                dmask = pdart_mask(int(F[y, x])) if node_rule == "pdart" else int(F[y, x])
                 for k in range(8):
-                    if F[y, x] >> k & 1:
+                    if dmask >> k & 1:
                         darts[(x, y, k)] = len(dart_list)
                         dart_list.append((x, y, k))
     n = len(dart_list)

@@ -51,7 +51,7 @@ def _images(rng, count):
         yield img.astype(np.uint8) * 255
 
 
-@pytest.mark.parametrize("rule", ["any8", "border4"])
+@pytest.mark.parametrize("rule", ["any8", "border4", "pdart"])
 def test_dart_cycles_equal_sequential_border_following(oracle, rule):
     rng = np.random.default_rng(20261003)
     resolved = 0
