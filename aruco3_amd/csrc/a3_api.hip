@@ -16,8 +16,10 @@ hipError_t launch_grey_threshold(hipStream_t, const uint8_t*, int, size_t, size_
 // k_contours.hip
 hipError_t launch_dart_count(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, unsigned long long*);
 hipError_t launch_dart_build(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, const uint32_t*, uint32_t*, uint32_t*, uint64_t*,
-                             uint32_t*, uint8_t*, uint8_t*, uint32_t*, JumpState*, uint32_t);
-hipError_t launch_jump(hipStream_t, const JumpState*, JumpState*, uint32_t, int, DeviceCounters*);
+                             uint32_t*, uint8_t*, uint8_t*, uint32_t*, uint32_t);
+size_t entry_state_bytes();
+hipError_t launch_rank_cycles(hipStream_t, uint32_t, int, const uint32_t*, const uint8_t*, const uint32_t*, JumpState*, uint32_t*, uint32_t*,
+                              uint32_t*, uint32_t*, unsigned int*, void*, void*, JumpState*, int, DeviceCounters*);
 hipError_t launch_resolve(hipStream_t, const JumpState*, uint32_t, int, const uint32_t*, const uint8_t*, const uint8_t*, uint64_t*, uint64_t*,
                           DeviceCounters*, int);
 hipError_t launch_select_scatter(hipStream_t, const JumpState*, uint32_t, const uint32_t*, const uint64_t*, const uint32_t*, uint32_t, uint32_t,
@@ -96,6 +98,7 @@ struct a3_ctx {
 
     DevBuf dict, in, grey, bin, frame_darts, frame_base, frame_cursor, pix_base, node_bits;
     DevBuf d_xy, d_info, d_F, d_succ, stA, stB, t_cur, t_next, cyc_slot;
+    DevBuf loc_dist, entry_bits, entry_list, entry_pos, es_a, es_b;
     DevBuf contours, cyc_start_off, points, counters, scratch_u32;
     DevBuf cands, cand_count, pre_xy, fin_xy, fin_count, work, outs, patches, markers, per_frame;
     DevBuf tmp_a, tmp_b, tmp_c, tmp_d;
@@ -142,6 +145,14 @@ int ensure_dart_pool(a3_ctx* ctx, uint64_t darts) {
     A3_HIP(ctx->t_cur.ensure(darts * 8));
     A3_HIP(ctx->t_next.ensure(darts * 8));
     A3_HIP(ctx->cyc_slot.ensure(darts * 4));
+    A3_HIP(ctx->loc_dist.ensure(darts * 4));
+    A3_HIP(ctx->entry_bits.ensure((darts + 31) / 32 * 4 + 4));
+    A3_HIP(ctx->entry_list.ensure(darts * 4));
+    A3_HIP(ctx->entry_pos.ensure(darts * 4));
+    // entries are darts whose predecessor lies in another 2048-dart tile; the bound darts is never reached in practice,
+    // but an adversarial image can come close, so size for it
+    A3_HIP(ctx->es_a.ensure(darts * entry_state_bytes()));
+    A3_HIP(ctx->es_b.ensure(darts * entry_state_bytes()));
     return A3_OK;
 }
 
@@ -219,6 +230,7 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     unsigned int* d_work_count = ctx->scratch_u32.as<unsigned int>() + 0;
     unsigned int* d_marker_total = ctx->scratch_u32.as<unsigned int>() + 1;
     unsigned int* d_err = ctx->scratch_u32.as<unsigned int>() + 4;
+    unsigned int* d_entry_count = ctx->scratch_u32.as<unsigned int>() + 5;
 
     // frame bases of every chunk, uploaded once
     std::vector<uint32_t> bases;
@@ -247,17 +259,16 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
         if (nd == 0) continue;
         A3_HIP(hipMemsetAsync(ctx->frame_cursor.p, 0, (size_t)c.count * 4, st));
         A3_HIP(launch_dart_build(st, d_bin, (int)W, (int)H, c.first, c.count, fb, ctx->frame_cursor.as<uint32_t>(), ctx->pix_base.as<uint32_t>(),
-                                 ctx->node_bits.as<uint64_t>(), ctx->d_xy.as<uint32_t>(), ctx->d_info.as<uint8_t>(), ctx->d_F.as<uint8_t>(), ctx->d_succ.as<uint32_t>(),
-                                 ctx->stA.as<JumpState>(), nd));
+                                 ctx->node_bits.as<uint64_t>(), ctx->d_xy.as<uint32_t>(), ctx->d_info.as<uint8_t>(), ctx->d_F.as<uint8_t>(), ctx->d_succ.as<uint32_t>(), nd));
         int rounds = 1;
         while ((1ull << rounds) < (uint64_t)c.max_frame_darts && rounds < 31) rounds++;
         rounds += 1;  // the round that observes "nothing moved"
         rounds_max = std::max(rounds_max, rounds);
-        JumpState* a = ctx->stA.as<JumpState>();
-        JumpState* b = ctx->stB.as<JumpState>();
-        for (int r = 0; r < rounds; r++) { A3_HIP(launch_jump(st, a, b, nd, r, ctr)); std::swap(a, b); }
-        // both buffers are final once converged; the last round always is the observing one, so `a` (last written or skipped) is valid
-        const JumpState* fin = a;
+        A3_HIP(launch_rank_cycles(st, nd, (int)W, ctx->d_xy.as<uint32_t>(), ctx->d_info.as<uint8_t>(), ctx->d_succ.as<uint32_t>(),
+                                  ctx->stA.as<JumpState>(), ctx->loc_dist.as<uint32_t>(), ctx->entry_bits.as<uint32_t>(),
+                                  ctx->entry_list.as<uint32_t>(), ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
+                                  ctx->stB.as<JumpState>(), rounds, ctr));
+        const JumpState* fin = ctx->stB.as<JumpState>();
         A3_HIP(launch_resolve(st, fin, nd, (int)W, ctx->d_xy.as<uint32_t>(), ctx->d_info.as<uint8_t>(), ctx->d_F.as<uint8_t>(),
                               ctx->t_cur.as<uint64_t>(), ctx->t_next.as<uint64_t>(), ctr, kResolveIters));
         A3_HIP(launch_select_scatter(st, fin, nd, ctx->d_succ.as<uint32_t>(), ctx->t_cur.as<uint64_t>(), fb, c.count, c.first, min_edge_length,
@@ -420,6 +431,7 @@ void a3_destroy(a3_ctx* ctx) {
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     DevBuf* bufs[] = {&ctx->dict, &ctx->in, &ctx->grey, &ctx->bin, &ctx->frame_darts, &ctx->frame_base, &ctx->frame_cursor, &ctx->pix_base,
                       &ctx->node_bits, &ctx->d_xy, &ctx->d_info, &ctx->d_F, &ctx->d_succ, &ctx->stA, &ctx->stB, &ctx->t_cur, &ctx->t_next, &ctx->cyc_slot,
+                      &ctx->loc_dist, &ctx->entry_bits, &ctx->entry_list, &ctx->entry_pos, &ctx->es_a, &ctx->es_b,
                       &ctx->contours, &ctx->cyc_start_off, &ctx->points, &ctx->counters, &ctx->scratch_u32, &ctx->cands, &ctx->cand_count,
                       &ctx->pre_xy, &ctx->fin_xy, &ctx->fin_count, &ctx->work, &ctx->outs, &ctx->patches, &ctx->markers, &ctx->per_frame,
                       &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_d};

@@ -91,15 +91,29 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* s_
     return base + inc - v;
 }
 
-// grid: (ceil(wpr*H/256), frames).  One packed word (64 pixels) per lane.
+// One packed word (64 pixels) per lane; a workgroup covers a compact tile of 4 words x 64 rows (256 x 64 pixels) so
+// that the darts it creates -- which get consecutive indices -- are neighbours in the image: successor pointers then
+// mostly stay inside a small index range, which k_local_contract exploits.
+constexpr int kTileWords = 4, kTileRows = 64;
+__host__ __device__ inline uint32_t dart_tiles_x(uint32_t W) { return (words_per_row(W) + kTileWords - 1) / kTileWords; }
+__host__ __device__ inline uint32_t dart_tiles(uint32_t W, uint32_t H) { return dart_tiles_x(W) * ((H + kTileRows - 1) / kTileRows); }
+
+__device__ __forceinline__ bool tile_word(int W, int H, int* j, int* y) {
+    const int tx = blockIdx.x % dart_tiles_x((uint32_t)W), ty = blockIdx.x / dart_tiles_x((uint32_t)W);
+    *j = tx * kTileWords + (threadIdx.x & (kTileWords - 1));
+    *y = ty * kTileRows + (threadIdx.x >> 2);
+    return *j < (int)words_per_row((uint32_t)W) && *y < H;
+}
+
+// grid: (dart_tiles(W,H), frames)
 __global__ __launch_bounds__(256) void k_dart_count(const uint64_t* __restrict__ bits, int W, int H, uint32_t first_frame,
                                                     unsigned long long* __restrict__ frame_darts) {
     __shared__ uint32_t s_wave[4];
     const int wpr = (int)words_per_row((uint32_t)W);
-    const uint32_t wi = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    const uint32_t f = blockIdx.y;
     uint32_t nd = 0;
-    if (wi < (uint32_t)(wpr * H)) {
-        const int y = wi / wpr, j = wi - y * wpr;
+    int j, y;
+    if (tile_word(W, H, &j, &y)) {
         const Nb8 nb = load_nb8(bits + (size_t)(first_frame + f) * wpr * H, wpr, H, j, y);
         if (nb.c) {
             uint64_t p[8];
@@ -122,9 +136,10 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_base;
     const int wpr = (int)words_per_row((uint32_t)W);
-    const uint32_t wi = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
-    const bool active = wi < (uint32_t)(wpr * H);
-    const int y = active ? wi / wpr : 0, j = active ? wi - y * wpr : 0;
+    const uint32_t f = blockIdx.y;
+    int j, y;
+    const bool active = tile_word(W, H, &j, &y);
+    const uint32_t wi = active ? (uint32_t)(y * wpr + j) : 0u;
     Nb8 nb;
     nb.c = 0;
     uint64_t p[8];
@@ -177,8 +192,7 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
 __global__ __launch_bounds__(256) void k_dart_link(int W, int H, const uint32_t* __restrict__ frame_base,
                                                    const uint32_t* __restrict__ pix_base, const uint64_t* __restrict__ node_bits,
                                                    const uint32_t* __restrict__ d_xy, uint8_t* __restrict__ d_info,
-                                                   const uint8_t* __restrict__ d_F, uint32_t* __restrict__ d_succ,
-                                                   JumpState* __restrict__ st) {
+                                                   const uint8_t* __restrict__ d_F, uint32_t* __restrict__ d_succ) {
     const uint32_t f = blockIdx.y;
     const uint32_t lo = frame_base[f], hi = frame_base[f + 1];
     const int wpr = (int)words_per_row((uint32_t)W);
@@ -204,36 +218,136 @@ __global__ __launch_bounds__(256) void k_dart_link(int W, int H, const uint32_t*
         }
         if (succ == d) { info |= kInfoBroken; d_info[d] = info; }
         d_succ[d] = succ;
-        const uint32_t q = (uint32_t)y * (uint32_t)W + (uint32_t)x;
-        const uint32_t ek = (info & kInfoW) ? 2u * q : ((info & kInfoE) ? 2u * q + 1u : kNoKey);
-        JumpState s;
-        s.key = ((uint64_t)ek << 32) | d;
-        s.ptr = succ;
-        s.off = 0;
-        st[d] = s;
     }
 }
 
-// one pointer-doubling round: window [d, d + 2^round) -> [d, d + 2^(round+1))
-__global__ __launch_bounds__(256) void k_jump(const JumpState* __restrict__ in, JumpState* __restrict__ out, uint32_t n_darts,
-                                              int round, DeviceCounters* __restrict__ ctr) {
-    // Converged in an earlier round (no key moved): key/off of BOTH ping-pong buffers are final, so later rounds do
-    // nothing and the consumers may read either buffer.
-    if (round > 0 && ctr->jump_changed[round - 1] == 0) return;
-    uint32_t changed = 0;
-    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
-        JumpState s = in[d];
-        const JumpState t = in[s.ptr];
-        if (t.key < s.key) {
-            s.key = t.key;
-            s.off = (1u << round) + t.off;
-            changed++;
+// ---------------------------------------------------------------------------------------
+// cycle leaders and ranks: pointer doubling, first inside LDS tiles, then over tile-crossing darts only
+// ---------------------------------------------------------------------------------------
+// A window is a path [d, ptr): `dist` hops long, `key` = smallest (event key, dart) on it, `off` = hops from d to that
+// dart.  Joining window(d) with window(ptr) doubles the path; once a window wraps a whole cycle its key is the cycle's
+// leader and off the hop distance to it.
+constexpr int kLT = 2048;                     // darts per local tile (consecutive indices = neighbouring pixels)
+constexpr uint32_t kFrozen = 0x80000000u;     // dist flag: the window reached a dart outside the tile
+
+// Phase 1: 11 doubling rounds inside one tile, entirely in LDS.  A window stops growing ("freezes") when its end leaves
+// the tile; cycles that close inside the tile finish here.  Darts that some frozen window ends on become "entries".
+__global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W, const uint32_t* __restrict__ d_xy,
+                                                        const uint8_t* __restrict__ d_info, const uint32_t* __restrict__ d_succ,
+                                                        JumpState* __restrict__ loc, uint32_t* __restrict__ loc_dist,
+                                                        uint32_t* __restrict__ entry_bits, uint32_t* __restrict__ entry_list,
+                                                        uint32_t* __restrict__ entry_pos, unsigned int* __restrict__ entry_count) {
+    __shared__ uint64_t s_key[kLT];
+    __shared__ uint32_t s_ptr[kLT], s_off[kLT], s_dist[kLT];
+    const uint32_t lo = blockIdx.x * kLT;
+    const uint32_t cnt = min((uint32_t)kLT, n_darts - lo);
+    for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
+        const uint32_t d = lo + i;
+        const uint32_t xy = d_xy[d];
+        const uint8_t info = d_info[d];
+        const uint32_t q = (xy >> 16) * (uint32_t)W + (xy & 0xFFFF);
+        const uint32_t ek = (info & kInfoW) ? 2u * q : ((info & kInfoE) ? 2u * q + 1u : kNoKey);
+        s_key[i] = ((uint64_t)ek << 32) | d;
+        s_ptr[i] = d_succ[d];
+        s_off[i] = 0;
+        s_dist[i] = 1;
+    }
+    __syncthreads();
+    constexpr int PER = kLT / 256;
+    for (int round = 0; round < 11; round++) {
+        uint64_t nk[PER]; uint32_t np[PER], no[PER], nd[PER];
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const uint32_t i = threadIdx.x + u * 256;
+            if (i < cnt) {
+                nk[u] = s_key[i]; np[u] = s_ptr[i]; no[u] = s_off[i]; nd[u] = s_dist[i];
+                const uint32_t t = np[u] - lo;          // unsigned: also catches ptr < lo
+                if (t < cnt) {
+                    const uint64_t tk = s_key[t];
+                    if (tk < nk[u]) { nk[u] = tk; no[u] = nd[u] + s_off[t]; }
+                    nd[u] += s_dist[t];
+                    np[u] = s_ptr[t];
+                }
+            }
         }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const uint32_t i = threadIdx.x + u * 256;
+            if (i < cnt) { s_key[i] = nk[u]; s_ptr[i] = np[u]; s_off[i] = no[u]; s_dist[i] = nd[u]; }
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
+        const uint32_t d = lo + i;
+        const uint32_t e = s_ptr[i];
+        const bool frozen = (e - lo) >= cnt;
+        JumpState r;
+        r.key = s_key[i]; r.ptr = e; r.off = s_off[i];
+        loc[d] = r;
+        loc_dist[d] = s_dist[i] | (frozen ? kFrozen : 0u);
+        if (frozen) {
+            const uint32_t bit = 1u << (e & 31);
+            if (!(atomicOr(&entry_bits[e >> 5], bit) & bit)) {
+                const uint32_t slot = atomicAdd(entry_count, 1u);
+                entry_list[slot] = e;
+                entry_pos[e] = slot;
+            }
+        }
+    }
+}
+
+struct __attribute__((aligned(8))) EntryState { uint64_t key; uint32_t ptr; uint32_t off; uint32_t dist; uint32_t pad; };
+
+// Phase 2 set-up: the reduced list over entries.  An entry's local window always freezes (its predecessor lies in another
+// tile, so it cannot sit on a tile-local cycle) unless its chain dead-ends inside the tile; then it points at itself.
+__global__ void k_entry_init(const uint32_t* __restrict__ entry_list, const unsigned int* __restrict__ entry_count,
+                             const JumpState* __restrict__ loc, const uint32_t* __restrict__ loc_dist,
+                             const uint32_t* __restrict__ entry_pos, EntryState* __restrict__ es) {
+    const uint32_t n = *entry_count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t e = entry_list[i];
+        const JumpState l = loc[e];
+        const uint32_t dd = loc_dist[e];
+        EntryState s;
+        s.key = l.key; s.off = l.off; s.dist = dd & ~kFrozen; s.pad = 0;
+        s.ptr = (dd & kFrozen) ? entry_pos[l.ptr] : i;
+        es[i] = s;
+    }
+}
+
+// Phase 2: doubling over entries (hop counts double per round; `dist` carries the real path length)
+__global__ __launch_bounds__(256) void k_entry_jump(const EntryState* __restrict__ in, EntryState* __restrict__ out,
+                                                    const unsigned int* __restrict__ entry_count, int round, DeviceCounters* __restrict__ ctr) {
+    // no key moved in the previous round => every window already wraps its cycle; both buffers hold final key/off
+    if (round > 0 && ctr->jump_changed[round - 1] == 0) return;
+    const uint32_t n = *entry_count;
+    uint32_t changed = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        EntryState s = in[i];
+        const EntryState t = in[s.ptr];
+        if (t.key < s.key) { s.key = t.key; s.off = s.dist + t.off; changed++; }
+        s.dist += t.dist;
         s.ptr = t.ptr;
-        out[d] = s;
+        out[i] = s;
     }
     for (int o = 32; o > 0; o >>= 1) changed += __shfl_down(changed, o);
     if ((threadIdx.x & 63) == 0 && changed) atomicAdd(&ctr->jump_changed[round], changed);
+}
+
+// Phase 3: every dart learns its cycle's leader and its hop distance to it
+__global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const JumpState* __restrict__ loc, const uint32_t* __restrict__ loc_dist,
+                                                       const uint32_t* __restrict__ entry_pos, const EntryState* __restrict__ es,
+                                                       JumpState* __restrict__ fin) {
+    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
+        JumpState s = loc[d];
+        const uint32_t dd = loc_dist[d];
+        if (dd & kFrozen) {
+            const EntryState g = es[entry_pos[s.ptr]];
+            if (g.key < s.key) { s.key = g.key; s.off = (dd & ~kFrozen) + g.off; }
+        }
+        fin[d] = s;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -527,25 +641,43 @@ static inline int blocks_for(uint64_t n, int per_block, int cap) {
 
 hipError_t launch_dart_count(hipStream_t st, const uint64_t* bits, int W, int H, uint32_t first_frame, uint32_t n_frames,
                              unsigned long long* frame_darts) {
-    const uint32_t words = words_per_row((uint32_t)W) * (uint32_t)H;
-    hipLaunchKernelGGL(k_dart_count, dim3((words + 255) / 256, n_frames), dim3(256), 0, st, bits, W, H, first_frame, frame_darts);
+    hipLaunchKernelGGL(k_dart_count, dim3(dart_tiles((uint32_t)W, (uint32_t)H), n_frames), dim3(256), 0, st, bits, W, H, first_frame, frame_darts);
     return hipGetLastError();
 }
 
 hipError_t launch_dart_build(hipStream_t st, const uint64_t* bits, int W, int H, uint32_t first_frame, uint32_t n_frames,
                              const uint32_t* frame_base, uint32_t* frame_cursor, uint32_t* pix_base, uint64_t* node_bits, uint32_t* d_xy,
-                             uint8_t* d_info, uint8_t* d_F, uint32_t* d_succ, JumpState* st0, uint32_t n_darts) {
-    const uint32_t words = words_per_row((uint32_t)W) * (uint32_t)H;
-    hipLaunchKernelGGL(k_dart_assign, dim3((words + 255) / 256, n_frames), dim3(256), 0, st, bits, W, H, first_frame, frame_base, frame_cursor,
+                             uint8_t* d_info, uint8_t* d_F, uint32_t* d_succ, uint32_t n_darts) {
+    hipLaunchKernelGGL(k_dart_assign, dim3(dart_tiles((uint32_t)W, (uint32_t)H), n_frames), dim3(256), 0, st, bits, W, H, first_frame, frame_base, frame_cursor,
                        pix_base, node_bits, d_xy, d_info, d_F);
     const uint32_t per_frame = n_frames ? (n_darts + n_frames - 1) / n_frames : 0;
     hipLaunchKernelGGL(k_dart_link, dim3(blocks_for(per_frame, 256, 1024), n_frames), dim3(256), 0, st, W, H, frame_base, pix_base, node_bits,
-                       d_xy, d_info, d_F, d_succ, st0);
+                       d_xy, d_info, d_F, d_succ);
     return hipGetLastError();
 }
 
-hipError_t launch_jump(hipStream_t st, const JumpState* in, JumpState* out, uint32_t n_darts, int round, DeviceCounters* ctr) {
-    hipLaunchKernelGGL(k_jump, dim3(blocks_for(n_darts, 256, 8192)), dim3(256), 0, st, in, out, n_darts, round, ctr);
+size_t entry_state_bytes() { return sizeof(EntryState); }
+
+// leaders + ranks for every dart of the chunk.  loc/fin: JumpState[n_darts]; es_a/es_b: EntryState[n_darts] (upper bound);
+// entry_bits: ceil(n_darts/32) words, zeroed here.
+hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uint32_t* d_xy, const uint8_t* d_info, const uint32_t* d_succ,
+                              JumpState* loc, uint32_t* loc_dist, uint32_t* entry_bits, uint32_t* entry_list, uint32_t* entry_pos,
+                              unsigned int* entry_count, void* es_a, void* es_b, JumpState* fin, int max_rounds, DeviceCounters* ctr) {
+    hipError_t e = hipMemsetAsync(entry_bits, 0, ((size_t)n_darts + 31) / 32 * 4, st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(entry_count, 0, 4, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_local_contract, dim3((n_darts + kLT - 1) / kLT), dim3(256), 0, st, n_darts, W, d_xy, d_info, d_succ, loc, loc_dist,
+                       entry_bits, entry_list, entry_pos, entry_count);
+    EntryState* a = reinterpret_cast<EntryState*>(es_a);
+    EntryState* b = reinterpret_cast<EntryState*>(es_b);
+    const dim3 grid(blocks_for(n_darts / 8 + 1, 256, 2048)), block(256);
+    hipLaunchKernelGGL(k_entry_init, grid, block, 0, st, entry_list, entry_count, loc, loc_dist, entry_pos, a);
+    for (int r = 0; r < max_rounds; r++) {
+        hipLaunchKernelGGL(k_entry_jump, grid, block, 0, st, a, b, entry_count, r, ctr);
+        EntryState* t = a; a = b; b = t;
+    }
+    hipLaunchKernelGGL(k_jump_finalize, dim3(blocks_for(n_darts, 256, 8192)), block, 0, st, n_darts, loc, loc_dist, entry_pos, a, fin);
     return hipGetLastError();
 }
 
