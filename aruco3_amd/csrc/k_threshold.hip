@@ -19,157 +19,189 @@
 
 namespace a3 {
 
-constexpr int T_TW = 240;           // output tile width  (30 groups of 8)
-constexpr int T_TH = 64;            // output tile height (8 segments of 8 rows)
-constexpr int T_R = 7;              // fast path radius
-constexpr int T_LW = 256;           // loaded columns: x0-8 .. x0+247
-constexpr int T_LH = T_TH + 2 * T_R;  // 78 loaded rows: y0-7 .. y0+70
-constexpr int T_G = T_TW / 8;       // 30 column groups
+constexpr int T_R = 7;               // fast path radius (threshold_window = 7)
+constexpr int T_LPX = 16;            // pixels per lane and row
+constexpr int T_OUT = 62 * T_LPX;    // 992 output columns per wave (lanes 0 and 63 only feed their neighbours)
+constexpr int T_PF = 3;              // rows of loads kept in flight per lane
 
 __device__ __forceinline__ uint32_t luma_of(uint32_t r, uint32_t g, uint32_t b) {
     return (2126u * r + 7152u * g + 722u * b) / 10000u;
 }
 
-// 4 consecutive pixels starting at (x, y) -> 4 grey bytes packed little-endian; 0 outside the image
-template <int FMT>
-__device__ __forceinline__ uint32_t load_grey4(const uint8_t* __restrict__ frame, size_t row_stride, int x, int y, int W, int H,
-                                               bool aligned) {
-    if (y < 0 || y >= H || x + 3 < 0 || x >= W) return 0u;
-    const uint8_t* row = frame + (size_t)y * row_stride;
-    constexpr int BPP = FMT == A3_FMT_RGB8 ? 3 : (FMT == A3_FMT_RGBA8 ? 4 : 1);
-    if (aligned && x >= 0 && x + 3 < W) {
-        if constexpr (FMT == A3_FMT_RGB8) {
-            const uint32_t* p = reinterpret_cast<const uint32_t*>(row + (size_t)x * 3);
-            uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-            uint32_t g0 = luma_of(d0 & 255u, (d0 >> 8) & 255u, (d0 >> 16) & 255u);
-            uint32_t g1 = luma_of(d0 >> 24, d1 & 255u, (d1 >> 8) & 255u);
-            uint32_t g2 = luma_of((d1 >> 16) & 255u, d1 >> 24, d2 & 255u);
-            uint32_t g3 = luma_of((d2 >> 8) & 255u, (d2 >> 16) & 255u, d2 >> 24);
-            return g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
-        } else if constexpr (FMT == A3_FMT_RGBA8) {
-            const uint4 q = *reinterpret_cast<const uint4*>(row + (size_t)x * 4);
-            uint32_t g0 = luma_of(q.x & 255u, (q.x >> 8) & 255u, (q.x >> 16) & 255u);
-            uint32_t g1 = luma_of(q.y & 255u, (q.y >> 8) & 255u, (q.y >> 16) & 255u);
-            uint32_t g2 = luma_of(q.z & 255u, (q.z >> 8) & 255u, (q.z >> 16) & 255u);
-            uint32_t g3 = luma_of(q.w & 255u, (q.w >> 8) & 255u, (q.w >> 16) & 255u);
-            return g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
-        } else {
-            return *reinterpret_cast<const uint32_t*>(row + x);
-        }
-    }
-    uint32_t out = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        int xi = x + i;
-        if (xi < 0 || xi >= W) continue;
-        const uint8_t* p = row + (size_t)xi * BPP;
-        uint32_t g = BPP == 1 ? (uint32_t)p[0] : luma_of(p[0], p[1], p[2]);
-        out |= g << (8 * i);
-    }
-    return out;
+// grey of one RGB(A) pixel held in the low 3 bytes of `px` (4th byte ignored): two byte-wise dot products with
+// the split weights 2126 = 8*256+78, 7152 = 27*256+240, 722 = 2*256+210, then the exact /10000.
+__device__ __forceinline__ uint32_t luma_dot(uint32_t px) {
+    const uint32_t lo = __builtin_amdgcn_udot4(px, 0x00D2F04Eu, 0u, false);
+    const uint32_t hi = __builtin_amdgcn_udot4(px, 0x00021B08u, 0u, false);
+    return (lo + (hi << 8)) / 10000u;
 }
 
-template <int FMT>
-__global__ __launch_bounds__(256) void k_grey_threshold7(const uint8_t* __restrict__ pixels, size_t row_stride, size_t frame_stride,
-                                                         int W, int H, uint8_t* __restrict__ grey, uint8_t* __restrict__ bits,
-                                                         int aligned_in, int aligned_out) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_g[T_LH][T_LW];
-    __shared__ __attribute__((aligned(16))) uint16_t s_h[T_LH][T_G][8];
+template <int FMT> struct RawRow { static constexpr int NDW = FMT == A3_FMT_RGB8 ? 12 : (FMT == A3_FMT_RGBA8 ? 16 : 4); uint32_t d[NDW]; };
 
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * T_TW, y0 = blockIdx.y * T_TH;
-    const uint32_t f = blockIdx.z;
+// 16 consecutive pixels of row y starting at x0 (a multiple of 16, may be negative or past the image): raw bytes,
+// zero where the image is not.  Fully-inside lanes use 16-byte vector loads.
+template <int FMT>
+__device__ __forceinline__ void load_raw16(const uint8_t* __restrict__ frame, size_t row_stride, int x0, int y, int W, int H, bool aligned,
+                                           RawRow<FMT>& r) {
+    constexpr int NDW = RawRow<FMT>::NDW;
+    constexpr int BPP = FMT == A3_FMT_RGB8 ? 3 : (FMT == A3_FMT_RGBA8 ? 4 : 1);
+#pragma unroll
+    for (int i = 0; i < NDW; i++) r.d[i] = 0u;
+    if (y < 0 || y >= H || x0 + T_LPX <= 0 || x0 >= W) return;
+    const uint8_t* row = frame + (size_t)y * row_stride;
+    if (aligned && x0 >= 0 && x0 + T_LPX <= W) {
+        const uint4* p = reinterpret_cast<const uint4*>(row + (size_t)x0 * BPP);
+#pragma unroll
+        for (int i = 0; i < NDW / 4; i++) { const uint4 v = p[i]; r.d[4 * i] = v.x; r.d[4 * i + 1] = v.y; r.d[4 * i + 2] = v.z; r.d[4 * i + 3] = v.w; }
+        return;
+    }
+    for (int i = 0; i < T_LPX; i++) {
+        const int x = x0 + i;
+        if (x < 0 || x >= W) continue;
+        for (int c = 0; c < BPP; c++) {
+            const int byte = i * BPP + c;
+            r.d[byte >> 2] |= (uint32_t)row[(size_t)x * BPP + c] << (8 * (byte & 3));
+        }
+    }
+}
+
+// raw row -> 16 grey bytes in 4 dwords
+template <int FMT>
+__device__ __forceinline__ void grey16(const RawRow<FMT>& r, uint32_t g[4]) {
+    if constexpr (FMT == A3_FMT_L8) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) g[i] = r.d[i];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t l[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int i = 4 * q + j;
+                uint32_t px;
+                if constexpr (FMT == A3_FMT_RGBA8) px = r.d[i];
+                else {
+                    const int byte = 3 * i, k = byte >> 2, sh = 8 * (byte & 3);   // compile-time after unrolling
+                    px = sh == 0 ? r.d[k] : __builtin_amdgcn_alignbit(k + 1 < 12 ? r.d[k + 1] : 0u, r.d[k], sh);
+                }
+                l[j] = luma_dot(px);
+            }
+            g[q] = l[0] | (l[1] << 8) | (l[2] << 16) | (l[3] << 24);
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_from_left(uint32_t v) {   // lane i <- lane i-1
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t wave_from_right(uint32_t v) {  // lane i <- lane i+1
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
+}
+
+// One wave walks down a strip: lane l owns columns xs - 16 + 16 l .. + 15 and keeps, in registers, the last 15 grey rows
+// of those 16 columns plus their running vertical sums (u16 pairs: 15*255 < 2^16).  Per output row it needs 7 column
+// sums from each neighbouring lane (wave shifts, no LDS), slides a 15-wide window over 30 column sums and compares
+// sum < (L+1)*area.  No LDS, no barriers; T_PF rows of loads stay in flight per lane.
+// grid: (strips_x * strips_y, frames), block 64.
+template <int FMT>
+__global__ __launch_bounds__(64) void k_grey_threshold7(const uint8_t* __restrict__ pixels, size_t row_stride, size_t frame_stride,
+                                                        int W, int H, int rows_per_wave, uint8_t* __restrict__ grey,
+                                                        uint8_t* __restrict__ bits, int aligned_in, int aligned_out) {
+    const int lane = threadIdx.x;
+    const int strips_x = (W + T_OUT - 1) / T_OUT;
+    const int sx = blockIdx.x % strips_x, sy = blockIdx.x / strips_x;
+    const uint32_t f = blockIdx.y;
     const uint8_t* frame = pixels + (size_t)f * frame_stride;
     uint8_t* gout = grey + (size_t)f * W * H;
-    const size_t bpr = (size_t)words_per_row((uint32_t)W) * 8;  // bytes per packed row
+    const size_t bpr = (size_t)words_per_row((uint32_t)W) * 8;
     uint8_t* bout = bits + (size_t)f * bpr * H;
 
-    // ---- phase A: load + convert; lane l of a wave owns columns 4l..4l+3 of one loaded row ----
-    const int lane_c = (tid & 63) * 4;
-    const int wave = tid >> 6;
-#pragma unroll 5
-    for (int r = wave; r < T_LH; r += 4) {
-        const int x = x0 - 8 + lane_c, y = y0 - T_R + r;
-        uint32_t g4 = load_grey4<FMT>(frame, row_stride, x, y, W, H, aligned_in != 0);
-        *reinterpret_cast<uint32_t*>(&s_g[r][lane_c]) = g4;
-        // the tile's own pixels also go out as Detection.grey
-        if (r >= T_R && r < T_R + T_TH && lane_c >= 8 && lane_c < 8 + T_TW && y < H && x < W) {
-            uint8_t* dst = gout + (size_t)y * W + x;
-            if (aligned_out && x + 3 < W) *reinterpret_cast<uint32_t*>(dst) = g4;
-            else {
-#pragma unroll
-                for (int i = 0; i < 4; i++) if (x + i < W) dst[i] = (uint8_t)(g4 >> (8 * i));
-            }
-        }
-    }
-    __syncthreads();
+    const int x0 = sx * T_OUT - T_LPX + T_LPX * lane;
+    const int y_begin = sy * rows_per_wave, y_end = min(H, y_begin + rows_per_wave);
+    const bool owner = lane >= 1 && lane <= 62 && x0 < W;   // lanes that write results
 
-    // ---- phase B: horizontal 15-tap sums, 8 outputs per task from 24 grey bytes ----
-    for (int t = tid; t < T_LH * T_G; t += 256) {
-        const int r = t / T_G, j = t - r * T_G;
-        const uint64_t* src = reinterpret_cast<const uint64_t*>(&s_g[r][8 * j]);
-        const uint64_t q0 = src[0], q1 = src[1], q2 = src[2];
-        uint32_t b[24];
+    // clipped window widths of the lane's 16 columns, 4 bits each (0 past the right edge: the comparison then fails)
+    uint32_t axp[2] = {0u, 0u};
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            b[i] = (uint32_t)(q0 >> (8 * i)) & 255u;
-            b[8 + i] = (uint32_t)(q1 >> (8 * i)) & 255u;
-            b[16 + i] = (uint32_t)(q2 >> (8 * i)) & 255u;
-        }
-        uint32_t s = 0;
-#pragma unroll
-        for (int k = 1; k <= 15; k++) s += b[k];
-        uint32_t o[8];
-        o[0] = s;
-#pragma unroll
-        for (int i = 1; i < 8; i++) { s += b[15 + i] - b[i]; o[i] = s; }
-        uint4 v;
-        v.x = o[0] | (o[1] << 16); v.y = o[2] | (o[3] << 16); v.z = o[4] | (o[5] << 16); v.w = o[6] | (o[7] << 16);
-        *reinterpret_cast<uint4*>(&s_h[r][j][0]) = v;
+    for (int i = 0; i < T_LPX; i++) {
+        const int x = x0 + i;
+        int a = 0;
+        if (x >= 0 && x < W) a = min(x + T_R, W - 1) - max(x - T_R, 0) + 1;
+        axp[i >> 3] |= (uint32_t)a << (4 * (i & 7));
     }
-    __syncthreads();
 
-    // ---- phase C: vertical sliding sums on packed u16 pairs, compare, store ----
-    if (tid < T_G * 8) {
-        const int j = tid % T_G, seg = tid / T_G;
-        const int xb = x0 + 8 * j;
-        if (xb < W) {
-            uint32_t ax[8];
+    uint32_t ring[15][4];   // ring[14] newest ... ring[0] oldest; shifted every row
+    uint32_t VE[4] = {0, 0, 0, 0}, VO[4] = {0, 0, 0, 0};   // column sums, VE[i] = v(4i) | v(4i+2)<<16, VO[i] = v(4i+1) | v(4i+3)<<16
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                int x = xb + i;
-                int hi = x + T_R < W - 1 ? x + T_R : W - 1, lo = x > T_R ? x - T_R : 0;
-                ax[i] = x < W ? (uint32_t)(hi - lo + 1) : 0u;
-            }
-            uint4 acc = make_uint4(0, 0, 0, 0);
-            const int rr0 = seg * 8;
+    for (int k = 0; k < 15; k++)
 #pragma unroll
-            for (int k = 0; k < 15; k++) {
-                uint4 v = *reinterpret_cast<const uint4*>(&s_h[rr0 + k][j][0]);
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-            }
+        for (int i = 0; i < 4; i++) ring[k][i] = 0u;
+
+    const int r_first = y_begin - T_R, n_rows = (y_end - y_begin) + 2 * T_R;
+    RawRow<FMT> q[T_PF];
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int rr = rr0 + i, y = y0 + rr;
-                if (i > 0) {
-                    uint4 a = *reinterpret_cast<const uint4*>(&s_h[rr + 14][j][0]);
-                    uint4 d = *reinterpret_cast<const uint4*>(&s_h[rr - 1][j][0]);
-                    acc.x += a.x - d.x; acc.y += a.y - d.y; acc.z += a.z - d.z; acc.w += a.w - d.w;
+    for (int k = 0; k < T_PF; k++) load_raw16<FMT>(frame, row_stride, x0, r_first + k, W, H, aligned_in != 0, q[k]);
+
+    for (int base = 0; base < n_rows; base += T_PF) {
+#pragma unroll
+        for (int k = 0; k < T_PF; k++) {
+            const int it = base + k;
+            if (it >= n_rows) break;
+            const int r = r_first + it;
+            RawRow<FMT> raw = q[k];
+            if (it + T_PF < n_rows) load_raw16<FMT>(frame, row_stride, x0, r + T_PF, W, H, aligned_in != 0, q[k]);
+            uint32_t g[4];
+            grey16<FMT>(raw, g);
+            // Detection.grey of the rows this wave owns
+            if (owner && r >= y_begin && r < y_end) {
+                uint8_t* dst = gout + (size_t)r * W + x0;
+                if (aligned_out && x0 + T_LPX <= W) *reinterpret_cast<uint4*>(dst) = make_uint4(g[0], g[1], g[2], g[3]);
+                else {
+#pragma unroll
+                    for (int i = 0; i < T_LPX; i++) if (x0 + i < W) dst[i] = (uint8_t)(g[i >> 2] >> (8 * (i & 3)));
                 }
-                if (y >= H) break;
-                const int yhi = y + T_R < H - 1 ? y + T_R : H - 1, ylo = y > T_R ? y - T_R : 0;
-                const uint32_t ay = (uint32_t)(yhi - ylo + 1);
-                const uint64_t gq = *reinterpret_cast<const uint64_t*>(&s_g[rr + T_R][8 + 8 * j]);
-                const uint32_t sums[8] = {acc.x & 0xFFFFu, acc.x >> 16, acc.y & 0xFFFFu, acc.y >> 16,
-                                          acc.z & 0xFFFFu, acc.z >> 16, acc.w & 0xFFFFu, acc.w >> 16};
-                uint32_t outb = 0;
-#pragma unroll
-                for (int p = 0; p < 8; p++) {
-                    uint32_t gv = (uint32_t)(gq >> (8 * p)) & 255u;
-                    if (sums[p] < (gv + 1u) * (ax[p] * ay)) outb |= 1u << p;   // ax == 0 past the right edge: stays 0
-                }
-                bout[(size_t)y * bpr + (xb >> 3)] = (uint8_t)outb;
             }
+            // vertical sliding sums: + newest row, - the row that leaves the 15-row window
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t o = ring[0][i];
+                VE[i] += (g[i] & 0x00FF00FFu) - (o & 0x00FF00FFu);
+                VO[i] += ((g[i] >> 8) & 0x00FF00FFu) - ((o >> 8) & 0x00FF00FFu);
+            }
+#pragma unroll
+            for (int s = 0; s < 14; s++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) ring[s][i] = ring[s + 1][i];
+#pragma unroll
+            for (int i = 0; i < 4; i++) ring[14][i] = g[i];
+
+            const int y = r - T_R;   // the row whose window is now complete (its grey is ring[7])
+            if (y < y_begin) continue;   // wave-uniform
+            // 30 column sums: 7 from the left lane, own 16, 7 from the right lane
+            const uint32_t le2 = wave_from_left(VE[2]), lo2 = wave_from_left(VO[2]), le3 = wave_from_left(VE[3]), lo3 = wave_from_left(VO[3]);
+            const uint32_t re0 = wave_from_right(VE[0]), ro0 = wave_from_right(VO[0]), re1 = wave_from_right(VE[1]), ro1 = wave_from_right(VO[1]);
+            uint32_t e[30];
+            e[0] = lo2 & 0xFFFFu; e[1] = le2 >> 16; e[2] = lo2 >> 16;                      // left v9 v10 v11
+            e[3] = le3 & 0xFFFFu; e[4] = lo3 & 0xFFFFu; e[5] = le3 >> 16; e[6] = lo3 >> 16; // left v12..v15
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                e[7 + 4 * i] = VE[i] & 0xFFFFu; e[8 + 4 * i] = VO[i] & 0xFFFFu; e[9 + 4 * i] = VE[i] >> 16; e[10 + 4 * i] = VO[i] >> 16;
+            }
+            e[23] = re0 & 0xFFFFu; e[24] = ro0 & 0xFFFFu; e[25] = re0 >> 16; e[26] = ro0 >> 16;  // right v0..v3
+            e[27] = re1 & 0xFFFFu; e[28] = ro1 & 0xFFFFu; e[29] = re1 >> 16;                      // right v4 v5 v6
+            uint32_t S = 0;
+#pragma unroll
+            for (int i = 0; i < 15; i++) S += e[i];
+            const uint32_t ay = (uint32_t)(min(y + T_R, H - 1) - max(y - T_R, 0) + 1);
+            uint32_t outb = 0;
+#pragma unroll
+            for (int i = 0; i < T_LPX; i++) {
+                if (i > 0) S += e[i + 14] - e[i - 1];
+                const uint32_t gv = (ring[7][i >> 2] >> (8 * (i & 3))) & 255u;
+                const uint32_t area = ((axp[i >> 3] >> (4 * (i & 7))) & 15u) * ay;
+                outb |= (S < (gv + 1u) * area ? 1u : 0u) << i;
+            }
+            if (owner) *reinterpret_cast<uint16_t*>(bout + (size_t)y * bpr + (x0 >> 3)) = (uint16_t)outb;
         }
     }
 }
@@ -178,12 +210,12 @@ __global__ __launch_bounds__(256) void k_grey_threshold7(const uint8_t* __restri
 template <int FMT>
 __global__ void k_grey_generic(const uint8_t* __restrict__ pixels, size_t row_stride, size_t frame_stride, int W, int H,
                                uint8_t* __restrict__ grey) {
-    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
-    if (x4 >= W) return;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
     const uint32_t f = blockIdx.z;
-    uint32_t g4 = load_grey4<FMT>(pixels + (size_t)f * frame_stride, row_stride, x4, y, W, H, false);
-    uint8_t* dst = grey + (size_t)f * W * H + (size_t)y * W + x4;
-    for (int i = 0; i < 4; i++) if (x4 + i < W) dst[i] = (uint8_t)(g4 >> (8 * i));
+    constexpr int BPP = FMT == A3_FMT_RGB8 ? 3 : (FMT == A3_FMT_RGBA8 ? 4 : 1);
+    const uint8_t* p = pixels + (size_t)f * frame_stride + (size_t)y * row_stride + (size_t)x * BPP;
+    grey[(size_t)f * W * H + (size_t)y * W + x] = BPP == 1 ? p[0] : (uint8_t)luma_of(p[0], p[1], p[2]);
 }
 
 // one wave per packed word: 64 consecutive pixels, result gathered with a ballot
@@ -210,28 +242,32 @@ __global__ __launch_bounds__(64) void k_threshold_generic(const uint8_t* __restr
 hipError_t launch_grey_threshold(hipStream_t st, const uint8_t* pixels, int fmt, size_t row_stride, size_t frame_stride, int W, int H,
                                  uint32_t n, uint32_t radius, uint8_t* grey, uint64_t* bits) {
     if (radius == (uint32_t)T_R) {
-        const int bpp = fmt == A3_FMT_RGB8 ? 3 : (fmt == A3_FMT_RGBA8 ? 4 : 1);
-        const size_t need = bpp == 3 ? 4 : (bpp == 4 ? 16 : 4);
-        const int aligned_in = ((uintptr_t)pixels % need == 0) && (row_stride % need == 0) && (frame_stride % need == 0);
-        const int aligned_out = (W % 4 == 0) && ((uintptr_t)grey % 4 == 0);
+        const int aligned_in = ((uintptr_t)pixels % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0);
+        const int aligned_out = (W % 16 == 0) && ((uintptr_t)grey % 16 == 0);
         uint8_t* bin = reinterpret_cast<uint8_t*>(bits);
         if (W % 64 != 0) {  // packed rows end in padding bits that no tile writes
             hipError_t e = hipMemsetAsync(bits, 0, (size_t)words_per_row((uint32_t)W) * 8 * H * n, st);
             if (e != hipSuccess) return e;
         }
-        dim3 grid((W + T_TW - 1) / T_TW, (H + T_TH - 1) / T_TH, n), block(256);
+        // rows per wave: enough waves to fill the chip several times over, few enough that the 14 extra rows each
+        // wave reads above/below its strip stay a small fraction
+        const int strips_x = (W + T_OUT - 1) / T_OUT;
+        int rows_per_wave = 72;
+        while (rows_per_wave > 24 && (long long)strips_x * ((H + rows_per_wave - 1) / rows_per_wave) * n < 3 * 256 * 8) rows_per_wave -= 8;
+        const int strips_y = (H + rows_per_wave - 1) / rows_per_wave;
+        dim3 grid(strips_x * strips_y, n), block(64);
         if (fmt == A3_FMT_RGB8)
-            hipLaunchKernelGGL(k_grey_threshold7<A3_FMT_RGB8>, grid, block, 0, st, pixels, row_stride, frame_stride, W, H, grey, bin, aligned_in, aligned_out);
+            hipLaunchKernelGGL(k_grey_threshold7<A3_FMT_RGB8>, grid, block, 0, st, pixels, row_stride, frame_stride, W, H, rows_per_wave, grey, bin, aligned_in, aligned_out);
         else if (fmt == A3_FMT_RGBA8)
-            hipLaunchKernelGGL(k_grey_threshold7<A3_FMT_RGBA8>, grid, block, 0, st, pixels, row_stride, frame_stride, W, H, grey, bin, aligned_in, aligned_out);
+            hipLaunchKernelGGL(k_grey_threshold7<A3_FMT_RGBA8>, grid, block, 0, st, pixels, row_stride, frame_stride, W, H, rows_per_wave, grey, bin, aligned_in, aligned_out);
         else
-            hipLaunchKernelGGL(k_grey_threshold7<A3_FMT_L8>, grid, block, 0, st, pixels, row_stride, frame_stride, W, H, grey, bin, aligned_in, aligned_out);
+            hipLaunchKernelGGL(k_grey_threshold7<A3_FMT_L8>, grid, block, 0, st, pixels, row_stride, frame_stride, W, H, rows_per_wave, grey, bin, aligned_in, aligned_out);
         return hipGetLastError();
     }
-    dim3 block(64), grid4(((W + 3) / 4 + 63) / 64, H, n), grid1(words_per_row((uint32_t)W), H, n);
-    if (fmt == A3_FMT_RGB8) hipLaunchKernelGGL(k_grey_generic<A3_FMT_RGB8>, grid4, block, 0, st, pixels, row_stride, frame_stride, W, H, grey);
-    else if (fmt == A3_FMT_RGBA8) hipLaunchKernelGGL(k_grey_generic<A3_FMT_RGBA8>, grid4, block, 0, st, pixels, row_stride, frame_stride, W, H, grey);
-    else hipLaunchKernelGGL(k_grey_generic<A3_FMT_L8>, grid4, block, 0, st, pixels, row_stride, frame_stride, W, H, grey);
+    dim3 block(64), gridg((W + 63) / 64, H, n), grid1(words_per_row((uint32_t)W), H, n);
+    if (fmt == A3_FMT_RGB8) hipLaunchKernelGGL(k_grey_generic<A3_FMT_RGB8>, gridg, block, 0, st, pixels, row_stride, frame_stride, W, H, grey);
+    else if (fmt == A3_FMT_RGBA8) hipLaunchKernelGGL(k_grey_generic<A3_FMT_RGBA8>, gridg, block, 0, st, pixels, row_stride, frame_stride, W, H, grey);
+    else hipLaunchKernelGGL(k_grey_generic<A3_FMT_L8>, gridg, block, 0, st, pixels, row_stride, frame_stride, W, H, grey);
     hipLaunchKernelGGL(k_threshold_generic, grid1, block, 0, st, grey, W, H, (int)radius, bits);
     return hipGetLastError();
 }
