@@ -15,6 +15,8 @@
 // 8 sums out per lane), then vertical sliding sums on packed u16 pairs (15*15*255 < 2^16,
 // so two sums share a dword and plain 32-bit adds never carry across).  Out-of-image
 // pixels are stored as 0, which makes the unclipped sum equal the clipped one.
+#include <cstdlib>
+
 #include "a3_common.h"
 
 namespace a3 {
@@ -22,7 +24,13 @@ namespace a3 {
 constexpr int T_R = 7;               // fast path radius (threshold_window = 7)
 constexpr int T_LPX = 16;            // pixels per lane and row
 constexpr int T_OUT = 62 * T_LPX;    // 992 output columns per wave (lanes 0 and 63 only feed their neighbours)
-constexpr int T_PF = 3;              // rows of loads kept in flight per lane
+#ifndef A3_T_PF
+#define A3_T_PF 3
+#endif
+#ifndef A3_T_WAVES
+#define A3_T_WAVES 2
+#endif
+constexpr int T_PF = A3_T_PF;        // rows of loads kept in flight per lane
 
 __device__ __forceinline__ uint32_t luma_of(uint32_t r, uint32_t g, uint32_t b) {
     return (2126u * r + 7152u * g + 722u * b) / 10000u;
@@ -33,14 +41,17 @@ __device__ __forceinline__ uint32_t luma_of(uint32_t r, uint32_t g, uint32_t b) 
 __device__ __forceinline__ uint32_t luma_dot(uint32_t px) {
     const uint32_t lo = __builtin_amdgcn_udot4(px, 0x00D2F04Eu, 0u, false);
     const uint32_t hi = __builtin_amdgcn_udot4(px, 0x00021B08u, 0u, false);
-    return (lo + (hi << 8)) / 10000u;
+    // l <= 10000*255 < 2^22; floor(l / 10000) == (l * 13743896) >> 37 for every such l (checked exhaustively),
+    // which is one full-rate v_mul_hi_u32_u24 plus a shift instead of a quarter-rate 32-bit multiply-high
+    const uint32_t l = (lo + (hi << 8)) & 0x3FFFFFu;
+    return (uint32_t)(((uint64_t)l * 13743896ull) >> 37);
 }
 
 template <int FMT> struct RawRow { static constexpr int NDW = FMT == A3_FMT_RGB8 ? 12 : (FMT == A3_FMT_RGBA8 ? 16 : 4); uint32_t d[NDW]; };
 
 // 16 consecutive pixels of row y starting at x0 (a multiple of 16, may be negative or past the image): raw bytes,
 // zero where the image is not.  Fully-inside lanes use 16-byte vector loads.
-template <int FMT>
+template <int FMT, bool FAST>
 __device__ __forceinline__ void load_raw16(const uint8_t* __restrict__ frame, size_t row_stride, int x0, int y, int W, int H, bool aligned,
                                            RawRow<FMT>& r) {
     constexpr int NDW = RawRow<FMT>::NDW;
@@ -49,7 +60,7 @@ __device__ __forceinline__ void load_raw16(const uint8_t* __restrict__ frame, si
     for (int i = 0; i < NDW; i++) r.d[i] = 0u;
     if (y < 0 || y >= H || x0 + T_LPX <= 0 || x0 >= W) return;
     const uint8_t* row = frame + (size_t)y * row_stride;
-    if (aligned && x0 >= 0 && x0 + T_LPX <= W) {
+    if (FAST || (aligned && x0 >= 0 && x0 + T_LPX <= W)) {
         const uint4* p = reinterpret_cast<const uint4*>(row + (size_t)x0 * BPP);
 #pragma unroll
         for (int i = 0; i < NDW / 4; i++) { const uint4 v = p[i]; r.d[4 * i] = v.x; r.d[4 * i + 1] = v.y; r.d[4 * i + 2] = v.z; r.d[4 * i + 3] = v.w; }
@@ -91,6 +102,13 @@ __device__ __forceinline__ void grey16(const RawRow<FMT>& r, uint32_t g[4]) {
     }
 }
 
+// full-rate 24-bit multiply (the compiler prefers the quarter-rate v_mul_lo_u32 when one operand is scalar)
+__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ uint32_t wave_from_left(uint32_t v) {   // lane i <- lane i-1
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
 }
@@ -103,8 +121,8 @@ __device__ __forceinline__ uint32_t wave_from_right(uint32_t v) {  // lane i <- 
 // sums from each neighbouring lane (wave shifts, no LDS), slides a 15-wide window over 30 column sums and compares
 // sum < (L+1)*area.  No LDS, no barriers; T_PF rows of loads stay in flight per lane.
 // grid: (strips_x * strips_y, frames), block 64.
-template <int FMT>
-__global__ __launch_bounds__(64) void k_grey_threshold7(const uint8_t* __restrict__ pixels, size_t row_stride, size_t frame_stride,
+template <int FMT, bool FAST>
+__global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_t* __restrict__ pixels, size_t row_stride, size_t frame_stride,
                                                         int W, int H, int rows_per_wave, uint8_t* __restrict__ grey,
                                                         uint8_t* __restrict__ bits, int aligned_in, int aligned_out) {
     const int lane = threadIdx.x;
@@ -130,7 +148,7 @@ __global__ __launch_bounds__(64) void k_grey_threshold7(const uint8_t* __restric
         axp[i >> 3] |= (uint32_t)a << (4 * (i & 7));
     }
 
-    uint32_t ring[15][4];   // ring[14] newest ... ring[0] oldest; shifted every row
+    uint32_t ring[15][4];   // the last 15 grey rows; row `it` lives in slot it % 15 (static: the row loop is unrolled 15x)
     uint32_t VE[4] = {0, 0, 0, 0}, VO[4] = {0, 0, 0, 0};   // column sums, VE[i] = v(4i) | v(4i+2)<<16, VO[i] = v(4i+1) | v(4i+3)<<16
 #pragma unroll
     for (int k = 0; k < 15; k++)
@@ -139,23 +157,46 @@ __global__ __launch_bounds__(64) void k_grey_threshold7(const uint8_t* __restric
 
     const int r_first = y_begin - T_R, n_rows = (y_end - y_begin) + 2 * T_R;
     RawRow<FMT> q[T_PF];
+    // FAST: every load is unconditional (row and column clamped into the image) so that the loop body has no branch
+    // around a load and the compiler can keep T_PF rows in flight with counted waits; what the clamped address
+    // fetched for an outside lane/row is discarded by zeroing the grey below.
+    constexpr int BPPK = FMT == A3_FMT_RGB8 ? 3 : (FMT == A3_FMT_RGBA8 ? 4 : 1);
+    const bool lane_in = x0 >= 0 && x0 + T_LPX <= W;
+    const uint8_t* lane_ptr = frame + (size_t)(lane_in ? x0 : 0) * BPPK;
+    auto issue = [&](int r, RawRow<FMT>& dst) {
+        if constexpr (FAST) {
+            const int rc = min(max(r, 0), H - 1);
+            const uint4* p = reinterpret_cast<const uint4*>(lane_ptr + (size_t)(uint32_t)rc * row_stride);
 #pragma unroll
-    for (int k = 0; k < T_PF; k++) load_raw16<FMT>(frame, row_stride, x0, r_first + k, W, H, aligned_in != 0, q[k]);
+            for (int i = 0; i < RawRow<FMT>::NDW / 4; i++) { const uint4 v = p[i]; dst.d[4 * i] = v.x; dst.d[4 * i + 1] = v.y; dst.d[4 * i + 2] = v.z; dst.d[4 * i + 3] = v.w; }
+        } else {
+            load_raw16<FMT, false>(frame, row_stride, x0, r, W, H, aligned_in != 0, dst);
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < T_PF; k++) issue(r_first + k, q[k]);
 
-    for (int base = 0; base < n_rows; base += T_PF) {
+    static_assert(15 % T_PF == 0, "the load queue index must be static inside the 15x unrolled body");
+    // FAST: whole blocks of 15 rows and no exit test inside the unrolled body (rows past the strip are clamped loads whose
+    // results are never stored), so the body is straight-line code apart from the store predicates
+    const int n_iter = FAST ? ((n_rows + 14) / 15) * 15 : n_rows;
+    for (int base = 0; base < n_iter; base += 15) {
 #pragma unroll
-        for (int k = 0; k < T_PF; k++) {
-            const int it = base + k;
-            if (it >= n_rows) break;
+        for (int k15 = 0; k15 < 15; k15++) {
+            const int k = k15 % T_PF;
+            const int it = base + k15;
+            if (!FAST && it >= n_iter) break;
             const int r = r_first + it;
-            RawRow<FMT> raw = q[k];
-            if (it + T_PF < n_rows) load_raw16<FMT>(frame, row_stride, x0, r + T_PF, W, H, aligned_in != 0, q[k]);
             uint32_t g[4];
-            grey16<FMT>(raw, g);
+            grey16<FMT>(q[k], g);                                   // consumes the row loaded T_PF iterations ago ...
+            if (FAST || it + T_PF < n_rows) issue(r + T_PF, q[k]);  // ... and its registers take the next load at once
+            if constexpr (FAST) {
+                if (!(lane_in && r >= 0 && r < H)) { g[0] = 0u; g[1] = 0u; g[2] = 0u; g[3] = 0u; }
+            }
             // Detection.grey of the rows this wave owns
             if (owner && r >= y_begin && r < y_end) {
                 uint8_t* dst = gout + (size_t)r * W + x0;
-                if (aligned_out && x0 + T_LPX <= W) *reinterpret_cast<uint4*>(dst) = make_uint4(g[0], g[1], g[2], g[3]);
+                if (FAST || (aligned_out && x0 + T_LPX <= W)) *reinterpret_cast<uint4*>(dst) = make_uint4(g[0], g[1], g[2], g[3]);
                 else {
 #pragma unroll
                     for (int i = 0; i < T_LPX; i++) if (x0 + i < W) dst[i] = (uint8_t)(g[i >> 2] >> (8 * (i & 3)));
@@ -164,19 +205,15 @@ __global__ __launch_bounds__(64) void k_grey_threshold7(const uint8_t* __restric
             // vertical sliding sums: + newest row, - the row that leaves the 15-row window
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const uint32_t o = ring[0][i];
+                const uint32_t o = ring[k15][i];   // the row that entered 15 iterations ago
                 VE[i] += (g[i] & 0x00FF00FFu) - (o & 0x00FF00FFu);
                 VO[i] += ((g[i] >> 8) & 0x00FF00FFu) - ((o >> 8) & 0x00FF00FFu);
+                ring[k15][i] = g[i];
             }
-#pragma unroll
-            for (int s = 0; s < 14; s++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) ring[s][i] = ring[s + 1][i];
-#pragma unroll
-            for (int i = 0; i < 4; i++) ring[14][i] = g[i];
+            const uint32_t* centre = ring[(k15 + 8) % 15];   // the row 7 iterations old: the one being thresholded
 
-            const int y = r - T_R;   // the row whose window is now complete (its grey is ring[7])
-            if (y < y_begin) continue;   // wave-uniform
+            const int y = r - T_R;   // the row whose window is now complete
+            if (y < y_begin || y >= y_end) continue;   // wave-uniform
             // 30 column sums: 7 from the left lane, own 16, 7 from the right lane
             const uint32_t le2 = wave_from_left(VE[2]), lo2 = wave_from_left(VO[2]), le3 = wave_from_left(VE[3]), lo3 = wave_from_left(VO[3]);
             const uint32_t re0 = wave_from_right(VE[0]), ro0 = wave_from_right(VO[0]), re1 = wave_from_right(VE[1]), ro1 = wave_from_right(VO[1]);
@@ -197,9 +234,9 @@ __global__ __launch_bounds__(64) void k_grey_threshold7(const uint8_t* __restric
 #pragma unroll
             for (int i = 0; i < T_LPX; i++) {
                 if (i > 0) S += e[i + 14] - e[i - 1];
-                const uint32_t gv = (ring[7][i >> 2] >> (8 * (i & 3))) & 255u;
-                const uint32_t area = ((axp[i >> 3] >> (4 * (i & 7))) & 15u) * ay;
-                outb |= (S < (gv + 1u) * area ? 1u : 0u) << i;
+                const uint32_t gv = (centre[i >> 2] >> (8 * (i & 3))) & 255u;
+                const uint32_t area = mul24((axp[i >> 3] >> (4 * (i & 7))) & 15u, ay);   // <= 225
+                outb |= (S < mul24(gv + 1u, area) ? 1u : 0u) << i;                       // <= 256*225
             }
             if (owner) *reinterpret_cast<uint16_t*>(bout + (size_t)y * bpr + (x0 >> 3)) = (uint16_t)outb;
         }
@@ -252,16 +289,18 @@ hipError_t launch_grey_threshold(hipStream_t st, const uint8_t* pixels, int fmt,
         // rows per wave: enough waves to fill the chip several times over, few enough that the 14 extra rows each
         // wave reads above/below its strip stay a small fraction
         const int strips_x = (W + T_OUT - 1) / T_OUT;
-        int rows_per_wave = 72;
-        while (rows_per_wave > 24 && (long long)strips_x * ((H + rows_per_wave - 1) / rows_per_wave) * n < 3 * 256 * 8) rows_per_wave -= 8;
+        int rows_per_wave = 106;   // 106 + 14 halo rows = 8 blocks of 15
+        if (const char* ev = getenv("A3_ROWS_PER_WAVE")) rows_per_wave = atoi(ev) > 0 ? atoi(ev) : rows_per_wave;  // tuning knob
+        while (rows_per_wave > 31 && (long long)strips_x * ((H + rows_per_wave - 1) / rows_per_wave) * n < 3 * 256 * 8) rows_per_wave -= 15;
         const int strips_y = (H + rows_per_wave - 1) / rows_per_wave;
         dim3 grid(strips_x * strips_y, n), block(64);
-        if (fmt == A3_FMT_RGB8)
-            hipLaunchKernelGGL(k_grey_threshold7<A3_FMT_RGB8>, grid, block, 0, st, pixels, row_stride, frame_stride, W, H, rows_per_wave, grey, bin, aligned_in, aligned_out);
-        else if (fmt == A3_FMT_RGBA8)
-            hipLaunchKernelGGL(k_grey_threshold7<A3_FMT_RGBA8>, grid, block, 0, st, pixels, row_stride, frame_stride, W, H, rows_per_wave, grey, bin, aligned_in, aligned_out);
-        else
-            hipLaunchKernelGGL(k_grey_threshold7<A3_FMT_L8>, grid, block, 0, st, pixels, row_stride, frame_stride, W, H, rows_per_wave, grey, bin, aligned_in, aligned_out);
+        const bool fast = aligned_in && aligned_out;   // W % 16 == 0: a lane's 16 pixels are all inside or all outside
+#define A3_LAUNCH_K1(F, B) hipLaunchKernelGGL((k_grey_threshold7<F, B>), grid, block, 0, st, pixels, row_stride, frame_stride, W, H, \
+                                              rows_per_wave, grey, bin, aligned_in, aligned_out)
+        if (fmt == A3_FMT_RGB8) { if (fast) A3_LAUNCH_K1(A3_FMT_RGB8, true); else A3_LAUNCH_K1(A3_FMT_RGB8, false); }
+        else if (fmt == A3_FMT_RGBA8) { if (fast) A3_LAUNCH_K1(A3_FMT_RGBA8, true); else A3_LAUNCH_K1(A3_FMT_RGBA8, false); }
+        else { if (fast) A3_LAUNCH_K1(A3_FMT_L8, true); else A3_LAUNCH_K1(A3_FMT_L8, false); }
+#undef A3_LAUNCH_K1
         return hipGetLastError();
     }
     dim3 block(64), gridg((W + 63) / 64, H, n), grid1(words_per_row((uint32_t)W), H, n);
