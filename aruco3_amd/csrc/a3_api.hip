@@ -19,10 +19,11 @@ hipError_t launch_dart_build(hipStream_t, const uint64_t*, int, int, uint32_t, u
                              uint32_t*, uint8_t*, uint8_t*, uint32_t*, uint32_t);
 size_t entry_state_bytes();
 hipError_t launch_rank_cycles(hipStream_t, uint32_t, int, const uint32_t*, const uint8_t*, const uint32_t*, JumpState*, uint32_t*, uint32_t*,
-                              uint32_t*, uint32_t*, unsigned int*, void*, void*, JumpState*, int, DeviceCounters*);
+                              uint32_t*, uint32_t*, unsigned int*, void*, void*, JumpState*, uint32_t*, unsigned int*, int, DeviceCounters*);
 hipError_t launch_resolve(hipStream_t, const JumpState*, uint32_t, int, const uint32_t*, const uint8_t*, const uint8_t*, uint64_t*, uint64_t*,
                           DeviceCounters*, int);
-hipError_t launch_select_scatter(hipStream_t, const JumpState*, uint32_t, const uint32_t*, const uint64_t*, const uint32_t*, uint32_t, uint32_t,
+hipError_t launch_select_scatter(hipStream_t, const JumpState*, uint32_t, const uint32_t*, const unsigned int*, const uint32_t*, const uint64_t*,
+                                 const uint32_t*, uint32_t, uint32_t,
                                  uint32_t, double, double, uint32_t*, ContourRec*, uint32_t*, uint32_t, uint64_t, DeviceCounters*,
                                  const uint32_t*, uint32_t*);
 hipError_t launch_unpack_bits(hipStream_t, const uint64_t*, int, int, uint8_t*);
@@ -146,7 +147,7 @@ int ensure_dart_pool(a3_ctx* ctx, uint64_t darts) {
     A3_HIP(ctx->t_next.ensure(darts * 8));
     A3_HIP(ctx->cyc_slot.ensure(darts * 4));
     A3_HIP(ctx->loc_dist.ensure(darts * 4));
-    A3_HIP(ctx->entry_bits.ensure((darts + 31) / 32 * 4 + 4));
+    A3_HIP(ctx->entry_bits.ensure(darts * 4 + 4));   // leader list (cycles with a start event): at most one per dart
     A3_HIP(ctx->entry_list.ensure(darts * 4));
     A3_HIP(ctx->entry_pos.ensure(darts * 4));
     // entries are darts whose predecessor lies in another 2048-dart tile; the bound darts is never reached in practice,
@@ -231,6 +232,7 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     unsigned int* d_marker_total = ctx->scratch_u32.as<unsigned int>() + 1;
     unsigned int* d_err = ctx->scratch_u32.as<unsigned int>() + 4;
     unsigned int* d_entry_count = ctx->scratch_u32.as<unsigned int>() + 5;
+    unsigned int* d_leader_count = ctx->scratch_u32.as<unsigned int>() + 6;
 
     // frame bases of every chunk, uploaded once
     std::vector<uint32_t> bases;
@@ -267,11 +269,11 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
         A3_HIP(launch_rank_cycles(st, nd, (int)W, ctx->d_xy.as<uint32_t>(), ctx->d_info.as<uint8_t>(), ctx->d_succ.as<uint32_t>(),
                                   ctx->stA.as<JumpState>(), ctx->loc_dist.as<uint32_t>(), ctx->entry_bits.as<uint32_t>(),
                                   ctx->entry_list.as<uint32_t>(), ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
-                                  ctx->stB.as<JumpState>(), rounds, ctr));
+                                  ctx->stB.as<JumpState>(), ctx->entry_bits.as<uint32_t>(), d_leader_count, rounds, ctr));
         const JumpState* fin = ctx->stB.as<JumpState>();
         A3_HIP(launch_resolve(st, fin, nd, (int)W, ctx->d_xy.as<uint32_t>(), ctx->d_info.as<uint8_t>(), ctx->d_F.as<uint8_t>(),
                               ctx->t_cur.as<uint64_t>(), ctx->t_next.as<uint64_t>(), ctr, kResolveIters));
-        A3_HIP(launch_select_scatter(st, fin, nd, ctx->d_succ.as<uint32_t>(), ctx->t_cur.as<uint64_t>(), fb, c.count, c.first, min_edge_length,
+        A3_HIP(launch_select_scatter(st, fin, nd, ctx->entry_bits.as<uint32_t>(), d_leader_count, ctx->d_succ.as<uint32_t>(), ctx->t_cur.as<uint64_t>(), fb, c.count, c.first, min_edge_length,
                                      ctx->cfg.contour_simplification_epsilon, image_diag, ctx->cyc_slot.as<uint32_t>(),
                                      ctx->contours.as<ContourRec>(),
                                      ctx->cyc_start_off.as<uint32_t>(), ctx->max_contours, ctx->max_points, ctr, ctx->d_xy.as<uint32_t>(),

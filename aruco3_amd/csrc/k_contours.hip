@@ -235,7 +235,7 @@ constexpr uint32_t kFrozen = 0x80000000u;     // dist flag: the window reached a
 __global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W, const uint32_t* __restrict__ d_xy,
                                                         const uint8_t* __restrict__ d_info, const uint32_t* __restrict__ d_succ,
                                                         JumpState* __restrict__ loc, uint32_t* __restrict__ loc_dist,
-                                                        uint32_t* __restrict__ entry_bits, uint32_t* __restrict__ entry_list,
+                                                        uint32_t* __restrict__ entry_list,
                                                         uint32_t* __restrict__ entry_pos, unsigned int* __restrict__ entry_count) {
     __shared__ uint64_t s_key[kLT];
     __shared__ uint32_t s_ptr[kLT], s_off[kLT], s_dist[kLT];
@@ -278,7 +278,18 @@ __global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W,
         }
         __syncthreads();
     }
-    for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
+    // results + entries.  The entries of the reduced list are exactly the successors that lie outside their
+    // predecessor's tile; succ is injective, so each is registered once, by that predecessor, with no global dedupe.
+    // Slots are counted per workgroup: one global atomic per tile.
+    __shared__ uint32_t s_new_count, s_new_base;
+    if (threadIdx.x == 0) s_new_count = 0;
+    __syncthreads();
+    uint32_t my_e[kLT / 256], my_slot[kLT / 256];
+#pragma unroll
+    for (int u = 0; u < kLT / 256; u++) {
+        const uint32_t i = threadIdx.x + u * 256;
+        my_slot[u] = kNone;
+        if (i >= cnt) continue;
         const uint32_t d = lo + i;
         const uint32_t e = s_ptr[i];
         const bool frozen = (e - lo) >= cnt;
@@ -286,15 +297,19 @@ __global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W,
         r.key = s_key[i]; r.ptr = e; r.off = s_off[i];
         loc[d] = r;
         loc_dist[d] = s_dist[i] | (frozen ? kFrozen : 0u);
-        if (frozen) {
-            const uint32_t bit = 1u << (e & 31);
-            if (!(atomicOr(&entry_bits[e >> 5], bit) & bit)) {
-                const uint32_t slot = atomicAdd(entry_count, 1u);
-                entry_list[slot] = e;
-                entry_pos[e] = slot;
-            }
-        }
+        const uint32_t s0 = d_succ[d];
+        if ((s0 - lo) >= cnt) { my_e[u] = s0; my_slot[u] = atomicAdd(&s_new_count, 1u); }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) s_new_base = s_new_count ? atomicAdd(entry_count, s_new_count) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kLT / 256; u++)
+        if (my_slot[u] != kNone) {
+            const uint32_t slot = s_new_base + my_slot[u];
+            entry_list[slot] = my_e[u];
+            entry_pos[my_e[u]] = slot;
+        }
 }
 
 struct __attribute__((aligned(8))) EntryState { uint64_t key; uint32_t ptr; uint32_t off; uint32_t dist; uint32_t pad; };
@@ -336,17 +351,34 @@ __global__ __launch_bounds__(256) void k_entry_jump(const EntryState* __restrict
 }
 
 // Phase 3: every dart learns its cycle's leader and its hop distance to it
+// ... and the leaders of cycles that carry at least one start event are collected (one atomic per wave) for the
+// per-border kernels that follow.
 __global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const JumpState* __restrict__ loc, const uint32_t* __restrict__ loc_dist,
                                                        const uint32_t* __restrict__ entry_pos, const EntryState* __restrict__ es,
-                                                       JumpState* __restrict__ fin) {
-    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
-        JumpState s = loc[d];
-        const uint32_t dd = loc_dist[d];
-        if (dd & kFrozen) {
-            const EntryState g = es[entry_pos[s.ptr]];
-            if (g.key < s.key) { s.key = g.key; s.off = (dd & ~kFrozen) + g.off; }
+                                                       JumpState* __restrict__ fin, uint32_t* __restrict__ leader_list,
+                                                       unsigned int* __restrict__ leader_count) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t d0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; d0 < n_darts; d0 += stride) {
+        const uint32_t d = d0 + lane;
+        bool is_leader = false;
+        if (d < n_darts) {
+            JumpState s = loc[d];
+            const uint32_t dd = loc_dist[d];
+            if (dd & kFrozen) {
+                const EntryState g = es[entry_pos[s.ptr]];
+                if (g.key < s.key) { s.key = g.key; s.off = (dd & ~kFrozen) + g.off; }
+            }
+            fin[d] = s;
+            is_leader = (uint32_t)s.key == d && (uint32_t)(s.key >> 32) != kNoKey;
         }
-        fin[d] = s;
+        const unsigned long long m = __ballot(is_leader);
+        if (m) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(leader_count, (unsigned int)__popcll(m));
+            base = __shfl(base, 0);
+            if (is_leader) leader_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = d;
+        }
     }
 }
 
@@ -425,42 +457,69 @@ __global__ void k_resolve_commit(const JumpState* __restrict__ st, uint32_t n_da
 // ---------------------------------------------------------------------------------------
 // select the borders worth materialising, then write their points in traversal order
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restrict__ st, uint32_t n_darts, const uint32_t* __restrict__ d_succ,
+__global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restrict__ st, const uint32_t* __restrict__ leader_list,
+                                                      const unsigned int* __restrict__ leader_count, const uint32_t* __restrict__ d_succ,
                                                       const uint64_t* __restrict__ t_cur, const uint32_t* __restrict__ frame_base,
                                                       uint32_t n_frames, uint32_t first_frame, uint32_t min_edge_length, double eps_factor,
                                                       double image_diag, uint32_t* __restrict__ cyc_slot, ContourRec* __restrict__ contours,
                                                       uint32_t* __restrict__ cyc_start_off, uint32_t max_contours, uint64_t max_points,
                                                       DeviceCounters* __restrict__ ctr) {
-    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
-        const JumpState s = st[d];
-        if ((uint32_t)s.key != d) continue;  // leaders only
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_leaders = *leader_count;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    // every lane of a wave runs the same number of iterations: the allocation below is wave-collective
+    for (uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; i0 < n_leaders; i0 += stride) {
+        const uint32_t i = i0 + lane;
+        bool traced = false, keep = false, broken = false;
+        uint32_t n = 0, d = 0;
+        uint64_t t = kInf64;
+        if (i < n_leaders) {
+            d = leader_list[i];
+            t = t_cur[d];
+            traced = t != kInf64;
+            if (traced) {
+                // the successor's window must have wrapped around to this leader, else this is a chain, not a cycle
+                const uint32_t sl = d_succ[d];
+                if (sl == d || (uint32_t)st[sl].key != d) broken = true;
+                else {
+                    n = st[sl].off + 1u;
+                    // Parity-safe pruning (src/aruco.rs:133-158):
+                    //  (1) a candidate keeps 4 points whose hull-adjacent pairs are >= sqrt(min_edge_length) apart; two
+                    //      border points i < j are at most min(j-i, n-(j-i)) 8-connected steps apart, i.e.
+                    //      dist^2 <= 2*(n/2)^2, so n^2 >= 2*min_edge_length is necessary;
+                    //  (2) Douglas-Peucker splits only when a point is further than eps = eps_factor*n from a chord,
+                    //      and no two pixels are further apart than the image diagonal (+1 slack for rounding).
+                    const double eps = (double)n * eps_factor;
+                    keep = n >= 5u && (uint64_t)n * n >= 2ull * min_edge_length && eps < image_diag + 1.0;
+                }
+            }
+        }
+        if (broken) atomicOr(&ctr->err_flags, kErrBrokenEvent);
+        // one atomic per wave and counter
+        const unsigned long long m_traced = __ballot(traced), m_keep = __ballot(keep);
+        if (lane == 0 && m_traced) atomicAdd(&ctr->traced, (unsigned int)__popcll(m_traced));
         uint32_t slot = kNone;
-        const uint64_t t = t_cur[d];
-        if (t != kInf64) {
-            atomicAdd(&ctr->traced, 1u);
-            // the successor's window must have wrapped around to this leader, else this is a chain, not a cycle
-            const uint32_t sl = d_succ[d];
-            if (sl == d || (uint32_t)st[sl].key != d) { atomicOr(&ctr->err_flags, kErrBrokenEvent); cyc_slot[d] = kNone; continue; }
-            const uint32_t n = st[sl].off + 1u;
-            // Parity-safe pruning (src/aruco.rs:133-158):
-            //  (1) a candidate keeps 4 points whose hull-adjacent pairs are >= sqrt(min_edge_length) apart; two border
-            //      points i < j are at most min(j-i, n-(j-i)) 8-connected steps apart, i.e. dist^2 <= 2*(n/2)^2, so
-            //      n^2 >= 2*min_edge_length is necessary;
-            //  (2) Douglas-Peucker splits only when a point is further than eps = eps_factor*n from a chord, and no two
-            //      pixels are further apart than the image diagonal (+1 slack for rounding).
-            const double eps = (double)n * eps_factor;
-            if (n >= 5u && (uint64_t)n * n >= 2ull * min_edge_length && eps < image_diag + 1.0) {
-                const uint32_t c = atomicAdd(&ctr->contours, 1u);
-                const unsigned long long pbase = atomicAdd(&ctr->points, (unsigned long long)n);
+        if (m_keep) {
+            uint32_t inc = keep ? n : 0u;   // wave inclusive scan of the point counts
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+            const uint32_t total = __shfl(inc, 63);
+            uint32_t cbase = 0; unsigned long long pbase = 0;
+            if (lane == 0) { cbase = atomicAdd(&ctr->contours, (unsigned int)__popcll(m_keep)); pbase = atomicAdd(&ctr->points, (unsigned long long)total); }
+            cbase = __shfl(cbase, 0);
+            pbase = __shfl(pbase, 0);
+            if (keep) {
+                const uint32_t c = cbase + (uint32_t)__popcll(m_keep & ((1ull << lane) - 1ull));
+                const unsigned long long pb = pbase + (inc - n);
                 if (c >= max_contours) atomicOr(&ctr->err_flags, kErrContourTable);
-                else if (pbase + n > max_points) atomicOr(&ctr->err_flags, kErrPointPool);
+                else if (pb + n > max_points) atomicOr(&ctr->err_flags, kErrPointPool);
                 else {
                     uint32_t lo = 0, hi = n_frames;  // frame of this dart: binary search in frame_base
                     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (frame_base[mid] <= d) lo = mid; else hi = mid; }
                     ContourRec r;
                     r.frame = first_frame + lo;
                     r.start_key = (uint32_t)(t >> 32);
-                    r.point_base = (uint32_t)pbase;
+                    r.point_base = (uint32_t)pb;
                     r.n = n;
                     contours[c] = r;
                     cyc_start_off[c] = st[(uint32_t)t].off;
@@ -468,7 +527,7 @@ __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restric
                 }
             }
         }
-        cyc_slot[d] = slot;
+        if (i < n_leaders) cyc_slot[d] = slot;
     }
 }
 
@@ -477,6 +536,7 @@ __global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restr
                                                         const uint32_t* __restrict__ cyc_start_off, uint32_t* __restrict__ points) {
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
         const JumpState s = st[d];
+        if ((uint32_t)(s.key >> 32) == kNoKey) continue;   // no start event anywhere on this cycle: never traced
         const uint32_t leader = (uint32_t)s.key;
         if ((uint32_t)st[leader].key != leader) continue;  // open chain: its "leader" slot was never written
         const uint32_t c = cyc_slot[leader];
@@ -662,13 +722,13 @@ size_t entry_state_bytes() { return sizeof(EntryState); }
 // entry_bits: ceil(n_darts/32) words, zeroed here.
 hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uint32_t* d_xy, const uint8_t* d_info, const uint32_t* d_succ,
                               JumpState* loc, uint32_t* loc_dist, uint32_t* entry_bits, uint32_t* entry_list, uint32_t* entry_pos,
-                              unsigned int* entry_count, void* es_a, void* es_b, JumpState* fin, int max_rounds, DeviceCounters* ctr) {
-    hipError_t e = hipMemsetAsync(entry_bits, 0, ((size_t)n_darts + 31) / 32 * 4, st);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(entry_count, 0, 4, st);
+                              unsigned int* entry_count, void* es_a, void* es_b, JumpState* fin, uint32_t* leader_list,
+                              unsigned int* leader_count, int max_rounds, DeviceCounters* ctr) {
+    (void)entry_bits;
+    hipError_t e = hipMemsetAsync(entry_count, 0, 4, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_local_contract, dim3((n_darts + kLT - 1) / kLT), dim3(256), 0, st, n_darts, W, d_xy, d_info, d_succ, loc, loc_dist,
-                       entry_bits, entry_list, entry_pos, entry_count);
+                       entry_list, entry_pos, entry_count);
     EntryState* a = reinterpret_cast<EntryState*>(es_a);
     EntryState* b = reinterpret_cast<EntryState*>(es_b);
     const dim3 grid(blocks_for(n_darts / 8 + 1, 256, 2048)), block(256);
@@ -677,7 +737,10 @@ hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uin
         hipLaunchKernelGGL(k_entry_jump, grid, block, 0, st, a, b, entry_count, r, ctr);
         EntryState* t = a; a = b; b = t;
     }
-    hipLaunchKernelGGL(k_jump_finalize, dim3(blocks_for(n_darts, 256, 8192)), block, 0, st, n_darts, loc, loc_dist, entry_pos, a, fin);
+    e = hipMemsetAsync(leader_count, 0, 4, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_jump_finalize, dim3(blocks_for(n_darts, 256, 8192)), block, 0, st, n_darts, loc, loc_dist, entry_pos, a, fin,
+                       leader_list, leader_count);
     return hipGetLastError();
 }
 
@@ -692,12 +755,14 @@ hipError_t launch_resolve(hipStream_t st, const JumpState* fin, uint32_t n_darts
     return hipGetLastError();
 }
 
-hipError_t launch_select_scatter(hipStream_t st, const JumpState* fin, uint32_t n_darts, const uint32_t* d_succ, const uint64_t* t_cur,
+hipError_t launch_select_scatter(hipStream_t st, const JumpState* fin, uint32_t n_darts, const uint32_t* leader_list,
+                                 const unsigned int* leader_count, const uint32_t* d_succ, const uint64_t* t_cur,
                                  const uint32_t* frame_base, uint32_t n_frames, uint32_t first_frame, uint32_t min_edge_length,
                                  double eps_factor, double image_diag, uint32_t* cyc_slot, ContourRec* contours, uint32_t* cyc_start_off,
                                  uint32_t max_contours, uint64_t max_points, DeviceCounters* ctr, const uint32_t* d_xy, uint32_t* points) {
     const dim3 grid(blocks_for(n_darts, 256, 4096)), block(256);
-    hipLaunchKernelGGL(k_cycle_select, grid, block, 0, st, fin, n_darts, d_succ, t_cur, frame_base, n_frames, first_frame, min_edge_length,
+    hipLaunchKernelGGL(k_cycle_select, dim3(blocks_for(n_darts / 64 + 1, 256, 1024)), block, 0, st, fin, leader_list, leader_count, d_succ, t_cur,
+                       frame_base, n_frames, first_frame, min_edge_length,
                        eps_factor, image_diag, cyc_slot, contours, cyc_start_off, max_contours, max_points, ctr);
     hipLaunchKernelGGL(k_scatter_points, grid, block, 0, st, fin, n_darts, d_xy, cyc_slot, contours, cyc_start_off, points);
     return hipGetLastError();

@@ -253,6 +253,9 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ grey
     __shared__ uint32_t s_otsu;
     __shared__ uint64_t s_codes[4];
     __shared__ unsigned long long s_best[4][4];
+    __shared__ uint32_t s_scan_w[4], s_scan_s[4];
+    __shared__ double s_var[4];
+    __shared__ int s_vt[4];
 
     const int tid = threadIdx.x;
     const uint32_t n_work = *work_count;
@@ -296,30 +299,51 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ grey
             uint8_t* dst = patches + (size_t)slot * S * S;
             for (uint32_t i = tid; i < S * S; i += 256) dst[i] = ok ? s_patch[i] : 0;
         }
-        // otsu_level: the reference's sequential scan, literally (f64)
-        if (tid == 0) {
+        // otsu_level (imageproc): the reference scans thresholds 0..255 keeping running integer sums and the first strict
+        // maximum of w_b * w_f * (mean_b - mean_f)^2 in f64.  The running sums are exact integers, so every threshold can
+        // be evaluated independently from prefix sums with the very same f64 operations; the first strict maximum is the
+        // largest variance, lowest threshold among equals, and it must exceed the initial 0.0.
+        {
+            const uint32_t hcnt = s_hist[tid];
+            uint32_t bw = hcnt, bs = (uint32_t)tid * hcnt;   // inclusive prefix sums over thresholds
+#pragma unroll
+            for (int o2 = 1; o2 < 64; o2 <<= 1) {
+                const uint32_t a = __shfl_up(bw, o2), b = __shfl_up(bs, o2);
+                if ((tid & 63) >= o2) { bw += a; bs += b; }
+            }
+            if ((tid & 63) == 63) { s_scan_w[tid >> 6] = bw; s_scan_s[tid >> 6] = bs; }
+            __syncthreads();
+            uint32_t total_sum_u = 0;
+            for (int w = 0; w < 4; w++) {
+                if (w < (tid >> 6)) { bw += s_scan_w[w]; bs += s_scan_s[w]; }
+                total_sum_u += s_scan_s[w];
+            }
             const uint32_t total_weight = pw * ph;
-            double total_pixel_sum = 0.0;
-            for (uint32_t t = 0; t < 256; t++) total_pixel_sum = total_pixel_sum + (double)(t * s_hist[t]);
-            double background_pixel_sum = 0.0;
-            uint32_t background_weight = 0;
-            double largest_variance = 0.0;
-            uint32_t best_threshold = 0;
-            for (uint32_t t = 0; t < 256; t++) {
-                background_weight += s_hist[t];
-                if (background_weight == 0) continue;
-                const uint32_t foreground_weight = total_weight - background_weight;
-                if (foreground_weight == 0) break;
-                background_pixel_sum += (double)(t * s_hist[t]);
+            const double total_pixel_sum = (double)total_sum_u;
+            double var = -1.0;   // "not a candidate"
+            const uint32_t fw = total_weight - bw;
+            if (bw != 0 && fw != 0) {
+                const double background_pixel_sum = (double)bs;
                 const double foreground_pixel_sum = total_pixel_sum - background_pixel_sum;
-                const double background_mean = background_pixel_sum / (double)background_weight;
-                const double foreground_mean = foreground_pixel_sum / (double)foreground_weight;
+                const double background_mean = background_pixel_sum / (double)bw;
+                const double foreground_mean = foreground_pixel_sum / (double)fw;
                 const double diff = background_mean - foreground_mean;
                 const double mean_diff_squared = diff * diff;
-                const double intra_class_variance = (double)background_weight * (double)foreground_weight * mean_diff_squared;
-                if (intra_class_variance > largest_variance) { largest_variance = intra_class_variance; best_threshold = t; }
+                var = (double)bw * (double)fw * mean_diff_squared;
             }
-            s_otsu = best_threshold;
+            int best_t = tid;
+            for (int o2 = 32; o2 > 0; o2 >>= 1) {
+                const double ov = __shfl_xor(var, o2);
+                const int ot = __shfl_xor(best_t, o2);
+                if (ov > var || (ov == var && ot < best_t)) { var = ov; best_t = ot; }
+            }
+            if ((tid & 63) == 0) { s_var[tid >> 6] = var; s_vt[tid >> 6] = best_t; }
+            __syncthreads();
+            if (tid == 0) {
+                double bv = s_var[0]; int bt = s_vt[0];
+                for (int w = 1; w < 4; w++) if (s_var[w] > bv || (s_var[w] == bv && s_vt[w] < bt)) { bv = s_var[w]; bt = s_vt[w]; }
+                s_otsu = bv > 0.0 ? (uint32_t)bt : 0u;
+            }
         }
         // resize weights (same table for both passes: the patch and the grid are square)
         if (tid >= 64 && tid < 64 + (int)n) {
