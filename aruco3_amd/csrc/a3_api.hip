@@ -16,16 +16,16 @@ hipError_t launch_grey_threshold(hipStream_t, const uint8_t*, int, size_t, size_
 // k_contours.hip
 hipError_t launch_dart_count(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, unsigned long long*);
 hipError_t launch_dart_build(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, const uint32_t*, uint32_t*, uint32_t*, uint64_t*,
-                             uint32_t*, uint8_t*, uint8_t*, uint32_t*, uint32_t);
+                             uint64_t*, uint32_t*, uint32_t);
 size_t entry_state_bytes();
-hipError_t launch_rank_cycles(hipStream_t, uint32_t, int, const uint32_t*, const uint8_t*, const uint32_t*, JumpState*, uint32_t*, uint32_t*,
+size_t leader_list_bytes(uint32_t);
+hipError_t launch_rank_cycles(hipStream_t, uint32_t, int, const uint64_t*, const uint32_t*, JumpState*, uint32_t*, uint32_t*,
                               uint32_t*, uint32_t*, unsigned int*, void*, void*, JumpState*, uint32_t*, unsigned int*, int, DeviceCounters*);
-hipError_t launch_resolve(hipStream_t, const JumpState*, uint32_t, int, const uint32_t*, const uint8_t*, const uint8_t*, uint64_t*, uint64_t*,
-                          DeviceCounters*, int);
+hipError_t launch_resolve(hipStream_t, const JumpState*, uint32_t, int, const uint64_t*, uint64_t*, uint64_t*, DeviceCounters*, int);
 hipError_t launch_select_scatter(hipStream_t, const JumpState*, uint32_t, const uint32_t*, const unsigned int*, const uint32_t*, const uint64_t*,
                                  const uint32_t*, uint32_t, uint32_t,
                                  uint32_t, double, double, uint32_t*, ContourRec*, uint32_t*, uint32_t, uint64_t, DeviceCounters*,
-                                 const uint32_t*, uint32_t*);
+                                 const uint64_t*, uint32_t*);
 hipError_t launch_unpack_bits(hipStream_t, const uint64_t*, int, int, uint8_t*);
 hipError_t launch_contour_quads(hipStream_t, const ContourRec*, const DeviceCounters*, uint32_t, const uint32_t*, double, uint32_t, uint32_t,
                                 uint32_t, CandRec*, uint32_t*, unsigned int*);
@@ -55,7 +55,7 @@ constexpr uint64_t kMaxDartsDefault = 48ull << 20;
 constexpr uint64_t kMaxPointsDefault = 64ull << 20;
 constexpr uint64_t kHardMaxDarts = 3ull << 30;   // 32-bit dart indices
 constexpr uint64_t kHardMaxPoints = 3ull << 30;
-constexpr int kResolveIters = 10;           // <= DeviceCounters::resolve_changed slots
+constexpr int kResolveItersMax = 16;        // == DeviceCounters::resolve_changed slots
 constexpr uint32_t kPatchCap = 32768;        // debug taps: warped patches kept per batch
 
 // grow-only device buffer
@@ -87,6 +87,9 @@ struct a3_ctx {
 
     uint64_t max_darts = kMaxDartsDefault, max_points = kMaxPointsDefault;
     uint32_t max_contours = kMaxContoursDefault;
+    // launch-count hints (every pass past convergence is an empty launch of ~5 us): start low, retry the batch with the
+    // maximum if a pass count turns out too small
+    int jump_rounds_hint = 10, resolve_iters_hint = 4;
     bool debug_taps = false;
     bool profiling = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -137,9 +140,7 @@ uint32_t mark_size_of(uint8_t num_bits) {  // src/dictionaries.rs:154-156
 }
 
 int ensure_dart_pool(a3_ctx* ctx, uint64_t darts) {
-    A3_HIP(ctx->d_xy.ensure(darts * 4));
-    A3_HIP(ctx->d_info.ensure(darts));
-    A3_HIP(ctx->d_F.ensure(darts));
+    A3_HIP(ctx->d_xy.ensure(darts * 8));   // dart records (dart_rec)
     A3_HIP(ctx->d_succ.ensure(darts * 4));
     A3_HIP(ctx->stA.ensure(darts * sizeof(JumpState)));
     A3_HIP(ctx->stB.ensure(darts * sizeof(JumpState)));
@@ -147,7 +148,7 @@ int ensure_dart_pool(a3_ctx* ctx, uint64_t darts) {
     A3_HIP(ctx->t_next.ensure(darts * 8));
     A3_HIP(ctx->cyc_slot.ensure(darts * 4));
     A3_HIP(ctx->loc_dist.ensure(darts * 4));
-    A3_HIP(ctx->entry_bits.ensure(darts * 4 + 4));   // leader list (cycles with a start event): at most one per dart
+    A3_HIP(ctx->entry_bits.ensure(leader_list_bytes((uint32_t)darts)));   // leader list (cycles with a start event), 16 shards
     A3_HIP(ctx->entry_list.ensure(darts * 4));
     A3_HIP(ctx->entry_pos.ensure(darts * 4));
     // entries are darts whose predecessor lies in another 2048-dart tile; the bound darts is never reached in practice,
@@ -181,7 +182,7 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     A3_HIP(ctx->per_frame.ensure((size_t)n * 4));
     const uint32_t marker_cap = (uint32_t)std::min<size_t>(std::max<size_t>(out_cap, 1), (size_t)n * kMaxCand);
     A3_HIP(ctx->markers.ensure((size_t)marker_cap * sizeof(a3_marker)));
-    A3_HIP(ctx->scratch_u32.ensure(64));
+    A3_HIP(ctx->scratch_u32.ensure(256));
     if (ctx->debug_taps) A3_HIP(ctx->patches.ensure((size_t)kPatchCap * S * S));
     ctx->W = W; ctx->H = H; ctx->frames = n;
     ctx->stats = a3_stats{};
@@ -227,12 +228,12 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
 
     A3_HIP(hipMemsetAsync(ctx->counters.p, 0, sizeof(DeviceCounters) * chunks.size(), st));
     A3_HIP(hipMemsetAsync(ctx->cand_count.p, 0, (size_t)n * 4, st));
-    A3_HIP(hipMemsetAsync(ctx->scratch_u32.p, 0, 64, st));
+    A3_HIP(hipMemsetAsync(ctx->scratch_u32.p, 0, 256, st));
     unsigned int* d_work_count = ctx->scratch_u32.as<unsigned int>() + 0;
     unsigned int* d_marker_total = ctx->scratch_u32.as<unsigned int>() + 1;
     unsigned int* d_err = ctx->scratch_u32.as<unsigned int>() + 4;
     unsigned int* d_entry_count = ctx->scratch_u32.as<unsigned int>() + 5;
-    unsigned int* d_leader_count = ctx->scratch_u32.as<unsigned int>() + 6;
+    unsigned int* d_leader_count = ctx->scratch_u32.as<unsigned int>() + 16;   // [16..31]
 
     // frame bases of every chunk, uploaded once
     std::vector<uint32_t> bases;
@@ -261,22 +262,23 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
         if (nd == 0) continue;
         A3_HIP(hipMemsetAsync(ctx->frame_cursor.p, 0, (size_t)c.count * 4, st));
         A3_HIP(launch_dart_build(st, d_bin, (int)W, (int)H, c.first, c.count, fb, ctx->frame_cursor.as<uint32_t>(), ctx->pix_base.as<uint32_t>(),
-                                 ctx->node_bits.as<uint64_t>(), ctx->d_xy.as<uint32_t>(), ctx->d_info.as<uint8_t>(), ctx->d_F.as<uint8_t>(), ctx->d_succ.as<uint32_t>(), nd));
+                                 ctx->node_bits.as<uint64_t>(), ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), nd));
         int rounds = 1;
         while ((1ull << rounds) < (uint64_t)c.max_frame_darts && rounds < 31) rounds++;
         rounds += 1;  // the round that observes "nothing moved"
+        rounds = std::min(rounds, ctx->jump_rounds_hint);
         rounds_max = std::max(rounds_max, rounds);
-        A3_HIP(launch_rank_cycles(st, nd, (int)W, ctx->d_xy.as<uint32_t>(), ctx->d_info.as<uint8_t>(), ctx->d_succ.as<uint32_t>(),
+        A3_HIP(launch_rank_cycles(st, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(),
                                   ctx->stA.as<JumpState>(), ctx->loc_dist.as<uint32_t>(), ctx->entry_bits.as<uint32_t>(),
                                   ctx->entry_list.as<uint32_t>(), ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
                                   ctx->stB.as<JumpState>(), ctx->entry_bits.as<uint32_t>(), d_leader_count, rounds, ctr));
         const JumpState* fin = ctx->stB.as<JumpState>();
-        A3_HIP(launch_resolve(st, fin, nd, (int)W, ctx->d_xy.as<uint32_t>(), ctx->d_info.as<uint8_t>(), ctx->d_F.as<uint8_t>(),
-                              ctx->t_cur.as<uint64_t>(), ctx->t_next.as<uint64_t>(), ctr, kResolveIters));
+        A3_HIP(launch_resolve(st, fin, nd, (int)W, ctx->d_xy.as<uint64_t>(),
+                              ctx->t_cur.as<uint64_t>(), ctx->t_next.as<uint64_t>(), ctr, ctx->resolve_iters_hint));
         A3_HIP(launch_select_scatter(st, fin, nd, ctx->entry_bits.as<uint32_t>(), d_leader_count, ctx->d_succ.as<uint32_t>(), ctx->t_cur.as<uint64_t>(), fb, c.count, c.first, min_edge_length,
                                      ctx->cfg.contour_simplification_epsilon, image_diag, ctx->cyc_slot.as<uint32_t>(),
                                      ctx->contours.as<ContourRec>(),
-                                     ctx->cyc_start_off.as<uint32_t>(), ctx->max_contours, ctx->max_points, ctr, ctx->d_xy.as<uint32_t>(),
+                                     ctx->cyc_start_off.as<uint32_t>(), ctx->max_contours, ctx->max_points, ctr, ctx->d_xy.as<uint64_t>(),
                                      ctx->points.as<uint32_t>()));
         A3_HIP(launch_contour_quads(st, ctx->contours.as<ContourRec>(), ctr, ctx->max_contours, ctx->points.as<uint32_t>(),
                                     ctx->cfg.contour_simplification_epsilon, min_edge_length, c.first, kMaxCand,
@@ -307,6 +309,7 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     const unsigned int* hs = reinterpret_cast<const unsigned int*>(hp + ctr_bytes);
     unsigned int flags = hs[4];
     uint64_t need_points = 0; uint32_t need_contours = 0;
+    bool jump_short = false;
     for (size_t ci = 0; ci < chunks.size(); ci++) {
         flags |= hc[ci].err_flags;
         need_points = std::max<uint64_t>(need_points, hc[ci].points);
@@ -315,9 +318,13 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
         ctx->stats.contours_materialised += hc[ci].contours;
         for (int r = 0; r < 32; r++) if (hc[ci].jump_changed[r]) ctx->stats.jump_rounds = std::max<uint32_t>(ctx->stats.jump_rounds, r + 1);
         uint32_t it = 1;  // pass k+1 ran iff pass k moved something
-        for (int r = 0; r < kResolveIters - 1; r++) if (hc[ci].resolve_changed[r]) it = r + 2;
+        for (int r = 0; r < kResolveItersMax - 1; r++) if (hc[ci].resolve_changed[r]) it = r + 2;
         ctx->stats.resolve_iterations = std::max(ctx->stats.resolve_iterations, it);
+        if (rounds_max > 0 && rounds_max < 32 && hc[ci].jump_changed[rounds_max - 1] != 0) jump_short = true;
     }
+    if (jump_short && ctx->jump_rounds_hint < 32) { ctx->jump_rounds_hint = 32; return 1; }             // re-run with all rounds
+    if ((flags & kErrResolve) && ctx->resolve_iters_hint < kResolveItersMax) { ctx->resolve_iters_hint = kResolveItersMax; return 1; }
+    ctx->jump_rounds_hint = std::max(ctx->jump_rounds_hint, std::min(32, (int)ctx->stats.jump_rounds + 3));
     if (flags & (kErrPointPool | kErrContourTable)) {
         // grow and let the caller loop re-run the batch
         if (need_points > ctx->max_points) ctx->max_points = std::min<uint64_t>(kHardMaxPoints, std::max(need_points, ctx->max_points * 2));

@@ -26,6 +26,12 @@ constexpr uint8_t kInfoW = 1u << 3;
 constexpr uint8_t kInfoE = 1u << 4;
 constexpr uint8_t kInfoBroken = 1u << 5;
 
+// per-dart record, one u64: bits 0-15 x, 16-31 y, 32-39 foreground-neighbour mask F of the pixel, 40-47 info byte
+__host__ __device__ inline uint64_t dart_rec(uint32_t xy, uint32_t F, uint32_t info) { return (uint64_t)xy | ((uint64_t)(F & 0xFFu) << 32) | ((uint64_t)(info & 0xFFu) << 40); }
+__host__ __device__ inline uint32_t rec_xy(uint64_t r) { return (uint32_t)r; }
+__host__ __device__ inline uint32_t rec_F(uint64_t r) { return (uint32_t)(r >> 32) & 0xFFu; }
+__host__ __device__ inline uint32_t rec_info(uint64_t r) { return (uint32_t)(r >> 40) & 0xFFu; }
+
 // state carried by the pointer-doubling rounds (16 bytes per dart = one dwordx4, ping-pong)
 struct __attribute__((aligned(16))) JumpState {
     uint64_t key;   // (start-event key << 32) | dart index : minimum over the window

@@ -105,16 +105,49 @@ __device__ __forceinline__ bool tile_word(int W, int H, int* j, int* y) {
     return *j < (int)words_per_row((uint32_t)W) && *y < H;
 }
 
+// The tile's words plus a one-word / one-row apron are staged in LDS with row-contiguous loads (6 words per row,
+// 66 rows) instead of nine strided 8-byte loads per lane.
+__device__ __forceinline__ Nb8 tile_nb8(const uint64_t* __restrict__ img, int W, int H, uint64_t (*s_t)[kTileWords + 2], bool* active, int* jo,
+                                        int* yo) {
+    const int wpr = (int)words_per_row((uint32_t)W);
+    const int tx = blockIdx.x % dart_tiles_x((uint32_t)W), ty = blockIdx.x / dart_tiles_x((uint32_t)W);
+    const int j0 = tx * kTileWords - 1, y0 = ty * kTileRows - 1;
+    for (int i = threadIdx.x; i < (kTileRows + 2) * (kTileWords + 2); i += 256) {
+        const int r = i / (kTileWords + 2), c = i - r * (kTileWords + 2);
+        s_t[r][c] = ldw(img, wpr, H, j0 + c, y0 + r);
+    }
+    __syncthreads();
+    const int jl = threadIdx.x & (kTileWords - 1), rl = threadIdx.x >> 2;
+    *jo = j0 + 1 + jl; *yo = y0 + 1 + rl;
+    *active = *jo < wpr && *yo < H;
+    Nb8 r;
+    const uint64_t al = s_t[rl][jl], a = s_t[rl][jl + 1], ar = s_t[rl][jl + 2];
+    const uint64_t cl = s_t[rl + 1][jl], c = s_t[rl + 1][jl + 1], cr = s_t[rl + 1][jl + 2];
+    const uint64_t bl = s_t[rl + 2][jl], b = s_t[rl + 2][jl + 1], br = s_t[rl + 2][jl + 2];
+    r.c = c;
+    r.n[0] = (c << 1) | (cl >> 63);
+    r.n[1] = (a << 1) | (al >> 63);
+    r.n[2] = a;
+    r.n[3] = (a >> 1) | (ar << 63);
+    r.n[4] = (c >> 1) | (cr << 63);
+    r.n[5] = (b >> 1) | (br << 63);
+    r.n[6] = b;
+    r.n[7] = (b << 1) | (bl >> 63);
+    return r;
+}
+
 // grid: (dart_tiles(W,H), frames)
 __global__ __launch_bounds__(256) void k_dart_count(const uint64_t* __restrict__ bits, int W, int H, uint32_t first_frame,
                                                     unsigned long long* __restrict__ frame_darts) {
     __shared__ uint32_t s_wave[4];
+    __shared__ uint64_t s_t[kTileRows + 2][kTileWords + 2];
     const int wpr = (int)words_per_row((uint32_t)W);
     const uint32_t f = blockIdx.y;
     uint32_t nd = 0;
     int j, y;
-    if (tile_word(W, H, &j, &y)) {
-        const Nb8 nb = load_nb8(bits + (size_t)(first_frame + f) * wpr * H, wpr, H, j, y);
+    bool active;
+    const Nb8 nb = tile_nb8(bits + (size_t)(first_frame + f) * wpr * H, W, H, s_t, &active, &j, &y);
+    if (active) {
         if (nb.c) {
             uint64_t p[8];
             pdart_words(nb, p);
@@ -132,21 +165,20 @@ __global__ __launch_bounds__(256) void k_dart_count(const uint64_t* __restrict__
 __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict__ bits, int W, int H, uint32_t first_frame,
                                                      const uint32_t* __restrict__ frame_base, uint32_t* __restrict__ frame_cursor,
                                                      uint32_t* __restrict__ pix_base, uint64_t* __restrict__ node_bits,
-                                                     uint32_t* __restrict__ d_xy, uint8_t* __restrict__ d_info, uint8_t* __restrict__ d_F) {
+                                                     uint64_t* __restrict__ d_rec) {
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_base;
+    __shared__ uint64_t s_t[kTileRows + 2][kTileWords + 2];
     const int wpr = (int)words_per_row((uint32_t)W);
     const uint32_t f = blockIdx.y;
     int j, y;
-    const bool active = tile_word(W, H, &j, &y);
+    bool active;
+    const Nb8 nb = tile_nb8(bits + (size_t)(first_frame + f) * wpr * H, W, H, s_t, &active, &j, &y);
     const uint32_t wi = active ? (uint32_t)(y * wpr + j) : 0u;
-    Nb8 nb;
-    nb.c = 0;
     uint64_t p[8];
     uint64_t nodes = 0;
     uint32_t nd = 0;
     if (active) {
-        nb = load_nb8(bits + (size_t)(first_frame + f) * wpr * H, wpr, H, j, y);
         if (nb.c) {
             pdart_words(nb, p);
 #pragma unroll
@@ -180,9 +212,8 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
         while (P) {
             const int k = __ffs(P) - 1;
             P &= P - 1;
-            d_xy[cur] = xy;
-            d_F[cur] = (uint8_t)F;
-            d_info[cur] = (uint8_t)(k | (k == kW ? kInfoW : 0) | (k == kE ? kInfoE : 0));
+            const uint32_t info = (uint32_t)k | (k == kW ? kInfoW : 0u) | (k == kE ? kInfoE : 0u);
+            d_rec[cur] = dart_rec(xy, F, info);   // one 8-byte store per dart
             cur++;
         }
     }
@@ -191,19 +222,18 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
 // successor of every dart + initial doubling state.  grid.y = frame, grid-stride over its darts.
 __global__ __launch_bounds__(256) void k_dart_link(int W, int H, const uint32_t* __restrict__ frame_base,
                                                    const uint32_t* __restrict__ pix_base, const uint64_t* __restrict__ node_bits,
-                                                   const uint32_t* __restrict__ d_xy, uint8_t* __restrict__ d_info,
-                                                   const uint8_t* __restrict__ d_F, uint32_t* __restrict__ d_succ) {
+                                                   const uint64_t* __restrict__ d_rec, uint32_t* __restrict__ d_succ) {
     const uint32_t f = blockIdx.y;
     const uint32_t lo = frame_base[f], hi = frame_base[f + 1];
     const int wpr = (int)words_per_row((uint32_t)W);
     const uint64_t* nbits = node_bits + (size_t)f * wpr * H;
     const uint32_t* pb = pix_base + (size_t)f * W * H;
     for (uint32_t d = lo + blockIdx.x * blockDim.x + threadIdx.x; d < hi; d += gridDim.x * blockDim.x) {
-        const uint32_t xy = d_xy[d];
+        const uint64_t rec = d_rec[d];
+        const uint32_t xy = rec_xy(rec);
         const int x = xy & 0xFFFF, y = xy >> 16;
-        const uint32_t F = d_F[d];
-        uint8_t info = d_info[d];
-        const int k = info & 7;
+        const uint32_t F = rec_F(rec);
+        const int k = rec_info(rec) & 7;
         // next foreground neighbour counter-clockwise after k: directions k-1, k-2, ..., k
         const uint32_t r = ((F >> k) | (F << (8 - k))) & 0xFFu;  // bit t <-> direction (k + t) & 7
         const int t = 31 - __clz(r);                              // bit 0 (k itself) is always set
@@ -212,11 +242,10 @@ __global__ __launch_bounds__(256) void k_dart_link(int W, int H, const uint32_t*
         uint32_t succ = d;  // chain end unless the target dart exists
         if ((nbits[(size_t)ny * wpr + (nx >> 6)] >> (nx & 63)) & 1ull) {
             const uint32_t tb = pb[(size_t)ny * W + nx];
-            const uint32_t tP = pdart_mask(d_F[tb]);
+            const uint32_t tP = pdart_mask(rec_F(d_rec[tb]));
             const int kin = (ko + 4) & 7;
             if ((tP >> kin) & 1u) succ = tb + __popc(tP & ((1u << kin) - 1u));
         }
-        if (succ == d) { info |= kInfoBroken; d_info[d] = info; }
         d_succ[d] = succ;
     }
 }
@@ -232,8 +261,8 @@ constexpr uint32_t kFrozen = 0x80000000u;     // dist flag: the window reached a
 
 // Phase 1: 11 doubling rounds inside one tile, entirely in LDS.  A window stops growing ("freezes") when its end leaves
 // the tile; cycles that close inside the tile finish here.  Darts that some frozen window ends on become "entries".
-__global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W, const uint32_t* __restrict__ d_xy,
-                                                        const uint8_t* __restrict__ d_info, const uint32_t* __restrict__ d_succ,
+__global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W, const uint64_t* __restrict__ d_rec,
+                                                        const uint32_t* __restrict__ d_succ,
                                                         JumpState* __restrict__ loc, uint32_t* __restrict__ loc_dist,
                                                         uint32_t* __restrict__ entry_list,
                                                         uint32_t* __restrict__ entry_pos, unsigned int* __restrict__ entry_count) {
@@ -243,8 +272,8 @@ __global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W,
     const uint32_t cnt = min((uint32_t)kLT, n_darts - lo);
     for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
         const uint32_t d = lo + i;
-        const uint32_t xy = d_xy[d];
-        const uint8_t info = d_info[d];
+        const uint64_t rec = d_rec[d];
+        const uint32_t xy = rec_xy(rec), info = rec_info(rec);
         const uint32_t q = (xy >> 16) * (uint32_t)W + (xy & 0xFFFF);
         const uint32_t ek = (info & kInfoW) ? 2u * q : ((info & kInfoE) ? 2u * q + 1u : kNoKey);
         s_key[i] = ((uint64_t)ek << 32) | d;
@@ -351,13 +380,17 @@ __global__ __launch_bounds__(256) void k_entry_jump(const EntryState* __restrict
 }
 
 // Phase 3: every dart learns its cycle's leader and its hop distance to it
+constexpr uint32_t kLeaderShards = 16;
+__host__ __device__ inline uint32_t leader_shard_cap(uint32_t n_darts) { return n_darts / kLeaderShards + 131072u + 64u; }
+
 // ... and the leaders of cycles that carry at least one start event are collected (one atomic per wave) for the
 // per-border kernels that follow.
 __global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const JumpState* __restrict__ loc, const uint32_t* __restrict__ loc_dist,
                                                        const uint32_t* __restrict__ entry_pos, const EntryState* __restrict__ es,
                                                        JumpState* __restrict__ fin, uint32_t* __restrict__ leader_list,
-                                                       unsigned int* __restrict__ leader_count) {
+                                                       unsigned int* __restrict__ leader_count /*[kLeaderShards]*/, uint32_t shard_cap) {
     const int lane = threadIdx.x & 63;
+    const uint32_t shard = blockIdx.x & (kLeaderShards - 1);   // spread the slot counter over 16 addresses
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t d0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; d0 < n_darts; d0 += stride) {
         const uint32_t d = d0 + lane;
@@ -375,9 +408,9 @@ __global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const J
         const unsigned long long m = __ballot(is_leader);
         if (m) {
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(leader_count, (unsigned int)__popcll(m));
+            if (lane == 0) base = atomicAdd(&leader_count[shard], (unsigned int)__popcll(m));
             base = __shfl(base, 0);
-            if (is_leader) leader_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = d;
+            if (is_leader) leader_list[(size_t)shard * shard_cap + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = d;
         }
     }
 }
@@ -404,20 +437,20 @@ __global__ void k_resolve_init(const JumpState* __restrict__ st, uint32_t n_dart
 //                                                           (reference: the `else if`, label(q) > 0)
 // and propose T'(cycle) = min key of its firing events.
 __global__ __launch_bounds__(256) void k_resolve_eval(const JumpState* __restrict__ st, uint32_t n_darts, int W,
-                                                      const uint32_t* __restrict__ d_xy, const uint8_t* __restrict__ d_info,
-                                                      const uint8_t* __restrict__ d_F, const uint64_t* __restrict__ t_cur,
+                                                      const uint64_t* __restrict__ d_rec, const uint64_t* __restrict__ t_cur,
                                                       uint64_t* __restrict__ t_next, int iter, DeviceCounters* __restrict__ ctr) {
     if (iter > 0 && ctr->resolve_changed[iter - 1] == 0) return;
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
-        const uint8_t info = d_info[d];
+        const uint64_t rec = d_rec[d];
+        const uint32_t info = rec_info(rec);
         if (!(info & (kInfoW | kInfoE))) continue;
         // an event dart must sit on an intact cycle, whose leader is its own leader (open chains never carry events)
         const uint32_t my_leader = (uint32_t)st[d].key;
         if ((uint32_t)st[my_leader].key != my_leader) { atomicOr(&ctr->err_flags, kErrBrokenEvent); continue; }
-        const uint32_t xy = d_xy[d];
+        const uint32_t xy = rec_xy(rec);
         const uint32_t x = xy & 0xFFFF, y = xy >> 16;
         const uint32_t q = y * (uint32_t)W + x;
-        const uint32_t F = d_F[d], P = pdart_mask(F);
+        const uint32_t F = rec_F(rec), P = pdart_mask(F);
         const int k = info & 7;
         const uint32_t base = d - __popc(P & ((1u << k) - 1u));
         const int cnt = __popc(P);
@@ -463,18 +496,23 @@ __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restric
                                                       uint32_t n_frames, uint32_t first_frame, uint32_t min_edge_length, double eps_factor,
                                                       double image_diag, uint32_t* __restrict__ cyc_slot, ContourRec* __restrict__ contours,
                                                       uint32_t* __restrict__ cyc_start_off, uint32_t max_contours, uint64_t max_points,
-                                                      DeviceCounters* __restrict__ ctr) {
+                                                      DeviceCounters* __restrict__ ctr, uint32_t shard_cap) {
     const int lane = threadIdx.x & 63;
-    const uint32_t n_leaders = *leader_count;
+    // the leader list is 16 segments of shard_cap slots; segment s holds leader_count[s] entries
+    uint32_t n_max = 0;
+    for (uint32_t sh = 0; sh < kLeaderShards; sh++) n_max = max(n_max, leader_count[sh]);
+    const uint32_t span = (n_max + 63u) & ~63u;           // per-shard index space, padded so a wave never straddles shards
+    const uint32_t n_leaders = span * kLeaderShards;
     const uint32_t stride = gridDim.x * blockDim.x;
     // every lane of a wave runs the same number of iterations: the allocation below is wave-collective
     for (uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; i0 < n_leaders; i0 += stride) {
-        const uint32_t i = i0 + lane;
+        const uint32_t sh = i0 / span, i = i0 - sh * span + lane;
+        const bool valid = i < leader_count[sh];
         bool traced = false, keep = false, broken = false;
         uint32_t n = 0, d = 0;
         uint64_t t = kInf64;
-        if (i < n_leaders) {
-            d = leader_list[i];
+        if (valid) {
+            d = leader_list[(size_t)sh * shard_cap + i];
             t = t_cur[d];
             traced = t != kInf64;
             if (traced) {
@@ -527,11 +565,11 @@ __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restric
                 }
             }
         }
-        if (i < n_leaders) cyc_slot[d] = slot;
+        if (valid) cyc_slot[d] = slot;
     }
 }
 
-__global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restrict__ st, uint32_t n_darts, const uint32_t* __restrict__ d_xy,
+__global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restrict__ st, uint32_t n_darts, const uint64_t* __restrict__ d_rec,
                                                         const uint32_t* __restrict__ cyc_slot, const ContourRec* __restrict__ contours,
                                                         const uint32_t* __restrict__ cyc_start_off, uint32_t* __restrict__ points) {
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
@@ -545,7 +583,7 @@ __global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restr
         const uint32_t so = cyc_start_off[c];
         // off = hops forward to the leader; position along the border counted from the start dart
         const uint32_t rank = so >= s.off ? so - s.off : so + r.n - s.off;
-        points[r.point_base + rank] = d_xy[d];
+        points[r.point_base + rank] = rec_xy(d_rec[d]);
     }
 }
 
@@ -706,28 +744,29 @@ hipError_t launch_dart_count(hipStream_t st, const uint64_t* bits, int W, int H,
 }
 
 hipError_t launch_dart_build(hipStream_t st, const uint64_t* bits, int W, int H, uint32_t first_frame, uint32_t n_frames,
-                             const uint32_t* frame_base, uint32_t* frame_cursor, uint32_t* pix_base, uint64_t* node_bits, uint32_t* d_xy,
-                             uint8_t* d_info, uint8_t* d_F, uint32_t* d_succ, uint32_t n_darts) {
+                             const uint32_t* frame_base, uint32_t* frame_cursor, uint32_t* pix_base, uint64_t* node_bits, uint64_t* d_rec,
+                             uint32_t* d_succ, uint32_t n_darts) {
     hipLaunchKernelGGL(k_dart_assign, dim3(dart_tiles((uint32_t)W, (uint32_t)H), n_frames), dim3(256), 0, st, bits, W, H, first_frame, frame_base, frame_cursor,
-                       pix_base, node_bits, d_xy, d_info, d_F);
+                       pix_base, node_bits, d_rec);
     const uint32_t per_frame = n_frames ? (n_darts + n_frames - 1) / n_frames : 0;
     hipLaunchKernelGGL(k_dart_link, dim3(blocks_for(per_frame, 256, 1024), n_frames), dim3(256), 0, st, W, H, frame_base, pix_base, node_bits,
-                       d_xy, d_info, d_F, d_succ);
+                       d_rec, d_succ);
     return hipGetLastError();
 }
 
 size_t entry_state_bytes() { return sizeof(EntryState); }
+size_t leader_list_bytes(uint32_t n_darts) { return (size_t)leader_shard_cap(n_darts) * kLeaderShards * 4; }
 
 // leaders + ranks for every dart of the chunk.  loc/fin: JumpState[n_darts]; es_a/es_b: EntryState[n_darts] (upper bound);
 // entry_bits: ceil(n_darts/32) words, zeroed here.
-hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uint32_t* d_xy, const uint8_t* d_info, const uint32_t* d_succ,
+hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uint64_t* d_rec, const uint32_t* d_succ,
                               JumpState* loc, uint32_t* loc_dist, uint32_t* entry_bits, uint32_t* entry_list, uint32_t* entry_pos,
                               unsigned int* entry_count, void* es_a, void* es_b, JumpState* fin, uint32_t* leader_list,
                               unsigned int* leader_count, int max_rounds, DeviceCounters* ctr) {
     (void)entry_bits;
     hipError_t e = hipMemsetAsync(entry_count, 0, 4, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_local_contract, dim3((n_darts + kLT - 1) / kLT), dim3(256), 0, st, n_darts, W, d_xy, d_info, d_succ, loc, loc_dist,
+    hipLaunchKernelGGL(k_local_contract, dim3((n_darts + kLT - 1) / kLT), dim3(256), 0, st, n_darts, W, d_rec, d_succ, loc, loc_dist,
                        entry_list, entry_pos, entry_count);
     EntryState* a = reinterpret_cast<EntryState*>(es_a);
     EntryState* b = reinterpret_cast<EntryState*>(es_b);
@@ -737,19 +776,18 @@ hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uin
         hipLaunchKernelGGL(k_entry_jump, grid, block, 0, st, a, b, entry_count, r, ctr);
         EntryState* t = a; a = b; b = t;
     }
-    e = hipMemsetAsync(leader_count, 0, 4, st);
+    e = hipMemsetAsync(leader_count, 0, 4 * kLeaderShards, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_jump_finalize, dim3(blocks_for(n_darts, 256, 8192)), block, 0, st, n_darts, loc, loc_dist, entry_pos, a, fin,
-                       leader_list, leader_count);
+                       leader_list, leader_count, leader_shard_cap(n_darts));
     return hipGetLastError();
 }
 
-hipError_t launch_resolve(hipStream_t st, const JumpState* fin, uint32_t n_darts, int W, const uint32_t* d_xy, const uint8_t* d_info,
-                          const uint8_t* d_F, uint64_t* t_cur, uint64_t* t_next, DeviceCounters* ctr, int max_iters) {
+hipError_t launch_resolve(hipStream_t st, const JumpState* fin, uint32_t n_darts, int W, const uint64_t* d_rec, uint64_t* t_cur, uint64_t* t_next, DeviceCounters* ctr, int max_iters) {
     const dim3 grid(blocks_for(n_darts, 256, 4096)), block(256);
     hipLaunchKernelGGL(k_resolve_init, grid, block, 0, st, fin, n_darts, t_cur, t_next);
     for (int it = 0; it < max_iters; it++) {
-        hipLaunchKernelGGL(k_resolve_eval, grid, block, 0, st, fin, n_darts, W, d_xy, d_info, d_F, t_cur, t_next, it, ctr);
+        hipLaunchKernelGGL(k_resolve_eval, grid, block, 0, st, fin, n_darts, W, d_rec, t_cur, t_next, it, ctr);
         hipLaunchKernelGGL(k_resolve_commit, grid, block, 0, st, fin, n_darts, t_cur, t_next, it, it == max_iters - 1 ? 1 : 0, ctr);
     }
     return hipGetLastError();
@@ -759,12 +797,12 @@ hipError_t launch_select_scatter(hipStream_t st, const JumpState* fin, uint32_t 
                                  const unsigned int* leader_count, const uint32_t* d_succ, const uint64_t* t_cur,
                                  const uint32_t* frame_base, uint32_t n_frames, uint32_t first_frame, uint32_t min_edge_length,
                                  double eps_factor, double image_diag, uint32_t* cyc_slot, ContourRec* contours, uint32_t* cyc_start_off,
-                                 uint32_t max_contours, uint64_t max_points, DeviceCounters* ctr, const uint32_t* d_xy, uint32_t* points) {
+                                 uint32_t max_contours, uint64_t max_points, DeviceCounters* ctr, const uint64_t* d_rec, uint32_t* points) {
     const dim3 grid(blocks_for(n_darts, 256, 4096)), block(256);
     hipLaunchKernelGGL(k_cycle_select, dim3(blocks_for(n_darts / 64 + 1, 256, 1024)), block, 0, st, fin, leader_list, leader_count, d_succ, t_cur,
                        frame_base, n_frames, first_frame, min_edge_length,
-                       eps_factor, image_diag, cyc_slot, contours, cyc_start_off, max_contours, max_points, ctr);
-    hipLaunchKernelGGL(k_scatter_points, grid, block, 0, st, fin, n_darts, d_xy, cyc_slot, contours, cyc_start_off, points);
+                       eps_factor, image_diag, cyc_slot, contours, cyc_start_off, max_contours, max_points, ctr, leader_shard_cap(n_darts));
+    hipLaunchKernelGGL(k_scatter_points, grid, block, 0, st, fin, n_darts, d_rec, cyc_slot, contours, cyc_start_off, points);
     return hipGetLastError();
 }
 
