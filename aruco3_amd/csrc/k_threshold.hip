@@ -16,6 +16,7 @@
 // so two sums share a dword and plain 32-bit adds never carry across).  Out-of-image
 // pixels are stored as 0, which makes the unclipped sum equal the clipped one.
 #include <cstdlib>
+#include <utility>
 
 #include "a3_common.h"
 
@@ -41,9 +42,11 @@ __device__ __forceinline__ uint32_t luma_of(uint32_t r, uint32_t g, uint32_t b) 
 __device__ __forceinline__ uint32_t luma_dot(uint32_t px) {
     const uint32_t lo = __builtin_amdgcn_udot4(px, 0x00D2F04Eu, 0u, false);
     const uint32_t hi = __builtin_amdgcn_udot4(px, 0x00021B08u, 0u, false);
-    // l <= 10000*255 < 2^22; floor(l / 10000) == (l * 13743896) >> 37 for every such l (checked exhaustively),
-    // which is one full-rate v_mul_hi_u32_u24 plus a shift instead of a quarter-rate 32-bit multiply-high
-    const uint32_t l = (lo + (hi << 8)) & 0x3FFFFFu;
+    // l <= 10000*255 < 2^22; floor(l / 10000) == (l * 13743896) >> 37 for every such l (checked exhaustively;
+    // 429497 >> 32 is NOT exact), i.e. one full-rate v_mul_hi_u32_u24 plus a shift instead of a quarter-rate
+    // 32-bit multiply-high
+    const uint32_t l = lo + (hi << 8);
+    __builtin_assume(l < (1u << 22));
     return (uint32_t)(((uint64_t)l * 13743896ull) >> 37);
 }
 
@@ -109,6 +112,30 @@ __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) {
     return r;
 }
 
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// s +/- one 16-bit half of a packed pair, operand-selected (SDWA): no separate unpack instruction
+template <int HALF> __device__ __forceinline__ uint32_t add_half(uint32_t s, uint32_t p) {
+    uint32_t r;
+    if constexpr (HALF == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(s), "v"(p));
+    else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(s), "v"(p));
+    return r;
+}
+template <int HALF> __device__ __forceinline__ uint32_t sub_half(uint32_t s, uint32_t p) {
+    uint32_t r;
+    if constexpr (HALF == 0) asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(s), "v"(p));
+    else asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(s), "v"(p));
+    return r;
+}
+// bits = (bits << 1) | (a < b): compare into vcc, then add-with-carry
+__device__ __forceinline__ uint32_t shift_in_lt(uint32_t bits, uint32_t a, uint32_t b) {
+    asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(a), "v"(b) : "vcc");
+    return bits;
+}
+
 __device__ __forceinline__ uint32_t wave_from_left(uint32_t v) {   // lane i <- lane i-1
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
 }
@@ -120,15 +147,23 @@ __device__ __forceinline__ uint32_t wave_from_right(uint32_t v) {  // lane i <- 
 // of those 16 columns plus their running vertical sums (u16 pairs: 15*255 < 2^16).  Per output row it needs 7 column
 // sums from each neighbouring lane (wave shifts, no LDS), slides a 15-wide window over 30 column sums and compares
 // sum < (L+1)*area.  No LDS, no barriers; T_PF rows of loads stay in flight per lane.
-// grid: (strips_x * strips_y, frames), block 64.
+// grid: 8 * ceil(frames * strips_x / 8) * strips_y workgroups of one wave.
 template <int FMT, bool FAST>
 __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_t* __restrict__ pixels, size_t row_stride, size_t frame_stride,
-                                                        int W, int H, int rows_per_wave, uint8_t* __restrict__ grey,
+                                                        int W, int H, int rows_per_wave, int strips_y, int n_pairs,
+                                                        uint8_t* __restrict__ grey,
                                                         uint8_t* __restrict__ bits, int aligned_in, int aligned_out) {
     const int lane = threadIdx.x;
+    // XCD-aware block -> strip mapping.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), each
+    // with its own L2.  Vertically adjacent strips of one column share 14 rows of input, so all strips of a
+    // (frame, column) pair are given to ONE XCD, in top-to-bottom order: the shared rows are then L2 hits instead of a
+    // second trip over the fabric.  (Placement only affects speed; any mapping is correct.)
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int pair = (k / strips_y) * 8 + xcd, sy = k % strips_y;
+    if (pair >= n_pairs) return;
     const int strips_x = (W + T_OUT - 1) / T_OUT;
-    const int sx = blockIdx.x % strips_x, sy = blockIdx.x / strips_x;
-    const uint32_t f = blockIdx.y;
+    const int sx = pair % strips_x;
+    const uint32_t f = pair / strips_x;
     const uint8_t* frame = pixels + (size_t)f * frame_stride;
     uint8_t* gout = grey + (size_t)f * W * H;
     const size_t bpr = (size_t)words_per_row((uint32_t)W) * 8;
@@ -148,6 +183,8 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
         axp[i >> 3] |= (uint32_t)a << (4 * (i & 7));
     }
 
+    uint32_t area[T_LPX];   // clipped window area of each column for the current row's window height
+    uint32_t ay_cur = 0;
     uint32_t ring[15][4];   // the last 15 grey rows; row `it` lives in slot it % 15 (static: the row loop is unrolled 15x)
     uint32_t VE[4] = {0, 0, 0, 0}, VO[4] = {0, 0, 0, 0};   // column sums, VE[i] = v(4i) | v(4i+2)<<16, VO[i] = v(4i+1) | v(4i+3)<<16
 #pragma unroll
@@ -203,13 +240,21 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
                 }
             }
             // vertical sliding sums: + newest row, - the row that leaves the 15-row window
+            // VE = (v0 | v2<<16), VO = (v1 | v3<<16): add the new row's bytes, subtract the leaving row's (the one that
+            // entered 15 iterations ago); each 16-bit half is updated in place by one byte-selecting SDWA instruction, the
+            // eight independent registers advance in lock step so that no dependent pair is back to back
+#define A3_SDWA(OP, DST, SRC, W, B) asm(OP " %0, %0, %1 dst_sel:WORD_" #W " dst_unused:UNUSED_PRESERVE src0_sel:WORD_" #W " src1_sel:BYTE_" #B : "+v"(DST) : "v"(SRC))
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint32_t o = ring[k15][i];   // the row that entered 15 iterations ago
-                VE[i] += (g[i] & 0x00FF00FFu) - (o & 0x00FF00FFu);
-                VO[i] += ((g[i] >> 8) & 0x00FF00FFu) - ((o >> 8) & 0x00FF00FFu);
-                ring[k15][i] = g[i];
-            }
+            for (int i = 0; i < 4; i++) { A3_SDWA("v_add_u32_sdwa", VE[i], g[i], 0, 0); A3_SDWA("v_add_u32_sdwa", VO[i], g[i], 0, 1); }
+#pragma unroll
+            for (int i = 0; i < 4; i++) { A3_SDWA("v_add_u32_sdwa", VE[i], g[i], 1, 2); A3_SDWA("v_add_u32_sdwa", VO[i], g[i], 1, 3); }
+#pragma unroll
+            for (int i = 0; i < 4; i++) { A3_SDWA("v_sub_u32_sdwa", VE[i], ring[k15][i], 0, 0); A3_SDWA("v_sub_u32_sdwa", VO[i], ring[k15][i], 0, 1); }
+#pragma unroll
+            for (int i = 0; i < 4; i++) { A3_SDWA("v_sub_u32_sdwa", VE[i], ring[k15][i], 1, 2); A3_SDWA("v_sub_u32_sdwa", VO[i], ring[k15][i], 1, 3); }
+#undef A3_SDWA
+#pragma unroll
+            for (int i = 0; i < 4; i++) ring[k15][i] = g[i];
             const uint32_t* centre = ring[(k15 + 8) % 15];   // the row 7 iterations old: the one being thresholded
 
             const int y = r - T_R;   // the row whose window is now complete
@@ -217,26 +262,31 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
             // 30 column sums: 7 from the left lane, own 16, 7 from the right lane
             const uint32_t le2 = wave_from_left(VE[2]), lo2 = wave_from_left(VO[2]), le3 = wave_from_left(VE[3]), lo3 = wave_from_left(VO[3]);
             const uint32_t re0 = wave_from_right(VE[0]), ro0 = wave_from_right(VO[0]), re1 = wave_from_right(VE[1]), ro1 = wave_from_right(VO[1]);
-            uint32_t e[30];
-            e[0] = lo2 & 0xFFFFu; e[1] = le2 >> 16; e[2] = lo2 >> 16;                      // left v9 v10 v11
-            e[3] = le3 & 0xFFFFu; e[4] = lo3 & 0xFFFFu; e[5] = le3 >> 16; e[6] = lo3 >> 16; // left v12..v15
+            uint32_t e[30];   // the 30 column sums: 7 from the left lane, own 16, 7 from the right lane
+            e[0] = lo2 & 0xFFFFu; e[1] = le2 >> 16; e[2] = lo2 >> 16;
+            e[3] = le3 & 0xFFFFu; e[4] = lo3 & 0xFFFFu; e[5] = le3 >> 16; e[6] = lo3 >> 16;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 e[7 + 4 * i] = VE[i] & 0xFFFFu; e[8 + 4 * i] = VO[i] & 0xFFFFu; e[9 + 4 * i] = VE[i] >> 16; e[10 + 4 * i] = VO[i] >> 16;
             }
-            e[23] = re0 & 0xFFFFu; e[24] = ro0 & 0xFFFFu; e[25] = re0 >> 16; e[26] = ro0 >> 16;  // right v0..v3
-            e[27] = re1 & 0xFFFFu; e[28] = ro1 & 0xFFFFu; e[29] = re1 >> 16;                      // right v4 v5 v6
+            e[23] = re0 & 0xFFFFu; e[24] = ro0 & 0xFFFFu; e[25] = re0 >> 16; e[26] = ro0 >> 16;
+            e[27] = re1 & 0xFFFFu; e[28] = ro1 & 0xFFFFu; e[29] = re1 >> 16;
+            const uint32_t ay = (uint32_t)(min(y + T_R, H - 1) - max(y - T_R, 0) + 1);
+            if (ay != ay_cur) {   // wave-uniform; only the first and last 7 image rows differ from 15
+                ay_cur = ay;
+#pragma unroll
+                for (int i = 0; i < T_LPX; i++) area[i] = mul24((axp[i >> 3] >> (4 * (i & 7))) & 15u, ay);
+            }
+            // window of pixel 15 first, then slide left: the comparison bits are shifted in from the top
             uint32_t S = 0;
 #pragma unroll
-            for (int i = 0; i < 15; i++) S += e[i];
-            const uint32_t ay = (uint32_t)(min(y + T_R, H - 1) - max(y - T_R, 0) + 1);
+            for (int j = 15; j < 30; j++) S += e[j];
             uint32_t outb = 0;
 #pragma unroll
-            for (int i = 0; i < T_LPX; i++) {
-                if (i > 0) S += e[i + 14] - e[i - 1];
+            for (int i = 15; i >= 0; i--) {
+                if (i < 15) S += e[i] - e[i + 15];
                 const uint32_t gv = (centre[i >> 2] >> (8 * (i & 3))) & 255u;
-                const uint32_t area = mul24((axp[i >> 3] >> (4 * (i & 7))) & 15u, ay);   // <= 225
-                outb |= (S < mul24(gv + 1u, area) ? 1u : 0u) << i;                       // <= 256*225
+                outb = shift_in_lt(outb, S, mad24(gv, area[i], area[i]));   // S < (L+1)*area
             }
             if (owner) *reinterpret_cast<uint16_t*>(bout + (size_t)y * bpr + (x0 >> 3)) = (uint16_t)outb;
         }
@@ -293,10 +343,11 @@ hipError_t launch_grey_threshold(hipStream_t st, const uint8_t* pixels, int fmt,
         if (const char* ev = getenv("A3_ROWS_PER_WAVE")) rows_per_wave = atoi(ev) > 0 ? atoi(ev) : rows_per_wave;  // tuning knob
         while (rows_per_wave > 31 && (long long)strips_x * ((H + rows_per_wave - 1) / rows_per_wave) * n < 3 * 256 * 8) rows_per_wave -= 15;
         const int strips_y = (H + rows_per_wave - 1) / rows_per_wave;
-        dim3 grid(strips_x * strips_y, n), block(64);
+        const int n_pairs = (int)n * strips_x;
+        dim3 grid(8 * ((n_pairs + 7) / 8) * strips_y), block(64);
         const bool fast = aligned_in && aligned_out;   // W % 16 == 0: a lane's 16 pixels are all inside or all outside
 #define A3_LAUNCH_K1(F, B) hipLaunchKernelGGL((k_grey_threshold7<F, B>), grid, block, 0, st, pixels, row_stride, frame_stride, W, H, \
-                                              rows_per_wave, grey, bin, aligned_in, aligned_out)
+                                              rows_per_wave, strips_y, n_pairs, grey, bin, aligned_in, aligned_out)
         if (fmt == A3_FMT_RGB8) { if (fast) A3_LAUNCH_K1(A3_FMT_RGB8, true); else A3_LAUNCH_K1(A3_FMT_RGB8, false); }
         else if (fmt == A3_FMT_RGBA8) { if (fast) A3_LAUNCH_K1(A3_FMT_RGBA8, true); else A3_LAUNCH_K1(A3_FMT_RGBA8, false); }
         else { if (fast) A3_LAUNCH_K1(A3_FMT_L8, true); else A3_LAUNCH_K1(A3_FMT_L8, false); }

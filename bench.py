@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
+                                                       "multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--synth-workers", type=int, default=0, help="host processes rendering frames (0 = auto)")
     ap.add_argument("--frames-cache", default="", help="npz path: reuse rendered frames between runs (profiling runs use it so that "
                                                         "nothing forks under the profiler)")
@@ -91,15 +93,21 @@ def main():
     from aruco3_amd.aruco import Detector, DetectorConfig
     from aruco3_amd.dictionaries import ARDictionary
 
+    if args.backend != "nccl":   # rehearsal: ranks may share a GPU, collectives run on host tensors
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     d = ARDictionary.new_from_named_dict("ARUCO") if rank == 0 or world == 1 else None
     if world > 1:
-        d = shard.broadcast_dictionary(d, dev, 0)   # RCCL broadcast, once
+        d = shard.broadcast_dictionary(d, coll_dev, 0)   # RCCL broadcast, once
     det = Detector(DetectorConfig.default(), d, device=local_rank)
     ctx = det._context()
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -113,7 +121,7 @@ def main():
     def step():
         markers, per = ctx.detect_batch(d_frames.data_ptr(), _lib.MEM_DEVICE, _lib.FMT_RGB8, w, h, w * c, h * w * c, n, out_cap=n * 64)
         if world > 1:
-            shard.gather_detections(markers, per, first_frame, dev)   # RCCL all-gather of the compact records
+            shard.gather_detections(markers, per, first_frame, coll_dev)   # RCCL all-gather of the compact records
         return markers, per
 
     markers, per = None, None
@@ -132,7 +140,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
