@@ -160,8 +160,11 @@ __global__ __launch_bounds__(256) void k_dart_count(const uint64_t* __restrict__
     if (threadIdx.x == 0 && total) atomicAdd(&frame_darts[f], (unsigned long long)total);
 }
 
-// Same traversal; hands every border pixel a contiguous dart range inside its frame's range and writes
-// the per-dart records.  node_bits: packed "this pixel owns darts" image (same layout as bits).
+// Same traversal; hands every border pixel a contiguous dart range inside its frame's range and writes the per-dart
+// records.  node_bits: packed "this pixel owns darts" image (same layout as bits).
+// Phase 1 works a word (64 pixels) per lane; phase 2 re-distributes the tile's border pixels evenly over the 256 lanes
+// (a word on a horizontal edge holds up to 64 of them, most words none), each lane locating its pixel by a binary
+// search over the per-word prefix sums and a rank-select in the word's node mask.
 __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict__ bits, int W, int H, uint32_t first_frame,
                                                      const uint32_t* __restrict__ frame_base, uint32_t* __restrict__ frame_cursor,
                                                      uint32_t* __restrict__ pix_base, uint64_t* __restrict__ node_bits,
@@ -169,46 +172,79 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_base;
     __shared__ uint64_t s_t[kTileRows + 2][kTileWords + 2];
+    __shared__ uint64_t s_nodes[256];
+    __shared__ uint32_t s_dbase[256], s_nbase[257];
     const int wpr = (int)words_per_row((uint32_t)W);
     const uint32_t f = blockIdx.y;
     int j, y;
     bool active;
     const Nb8 nb = tile_nb8(bits + (size_t)(first_frame + f) * wpr * H, W, H, s_t, &active, &j, &y);
-    const uint32_t wi = active ? (uint32_t)(y * wpr + j) : 0u;
-    uint64_t p[8];
     uint64_t nodes = 0;
     uint32_t nd = 0;
     if (active) {
         if (nb.c) {
+            uint64_t p[8];
             pdart_words(nb, p);
 #pragma unroll
             for (int k = 0; k < 8; k++) { nd += __popcll(p[k]); nodes |= p[k]; }
         }
-        node_bits[(size_t)f * wpr * H + wi] = nodes;
+        node_bits[(size_t)f * wpr * H + (size_t)y * wpr + j] = nodes;
     }
-    uint32_t total;
-    const uint32_t excl = block_excl_scan_256(nd, s_wave, &total);
-    if (threadIdx.x == 0) s_base = total ? atomicAdd(&frame_cursor[f], total) : 0u;
+    uint32_t total_d, total_n;
+    const uint32_t excl_d = block_excl_scan_256(nd, s_wave, &total_d);
     __syncthreads();
-    if (!nodes) return;
-    uint32_t cur = frame_base[f] + s_base + excl;
-    uint32_t* pb = pix_base + (size_t)f * W * H + (size_t)y * W;
-    while (nodes) {
-        const int i = __ffsll((long long)nodes) - 1;
-        nodes &= nodes - 1;
-        const int x = 64 * j + i;
-        uint32_t F = 0, P = 0;
+    const uint32_t excl_n = block_excl_scan_256((uint32_t)__popcll(nodes), s_wave, &total_n);
+    s_nodes[threadIdx.x] = nodes;
+    s_dbase[threadIdx.x] = excl_d;
+    s_nbase[threadIdx.x] = excl_n;
+    if (threadIdx.x == 0) { s_base = total_d ? atomicAdd(&frame_cursor[f], total_d) : 0u; s_nbase[256] = total_n; }
+    __syncthreads();
+    const uint32_t dart0 = frame_base[f] + s_base;
+    const int tx = blockIdx.x % dart_tiles_x((uint32_t)W), ty = blockIdx.x / dart_tiles_x((uint32_t)W);
+    uint32_t* pbf = pix_base + (size_t)f * W * H;
+    for (uint32_t n = threadIdx.x; n < total_n; n += 256) {
+        // word holding the n-th border pixel of the tile: largest w with s_nbase[w] <= n
+        uint32_t lo = 0, hi = 256;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_nbase[mid] <= n) lo = mid; else hi = mid; }
+        const uint32_t w = lo, r = n - s_nbase[w];
+        const uint64_t m = s_nodes[w];
+        // position of the r-th (0-based) set bit of m
+        uint32_t blo = 0, bhi = 63;
+        while (blo < bhi) { const uint32_t mid = (blo + bhi) >> 1; if ((uint32_t)__popcll(m & ((2ull << mid) - 1ull)) >= r + 1u) bhi = mid; else blo = mid + 1; }
+        const int i = (int)blo;
+        const int jl = w & (kTileWords - 1), rl = w >> 2;
+        const int wj = tx * kTileWords + jl, wy = ty * kTileRows + rl;
+        // neighbourhood words of that word, from the staged tile
+        Nb8 q;
+        {
+            const uint64_t al = s_t[rl][jl], a = s_t[rl][jl + 1], ar = s_t[rl][jl + 2];
+            const uint64_t cl = s_t[rl + 1][jl], c = s_t[rl + 1][jl + 1], cr = s_t[rl + 1][jl + 2];
+            const uint64_t bl = s_t[rl + 2][jl], b = s_t[rl + 2][jl + 1], br = s_t[rl + 2][jl + 2];
+            q.c = c;
+            q.n[0] = (c << 1) | (cl >> 63); q.n[1] = (a << 1) | (al >> 63); q.n[2] = a; q.n[3] = (a >> 1) | (ar << 63);
+            q.n[4] = (c >> 1) | (cr << 63); q.n[5] = (b >> 1) | (br << 63); q.n[6] = b; q.n[7] = (b << 1) | (bl >> 63);
+        }
+        uint64_t pw[8];
+        pdart_words(q, pw);
+        const uint64_t below = (1ull << i) - 1ull;
+        uint32_t F = 0, P = 0, off = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) { F |= (uint32_t)((nb.n[k] >> i) & 1ull) << k; P |= (uint32_t)((p[k] >> i) & 1ull) << k; }
-        pb[x] = cur;
+        for (int k = 0; k < 8; k++) {
+            F |= (uint32_t)((q.n[k] >> i) & 1ull) << k;
+            P |= (uint32_t)((pw[k] >> i) & 1ull) << k;
+            off += (uint32_t)__popcll(pw[k] & below);   // darts of the word's earlier border pixels
+        }
+        const int x = 64 * wj + i;
+        uint32_t cur = dart0 + s_dbase[w] + off;
+        pbf[(size_t)wy * W + x] = cur;
         // event darts: first foreground neighbour clockwise from W (resp. E) when that side is background
         int kW = -1, kE = -1;
         if (x > 0 && !(F & 1u)) kW = __ffs(F >> 1);  // 1-based position in F>>1 == direction index
         if (x + 1 < W && !(F & 16u)) {
-            const uint32_t r = ((F >> 5) | (F << 3)) & 0xFFu;  // bit t <-> direction (5 + t) & 7
-            kE = (5 + __ffs(r) - 1) & 7;
+            const uint32_t rr = ((F >> 5) | (F << 3)) & 0xFFu;  // bit t <-> direction (5 + t) & 7
+            kE = (5 + __ffs(rr) - 1) & 7;
         }
-        const uint32_t xy = (uint32_t)x | ((uint32_t)y << 16);
+        const uint32_t xy = (uint32_t)x | ((uint32_t)wy << 16);
         while (P) {
             const int k = __ffs(P) - 1;
             P &= P - 1;
