@@ -30,6 +30,8 @@
 //
 // Border pixels are found 64 at a time with word-wide bit operations on the packed image;
 // dart ranges are handed out with a block scan and one atomic per workgroup.
+#include <algorithm>
+
 #include "a3_common.h"
 
 namespace a3 {
@@ -417,7 +419,8 @@ __global__ __launch_bounds__(256) void k_entry_jump(const EntryState* __restrict
 
 // Phase 3: every dart learns its cycle's leader and its hop distance to it
 constexpr uint32_t kLeaderShards = 16;
-__host__ __device__ inline uint32_t leader_shard_cap(uint32_t n_darts) { return n_darts / kLeaderShards + 131072u + 64u; }
+// darts handled by the blocks of one shard: n/16 plus at most one 256-dart slice per block of the shard and iteration
+__host__ __device__ inline uint32_t leader_shard_cap(uint32_t n_darts) { return n_darts / kLeaderShards + n_darts / 64u + 262144u; }
 
 // ... and the leaders of cycles that carry at least one start event are collected (one atomic per wave) for the
 // per-border kernels that follow.
@@ -425,29 +428,32 @@ __global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const J
                                                        const uint32_t* __restrict__ entry_pos, const EntryState* __restrict__ es,
                                                        JumpState* __restrict__ fin, uint32_t* __restrict__ leader_list,
                                                        unsigned int* __restrict__ leader_count /*[kLeaderShards]*/, uint32_t shard_cap) {
-    const int lane = threadIdx.x & 63;
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_base;
     const uint32_t shard = blockIdx.x & (kLeaderShards - 1);   // spread the slot counter over 16 addresses
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t d0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; d0 < n_darts; d0 += stride) {
-        const uint32_t d = d0 + lane;
-        bool is_leader = false;
-        if (d < n_darts) {
-            JumpState s = loc[d];
-            const uint32_t dd = loc_dist[d];
-            if (dd & kFrozen) {
-                const EntryState g = es[entry_pos[s.ptr]];
-                if (g.key < s.key) { s.key = g.key; s.off = (dd & ~kFrozen) + g.off; }
-            }
-            fin[d] = s;
-            is_leader = (uint32_t)s.key == d && (uint32_t)(s.key >> 32) != kNoKey;
+    const uint32_t stride = gridDim.x * blockDim.x;            // the launcher keeps ceil(n_darts / stride) <= 32
+    uint32_t mask = 0;                                          // bit i: my i-th dart leads a cycle that has a start event
+    int it = 0;
+    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += stride, it++) {
+        JumpState s = loc[d];
+        const uint32_t dd = loc_dist[d];
+        if (dd & kFrozen) {
+            const EntryState g = es[entry_pos[s.ptr]];
+            if (g.key < s.key) { s.key = g.key; s.off = (dd & ~kFrozen) + g.off; }
         }
-        const unsigned long long m = __ballot(is_leader);
-        if (m) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&leader_count[shard], (unsigned int)__popcll(m));
-            base = __shfl(base, 0);
-            if (is_leader) leader_list[(size_t)shard * shard_cap + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = d;
-        }
+        fin[d] = s;
+        if ((uint32_t)s.key == d && (uint32_t)(s.key >> 32) != kNoKey) mask |= 1u << it;
+    }
+    // one global atomic per workgroup: leaders are counted in a block scan first
+    uint32_t total;
+    const uint32_t excl = block_excl_scan_256((uint32_t)__popc(mask), s_wave, &total);
+    if (threadIdx.x == 0) s_base = total ? atomicAdd(&leader_count[shard], total) : 0u;
+    __syncthreads();
+    uint32_t slot = s_base + excl;
+    while (mask) {
+        const int i = __ffs(mask) - 1;
+        mask &= mask - 1;
+        leader_list[(size_t)shard * shard_cap + slot++] = blockIdx.x * blockDim.x + threadIdx.x + (uint32_t)i * stride;
     }
 }
 
@@ -534,6 +540,7 @@ __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restric
                                                       uint32_t* __restrict__ cyc_start_off, uint32_t max_contours, uint64_t max_points,
                                                       DeviceCounters* __restrict__ ctr, uint32_t shard_cap) {
     const int lane = threadIdx.x & 63;
+    uint32_t n_traced = 0;
     // the leader list is 16 segments of shard_cap slots; segment s holds leader_count[s] entries
     uint32_t n_max = 0;
     for (uint32_t sh = 0; sh < kLeaderShards; sh++) n_max = max(n_max, leader_count[sh]);
@@ -571,7 +578,7 @@ __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restric
         if (broken) atomicOr(&ctr->err_flags, kErrBrokenEvent);
         // one atomic per wave and counter
         const unsigned long long m_traced = __ballot(traced), m_keep = __ballot(keep);
-        if (lane == 0 && m_traced) atomicAdd(&ctr->traced, (unsigned int)__popcll(m_traced));
+        n_traced += (uint32_t)__popcll(m_traced);   // wave-uniform; added to the global statistic once per wave at the end
         uint32_t slot = kNone;
         if (m_keep) {
             uint32_t inc = keep ? n : 0u;   // wave inclusive scan of the point counts
@@ -603,6 +610,7 @@ __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restric
         }
         if (valid) cyc_slot[d] = slot;
     }
+    if (lane == 0 && n_traced) atomicAdd(&ctr->traced, n_traced);
 }
 
 __global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restrict__ st, uint32_t n_darts, const uint64_t* __restrict__ d_rec,
@@ -814,7 +822,8 @@ hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uin
     }
     e = hipMemsetAsync(leader_count, 0, 4 * kLeaderShards, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_jump_finalize, dim3(blocks_for(n_darts, 256, 8192)), block, 0, st, n_darts, loc, loc_dist, entry_pos, a, fin,
+    const int fin_blocks = std::max(blocks_for(n_darts, 256, 8192), (int)(((uint64_t)n_darts + 256ull * 32 - 1) / (256ull * 32)));
+    hipLaunchKernelGGL(k_jump_finalize, dim3(fin_blocks), block, 0, st, n_darts, loc, loc_dist, entry_pos, a, fin,
                        leader_list, leader_count, leader_shard_cap(n_darts));
     return hipGetLastError();
 }
