@@ -33,8 +33,9 @@ hipError_t launch_contour_quads(hipStream_t, const ContourRec*, const DeviceCoun
 size_t decode_out_bytes();
 hipError_t launch_frame_candidates(hipStream_t, const CandRec*, const uint32_t*, uint32_t, uint32_t, float, uint16_t*, uint16_t*, uint32_t*,
                                    uint32_t*, unsigned int*);
+size_t proj_rec_bytes();
 hipError_t launch_decode(hipStream_t, const uint8_t*, int, int, uint32_t, const uint16_t*, const uint32_t*, const unsigned int*, uint32_t,
-                         uint32_t, uint32_t, uint32_t, const uint64_t*, uint32_t, uint32_t, int, void*, uint8_t*, int);
+                         uint32_t, uint32_t, uint32_t, const uint64_t*, uint32_t, uint32_t, int, void*, void*, uint8_t*, int);
 hipError_t launch_compact_markers(hipStream_t, const void*, const uint16_t*, const uint32_t*, uint32_t, uint32_t, uint32_t, a3_marker*,
                                   uint32_t, uint32_t*, unsigned int*, unsigned int*);
 hipError_t launch_pose(hipStream_t, const uint32_t*, const float*, uint32_t, int, float, float, float, float, float, float, float, a3_pose*);
@@ -104,7 +105,7 @@ struct a3_ctx {
     DevBuf d_xy, d_info, d_F, d_succ, stA, stB, t_cur, t_next, cyc_slot;
     DevBuf loc_dist, entry_bits, entry_list, entry_pos, es_a, es_b;
     DevBuf contours, cyc_start_off, points, counters, scratch_u32;
-    DevBuf cands, cand_count, pre_xy, fin_xy, fin_count, work, outs, patches, markers, per_frame;
+    DevBuf cands, cand_count, pre_xy, fin_xy, fin_count, work, outs, proj, patches, markers, per_frame;
     DevBuf tmp_a, tmp_b, tmp_c, tmp_d;
     void* pinned = nullptr;
     size_t pinned_cap = 0;
@@ -179,6 +180,7 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     A3_HIP(ctx->fin_count.ensure((size_t)n * 4));
     A3_HIP(ctx->work.ensure((size_t)n * kMaxCand * 4));
     A3_HIP(ctx->outs.ensure((size_t)n * kMaxCand * decode_out_bytes()));
+    A3_HIP(ctx->proj.ensure((size_t)n * kMaxCand * proj_rec_bytes()));
     A3_HIP(ctx->per_frame.ensure((size_t)n * 4));
     const uint32_t marker_cap = (uint32_t)std::min<size_t>(std::max<size_t>(out_cap, 1), (size_t)n * kMaxCand);
     A3_HIP(ctx->markers.ensure((size_t)marker_cap * sizeof(a3_marker)));
@@ -292,7 +294,7 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
                                    ctx->work.as<uint32_t>(), d_work_count));
     A3_HIP(launch_decode(st, ctx->grey.as<uint8_t>(), (int)W, (int)H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), d_work_count,
                          kMaxCand, S, ctx->mark_size, S, ctx->dict.as<uint64_t>(), ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors,
-                         ctx->outs.p, ctx->debug_taps ? ctx->patches.as<uint8_t>() : nullptr, 2048));
+                         ctx->proj.p, ctx->outs.p, ctx->debug_taps ? ctx->patches.as<uint8_t>() : nullptr, 4096));
     A3_HIP(launch_compact_markers(st, ctx->outs.p, ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(), n, 0, kMaxCand,
                                   ctx->markers.as<a3_marker>(), marker_cap, ctx->per_frame.as<uint32_t>(), d_marker_total, d_err));
     if (ctx->profiling) A3_HIP(hipEventRecord(ctx->ev[3], st));
@@ -442,7 +444,7 @@ void a3_destroy(a3_ctx* ctx) {
                       &ctx->node_bits, &ctx->d_xy, &ctx->d_info, &ctx->d_F, &ctx->d_succ, &ctx->stA, &ctx->stB, &ctx->t_cur, &ctx->t_next, &ctx->cyc_slot,
                       &ctx->loc_dist, &ctx->entry_bits, &ctx->entry_list, &ctx->entry_pos, &ctx->es_a, &ctx->es_b,
                       &ctx->contours, &ctx->cyc_start_off, &ctx->points, &ctx->counters, &ctx->scratch_u32, &ctx->cands, &ctx->cand_count,
-                      &ctx->pre_xy, &ctx->fin_xy, &ctx->fin_count, &ctx->work, &ctx->outs, &ctx->patches, &ctx->markers, &ctx->per_frame,
+                      &ctx->pre_xy, &ctx->fin_xy, &ctx->fin_count, &ctx->work, &ctx->outs, &ctx->proj, &ctx->patches, &ctx->markers, &ctx->per_frame,
                       &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_d};
     for (DevBuf* b : bufs) b->release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);

@@ -232,13 +232,32 @@ __device__ uint32_t resize_weights(uint32_t in_len, uint32_t out_len, uint32_t o
     return (uint32_t)left;
 }
 
+// The 8x8 solve needs ~200 VGPRs for one lane's work; inside k_decode it would cap that kernel at two workgroups per
+// CU, so it runs first, one lane per candidate, and leaves 9 floats + a flag per candidate.
+struct __attribute__((aligned(8))) ProjRec { float inv[9]; int ok; };
+
+__global__ __launch_bounds__(64) void k_projection(const uint16_t* __restrict__ fin_xy, const uint32_t* __restrict__ work,
+                                                   const unsigned int* __restrict__ work_count, uint32_t S, ProjRec* __restrict__ proj) {
+    const uint32_t n_work = *work_count;
+    for (uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x; wi < n_work; wi += gridDim.x * blockDim.x) {
+        const uint32_t slot = work[wi];
+        const uint16_t* q = fin_xy + (size_t)slot * 8;
+        float from[8];
+        for (int i = 0; i < 8; i++) from[i] = (float)q[i];
+        ProjRec r;
+        r.ok = solve_projection(from, (float)S, r.inv) ? 1 : 0;
+        proj[wi] = r;
+    }
+}
+
 // grid-stride over the work list; block = 256 threads; dynamic LDS:
 //   patch S*S | tmp n*S f32 | wtab n*max_taps f32 | wleft n u32 | wcnt n u32 | bits n*n
 __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ grey, int W, int H, uint32_t first_frame,
                                                 const uint16_t* __restrict__ fin_xy, const uint32_t* __restrict__ work,
                                                 const unsigned int* __restrict__ work_count, uint32_t max_cand, uint32_t S, uint32_t n,
                                                 uint32_t max_taps, const uint64_t* __restrict__ dict, uint32_t n_codes, uint32_t tau,
-                                                int filter, DecodeOut* __restrict__ outs, uint8_t* __restrict__ patches /*nullable*/) {
+                                                int filter, const ProjRec* __restrict__ proj, DecodeOut* __restrict__ outs,
+                                                uint8_t* __restrict__ patches /*nullable*/) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* s_patch = smem;
     size_t o = ((size_t)S * S + 15) & ~(size_t)15;
@@ -263,16 +282,9 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ grey
         const uint32_t slot = work[wi];
         const uint32_t fl = slot / max_cand;
         const uint8_t* img = grey + (size_t)(first_frame + fl) * W * H;
-        const uint16_t* q = fin_xy + (size_t)slot * 8;
         __syncthreads();
-        if (tid == 0) {
-            float from[8];
-            for (int i = 0; i < 8; i++) from[i] = (float)q[i];
-            float inv[9];
-            const bool ok = solve_projection(from, (float)S, inv);
-            for (int i = 0; i < 9; i++) s_inv[i] = inv[i];
-            s_ok = ok;
-        }
+        if (tid < 9) s_inv[tid] = proj[wi].inv[tid];
+        if (tid == 9) s_ok = proj[wi].ok;
         s_hist[tid] = 0;
         __syncthreads();
         const bool ok = s_ok != 0;
@@ -733,11 +745,15 @@ hipError_t launch_frame_candidates(hipStream_t st, const CandRec* cands, const u
     return hipGetLastError();
 }
 
+size_t proj_rec_bytes() { return sizeof(ProjRec); }
+
 hipError_t launch_decode(hipStream_t st, const uint8_t* grey, int W, int H, uint32_t first_frame, const uint16_t* fin_xy, const uint32_t* work,
                          const unsigned int* work_count, uint32_t max_cand, uint32_t S, uint32_t n, uint32_t max_taps, const uint64_t* dict,
-                         uint32_t n_codes, uint32_t tau, int filter, void* outs, uint8_t* patches, int grid_blocks) {
+                         uint32_t n_codes, uint32_t tau, int filter, void* proj, void* outs, uint8_t* patches, int grid_blocks) {
+    hipLaunchKernelGGL(k_projection, dim3(256), dim3(64), 0, st, fin_xy, work, work_count, S, reinterpret_cast<ProjRec*>(proj));
     hipLaunchKernelGGL(k_decode, dim3(grid_blocks), dim3(256), decode_lds_bytes(S, n, max_taps), st, grey, W, H, first_frame, fin_xy, work,
-                       work_count, max_cand, S, n, max_taps, dict, n_codes, tau, filter, reinterpret_cast<DecodeOut*>(outs), patches);
+                       work_count, max_cand, S, n, max_taps, dict, n_codes, tau, filter, reinterpret_cast<const ProjRec*>(proj),
+                       reinterpret_cast<DecodeOut*>(outs), patches);
     return hipGetLastError();
 }
 
