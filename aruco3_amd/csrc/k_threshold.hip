@@ -192,7 +192,13 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
 #pragma unroll
         for (int i = 0; i < 4; i++) ring[k][i] = 0u;
 
-    const int r_first = y_begin - T_R, n_rows = (y_end - y_begin) + 2 * T_R;
+    // Odd strips walk upwards.  Strip k (going down) and strip k+1 (going up) then both reach their common boundary --
+    // the 14 rows each must also read from the other's territory -- at the END of their runs, and strips k+1 and k+2
+    // both START at theirs: neighbours touch the shared rows at about the same time, so the second one finds them in
+    // the XCD's L2 instead of fetching them again from HBM.  The box filter is symmetric, so direction only changes
+    // the order rows enter and leave the window.
+    const int dir = (sy & 1) ? -1 : 1;
+    const int r_first = dir > 0 ? y_begin - T_R : y_end - 1 + T_R, n_rows = (y_end - y_begin) + 2 * T_R;
     RawRow<FMT> q[T_PF];
     // FAST: every load is unconditional (row and column clamped into the image) so that the loop body has no branch
     // around a load and the compiler can keep T_PF rows in flight with counted waits; what the clamped address
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
         }
     };
 #pragma unroll
-    for (int k = 0; k < T_PF; k++) issue(r_first + k, q[k]);
+    for (int k = 0; k < T_PF; k++) issue(r_first + dir * k, q[k]);
 
     static_assert(15 % T_PF == 0, "the load queue index must be static inside the 15x unrolled body");
     // FAST: whole blocks of 15 rows and no exit test inside the unrolled body (rows past the strip are clamped loads whose
@@ -223,10 +229,10 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
             const int k = k15 % T_PF;
             const int it = base + k15;
             if (!FAST && it >= n_iter) break;
-            const int r = r_first + it;
+            const int r = r_first + dir * it;
             uint32_t g[4];
             grey16<FMT>(q[k], g);                                   // consumes the row loaded T_PF iterations ago ...
-            if (FAST || it + T_PF < n_rows) issue(r + T_PF, q[k]);  // ... and its registers take the next load at once
+            if (FAST || it + T_PF < n_rows) issue(r + dir * T_PF, q[k]);  // ... and its registers take the next load at once
             if constexpr (FAST) {
                 if (!(lane_in && r >= 0 && r < H)) { g[0] = 0u; g[1] = 0u; g[2] = 0u; g[3] = 0u; }
             }
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
             for (int i = 0; i < 4; i++) ring[k15][i] = g[i];
             const uint32_t* centre = ring[(k15 + 8) % 15];   // the row 7 iterations old: the one being thresholded
 
-            const int y = r - T_R;   // the row whose window is now complete
+            const int y = r - dir * T_R;   // the row whose window is now complete
             if (y < y_begin || y >= y_end) continue;   // wave-uniform
             // 30 column sums: 7 from the left lane, own 16, 7 from the right lane
             const uint32_t le2 = wave_from_left(VE[2]), lo2 = wave_from_left(VO[2]), le3 = wave_from_left(VE[3]), lo3 = wave_from_left(VO[3]);
