@@ -16,7 +16,7 @@ hipError_t launch_grey_threshold(hipStream_t, const uint8_t*, int, size_t, size_
 // k_contours.hip
 hipError_t launch_dart_count(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, unsigned long long*);
 hipError_t launch_dart_build(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, const uint32_t*, uint32_t*, uint32_t*, uint64_t*,
-                             uint64_t*, uint32_t*, uint32_t);
+                             uint64_t*, uint32_t*, uint32_t*, unsigned int*, uint32_t);
 size_t entry_state_bytes();
 size_t leader_list_bytes(uint32_t);
 hipError_t launch_rank_cycles(hipStream_t, uint32_t, int, const uint64_t*, const uint32_t*, JumpState*, uint32_t*, uint32_t*,
@@ -235,6 +235,7 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     unsigned int* d_marker_total = ctx->scratch_u32.as<unsigned int>() + 1;
     unsigned int* d_err = ctx->scratch_u32.as<unsigned int>() + 4;
     unsigned int* d_entry_count = ctx->scratch_u32.as<unsigned int>() + 5;
+    unsigned int* d_cross_count = ctx->scratch_u32.as<unsigned int>() + 6;
     unsigned int* d_leader_count = ctx->scratch_u32.as<unsigned int>() + 16;   // [16..31]
 
     // frame bases of every chunk, uploaded once
@@ -264,7 +265,8 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
         if (nd == 0) continue;
         A3_HIP(hipMemsetAsync(ctx->frame_cursor.p, 0, (size_t)c.count * 4, st));
         A3_HIP(launch_dart_build(st, d_bin, (int)W, (int)H, c.first, c.count, fb, ctx->frame_cursor.as<uint32_t>(), ctx->pix_base.as<uint32_t>(),
-                                 ctx->node_bits.as<uint64_t>(), ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), nd));
+                                 ctx->node_bits.as<uint64_t>(), ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(),
+                                 ctx->cyc_slot.as<uint32_t>() /* free until k_cycle_select: holds the cross-tile list */, d_cross_count, nd));
         int rounds = 1;
         while ((1ull << rounds) < (uint64_t)c.max_frame_darts && rounds < 31) rounds++;
         rounds += 1;  // the round that observes "nothing moved"
@@ -326,7 +328,7 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     }
     if (jump_short && ctx->jump_rounds_hint < 32) { ctx->jump_rounds_hint = 32; return 1; }             // re-run with all rounds
     if ((flags & kErrResolve) && ctx->resolve_iters_hint < kResolveItersMax) { ctx->resolve_iters_hint = kResolveItersMax; return 1; }
-    ctx->jump_rounds_hint = std::max(ctx->jump_rounds_hint, std::min(32, (int)ctx->stats.jump_rounds + 3));
+    ctx->jump_rounds_hint = std::max(4, std::min(32, (int)ctx->stats.jump_rounds + 2));   // follow the workload, both ways
     if (flags & (kErrPointPool | kErrContourTable)) {
         // grow and let the caller loop re-run the batch
         if (need_points > ctx->max_points) ctx->max_points = std::min<uint64_t>(kHardMaxPoints, std::max(need_points, ctx->max_points * 2));

@@ -170,9 +170,12 @@ __global__ __launch_bounds__(256) void k_dart_count(const uint64_t* __restrict__
 __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict__ bits, int W, int H, uint32_t first_frame,
                                                      const uint32_t* __restrict__ frame_base, uint32_t* __restrict__ frame_cursor,
                                                      uint32_t* __restrict__ pix_base, uint64_t* __restrict__ node_bits,
-                                                     uint64_t* __restrict__ d_rec) {
+                                                     uint64_t* __restrict__ d_rec, uint32_t* __restrict__ d_succ,
+                                                     uint32_t* __restrict__ cross_list, unsigned int* __restrict__ cross_count) {
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_base;
+    __shared__ uint32_t s_cross_n, s_cross_base;
+    __shared__ uint32_t s_cross[(2 * kTileWords * 64 + 2 * kTileRows) * 4];
     __shared__ uint64_t s_t[kTileRows + 2][kTileWords + 2];
     __shared__ uint64_t s_nodes[256];
     __shared__ uint32_t s_dbase[256], s_nbase[257];
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
     s_nodes[threadIdx.x] = nodes;
     s_dbase[threadIdx.x] = excl_d;
     s_nbase[threadIdx.x] = excl_n;
-    if (threadIdx.x == 0) { s_base = total_d ? atomicAdd(&frame_cursor[f], total_d) : 0u; s_nbase[256] = total_n; }
+    if (threadIdx.x == 0) { s_base = total_d ? atomicAdd(&frame_cursor[f], total_d) : 0u; s_nbase[256] = total_n; s_cross_n = 0; }
     __syncthreads();
     const uint32_t dart0 = frame_base[f] + s_base;
     const int tx = blockIdx.x % dart_tiles_x((uint32_t)W), ty = blockIdx.x / dart_tiles_x((uint32_t)W);
@@ -238,7 +241,8 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
         }
         const int x = 64 * wj + i;
         uint32_t cur = dart0 + s_dbase[w] + off;
-        pbf[(size_t)wy * W + x] = cur;
+        // only pixels on the rim of the tile can be the target of a successor pointer from another tile
+        if (i == 0 || i == 63 || rl == 0 || rl == kTileRows - 1) pbf[(size_t)wy * W + x] = cur;
         // event darts: first foreground neighbour clockwise from W (resp. E) when that side is background
         int kW = -1, kE = -1;
         if (x > 0 && !(F & 1u)) kW = __ffs(F >> 1);  // 1-based position in F>>1 == direction index
@@ -252,30 +256,66 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
             P &= P - 1;
             const uint32_t info = (uint32_t)k | (k == kW ? kInfoW : 0u) | (k == kE ? kInfoE : 0u);
             d_rec[cur] = dart_rec(xy, F, info);   // one 8-byte store per dart
+            // successor: next foreground neighbour counter-clockwise after k; resolved here when the target pixel lies in
+            // this tile (its dart indices follow from the tile's prefix sums), otherwise left to k_dart_link
+            const uint32_t rr = ((F >> k) | (F << (8 - k))) & 0xFFu;   // bit t <-> direction (k + t) & 7
+            const int ko = (k + (31 - __clz(rr))) & 7, kin = (ko + 4) & 7;
+            const int lx = jl * 64 + i + kDX[ko], ly = rl + kDY[ko];
+            uint32_t succ;
+            if (lx >= 0 && lx < kTileWords * 64 && ly >= 0 && ly < kTileRows) {
+                const int j2 = lx >> 6, i2 = lx & 63, w2 = ly * kTileWords + j2;
+                Nb8 t;
+                const uint64_t al = s_t[ly][j2], a = s_t[ly][j2 + 1], ar = s_t[ly][j2 + 2];
+                const uint64_t cl = s_t[ly + 1][j2], c = s_t[ly + 1][j2 + 1], cr = s_t[ly + 1][j2 + 2];
+                const uint64_t bl = s_t[ly + 2][j2], b = s_t[ly + 2][j2 + 1], br = s_t[ly + 2][j2 + 2];
+                t.c = c;
+                t.n[0] = (c << 1) | (cl >> 63); t.n[1] = (a << 1) | (al >> 63); t.n[2] = a; t.n[3] = (a >> 1) | (ar << 63);
+                t.n[4] = (c >> 1) | (cr << 63); t.n[5] = (b >> 1) | (br << 63); t.n[6] = b; t.n[7] = (b << 1) | (bl >> 63);
+                uint64_t tw[8];
+                pdart_words(t, tw);
+                const uint64_t below2 = (1ull << i2) - 1ull;
+                uint32_t P2 = 0, off2 = 0;
+#pragma unroll
+                for (int kk = 0; kk < 8; kk++) { P2 |= (uint32_t)((tw[kk] >> i2) & 1ull) << kk; off2 += (uint32_t)__popcll(tw[kk] & below2); }
+                succ = ((P2 >> kin) & 1u) ? dart0 + s_dbase[w2] + off2 + (uint32_t)__popc(P2 & ((1u << kin) - 1u)) : cur;   // cur = chain end
+            } else {
+                succ = kNone;
+                s_cross[atomicAdd(&s_cross_n, 1u)] = cur;   // only rim pixels get here: at most 640 pixels x 4 darts
+            }
+            d_succ[cur] = succ;
             cur++;
         }
     }
+    // the darts whose successor lies in another tile go on a list for k_dart_link: one global atomic per tile
+    __syncthreads();
+    if (threadIdx.x == 0) s_cross_base = s_cross_n ? atomicAdd(cross_count, s_cross_n) : 0u;
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < s_cross_n; c += 256) cross_list[s_cross_base + c] = s_cross[c];
 }
 
-// successor of every dart + initial doubling state.  grid.y = frame, grid-stride over its darts.
-__global__ __launch_bounds__(256) void k_dart_link(int W, int H, const uint32_t* __restrict__ frame_base,
-                                                   const uint32_t* __restrict__ pix_base, const uint64_t* __restrict__ node_bits,
-                                                   const uint64_t* __restrict__ d_rec, uint32_t* __restrict__ d_succ) {
-    const uint32_t f = blockIdx.y;
-    const uint32_t lo = frame_base[f], hi = frame_base[f + 1];
+// successors that leave their tile (listed by k_dart_assign): looked up through the target pixel's first-dart index
+// (pix_base, written for tile-rim pixels) and its node bit.
+__global__ __launch_bounds__(256) void k_dart_link(int W, int H, uint32_t first_dart_frame0, const uint32_t* __restrict__ frame_base,
+                                                   uint32_t n_frames, const uint32_t* __restrict__ pix_base,
+                                                   const uint64_t* __restrict__ node_bits, const uint64_t* __restrict__ d_rec,
+                                                   uint32_t* __restrict__ d_succ, const uint32_t* __restrict__ cross_list,
+                                                   const unsigned int* __restrict__ cross_count) {
     const int wpr = (int)words_per_row((uint32_t)W);
-    const uint64_t* nbits = node_bits + (size_t)f * wpr * H;
-    const uint32_t* pb = pix_base + (size_t)f * W * H;
-    for (uint32_t d = lo + blockIdx.x * blockDim.x + threadIdx.x; d < hi; d += gridDim.x * blockDim.x) {
+    const uint32_t n = *cross_count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t d = cross_list[i];
+        uint32_t lo = 0, hi = n_frames;   // frame of this dart
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (frame_base[mid] <= d) lo = mid; else hi = mid; }
+        const uint32_t f = lo;
+        const uint64_t* nbits = node_bits + (size_t)f * wpr * H;
+        const uint32_t* pb = pix_base + (size_t)f * W * H;
         const uint64_t rec = d_rec[d];
         const uint32_t xy = rec_xy(rec);
         const int x = xy & 0xFFFF, y = xy >> 16;
         const uint32_t F = rec_F(rec);
         const int k = rec_info(rec) & 7;
-        // next foreground neighbour counter-clockwise after k: directions k-1, k-2, ..., k
         const uint32_t r = ((F >> k) | (F << (8 - k))) & 0xFFu;  // bit t <-> direction (k + t) & 7
-        const int t = 31 - __clz(r);                              // bit 0 (k itself) is always set
-        const int ko = (k + t) & 7;
+        const int ko = (k + (31 - __clz(r))) & 7;
         const int nx = x + kDX[ko], ny = y + kDY[ko];
         uint32_t succ = d;  // chain end unless the target dart exists
         if ((nbits[(size_t)ny * wpr + (nx >> 6)] >> (nx & 63)) & 1ull) {
@@ -789,12 +829,13 @@ hipError_t launch_dart_count(hipStream_t st, const uint64_t* bits, int W, int H,
 
 hipError_t launch_dart_build(hipStream_t st, const uint64_t* bits, int W, int H, uint32_t first_frame, uint32_t n_frames,
                              const uint32_t* frame_base, uint32_t* frame_cursor, uint32_t* pix_base, uint64_t* node_bits, uint64_t* d_rec,
-                             uint32_t* d_succ, uint32_t n_darts) {
+                             uint32_t* d_succ, uint32_t* cross_list, unsigned int* cross_count, uint32_t n_darts) {
+    hipError_t e = hipMemsetAsync(cross_count, 0, 4, st);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_dart_assign, dim3(dart_tiles((uint32_t)W, (uint32_t)H), n_frames), dim3(256), 0, st, bits, W, H, first_frame, frame_base, frame_cursor,
-                       pix_base, node_bits, d_rec);
-    const uint32_t per_frame = n_frames ? (n_darts + n_frames - 1) / n_frames : 0;
-    hipLaunchKernelGGL(k_dart_link, dim3(blocks_for(per_frame, 256, 1024), n_frames), dim3(256), 0, st, W, H, frame_base, pix_base, node_bits,
-                       d_rec, d_succ);
+                       pix_base, node_bits, d_rec, d_succ, cross_list, cross_count);
+    hipLaunchKernelGGL(k_dart_link, dim3(blocks_for(n_darts / 16 + 1, 256, 2048)), dim3(256), 0, st, W, H, 0u, frame_base, n_frames, pix_base, node_bits,
+                       d_rec, d_succ, cross_list, cross_count);
     return hipGetLastError();
 }
 
