@@ -13,7 +13,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libaruco3_hip.so"
 
 OK, ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_INTERNAL, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
-FMT_RGB8, FMT_RGBA8, FMT_L8 = 0, 1, 2
+FMT_RGB8, FMT_RGBA8, FMT_L8, FMT_BGRA8 = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
 STAGE_THRESHOLD, STAGE_CONTOUR, STAGE_DECODE = 0, 1, 2
 

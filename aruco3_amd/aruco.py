@@ -108,9 +108,15 @@ class Detector:
     def detect(self, image, populate: bool = False) -> Detection:
         return self.detect_batch(image, populate=populate)[0]
 
-    def detect_batch(self, images, populate: bool = False, stream: int = None, out_cap: int = 0) -> List[Detection]:
+    def detect_batch(self, images, populate: bool = False, stream: int = None, out_cap: int = 0, bgra: bool = False) -> List[Detection]:
+        """`bgra=True`: 4-channel frames are in webcam byte order B,G,R,A (examples/webcam_kamera.rs:38-52 re-orders them on
+        the CPU before `detect`; here the kernel reads them as they are)."""
         ctx = self._context()
         ptr, mem, fmt, w, h, rs, fs, n, keep = _as_frames(images)
+        if bgra:
+            if fmt != _lib.FMT_RGBA8:
+                raise ValueError("bgra=True needs 4-channel frames")
+            fmt = _lib.FMT_BGRA8
         if stream is not None:
             ctx.set_stream(stream)
         ctx.set_debug_taps(populate)

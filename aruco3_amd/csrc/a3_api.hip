@@ -487,14 +487,14 @@ int a3_detect_batch(a3_ctx* ctx, const void* pixels, int memory, int fmt, uint32
     *out_n = 0;
     if (n_frames == 0) return A3_OK;
     if (!pixels) return fail(ctx, A3_ERR_INVALID, "a3_detect_batch: null pixels");
-    if (fmt != A3_FMT_RGB8 && fmt != A3_FMT_RGBA8 && fmt != A3_FMT_L8) return fail(ctx, A3_ERR_INVALID, "unknown pixel format");
+    if (fmt != A3_FMT_RGB8 && fmt != A3_FMT_RGBA8 && fmt != A3_FMT_L8 && fmt != A3_FMT_BGRA8) return fail(ctx, A3_ERR_INVALID, "unknown pixel format");
     if (width == 0 || height == 0) {  // an empty image has no contours
         if (per_frame_count) memset(per_frame_count, 0, (size_t)n_frames * 4);
         return A3_OK;
     }
     if (width > 65535 || height > 65535 || (uint64_t)width * height >= (1ull << 30))
         return fail(ctx, A3_ERR_INVALID, "image dimensions above 65535 (or 2^30 pixels) are not supported");
-    const size_t bpp = fmt == A3_FMT_RGB8 ? 3 : (fmt == A3_FMT_RGBA8 ? 4 : 1);
+    const size_t bpp = fmt == A3_FMT_RGB8 ? 3 : (fmt == A3_FMT_L8 ? 1 : 4);
     if (row_stride == 0) row_stride = (size_t)width * bpp;
     if (row_stride < (size_t)width * bpp) return fail(ctx, A3_ERR_INVALID, "row_stride smaller than a row");
     if (frame_stride == 0) frame_stride = row_stride * height;

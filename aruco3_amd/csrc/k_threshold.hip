@@ -39,9 +39,11 @@ __device__ __forceinline__ uint32_t luma_of(uint32_t r, uint32_t g, uint32_t b) 
 
 // grey of one RGB(A) pixel held in the low 3 bytes of `px` (4th byte ignored): two byte-wise dot products with
 // the split weights 2126 = 8*256+78, 7152 = 27*256+240, 722 = 2*256+210, then the exact /10000.
+template <bool BGR = false>
 __device__ __forceinline__ uint32_t luma_dot(uint32_t px) {
-    const uint32_t lo = __builtin_amdgcn_udot4(px, 0x00D2F04Eu, 0u, false);
-    const uint32_t hi = __builtin_amdgcn_udot4(px, 0x00021B08u, 0u, false);
+    // byte 0 of px is R (RGB/RGBA) or B (BGRA): the weight bytes swap ends
+    const uint32_t lo = __builtin_amdgcn_udot4(px, BGR ? 0x004EF0D2u : 0x00D2F04Eu, 0u, false);
+    const uint32_t hi = __builtin_amdgcn_udot4(px, BGR ? 0x00081B02u : 0x00021B08u, 0u, false);
     // l <= 10000*255 < 2^22; floor(l / 10000) == (l * 13743896) >> 37 for every such l (checked exhaustively;
     // 429497 >> 32 is NOT exact), i.e. one full-rate v_mul_hi_u32_u24 plus a shift instead of a quarter-rate
     // 32-bit multiply-high
@@ -50,7 +52,7 @@ __device__ __forceinline__ uint32_t luma_dot(uint32_t px) {
     return (uint32_t)(((uint64_t)l * 13743896ull) >> 37);
 }
 
-template <int FMT> struct RawRow { static constexpr int NDW = FMT == A3_FMT_RGB8 ? 12 : (FMT == A3_FMT_RGBA8 ? 16 : 4); uint32_t d[NDW]; };
+template <int FMT> struct RawRow { static constexpr int NDW = FMT == A3_FMT_RGB8 ? 12 : (FMT == A3_FMT_L8 ? 4 : 16); uint32_t d[NDW]; };
 
 // 16 consecutive pixels of row y starting at x0 (a multiple of 16, may be negative or past the image): raw bytes,
 // zero where the image is not.  Fully-inside lanes use 16-byte vector loads.
@@ -58,7 +60,7 @@ template <int FMT, bool FAST>
 __device__ __forceinline__ void load_raw16(const uint8_t* __restrict__ frame, size_t row_stride, int x0, int y, int W, int H, bool aligned,
                                            RawRow<FMT>& r) {
     constexpr int NDW = RawRow<FMT>::NDW;
-    constexpr int BPP = FMT == A3_FMT_RGB8 ? 3 : (FMT == A3_FMT_RGBA8 ? 4 : 1);
+    constexpr int BPP = FMT == A3_FMT_RGB8 ? 3 : (FMT == A3_FMT_L8 ? 1 : 4);
 #pragma unroll
     for (int i = 0; i < NDW; i++) r.d[i] = 0u;
     if (y < 0 || y >= H || x0 + T_LPX <= 0 || x0 >= W) return;
@@ -93,12 +95,12 @@ __device__ __forceinline__ void grey16(const RawRow<FMT>& r, uint32_t g[4]) {
             for (int j = 0; j < 4; j++) {
                 const int i = 4 * q + j;
                 uint32_t px;
-                if constexpr (FMT == A3_FMT_RGBA8) px = r.d[i];
+                if constexpr (FMT == A3_FMT_RGBA8 || FMT == A3_FMT_BGRA8) px = r.d[i];
                 else {
                     const int byte = 3 * i, k = byte >> 2, sh = 8 * (byte & 3);   // compile-time after unrolling
                     px = sh == 0 ? r.d[k] : __builtin_amdgcn_alignbit(k + 1 < 12 ? r.d[k + 1] : 0u, r.d[k], sh);
                 }
-                l[j] = luma_dot(px);
+                l[j] = luma_dot<FMT == A3_FMT_BGRA8>(px);
             }
             g[q] = l[0] | (l[1] << 8) | (l[2] << 16) | (l[3] << 24);
         }
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
     // FAST: every load is unconditional (row and column clamped into the image) so that the loop body has no branch
     // around a load and the compiler can keep T_PF rows in flight with counted waits; what the clamped address
     // fetched for an outside lane/row is discarded by zeroing the grey below.
-    constexpr int BPPK = FMT == A3_FMT_RGB8 ? 3 : (FMT == A3_FMT_RGBA8 ? 4 : 1);
+    constexpr int BPPK = FMT == A3_FMT_RGB8 ? 3 : (FMT == A3_FMT_L8 ? 1 : 4);
     const bool lane_in = x0 >= 0 && x0 + T_LPX <= W;
     const uint8_t* lane_ptr = frame + (size_t)(lane_in ? x0 : 0) * BPPK;
     auto issue = [&](int r, RawRow<FMT>& dst) {
@@ -306,9 +308,10 @@ __global__ void k_grey_generic(const uint8_t* __restrict__ pixels, size_t row_st
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= W) return;
     const uint32_t f = blockIdx.z;
-    constexpr int BPP = FMT == A3_FMT_RGB8 ? 3 : (FMT == A3_FMT_RGBA8 ? 4 : 1);
+    constexpr int BPP = FMT == A3_FMT_RGB8 ? 3 : (FMT == A3_FMT_L8 ? 1 : 4);
     const uint8_t* p = pixels + (size_t)f * frame_stride + (size_t)y * row_stride + (size_t)x * BPP;
-    grey[(size_t)f * W * H + (size_t)y * W + x] = BPP == 1 ? p[0] : (uint8_t)luma_of(p[0], p[1], p[2]);
+    grey[(size_t)f * W * H + (size_t)y * W + x] =
+        BPP == 1 ? p[0] : (uint8_t)(FMT == A3_FMT_BGRA8 ? luma_of(p[2], p[1], p[0]) : luma_of(p[0], p[1], p[2]));
 }
 
 // one wave per packed word: 64 consecutive pixels, result gathered with a ballot
@@ -356,6 +359,7 @@ hipError_t launch_grey_threshold(hipStream_t st, const uint8_t* pixels, int fmt,
                                               rows_per_wave, strips_y, n_pairs, grey, bin, aligned_in, aligned_out)
         if (fmt == A3_FMT_RGB8) { if (fast) A3_LAUNCH_K1(A3_FMT_RGB8, true); else A3_LAUNCH_K1(A3_FMT_RGB8, false); }
         else if (fmt == A3_FMT_RGBA8) { if (fast) A3_LAUNCH_K1(A3_FMT_RGBA8, true); else A3_LAUNCH_K1(A3_FMT_RGBA8, false); }
+        else if (fmt == A3_FMT_BGRA8) { if (fast) A3_LAUNCH_K1(A3_FMT_BGRA8, true); else A3_LAUNCH_K1(A3_FMT_BGRA8, false); }
         else { if (fast) A3_LAUNCH_K1(A3_FMT_L8, true); else A3_LAUNCH_K1(A3_FMT_L8, false); }
 #undef A3_LAUNCH_K1
         return hipGetLastError();
@@ -363,6 +367,7 @@ hipError_t launch_grey_threshold(hipStream_t st, const uint8_t* pixels, int fmt,
     dim3 block(64), gridg((W + 63) / 64, H, n), grid1(words_per_row((uint32_t)W), H, n);
     if (fmt == A3_FMT_RGB8) hipLaunchKernelGGL(k_grey_generic<A3_FMT_RGB8>, gridg, block, 0, st, pixels, row_stride, frame_stride, W, H, grey);
     else if (fmt == A3_FMT_RGBA8) hipLaunchKernelGGL(k_grey_generic<A3_FMT_RGBA8>, gridg, block, 0, st, pixels, row_stride, frame_stride, W, H, grey);
+    else if (fmt == A3_FMT_BGRA8) hipLaunchKernelGGL(k_grey_generic<A3_FMT_BGRA8>, gridg, block, 0, st, pixels, row_stride, frame_stride, W, H, grey);
     else hipLaunchKernelGGL(k_grey_generic<A3_FMT_L8>, gridg, block, 0, st, pixels, row_stride, frame_stride, W, H, grey);
     hipLaunchKernelGGL(k_threshold_generic, grid1, block, 0, st, grey, W, H, (int)radius, bits);
     return hipGetLastError();

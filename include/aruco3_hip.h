@@ -33,7 +33,8 @@ enum {
 };
 
 /* pixel layouts accepted where the reference takes an image::DynamicImage (src/aruco.rs:52,60) */
-enum { A3_FMT_RGB8 = 0, A3_FMT_RGBA8 = 1, A3_FMT_L8 = 2 };
+enum { A3_FMT_RGB8 = 0, A3_FMT_RGBA8 = 1, A3_FMT_L8 = 2,
+       A3_FMT_BGRA8 = 3 /* webcam byte order (examples/webcam_kamera.rs:38-52 swizzles it on the CPU first) */ };
 /* where `pixels` lives */
 enum { A3_MEM_HOST = 0, A3_MEM_DEVICE = 1 };
 

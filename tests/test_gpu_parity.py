@@ -378,3 +378,52 @@ def test_noise_1080p_reference_bench_input(dicts, oracle):
     ctx = _check(det, oracle, frame[None])
     st = ctx.stats()
     assert st["darts"] > 1_000_000 and st["contours_traced"] > 100_000
+
+
+def test_bgra_webcam_byte_order(hip, dicts, oracle):
+    """frames in B,G,R,A order (what examples/webcam_kamera.rs:38-52 swizzles on the CPU) give the
+    result of the same frames in R,G,B,A order; also on a width that forces the per-pixel load path."""
+    from aruco3_amd import synth
+
+    d = dicts.new_from_named_dict("ARUCO_DEFAULT")
+    for (w, h) in ((640, 480), (333, 251)):
+        spec = synth.SynthSpec(w, h, n_markers=(2, 2), side=(90.0, 110.0), min_center_sep=130.0)
+        rgb = synth.render_frame(spec, d.code_list, d.num_bits, 77)[0]
+        rgba = np.concatenate([rgb, np.full((h, w, 1), 255, np.uint8)], axis=2)
+        bgra = np.ascontiguousarray(rgba[..., [2, 1, 0, 3]])
+        det = _detector(dicts, "ARUCO_DEFAULT")
+        ctx = det._context()
+        ctx.set_debug_taps(True)
+        markers, per = ctx.detect_batch(bgra.ctypes.data, hip.MEM_HOST, hip.FMT_BGRA8, w, h, w * 4, w * h * 4, 1)
+        res = oracle.detect(rgba, d.code_list, d.num_bits, d._tau)
+        assert_frame_parity(ctx, 0, rgba, res, w, h)
+        assert markers_of_hip(markers) == markers_of_oracle(res)
+        out = det.detect_batch(bgra, bgra=True)[0]
+        assert [m.id for m in out.markers] == [m["id"] for m in res["markers"]]
+
+
+def test_make_binary_image_cell_order_q6(dicts, oracle):
+    """SURVEY quirk Q6: a marker drawn in ARDictionary::make_binary_image's LSB-first cell order (src/dictionaries.rs:212-232,
+    what examples/macroquad_detect.rs:27-43 renders) is the canonical marker turned by 180 degrees; it is still read, with
+    rotation index 2, and the corner list starts at the opposite corner."""
+    from aruco3_amd import synth
+
+    d = dicts.new_from_named_dict("ARUCO")
+    frames = {}
+    for order in ("msb", "lsb"):
+        spec = synth.SynthSpec(640, 480, n_markers=(2, 2), side=(120.0, 120.0), rotation_deg=(0.0, 0.0), perspective=0.0, min_center_sep=200.0,
+                               cell_order=order)
+        frames[order] = synth.render_frame(spec, d.code_list, d.num_bits, 5150)
+    det = _detector(dicts, "ARUCO")
+    _check(det, oracle, np.stack([frames["msb"][0], frames["lsb"][0]]))
+    _, markers, per = _run(det, np.stack([frames["msb"][0], frames["lsb"][0]]), populate=False)
+    a, b = markers[: int(per[0])], markers[int(per[0]):]
+    # (an axis-aligned marker yields two surviving candidates, its outer and its inner border, whose corner lists start at
+    #  different corners -- discard_too_near compares same-index corners only, src/aruco.rs:189-190)
+    assert set(a["id"].tolist()) == set(t.id for t in frames["msb"][1])
+    assert set(b["id"].tolist()) == set(t.id for t in frames["lsb"][1])
+    # identical geometry, cells mirrored through the centre: every rotation index moves by 2
+    for i in set(a["id"].tolist()):
+        ra = sorted((int(m["rotation"]) + 2) % 4 for m in a if m["id"] == i)
+        rb = sorted(int(m["rotation"]) for m in b if m["id"] == i)
+        assert ra == rb
