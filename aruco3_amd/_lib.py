@@ -20,7 +20,7 @@ STAGE_THRESHOLD, STAGE_CONTOUR, STAGE_DECODE = 0, 1, 2
 # every symbol include/aruco3_hip.h declares
 SYMBOLS = [
     "a3_abi_version", "a3_default_config", "a3_create", "a3_destroy", "a3_last_error", "a3_set_stream", "a3_set_pool_limits",
-    "a3_get_tau", "a3_set_debug_taps", "a3_detect_batch", "a3_get_stats", "a3_download_grey", "a3_download_thresholded",
+    "a3_get_tau", "a3_set_debug_taps", "a3_detect_batch", "a3_detect_batch_pose", "a3_get_stats", "a3_download_grey", "a3_download_thresholded",
     "a3_candidate_count", "a3_download_candidates", "a3_download_homographies", "a3_estimate_pose", "a3_estimate_pose_normalized",
     "a3_find_nearest", "a3_calculate_tau", "a3_set_profiling", "a3_get_profile", "a3_selftest_ieee",
 ]
@@ -118,6 +118,9 @@ def load():
     L.a3_detect_batch.restype = C.c_int
     L.a3_detect_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_size_t, C.c_size_t, C.c_uint32, vp, C.c_size_t, u32p,
                                   C.POINTER(C.c_size_t)]
+    L.a3_detect_batch_pose.restype = C.c_int
+    L.a3_detect_batch_pose.argtypes = [vp, vp, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_size_t, C.c_size_t, C.c_uint32, C.c_float,
+                                       C.POINTER(Intrinsics), vp, vp, C.c_size_t, u32p, C.POINTER(C.c_size_t)]
     L.a3_get_stats.restype = C.c_int
     L.a3_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.a3_download_grey.restype = C.c_int
@@ -226,6 +229,20 @@ class Context:
                                     out.ctypes.data_as(C.c_void_p), cap, _p(per, C.c_uint32), C.byref(n))
         check(rc, self.handle)
         return out[: n.value], per[:n_frames]
+
+    def detect_batch_pose(self, pixels_ptr: int, memory: int, fmt: int, width: int, height: int, row_stride: int, frame_stride: int,
+                          n_frames: int, marker_size_mm: float, intrinsics: "Intrinsics" = None, out_cap: int = 0):
+        """-> (markers, per-frame counts, poses float32 [n_markers, 2, 13] = error, 9 rotation row-major, 3 translation)"""
+        cap = out_cap or max(64 * n_frames, 64)
+        out = np.zeros(cap, dtype=MARKER_DTYPE)
+        poses = np.zeros((cap, 2, 13), dtype=np.float32)
+        per = np.zeros(max(n_frames, 1), dtype=np.uint32)
+        n = C.c_size_t()
+        rc = load().a3_detect_batch_pose(self.handle, C.c_void_p(pixels_ptr), memory, fmt, width, height, row_stride, frame_stride, n_frames,
+                                         marker_size_mm, C.byref(intrinsics) if intrinsics else None, out.ctypes.data_as(C.c_void_p),
+                                         poses.ctypes.data_as(C.c_void_p), cap, _p(per, C.c_uint32), C.byref(n))
+        check(rc, self.handle)
+        return out[: n.value], per[:n_frames], poses[: n.value]
 
     # ---- Detection.grey / thresholded / candidates / homographies of the last batch ----
     def download_grey(self, frame: int, w: int, h: int, thresholded: bool = False) -> np.ndarray:

@@ -138,6 +138,36 @@ class Detector:
             out.append(det)
         return out
 
+    def detect_batch_with_pose(self, images, marker_size_mm: float, intrinsics=None, stream: int = None, out_cap: int = 0):
+        """detect + `pose::solve_with_undistorted_points` / `solve_with_intrinsics` of every marker (src/pose.rs:52-81) in one
+        device pass, the way examples/webcam_kamera.rs:56-71 chains them.  -> [(Detection, [(MarkerPose, MarkerPose), ...])]"""
+        from .pose import MarkerPose
+
+        ctx = self._context()
+        ptr, mem, fmt, w, h, rs, fs, n, keep = _as_frames(images)
+        if stream is not None:
+            ctx.set_stream(stream)
+        ctx.set_debug_taps(False)
+        intr = None
+        if intrinsics is not None:
+            ci = intrinsics
+            intr = _lib.Intrinsics(ci.image_width, ci.image_height, ci.focal_x, ci.focal_y, ci.principal_x, ci.principal_y)
+        markers, per, poses = ctx.detect_batch_pose(ptr, mem, fmt, w, h, rs, fs, n, marker_size_mm, intr, out_cap)
+        out = []
+        pos = 0
+        for f in range(n):
+            det = Detection()
+            pp = []
+            for i in range(pos, pos + int(per[f])):
+                m = markers[i]
+                c = m["corners"]
+                det.markers.append(Marker(int(m["id"]), int(m["code"]), [(int(c[2 * k]), int(c[2 * k + 1])) for k in range(4)],
+                                          int(m["hamming_distance"])))
+                pp.append(tuple(MarkerPose(float(q[0]), q[1:10].reshape(3, 3).copy(), q[10:13].copy()) for q in poses[i]))
+            pos += int(per[f])
+            out.append((det, pp))
+        return out
+
     def detect_batch_raw(self, images, stream: int = None, out_cap: int = 0):
         """Batch entry without Python object construction: (structured marker array, per-frame counts)."""
         ctx = self._context()

@@ -3,6 +3,7 @@
 // a3_create fails with A3_ERR_NO_DEVICE.
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -38,7 +39,8 @@ hipError_t launch_decode(hipStream_t, const uint8_t*, int, int, uint32_t, const 
                          uint32_t, uint32_t, uint32_t, const uint64_t*, uint32_t, uint32_t, int, void*, void*, uint8_t*, int);
 hipError_t launch_compact_markers(hipStream_t, const void*, const uint16_t*, const uint32_t*, uint32_t, uint32_t, uint32_t, a3_marker*,
                                   uint32_t, uint32_t*, unsigned int*, unsigned int*);
-hipError_t launch_pose(hipStream_t, const uint32_t*, const float*, uint32_t, int, float, float, float, float, float, float, float, a3_pose*);
+hipError_t launch_pose(hipStream_t, const uint32_t*, uint32_t, const float*, uint32_t, const unsigned int*, int, float, float, float, float,
+                       float, float, float, a3_pose*);
 hipError_t launch_find_nearest(hipStream_t, const uint64_t*, uint32_t, const uint64_t*, uint32_t, uint32_t*, uint8_t*);
 hipError_t launch_calc_tau(hipStream_t, const uint64_t*, uint32_t, unsigned int*);
 hipError_t launch_selftest(hipStream_t, const double*, const double*, uint32_t, double*, double*, float*, float*);
@@ -91,6 +93,12 @@ struct a3_ctx {
     // launch-count hints (every pass past convergence is an empty launch of ~5 us): start low, retry the batch with the
     // maximum if a pass count turns out too small
     int jump_rounds_hint = 10, resolve_iters_hint = 4;
+    // a3_detect_batch_pose: poses of every marker are computed on the device right after detection
+    bool want_pose = false;
+    float pose_size_mm = 0.0f;
+    bool pose_has_intr = false;
+    a3_intrinsics pose_intr{};
+    a3_pose* pose_out = nullptr;
     bool debug_taps = false;
     bool profiling = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -299,6 +307,13 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
                          ctx->proj.p, ctx->outs.p, ctx->debug_taps ? ctx->patches.as<uint8_t>() : nullptr, 4096));
     A3_HIP(launch_compact_markers(st, ctx->outs.p, ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(), n, 0, kMaxCand,
                                   ctx->markers.as<a3_marker>(), marker_cap, ctx->per_frame.as<uint32_t>(), d_marker_total, d_err));
+    if (ctx->want_pose) {   // IPPE on the device-resident marker list (src/pose.rs:52-81), no extra round trip
+        A3_HIP(ctx->tmp_b.ensure((size_t)marker_cap * 2 * sizeof(a3_pose)));
+        const a3_intrinsics& in = ctx->pose_intr;
+        A3_HIP(launch_pose(st, reinterpret_cast<const uint32_t*>(ctx->markers.as<uint8_t>() + offsetof(a3_marker, corners)),
+                           (uint32_t)(sizeof(a3_marker) / 4), nullptr, marker_cap, d_marker_total, ctx->pose_has_intr ? 1 : 0, ctx->pose_size_mm,
+                           (float)W, (float)H, in.focal_x, in.focal_y, in.principal_x, in.principal_y, ctx->tmp_b.as<a3_pose>()));
+    }
     if (ctx->profiling) A3_HIP(hipEventRecord(ctx->ev[3], st));
 
     // ---- results ----
@@ -344,6 +359,8 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     if (per_frame_count) memcpy(per_frame_count, hpf, (size_t)n * 4);
     if (total) {
         A3_HIP(hipMemcpyAsync(out, ctx->markers.p, (size_t)total * sizeof(a3_marker), hipMemcpyDeviceToHost, st));
+        if (ctx->want_pose && ctx->pose_out)
+            A3_HIP(hipMemcpyAsync(ctx->pose_out, ctx->tmp_b.p, (size_t)total * 2 * sizeof(a3_pose), hipMemcpyDeviceToHost, st));
         A3_HIP(hipStreamSynchronize(st));
     }
     *out_n = total;
@@ -514,6 +531,21 @@ int a3_detect_batch(a3_ctx* ctx, const void* pixels, int memory, int fmt, uint32
     return fail(ctx, A3_ERR_CAPACITY, "contour pools kept overflowing");
 }
 
+int a3_detect_batch_pose(a3_ctx* ctx, const void* pixels, int memory, int fmt, uint32_t width, uint32_t height, size_t row_stride,
+                         size_t frame_stride, uint32_t n_frames, float marker_size_mm, const a3_intrinsics* intr, a3_marker* out,
+                         a3_pose* poses, size_t out_cap, uint32_t* per_frame_count, size_t* out_n) {
+    if (!ctx || !poses) return A3_ERR_INVALID;
+    ctx->want_pose = true;
+    ctx->pose_size_mm = marker_size_mm;
+    ctx->pose_has_intr = intr != nullptr;
+    if (intr) ctx->pose_intr = *intr;
+    ctx->pose_out = poses;
+    const int rc = a3_detect_batch(ctx, pixels, memory, fmt, width, height, row_stride, frame_stride, n_frames, out, out_cap, per_frame_count, out_n);
+    ctx->want_pose = false;
+    ctx->pose_out = nullptr;
+    return rc;
+}
+
 int a3_get_stats(const a3_ctx* ctx, a3_stats* stats) {
     if (!ctx || !stats) return A3_ERR_INVALID;
     *stats = ctx->stats;
@@ -604,7 +636,7 @@ static int pose_common(a3_ctx* ctx, const uint32_t* corners, const float* norm, 
     A3_HIP(hipMemcpyAsync(ctx->tmp_a.p, corners ? (const void*)corners : (const void*)norm, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     float fx = 1, fy = 1, cx = 0, cy = 0;
     if (intr) { fx = intr->focal_x; fy = intr->focal_y; cx = intr->principal_x; cy = intr->principal_y; }
-    A3_HIP(launch_pose(ctx->stream, corners ? ctx->tmp_a.as<uint32_t>() : nullptr, norm ? ctx->tmp_a.as<float>() : nullptr, (uint32_t)n, mode,
+    A3_HIP(launch_pose(ctx->stream, corners ? ctx->tmp_a.as<uint32_t>() : nullptr, 8u, norm ? ctx->tmp_a.as<float>() : nullptr, (uint32_t)n, nullptr, mode,
                        size_mm, (float)iw, (float)ih, fx, fy, cx, cy, ctx->tmp_b.as<a3_pose>()));
     A3_HIP(hipMemcpyAsync(out, ctx->tmp_b.p, n * 2 * sizeof(a3_pose), hipMemcpyDeviceToHost, ctx->stream));
     A3_HIP(hipStreamSynchronize(ctx->stream));

@@ -662,14 +662,18 @@ __device__ void solve_normalized(const float pts[8], float marker_size_mm, a3_po
 }
 
 // mode 0: pts = corners / (w,h) (solve_with_undistorted_points); 1: unproject through intrinsics; 2: already normalised
-__global__ void k_pose(const uint32_t* __restrict__ corners, const float* __restrict__ norm_pts, uint32_t n, int mode, float marker_size_mm,
+// corner_stride: u32 words between the corner lists of consecutive markers (8 for a packed list, 14 inside a3_marker[]);
+// n_dev (optional): marker count produced on the device by k_compact_markers.
+__global__ void k_pose(const uint32_t* __restrict__ corners, uint32_t corner_stride, const float* __restrict__ norm_pts, uint32_t n,
+                       const unsigned int* __restrict__ n_dev, int mode, float marker_size_mm,
                        float iw, float ih, float fx, float fy, float cx, float cy, a3_pose* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) n = min(n, *n_dev);
     if (i >= n) return;
     float pts[8];
     for (int k = 0; k < 4; k++) {
         if (mode == 2) { pts[2 * k] = norm_pts[8 * i + 2 * k]; pts[2 * k + 1] = norm_pts[8 * i + 2 * k + 1]; continue; }
-        const float x = (float)corners[8 * i + 2 * k], y = (float)corners[8 * i + 2 * k + 1];
+        const float x = (float)corners[(size_t)corner_stride * i + 2 * k], y = (float)corners[(size_t)corner_stride * i + 2 * k + 1];
         if (mode == 0) { pts[2 * k] = x / iw; pts[2 * k + 1] = y / ih; }            // src/pose.rs:60
         else { pts[2 * k] = (x - cx) / fx; pts[2 * k + 1] = (y - cy) / fy; }         // src/pinhole.rs:88-93
     }
@@ -767,9 +771,11 @@ hipError_t launch_compact_markers(hipStream_t st, const void* outs, const uint16
     return hipGetLastError();
 }
 
-hipError_t launch_pose(hipStream_t st, const uint32_t* corners, const float* norm_pts, uint32_t n, int mode, float marker_size_mm, float iw,
-                       float ih, float fx, float fy, float cx, float cy, a3_pose* out) {
-    hipLaunchKernelGGL(k_pose, dim3((n + 63) / 64), dim3(64), 0, st, corners, norm_pts, n, mode, marker_size_mm, iw, ih, fx, fy, cx, cy, out);
+hipError_t launch_pose(hipStream_t st, const uint32_t* corners, uint32_t corner_stride, const float* norm_pts, uint32_t n,
+                       const unsigned int* n_dev, int mode, float marker_size_mm, float iw, float ih, float fx, float fy, float cx, float cy,
+                       a3_pose* out) {
+    hipLaunchKernelGGL(k_pose, dim3((n + 63) / 64), dim3(64), 0, st, corners, corner_stride, norm_pts, n, n_dev, mode, marker_size_mm, iw, ih,
+                       fx, fy, cx, cy, out);
     return hipGetLastError();
 }
 

@@ -111,6 +111,13 @@ int  a3_set_debug_taps(a3_ctx *ctx, int enabled);
 int  a3_detect_batch(a3_ctx *ctx, const void *pixels, int memory, int fmt, uint32_t width, uint32_t height,
                      size_t row_stride, size_t frame_stride, uint32_t n_frames,
                      a3_marker *out, size_t out_cap, uint32_t *per_frame_count, size_t *out_n);
+/* detect + pose in one call (BASELINE config 5; callers always solve the pose right after detect,
+ * examples/webcam_kamera.rs:67-71): poses[2*i], poses[2*i+1] belong to out[i], lower error first.
+ * intr == NULL: solve_with_undistorted_points with the frame size, else solve_with_intrinsics. */
+int  a3_detect_batch_pose(a3_ctx *ctx, const void *pixels, int memory, int fmt, uint32_t width, uint32_t height,
+                          size_t row_stride, size_t frame_stride, uint32_t n_frames, float marker_size_mm,
+                          const a3_intrinsics *intr, a3_marker *out, a3_pose *poses, size_t out_cap,
+                          uint32_t *per_frame_count, size_t *out_n);
 int  a3_get_stats(const a3_ctx *ctx, a3_stats *stats);
 
 /* Detection.grey / .candidates / .homographies of the last batch (src/aruco.rs:16-21,115-120),

@@ -427,3 +427,44 @@ def test_make_binary_image_cell_order_q6(dicts, oracle):
         ra = sorted((int(m["rotation"]) + 2) % 4 for m in a if m["id"] == i)
         rb = sorted(int(m["rotation"]) for m in b if m["id"] == i)
         assert ra == rb
+
+
+def test_detect_with_pose_in_one_call(hip, dicts, oracle):
+    """SURVEY section 8f item 2 / BASELINE config 5: a3_detect_batch_pose returns the two IPPE poses of every marker with the
+    detections; they equal a separate solve on the returned corners, with and without intrinsics."""
+    from aruco3_amd import synth
+
+    frames, _ = synth.config_frames(1, 3)
+    det = _detector(dicts, "ARUCO_DEFAULT")
+    ctx = det._context()
+    n, h, w, c = frames.shape
+    for intr in (None, hip.Intrinsics(w, h, 600.0, 610.0, w / 2.0, h / 2.0)):
+        markers, per, poses = ctx.detect_batch_pose(frames.ctypes.data, hip.MEM_HOST, hip.FMT_RGB8, w, h, w * c, h * w * c, n, 25.0, intr)
+        assert len(markers) == int(per.sum()) == len(poses) and len(markers) >= 8
+        for i, m in enumerate(markers):
+            if intr is None:
+                ref = oracle.solve_with_undistorted_points(m["corners"], 25.0, (w, h))
+            else:
+                ref = oracle.solve_with_intrinsics(m["corners"], 25.0, 600.0, 610.0, w / 2.0, h / 2.0)
+            for j in range(2):
+                e, r, t = ref[j]
+                assert abs(poses[i, j, 0] - e) <= 1e-4
+                assert np.allclose(poses[i, j, 1:10].reshape(3, 3), r, atol=1e-4, rtol=0)
+                assert np.allclose(poses[i, j, 10:13], t, atol=1e-4 * max(1.0, float(np.abs(t).max())), rtol=0)
+
+
+def test_detector_detect_batch_with_pose(dicts, oracle):
+    from aruco3_amd import synth
+    from aruco3_amd.pinhole import CameraIntrinsics
+
+    frames, _ = synth.config_frames(1, 2)
+    det = _detector(dicts, "ARUCO_DEFAULT")
+    h, w = frames.shape[1:3]
+    plain = det.detect_batch(frames)
+    fused = det.detect_batch_with_pose(frames, 30.0, CameraIntrinsics.new(w, h, 700.0, 700.0))
+    assert len(fused) == len(plain)
+    for (d, poses), p in zip(fused, plain):
+        assert [(m.id, m.corners) for m in d.markers] == [(m.id, m.corners) for m in p.markers]
+        assert len(poses) == len(d.markers)
+        for a, b in poses:
+            assert a.error <= b.error and a.rotation.shape == (3, 3)
