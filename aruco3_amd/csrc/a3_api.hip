@@ -22,7 +22,8 @@ size_t entry_state_bytes();
 size_t leader_list_bytes(uint32_t);
 hipError_t launch_rank_cycles(hipStream_t, uint32_t, int, const uint64_t*, const uint32_t*, JumpState*, uint32_t*, uint32_t*,
                               uint32_t*, uint32_t*, unsigned int*, void*, void*, JumpState*, uint32_t*, unsigned int*, int, DeviceCounters*);
-hipError_t launch_resolve(hipStream_t, const JumpState*, uint32_t, int, const uint64_t*, uint64_t*, uint64_t*, DeviceCounters*, int);
+hipError_t launch_resolve(hipStream_t, const JumpState*, uint32_t, int, const uint64_t*, const uint32_t*, const unsigned int*, uint64_t*, uint64_t*,
+                          DeviceCounters*, int);
 hipError_t launch_select_scatter(hipStream_t, const JumpState*, uint32_t, const uint32_t*, const unsigned int*, const uint32_t*, const uint64_t*,
                                  const uint32_t*, uint32_t, uint32_t,
                                  uint32_t, double, double, uint32_t*, ContourRec*, uint32_t*, uint32_t, uint64_t, DeviceCounters*,
@@ -285,7 +286,7 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
                                   ctx->entry_list.as<uint32_t>(), ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
                                   ctx->stB.as<JumpState>(), ctx->entry_bits.as<uint32_t>(), d_leader_count, rounds, ctr));
         const JumpState* fin = ctx->stB.as<JumpState>();
-        A3_HIP(launch_resolve(st, fin, nd, (int)W, ctx->d_xy.as<uint64_t>(),
+        A3_HIP(launch_resolve(st, fin, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->entry_bits.as<uint32_t>(), d_leader_count,
                               ctx->t_cur.as<uint64_t>(), ctx->t_next.as<uint64_t>(), ctr, ctx->resolve_iters_hint));
         A3_HIP(launch_select_scatter(st, fin, nd, ctx->entry_bits.as<uint32_t>(), d_leader_count, ctx->d_succ.as<uint32_t>(), ctx->t_cur.as<uint64_t>(), fb, c.count, c.first, min_edge_length,
                                      ctx->cfg.contour_simplification_epsilon, image_diag, ctx->cyc_slot.as<uint32_t>(),
@@ -336,7 +337,7 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
         ctx->stats.contours_traced += hc[ci].traced;
         ctx->stats.contours_materialised += hc[ci].contours;
         for (int r = 0; r < 32; r++) if (hc[ci].jump_changed[r]) ctx->stats.jump_rounds = std::max<uint32_t>(ctx->stats.jump_rounds, r + 1);
-        uint32_t it = 1;  // pass k+1 ran iff pass k moved something
+        uint32_t it = hc[ci].resolve_needed ? 1 : 0;  // 0: k_resolve_fast confirmed the natural starts; pass k+1 ran iff pass k moved something
         for (int r = 0; r < kResolveItersMax - 1; r++) if (hc[ci].resolve_changed[r]) it = r + 2;
         ctx->stats.resolve_iterations = std::max(ctx->stats.resolve_iterations, it);
         if (rounds_max > 0 && rounds_max < 32 && hc[ci].jump_changed[rounds_max - 1] != 0) jump_short = true;

@@ -74,7 +74,7 @@ struct DeviceCounters {
     unsigned int traced;            // cycles with a start event (stat)
     unsigned int err_flags;         // bit 0: event dart on a broken chain, bit 1: point pool overflow,
                                     // bit 2: contour table overflow, bit 3: candidate table overflow
-    unsigned int pad0;
+    unsigned int resolve_needed;    // set by k_resolve_fast: some border's first start event does not fire -> run the fixpoint passes
     unsigned int jump_changed[32];     // per doubling round: darts whose key changed
     unsigned int resolve_changed[16];  // per start-resolution pass: cycles whose start moved
     unsigned int pad[2];

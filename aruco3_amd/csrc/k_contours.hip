@@ -502,9 +502,57 @@ __global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const J
 // ---------------------------------------------------------------------------------------
 constexpr uint64_t kInf64 = ~0ull;
 
+// Fast path, one lane per border that has a start event: under the natural assignment T0 (every border starts at its
+// smallest event, which is its leader dart) evaluate only that smallest event.  If it fires for every border, the Jacobi
+// step of k_resolve_eval maps T0 to itself (T'(c) = min firing event >= min event = T0(c)), so T0 is the fixpoint and the
+// passes over all darts below are skipped; this is the case unless a component's first pixel lies in column 0.
+// T0 is written for the listed leaders only -- the only slots k_cycle_select reads.
+__global__ __launch_bounds__(256) void k_resolve_fast(const JumpState* __restrict__ st, const uint32_t* __restrict__ leader_list,
+                                                      const unsigned int* __restrict__ leader_count, uint32_t shard_cap, int W,
+                                                      const uint64_t* __restrict__ d_rec, uint64_t* __restrict__ t_cur,
+                                                      DeviceCounters* __restrict__ ctr) {
+    uint32_t n_max = 0;
+    for (uint32_t sh = 0; sh < kLeaderShards; sh++) n_max = max(n_max, leader_count[sh]);
+    const uint32_t span = (n_max + 63u) & ~63u;
+    const uint32_t n_leaders = span * kLeaderShards;
+    bool moved = false;
+    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n_leaders; i0 += gridDim.x * blockDim.x) {
+        const uint32_t sh = i0 / span, i = i0 - sh * span;
+        if (i >= leader_count[sh]) continue;
+        const uint32_t d = leader_list[(size_t)sh * shard_cap + i];
+        const uint64_t key0 = st[d].key;            // (smallest event key << 32) | d
+        t_cur[d] = key0;
+        const uint64_t rec = d_rec[d];
+        const uint32_t info = rec_info(rec);
+        const uint32_t xy = rec_xy(rec);
+        const uint32_t x = xy & 0xFFFF, y = xy >> 16;
+        const uint32_t q = y * (uint32_t)W + x;
+        const uint32_t F = rec_F(rec), P = pdart_mask(F);
+        const int k = info & 7;
+        const uint32_t base = d - __popc(P & ((1u << k) - 1u));
+        const int cnt = __popc(P);
+        bool wfires = true;
+        for (int j = 0; j < cnt; j++) {
+            const uint64_t kj = st[base + j].key;
+            const uint32_t leader = (uint32_t)kj;
+            // T0 of the border through this dart: its key, provided the dart sits on an intact cycle with an event
+            uint32_t t = (uint32_t)(kj >> 32);
+            if (leader != d && (uint32_t)st[leader].key != leader) t = kNoKey;
+            if (t < 2u * q) { wfires = false; break; }
+        }
+        const bool has_w = x > 0 && !(F & 1u);
+        uint32_t key = kNoKey;
+        if ((info & kInfoW) && wfires) key = 2u * q;
+        else if ((info & kInfoE) && !(has_w && wfires)) key = 2u * q + 1u;
+        if (key != (uint32_t)(key0 >> 32)) moved = true;
+    }
+    if (moved) ctr->resolve_needed = 1u;
+}
+
 // leaders get their natural start (their own key: the smallest event on the cycle); every other slot is "never"
 __global__ void k_resolve_init(const JumpState* __restrict__ st, uint32_t n_darts, uint64_t* __restrict__ t_cur,
-                               uint64_t* __restrict__ t_next) {
+                               uint64_t* __restrict__ t_next, const DeviceCounters* __restrict__ ctr) {
+    if (!ctr->resolve_needed) return;
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
         const uint64_t key = st[d].key;
         const bool natural = (uint32_t)key == d && (uint32_t)(key >> 32) != kNoKey;
@@ -521,7 +569,7 @@ __global__ void k_resolve_init(const JumpState* __restrict__ st, uint32_t n_dart
 __global__ __launch_bounds__(256) void k_resolve_eval(const JumpState* __restrict__ st, uint32_t n_darts, int W,
                                                       const uint64_t* __restrict__ d_rec, const uint64_t* __restrict__ t_cur,
                                                       uint64_t* __restrict__ t_next, int iter, DeviceCounters* __restrict__ ctr) {
-    if (iter > 0 && ctr->resolve_changed[iter - 1] == 0) return;
+    if (!ctr->resolve_needed || (iter > 0 && ctr->resolve_changed[iter - 1] == 0)) return;
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
         const uint64_t rec = d_rec[d];
         const uint32_t info = rec_info(rec);
@@ -554,7 +602,7 @@ __global__ __launch_bounds__(256) void k_resolve_eval(const JumpState* __restric
 // adopt T' as T, count the cycles whose start moved (into this pass's slot), clear T' for the next pass
 __global__ void k_resolve_commit(const JumpState* __restrict__ st, uint32_t n_darts, uint64_t* __restrict__ t_cur,
                                  uint64_t* __restrict__ t_next, int iter, int last, DeviceCounters* __restrict__ ctr) {
-    if (iter > 0 && ctr->resolve_changed[iter - 1] == 0) return;
+    if (!ctr->resolve_needed || (iter > 0 && ctr->resolve_changed[iter - 1] == 0)) return;
     uint32_t changed = 0;
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
         if ((uint32_t)st[d].key != d) continue;
@@ -869,9 +917,12 @@ hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uin
     return hipGetLastError();
 }
 
-hipError_t launch_resolve(hipStream_t st, const JumpState* fin, uint32_t n_darts, int W, const uint64_t* d_rec, uint64_t* t_cur, uint64_t* t_next, DeviceCounters* ctr, int max_iters) {
+hipError_t launch_resolve(hipStream_t st, const JumpState* fin, uint32_t n_darts, int W, const uint64_t* d_rec, const uint32_t* leader_list,
+                          const unsigned int* leader_count, uint64_t* t_cur, uint64_t* t_next, DeviceCounters* ctr, int max_iters) {
     const dim3 grid(blocks_for(n_darts, 256, 4096)), block(256);
-    hipLaunchKernelGGL(k_resolve_init, grid, block, 0, st, fin, n_darts, t_cur, t_next);
+    hipLaunchKernelGGL(k_resolve_fast, dim3(blocks_for(n_darts / 16 + 1, 256, 1024)), block, 0, st, fin, leader_list, leader_count,
+                       leader_shard_cap(n_darts), W, d_rec, t_cur, ctr);
+    hipLaunchKernelGGL(k_resolve_init, grid, block, 0, st, fin, n_darts, t_cur, t_next, ctr);
     for (int it = 0; it < max_iters; it++) {
         hipLaunchKernelGGL(k_resolve_eval, grid, block, 0, st, fin, n_darts, W, d_rec, t_cur, t_next, it, ctr);
         hipLaunchKernelGGL(k_resolve_commit, grid, block, 0, st, fin, n_darts, t_cur, t_next, it, it == max_iters - 1 ? 1 : 0, ctr);

@@ -80,7 +80,7 @@ typedef struct a3_stats {
     uint64_t candidates_pre;        /* after contours_to_candidates */
     uint64_t candidates;            /* after discard_too_near */
     uint64_t markers;
-    uint32_t resolve_iterations;    /* start-resolution passes (1 = no anomaly) */
+    uint32_t resolve_iterations;    /* start-resolution passes over all darts (0 = none needed) */
     uint32_t jump_rounds;           /* pointer-doubling rounds that did work */
     uint32_t chunks;                /* sub-batches the frames were split into */
     uint32_t reserved;

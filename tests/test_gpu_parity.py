@@ -468,3 +468,24 @@ def test_detector_detect_batch_with_pose(dicts, oracle):
         assert len(poses) == len(d.markers)
         for a, b in poses:
             assert a.error <= b.error and a.rotation.shape == (3, 3)
+
+
+def test_start_resolution_fast_and_full_paths(dicts, oracle):
+    """k_resolve_fast confirms the natural border starts on ordinary frames (no pass over all darts); a component whose
+    first pixel lies in column 0 forces the fixpoint passes.  Both give the oracle's candidates."""
+    from aruco3_amd import synth
+
+    det = _detector(dicts, "ARUCO_DEFAULT")
+    frames, _ = synth.config_frames(1, 1)
+    _check(det, oracle, frames)
+    assert det._context().stats()["resolve_iterations"] == 0
+    # bright background = one foreground component whose first pixel is (0, 0); two dark pixels touching column 0
+    # diagonally make its outer border's natural start event not fire (found by searching tests/dart_model.py)
+    a = np.full((96, 128), 210, np.uint8)
+    a[3, 1] = 20; a[4, 0] = 20
+    a[30:60, 40:90] = 20
+    _check(det, oracle, a[None, ..., None])
+    assert det._context().stats()["resolve_iterations"] >= 1
+    rng = np.random.default_rng(5)
+    noise = rng.integers(0, 256, size=(2, 200, 320, 3), dtype=np.uint8)
+    _check(det, oracle, noise)
