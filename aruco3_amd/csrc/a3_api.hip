@@ -15,10 +15,12 @@ namespace a3 {
 // k_threshold.hip
 hipError_t launch_grey_threshold(hipStream_t, const uint8_t*, int, size_t, size_t, int, int, uint32_t, uint32_t, uint8_t*, uint64_t*);
 // k_contours.hip
-hipError_t launch_dart_count(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, unsigned long long*);
-hipError_t launch_dart_build(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, const uint32_t*, uint32_t*, uint32_t*, uint64_t*,
-                             uint64_t*, uint32_t*, uint32_t*, unsigned int*, uint32_t);
+hipError_t launch_dart_count(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, unsigned long long*, uint32_t*);
+size_t tile_darts_bytes(uint32_t W, uint32_t H, uint32_t n_frames);
+hipError_t launch_dart_build(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, const uint32_t*, uint32_t*, uint32_t*, const uint32_t*,
+                             uint64_t*, uint32_t*, uint32_t);
 size_t entry_state_bytes();
+size_t entry_slots(uint32_t);
 size_t leader_list_bytes(uint32_t);
 hipError_t launch_rank_cycles(hipStream_t, uint32_t, int, const uint64_t*, const uint32_t*, JumpState*, uint32_t*, uint32_t*,
                               uint32_t*, uint32_t*, unsigned int*, void*, void*, JumpState*, uint32_t*, unsigned int*, int, DeviceCounters*);
@@ -94,6 +96,7 @@ struct a3_ctx {
     // launch-count hints (every pass past convergence is an empty launch of ~5 us): start low, retry the batch with the
     // maximum if a pass count turns out too small
     int jump_rounds_hint = 10, resolve_iters_hint = 4;
+    int resolve_full_ttl = 0;   // > 0: launch the fixpoint passes over all darts too (a recent batch needed them); else only k_resolve_fast
     // a3_detect_batch_pose: poses of every marker are computed on the device right after detection
     bool want_pose = false;
     float pose_size_mm = 0.0f;
@@ -110,11 +113,15 @@ struct a3_ctx {
     // last batch geometry (for the debug downloads)
     uint32_t W = 0, H = 0, frames = 0;
 
-    DevBuf dict, in, grey, bin, frame_darts, frame_base, frame_cursor, pix_base, node_bits;
+    DevBuf dict, in, grey, bin, frame_darts, frame_base, pix_base, tile_darts;
     DevBuf d_xy, d_info, d_F, d_succ, stA, stB, t_cur, t_next, cyc_slot;
     DevBuf loc_dist, entry_bits, entry_list, entry_pos, es_a, es_b;
-    DevBuf contours, cyc_start_off, points, counters, scratch_u32;
-    DevBuf cands, cand_count, pre_xy, fin_xy, fin_count, work, outs, proj, patches, markers, per_frame;
+    DevBuf contours, cyc_start_off, points;
+    DevBuf cands, pre_xy, fin_xy, fin_count, work, outs, proj, patches, markers;
+    // one allocation zeroed by one memset per batch and read back with one copy: [scratch 256 B | counters | per_frame | frame_cursor | cand_count]
+    DevBuf zero_blk;
+    unsigned int* scratch_u32 = nullptr; DeviceCounters* counters = nullptr; uint32_t* per_frame = nullptr; uint32_t* frame_cursor = nullptr; uint32_t* cand_count = nullptr;
+    uint32_t last_marker_total = 0;   // sizes the speculative marker read-back of the next batch
     DevBuf tmp_a, tmp_b, tmp_c, tmp_d;
     void* pinned = nullptr;
     size_t pinned_cap = 0;
@@ -159,12 +166,13 @@ int ensure_dart_pool(a3_ctx* ctx, uint64_t darts) {
     A3_HIP(ctx->cyc_slot.ensure(darts * 4));
     A3_HIP(ctx->loc_dist.ensure(darts * 4));
     A3_HIP(ctx->entry_bits.ensure(leader_list_bytes((uint32_t)darts)));   // leader list (cycles with a start event), 16 shards
-    A3_HIP(ctx->entry_list.ensure(darts * 4));
+    const size_t eslots = entry_slots((uint32_t)darts);   // sharded slot space: darts + at most 16 tiles of padding
+    A3_HIP(ctx->entry_list.ensure(eslots * 4));
     A3_HIP(ctx->entry_pos.ensure(darts * 4));
     // entries are darts whose predecessor lies in another 2048-dart tile; the bound darts is never reached in practice,
     // but an adversarial image can come close, so size for it
-    A3_HIP(ctx->es_a.ensure(darts * entry_state_bytes()));
-    A3_HIP(ctx->es_b.ensure(darts * entry_state_bytes()));
+    A3_HIP(ctx->es_a.ensure(eslots * entry_state_bytes()));
+    A3_HIP(ctx->es_b.ensure(eslots * entry_state_bytes()));
     return A3_OK;
 }
 
@@ -183,17 +191,14 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     A3_HIP(ctx->bin.ensure(bits_per_frame * n));
     A3_HIP(ctx->frame_darts.ensure((size_t)n * 8));
     A3_HIP(ctx->cands.ensure((size_t)n * kMaxCand * sizeof(CandRec)));
-    A3_HIP(ctx->cand_count.ensure((size_t)n * 4));
     A3_HIP(ctx->pre_xy.ensure((size_t)n * kMaxCand * 16));
     A3_HIP(ctx->fin_xy.ensure((size_t)n * kMaxCand * 16));
     A3_HIP(ctx->fin_count.ensure((size_t)n * 4));
     A3_HIP(ctx->work.ensure((size_t)n * kMaxCand * 4));
     A3_HIP(ctx->outs.ensure((size_t)n * kMaxCand * decode_out_bytes()));
     A3_HIP(ctx->proj.ensure((size_t)n * kMaxCand * proj_rec_bytes()));
-    A3_HIP(ctx->per_frame.ensure((size_t)n * 4));
     const uint32_t marker_cap = (uint32_t)std::min<size_t>(std::max<size_t>(out_cap, 1), (size_t)n * kMaxCand);
     A3_HIP(ctx->markers.ensure((size_t)marker_cap * sizeof(a3_marker)));
-    A3_HIP(ctx->scratch_u32.ensure(256));
     if (ctx->debug_taps) A3_HIP(ctx->patches.ensure((size_t)kPatchCap * S * S));
     ctx->W = W; ctx->H = H; ctx->frames = n;
     ctx->stats = a3_stats{};
@@ -206,7 +211,9 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
 
     // ---- contour graph size per frame -> chunk plan ----
     A3_HIP(hipMemsetAsync(ctx->frame_darts.p, 0, (size_t)n * 8, st));
-    A3_HIP(launch_dart_count(st, ctx->bin.as<uint64_t>(), (int)W, (int)H, 0, n, ctx->frame_darts.as<unsigned long long>()));
+    A3_HIP(ctx->tile_darts.ensure(tile_darts_bytes(W, H, n)));
+    A3_HIP(launch_dart_count(st, ctx->bin.as<uint64_t>(), (int)W, (int)H, 0, n, ctx->frame_darts.as<unsigned long long>(),
+                             ctx->tile_darts.as<uint32_t>()));
     if (int rc = ensure_pinned(ctx, std::max<size_t>((size_t)n * 8, 1 << 16))) return rc;
     A3_HIP(hipMemcpyAsync(ctx->pinned, ctx->frame_darts.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
     A3_HIP(hipStreamSynchronize(st));
@@ -219,7 +226,7 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     {
         Chunk c{0, 0, 0, 0};
         for (uint32_t f = 0; f < n; f++) {
-            if (c.count && c.darts + fd[f] > ctx->max_darts) { chunks.push_back(c); c = Chunk{f, 0, 0, 0}; }
+            if (c.count && (c.darts + fd[f] > ctx->max_darts || c.count >= kMaxChunkFrames)) { chunks.push_back(c); c = Chunk{f, 0, 0, 0}; }
             c.count++; c.darts += fd[f]; c.max_frame_darts = (uint32_t)std::max<uint64_t>(c.max_frame_darts, fd[f]);
         }
         if (c.count) chunks.push_back(c);
@@ -229,23 +236,29 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     ctx->stats.chunks = (uint32_t)chunks.size();
     if (int rc = ensure_dart_pool(ctx, std::max<uint64_t>(max_chunk_darts, 1))) return rc;
     A3_HIP(ctx->pix_base.ensure((size_t)max_chunk_frames * npx * 4));
-    A3_HIP(ctx->node_bits.ensure((size_t)max_chunk_frames * bits_per_frame));
     A3_HIP(ctx->frame_base.ensure((size_t)(max_chunk_frames + 1) * 4 * chunks.size()));
-    A3_HIP(ctx->frame_cursor.ensure((size_t)max_chunk_frames * 4));
-    A3_HIP(ctx->counters.ensure(sizeof(DeviceCounters) * chunks.size()));
+    const size_t ctr_bytes = sizeof(DeviceCounters) * chunks.size();
+    const size_t head_bytes = 256 + ctr_bytes + (size_t)n * 4;                       // what the host reads back
+    const size_t zero_bytes = head_bytes + (size_t)max_chunk_frames * 4 + (size_t)n * 4;
+    A3_HIP(ctx->zero_blk.ensure(zero_bytes));
+    {
+        uint8_t* z = ctx->zero_blk.as<uint8_t>();
+        ctx->scratch_u32 = reinterpret_cast<unsigned int*>(z);
+        ctx->counters = reinterpret_cast<DeviceCounters*>(z + 256);
+        ctx->per_frame = reinterpret_cast<uint32_t*>(z + 256 + ctr_bytes);
+        ctx->frame_cursor = ctx->per_frame + n;
+        ctx->cand_count = ctx->frame_cursor + max_chunk_frames;
+    }
     A3_HIP(ctx->contours.ensure((size_t)ctx->max_contours * sizeof(ContourRec)));
     A3_HIP(ctx->cyc_start_off.ensure((size_t)ctx->max_contours * 4));
     A3_HIP(ctx->points.ensure(ctx->max_points * 4));
 
-    A3_HIP(hipMemsetAsync(ctx->counters.p, 0, sizeof(DeviceCounters) * chunks.size(), st));
-    A3_HIP(hipMemsetAsync(ctx->cand_count.p, 0, (size_t)n * 4, st));
-    A3_HIP(hipMemsetAsync(ctx->scratch_u32.p, 0, 256, st));
-    unsigned int* d_work_count = ctx->scratch_u32.as<unsigned int>() + 0;
-    unsigned int* d_marker_total = ctx->scratch_u32.as<unsigned int>() + 1;
-    unsigned int* d_err = ctx->scratch_u32.as<unsigned int>() + 4;
-    unsigned int* d_entry_count = ctx->scratch_u32.as<unsigned int>() + 5;
-    unsigned int* d_cross_count = ctx->scratch_u32.as<unsigned int>() + 6;
-    unsigned int* d_leader_count = ctx->scratch_u32.as<unsigned int>() + 16;   // [16..31]
+    A3_HIP(hipMemsetAsync(ctx->zero_blk.p, 0, zero_bytes, st));
+    unsigned int* d_work_count = ctx->scratch_u32 + 0;
+    unsigned int* d_marker_total = ctx->scratch_u32 + 1;
+    unsigned int* d_err = ctx->scratch_u32 + 4;
+    unsigned int* d_entry_count = ctx->scratch_u32 + 32;    // [32..47]
+    unsigned int* d_leader_count = ctx->scratch_u32 + 16;   // [16..31]
 
     // frame bases of every chunk, uploaded once
     std::vector<uint32_t> bases;
@@ -268,14 +281,16 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     int rounds_max = 0;
     for (size_t ci = 0; ci < chunks.size(); ci++) {
         const Chunk& c = chunks[ci];
-        DeviceCounters* ctr = ctx->counters.as<DeviceCounters>() + ci;
+        DeviceCounters* ctr = ctx->counters + ci;
         const uint32_t* fb = ctx->frame_base.as<uint32_t>() + ci * (max_chunk_frames + 1);
         const uint32_t nd = (uint32_t)c.darts;
         if (nd == 0) continue;
-        A3_HIP(hipMemsetAsync(ctx->frame_cursor.p, 0, (size_t)c.count * 4, st));
-        A3_HIP(launch_dart_build(st, d_bin, (int)W, (int)H, c.first, c.count, fb, ctx->frame_cursor.as<uint32_t>(), ctx->pix_base.as<uint32_t>(),
-                                 ctx->node_bits.as<uint64_t>(), ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(),
-                                 ctx->cyc_slot.as<uint32_t>() /* free until k_cycle_select: holds the cross-tile list */, d_cross_count, nd));
+        if (ci > 0) {   // the batch-wide memset covered the first chunk
+            A3_HIP(hipMemsetAsync(ctx->frame_cursor, 0, (size_t)c.count * 4, st));
+            A3_HIP(hipMemsetAsync(d_leader_count, 0, 4 * 32, st));   // leader + entry counters, adjacent
+        }
+        A3_HIP(launch_dart_build(st, d_bin, (int)W, (int)H, c.first, c.count, fb, ctx->frame_cursor, ctx->pix_base.as<uint32_t>(),
+                                 ctx->tile_darts.as<uint32_t>(), ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), nd));
         int rounds = 1;
         while ((1ull << rounds) < (uint64_t)c.max_frame_darts && rounds < 31) rounds++;
         rounds += 1;  // the round that observes "nothing moved"
@@ -287,7 +302,7 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
                                   ctx->stB.as<JumpState>(), ctx->entry_bits.as<uint32_t>(), d_leader_count, rounds, ctr));
         const JumpState* fin = ctx->stB.as<JumpState>();
         A3_HIP(launch_resolve(st, fin, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->entry_bits.as<uint32_t>(), d_leader_count,
-                              ctx->t_cur.as<uint64_t>(), ctx->t_next.as<uint64_t>(), ctr, ctx->resolve_iters_hint));
+                              ctx->t_cur.as<uint64_t>(), ctx->t_next.as<uint64_t>(), ctr, ctx->resolve_full_ttl > 0 ? ctx->resolve_iters_hint : 0));
         A3_HIP(launch_select_scatter(st, fin, nd, ctx->entry_bits.as<uint32_t>(), d_leader_count, ctx->d_succ.as<uint32_t>(), ctx->t_cur.as<uint64_t>(), fb, c.count, c.first, min_edge_length,
                                      ctx->cfg.contour_simplification_epsilon, image_diag, ctx->cyc_slot.as<uint32_t>(),
                                      ctx->contours.as<ContourRec>(),
@@ -295,19 +310,19 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
                                      ctx->points.as<uint32_t>()));
         A3_HIP(launch_contour_quads(st, ctx->contours.as<ContourRec>(), ctr, ctx->max_contours, ctx->points.as<uint32_t>(),
                                     ctx->cfg.contour_simplification_epsilon, min_edge_length, c.first, kMaxCand,
-                                    ctx->cands.as<CandRec>() + (size_t)c.first * kMaxCand, ctx->cand_count.as<uint32_t>() + c.first, d_err));
+                                    ctx->cands.as<CandRec>() + (size_t)c.first * kMaxCand, ctx->cand_count + c.first, d_err));
     }
     if (ctx->profiling) A3_HIP(hipEventRecord(ctx->ev[2], st));
 
     // ---- candidates -> markers, all frames at once ----
-    A3_HIP(launch_frame_candidates(st, ctx->cands.as<CandRec>(), ctx->cand_count.as<uint32_t>(), n, kMaxCand, min_corner_separation,
+    A3_HIP(launch_frame_candidates(st, ctx->cands.as<CandRec>(), ctx->cand_count, n, kMaxCand, min_corner_separation,
                                    ctx->pre_xy.as<uint16_t>(), ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(),
                                    ctx->work.as<uint32_t>(), d_work_count));
     A3_HIP(launch_decode(st, ctx->grey.as<uint8_t>(), (int)W, (int)H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), d_work_count,
                          kMaxCand, S, ctx->mark_size, S, ctx->dict.as<uint64_t>(), ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors,
                          ctx->proj.p, ctx->outs.p, ctx->debug_taps ? ctx->patches.as<uint8_t>() : nullptr, 4096));
     A3_HIP(launch_compact_markers(st, ctx->outs.p, ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(), n, 0, kMaxCand,
-                                  ctx->markers.as<a3_marker>(), marker_cap, ctx->per_frame.as<uint32_t>(), d_marker_total, d_err));
+                                  ctx->markers.as<a3_marker>(), marker_cap, ctx->per_frame, d_marker_total, d_err));
     if (ctx->want_pose) {   // IPPE on the device-resident marker list (src/pose.rs:52-81), no extra round trip
         A3_HIP(ctx->tmp_b.ensure((size_t)marker_cap * 2 * sizeof(a3_pose)));
         const a3_intrinsics& in = ctx->pose_intr;
@@ -317,21 +332,26 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     }
     if (ctx->profiling) A3_HIP(hipEventRecord(ctx->ev[3], st));
 
-    // ---- results ----
-    const size_t ctr_bytes = sizeof(DeviceCounters) * chunks.size();
-    if (int rc = ensure_pinned(ctx, ctr_bytes + 64 + (size_t)n * 4 + (1 << 16))) return rc;
+    // ---- results: one copy of [scratch | counters | per-frame counts], one speculative copy of the marker list ----
+    const size_t pose_bytes = (ctx->want_pose && ctx->pose_out) ? 2 * sizeof(a3_pose) : 0;
+    const uint32_t guess = (uint32_t)std::min<size_t>(marker_cap, (size_t)ctx->last_marker_total + ctx->last_marker_total / 4 + 64);
+    const size_t head_pad = (head_bytes + 255) & ~(size_t)255;
+    if (int rc = ensure_pinned(ctx, head_pad + (size_t)marker_cap * (sizeof(a3_marker) + 2 * sizeof(a3_pose)) + (1 << 16))) return rc;
     uint8_t* hp = (uint8_t*)ctx->pinned;
-    A3_HIP(hipMemcpyAsync(hp, ctx->counters.p, ctr_bytes, hipMemcpyDeviceToHost, st));
-    A3_HIP(hipMemcpyAsync(hp + ctr_bytes, ctx->scratch_u32.p, 64, hipMemcpyDeviceToHost, st));
-    A3_HIP(hipMemcpyAsync(hp + ctr_bytes + 64, ctx->per_frame.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    a3_marker* h_markers = reinterpret_cast<a3_marker*>(hp + head_pad);
+    a3_pose* h_poses = reinterpret_cast<a3_pose*>(hp + head_pad + (size_t)marker_cap * sizeof(a3_marker));
+    A3_HIP(hipMemcpyAsync(hp, ctx->zero_blk.p, head_bytes, hipMemcpyDeviceToHost, st));
+    A3_HIP(hipMemcpyAsync(h_markers, ctx->markers.p, (size_t)guess * sizeof(a3_marker), hipMemcpyDeviceToHost, st));
+    if (pose_bytes) A3_HIP(hipMemcpyAsync(h_poses, ctx->tmp_b.p, (size_t)guess * pose_bytes, hipMemcpyDeviceToHost, st));
     A3_HIP(hipStreamSynchronize(st));
-    const DeviceCounters* hc = reinterpret_cast<const DeviceCounters*>(hp);
-    const unsigned int* hs = reinterpret_cast<const unsigned int*>(hp + ctr_bytes);
+    const unsigned int* hs = reinterpret_cast<const unsigned int*>(hp);
+    const DeviceCounters* hc = reinterpret_cast<const DeviceCounters*>(hp + 256);
     unsigned int flags = hs[4];
     uint64_t need_points = 0; uint32_t need_contours = 0;
-    bool jump_short = false;
+    bool jump_short = false, resolve_needed = false;
     for (size_t ci = 0; ci < chunks.size(); ci++) {
         flags |= hc[ci].err_flags;
+        resolve_needed |= hc[ci].resolve_needed != 0;
         need_points = std::max<uint64_t>(need_points, hc[ci].points);
         need_contours = std::max(need_contours, hc[ci].contours);
         ctx->stats.contours_traced += hc[ci].traced;
@@ -343,6 +363,11 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
         if (rounds_max > 0 && rounds_max < 32 && hc[ci].jump_changed[rounds_max - 1] != 0) jump_short = true;
     }
     if (jump_short && ctx->jump_rounds_hint < 32) { ctx->jump_rounds_hint = 32; return 1; }             // re-run with all rounds
+    if (resolve_needed) {
+        const bool ran = ctx->resolve_full_ttl > 0;
+        ctx->resolve_full_ttl = 64;        // keep the full passes in the launch sequence for the next batches
+        if (!ran) return 1;                // they were not launched this time: re-run
+    } else if (ctx->resolve_full_ttl > 0) ctx->resolve_full_ttl--;
     if ((flags & kErrResolve) && ctx->resolve_iters_hint < kResolveItersMax) { ctx->resolve_iters_hint = kResolveItersMax; return 1; }
     ctx->jump_rounds_hint = std::max(4, std::min(32, (int)ctx->stats.jump_rounds + 2));   // follow the workload, both ways
     if (flags & (kErrPointPool | kErrContourTable)) {
@@ -356,14 +381,18 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     if (flags & kErrCandTable) return fail(ctx, A3_ERR_CAPACITY, "more candidates / markers than the output tables hold");
     const uint32_t total = hs[1];
     if (total > out_cap) return fail(ctx, A3_ERR_CAPACITY, "out_cap is smaller than the number of markers found");
-    const uint32_t* hpf = reinterpret_cast<const uint32_t*>(hp + ctr_bytes + 64);
+    const uint32_t* hpf = reinterpret_cast<const uint32_t*>(hp + 256 + ctr_bytes);
     if (per_frame_count) memcpy(per_frame_count, hpf, (size_t)n * 4);
-    if (total) {
-        A3_HIP(hipMemcpyAsync(out, ctx->markers.p, (size_t)total * sizeof(a3_marker), hipMemcpyDeviceToHost, st));
-        if (ctx->want_pose && ctx->pose_out)
-            A3_HIP(hipMemcpyAsync(ctx->pose_out, ctx->tmp_b.p, (size_t)total * 2 * sizeof(a3_pose), hipMemcpyDeviceToHost, st));
+    if (total > guess) {   // the guess was short: fetch the rest
+        A3_HIP(hipMemcpyAsync(h_markers + guess, ctx->markers.as<a3_marker>() + guess, (size_t)(total - guess) * sizeof(a3_marker), hipMemcpyDeviceToHost, st));
+        if (pose_bytes) A3_HIP(hipMemcpyAsync(h_poses + 2 * (size_t)guess, ctx->tmp_b.as<a3_pose>() + 2 * (size_t)guess, (size_t)(total - guess) * pose_bytes, hipMemcpyDeviceToHost, st));
         A3_HIP(hipStreamSynchronize(st));
     }
+    if (total) {
+        memcpy(out, h_markers, (size_t)total * sizeof(a3_marker));
+        if (pose_bytes) memcpy(ctx->pose_out, h_poses, (size_t)total * pose_bytes);
+    }
+    ctx->last_marker_total = total;
     *out_n = total;
     ctx->stats.markers = total;
     if (ctx->profiling) {
@@ -460,11 +489,11 @@ void a3_destroy(a3_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
-    DevBuf* bufs[] = {&ctx->dict, &ctx->in, &ctx->grey, &ctx->bin, &ctx->frame_darts, &ctx->frame_base, &ctx->frame_cursor, &ctx->pix_base,
-                      &ctx->node_bits, &ctx->d_xy, &ctx->d_info, &ctx->d_F, &ctx->d_succ, &ctx->stA, &ctx->stB, &ctx->t_cur, &ctx->t_next, &ctx->cyc_slot,
+    DevBuf* bufs[] = {&ctx->dict, &ctx->in, &ctx->grey, &ctx->bin, &ctx->frame_darts, &ctx->frame_base, &ctx->pix_base,
+                      &ctx->tile_darts, &ctx->d_xy, &ctx->d_info, &ctx->d_F, &ctx->d_succ, &ctx->stA, &ctx->stB, &ctx->t_cur, &ctx->t_next, &ctx->cyc_slot,
                       &ctx->loc_dist, &ctx->entry_bits, &ctx->entry_list, &ctx->entry_pos, &ctx->es_a, &ctx->es_b,
-                      &ctx->contours, &ctx->cyc_start_off, &ctx->points, &ctx->counters, &ctx->scratch_u32, &ctx->cands, &ctx->cand_count,
-                      &ctx->pre_xy, &ctx->fin_xy, &ctx->fin_count, &ctx->work, &ctx->outs, &ctx->proj, &ctx->patches, &ctx->markers, &ctx->per_frame,
+                      &ctx->contours, &ctx->cyc_start_off, &ctx->points, &ctx->zero_blk, &ctx->cands,
+                      &ctx->pre_xy, &ctx->fin_xy, &ctx->fin_count, &ctx->work, &ctx->outs, &ctx->proj, &ctx->patches, &ctx->markers,
                       &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_d};
     for (DevBuf* b : bufs) b->release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -525,7 +554,7 @@ int a3_detect_batch(a3_ctx* ctx, const void* pixels, int memory, int fmt, uint32
         A3_HIP(hipMemcpyAsync(ctx->in.p, pixels, bytes, hipMemcpyHostToDevice, ctx->stream));
         d_pixels = ctx->in.as<uint8_t>();
     } else if (memory != A3_MEM_DEVICE) return fail(ctx, A3_ERR_INVALID, "memory must be A3_MEM_HOST or A3_MEM_DEVICE");
-    for (int attempt = 0; attempt < 6; attempt++) {
+    for (int attempt = 0; attempt < 8; attempt++) {
         const int rc = run_batch(ctx, d_pixels, fmt, width, height, row_stride, frame_stride, n_frames, out, out_cap, per_frame_count, out_n);
         if (rc != 1) return rc;
     }
@@ -580,7 +609,7 @@ int a3_candidate_count(a3_ctx* ctx, uint32_t frame, uint32_t* n_pre, uint32_t* n
     if (frame >= ctx->frames) return fail(ctx, A3_ERR_INVALID, "frame index outside the last batch");
     A3_HIP(hipSetDevice(ctx->device));
     uint32_t a = 0, b = 0;
-    A3_HIP(hipMemcpy(&a, ctx->cand_count.as<uint32_t>() + frame, 4, hipMemcpyDeviceToHost));
+    A3_HIP(hipMemcpy(&a, ctx->cand_count + frame, 4, hipMemcpyDeviceToHost));
     A3_HIP(hipMemcpy(&b, ctx->fin_count.as<uint32_t>() + frame, 4, hipMemcpyDeviceToHost));
     if (n_pre) *n_pre = std::min(a, kMaxCand);
     if (n_final) *n_final = b;

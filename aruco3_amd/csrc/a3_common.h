@@ -26,8 +26,13 @@ constexpr uint8_t kInfoW = 1u << 3;
 constexpr uint8_t kInfoE = 1u << 4;
 constexpr uint8_t kInfoBroken = 1u << 5;
 
-// per-dart record, one u64: bits 0-15 x, 16-31 y, 32-39 foreground-neighbour mask F of the pixel, 40-47 info byte
-__host__ __device__ inline uint64_t dart_rec(uint32_t xy, uint32_t F, uint32_t info) { return (uint64_t)xy | ((uint64_t)(F & 0xFFu) << 32) | ((uint64_t)(info & 0xFFu) << 40); }
+// per-dart record, one u64: bits 0-15 x, 16-31 y, 32-39 foreground-neighbour mask F of the pixel, 40-47 info byte,
+// 48-63 frame index inside the chunk (chunks hold at most 65536 frames)
+constexpr uint32_t kMaxChunkFrames = 65536u;
+__host__ __device__ inline uint64_t dart_rec(uint32_t xy, uint32_t F, uint32_t info, uint32_t frame) {
+    return (uint64_t)xy | ((uint64_t)(F & 0xFFu) << 32) | ((uint64_t)(info & 0xFFu) << 40) | ((uint64_t)(frame & 0xFFFFu) << 48);
+}
+__host__ __device__ inline uint32_t rec_frame(uint64_t r) { return (uint32_t)(r >> 48); }
 __host__ __device__ inline uint32_t rec_xy(uint64_t r) { return (uint32_t)r; }
 __host__ __device__ inline uint32_t rec_F(uint64_t r) { return (uint32_t)(r >> 32) & 0xFFu; }
 __host__ __device__ inline uint32_t rec_info(uint64_t r) { return (uint32_t)(r >> 40) & 0xFFu; }

@@ -140,7 +140,7 @@ __device__ __forceinline__ Nb8 tile_nb8(const uint64_t* __restrict__ img, int W,
 
 // grid: (dart_tiles(W,H), frames)
 __global__ __launch_bounds__(256) void k_dart_count(const uint64_t* __restrict__ bits, int W, int H, uint32_t first_frame,
-                                                    unsigned long long* __restrict__ frame_darts) {
+                                                    unsigned long long* __restrict__ frame_darts, uint32_t* __restrict__ tile_darts) {
     __shared__ uint32_t s_wave[4];
     __shared__ uint64_t s_t[kTileRows + 2][kTileWords + 2];
     const int wpr = (int)words_per_row((uint32_t)W);
@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256) void k_dart_count(const uint64_t* __restrict__
     uint32_t nd = 0;
     int j, y;
     bool active;
+    // (nine direct loads per lane instead of the staged tile were tried: 121 us instead of 86 us)
     const Nb8 nb = tile_nb8(bits + (size_t)(first_frame + f) * wpr * H, W, H, s_t, &active, &j, &y);
     if (active) {
         if (nb.c) {
@@ -159,50 +160,75 @@ __global__ __launch_bounds__(256) void k_dart_count(const uint64_t* __restrict__
     }
     uint32_t total;
     block_excl_scan_256(nd, s_wave, &total);
-    if (threadIdx.x == 0 && total) atomicAdd(&frame_darts[f], (unsigned long long)total);
+    if (threadIdx.x == 0) {
+        tile_darts[(size_t)(first_frame + f) * gridDim.x + blockIdx.x] = total;   // lets k_dart_assign skip empty tiles outright
+        if (total) atomicAdd(&frame_darts[f], (unsigned long long)total);
+    }
 }
 
 // Same traversal; hands every border pixel a contiguous dart range inside its frame's range and writes the per-dart
-// records.  node_bits: packed "this pixel owns darts" image (same layout as bits).
+// records.  Tiles without darts (most of a clean frame) leave at once.
 // Phase 1 works a word (64 pixels) per lane; phase 2 re-distributes the tile's border pixels evenly over the 256 lanes
 // (a word on a horizontal edge holds up to 64 of them, most words none), each lane locating its pixel by a binary
 // search over the per-word prefix sums and a rank-select in the word's node mask.
+// neighbour mask of pixel i of tile word (rl, jl), straight from the staged tile (ring order W NW N NE E SE S SW)
+__device__ __forceinline__ uint32_t row3(uint64_t l, uint64_t c, uint64_t r, int i) {
+    // pixels i-1, i, i+1 of the word as bits 0..2; pixel -1 is bit 63 of the left word, pixel 64 bit 0 of the right one
+    const uint64_t v = i == 0 ? ((c << 1) | (l >> 63)) : (c >> (i - 1));
+    return ((uint32_t)v & 7u) | (i == 63 ? ((uint32_t)r & 1u) << 2 : 0u);
+}
+__device__ __forceinline__ uint32_t tile_F(const uint64_t (*s_t)[kTileWords + 2], int rl, int jl, int i) {
+    const uint32_t top = row3(s_t[rl][jl], s_t[rl][jl + 1], s_t[rl][jl + 2], i);
+    const uint32_t mid = row3(s_t[rl + 1][jl], s_t[rl + 1][jl + 1], s_t[rl + 1][jl + 2], i);
+    const uint32_t bot = row3(s_t[rl + 2][jl], s_t[rl + 2][jl + 1], s_t[rl + 2][jl + 2], i);
+    return (mid & 1u) | ((top & 7u) << 1) | ((mid & 4u) << 2) | ((bot & 4u) << 3) | ((bot & 2u) << 5) | ((bot & 1u) << 7);
+}
+// kDX / kDY without a table load
+__device__ __forceinline__ int dir_dx(int k) { return (int)((0x1A90u >> (2 * k)) & 3u) - 1; }
+__device__ __forceinline__ int dir_dy(int k) { return (int)((0xA901u >> (2 * k)) & 3u) - 1; }
+
 __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict__ bits, int W, int H, uint32_t first_frame,
                                                      const uint32_t* __restrict__ frame_base, uint32_t* __restrict__ frame_cursor,
-                                                     uint32_t* __restrict__ pix_base, uint64_t* __restrict__ node_bits,
-                                                     uint64_t* __restrict__ d_rec, uint32_t* __restrict__ d_succ,
-                                                     uint32_t* __restrict__ cross_list, unsigned int* __restrict__ cross_count) {
+                                                     uint32_t* __restrict__ pix_base, const uint32_t* __restrict__ tile_darts,
+                                                     uint64_t* __restrict__ d_rec, uint32_t* __restrict__ d_succ) {
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_base;
-    __shared__ uint32_t s_cross_n, s_cross_base;
-    __shared__ uint32_t s_cross[(2 * kTileWords * 64 + 2 * kTileRows) * 4];
     __shared__ uint64_t s_t[kTileRows + 2][kTileWords + 2];
     __shared__ uint64_t s_nodes[256];
+    __shared__ uint64_t s_c0[256], s_c1[256], s_c2[256];   // darts per pixel (0..4) as three bit planes
     __shared__ uint32_t s_dbase[256], s_nbase[257];
     const int wpr = (int)words_per_row((uint32_t)W);
     const uint32_t f = blockIdx.y;
+    if (tile_darts[(size_t)(first_frame + f) * gridDim.x + blockIdx.x] == 0u) return;   // uniform for the workgroup
     int j, y;
     bool active;
     const Nb8 nb = tile_nb8(bits + (size_t)(first_frame + f) * wpr * H, W, H, s_t, &active, &j, &y);
-    uint64_t nodes = 0;
+    uint64_t nodes = 0, c0 = 0, c1 = 0, c2 = 0;
     uint32_t nd = 0;
-    if (active) {
-        if (nb.c) {
-            uint64_t p[8];
-            pdart_words(nb, p);
+    if (active && nb.c) {
+        uint64_t p[8];
+        pdart_words(nb, p);
 #pragma unroll
-            for (int k = 0; k < 8; k++) { nd += __popcll(p[k]); nodes |= p[k]; }
-        }
-        node_bits[(size_t)f * wpr * H + (size_t)y * wpr + j] = nodes;
+        for (int k = 0; k < 8; k++) { nd += __popcll(p[k]); nodes |= p[k]; }
+        // bit-sliced sum of the eight direction planes (a pixel owns at most 4 darts)
+        const uint64_t s1 = p[0] ^ p[1] ^ p[2], k1 = (p[0] & p[1]) | (p[2] & (p[0] ^ p[1]));
+        const uint64_t s2 = p[3] ^ p[4] ^ p[5], k2 = (p[3] & p[4]) | (p[5] & (p[3] ^ p[4]));
+        const uint64_t s3 = p[6] ^ p[7], k3 = p[6] & p[7];
+        c0 = s1 ^ s2 ^ s3;
+        const uint64_t k4 = (s1 & s2) | (s3 & (s1 ^ s2));
+        const uint64_t t = k1 ^ k2 ^ k3, q1 = (k1 & k2) | (k3 & (k1 ^ k2));
+        c1 = t ^ k4;
+        c2 = q1 | (t & k4);
     }
     uint32_t total_d, total_n;
     const uint32_t excl_d = block_excl_scan_256(nd, s_wave, &total_d);
     __syncthreads();
     const uint32_t excl_n = block_excl_scan_256((uint32_t)__popcll(nodes), s_wave, &total_n);
     s_nodes[threadIdx.x] = nodes;
+    s_c0[threadIdx.x] = c0; s_c1[threadIdx.x] = c1; s_c2[threadIdx.x] = c2;
     s_dbase[threadIdx.x] = excl_d;
     s_nbase[threadIdx.x] = excl_n;
-    if (threadIdx.x == 0) { s_base = total_d ? atomicAdd(&frame_cursor[f], total_d) : 0u; s_nbase[256] = total_n; s_cross_n = 0; }
+    if (threadIdx.x == 0) { s_base = total_d ? atomicAdd(&frame_cursor[f], total_d) : 0u; s_nbase[256] = total_n; }
     __syncthreads();
     const uint32_t dart0 = frame_base[f] + s_base;
     const int tx = blockIdx.x % dart_tiles_x((uint32_t)W), ty = blockIdx.x / dart_tiles_x((uint32_t)W);
@@ -210,35 +236,22 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
     for (uint32_t n = threadIdx.x; n < total_n; n += 256) {
         // word holding the n-th border pixel of the tile: largest w with s_nbase[w] <= n
         uint32_t lo = 0, hi = 256;
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_nbase[mid] <= n) lo = mid; else hi = mid; }
+#pragma unroll
+        for (int it = 0; it < 8; it++) { const uint32_t mid = (lo + hi) >> 1; if (s_nbase[mid] <= n) lo = mid; else hi = mid; }
         const uint32_t w = lo, r = n - s_nbase[w];
         const uint64_t m = s_nodes[w];
         // position of the r-th (0-based) set bit of m
         uint32_t blo = 0, bhi = 63;
-        while (blo < bhi) { const uint32_t mid = (blo + bhi) >> 1; if ((uint32_t)__popcll(m & ((2ull << mid) - 1ull)) >= r + 1u) bhi = mid; else blo = mid + 1; }
+#pragma unroll
+        for (int it = 0; it < 6; it++) { const uint32_t mid = (blo + bhi) >> 1; if ((uint32_t)__popcll(m & ((2ull << mid) - 1ull)) >= r + 1u) bhi = mid; else blo = mid + 1; }
         const int i = (int)blo;
         const int jl = w & (kTileWords - 1), rl = w >> 2;
         const int wj = tx * kTileWords + jl, wy = ty * kTileRows + rl;
-        // neighbourhood words of that word, from the staged tile
-        Nb8 q;
-        {
-            const uint64_t al = s_t[rl][jl], a = s_t[rl][jl + 1], ar = s_t[rl][jl + 2];
-            const uint64_t cl = s_t[rl + 1][jl], c = s_t[rl + 1][jl + 1], cr = s_t[rl + 1][jl + 2];
-            const uint64_t bl = s_t[rl + 2][jl], b = s_t[rl + 2][jl + 1], br = s_t[rl + 2][jl + 2];
-            q.c = c;
-            q.n[0] = (c << 1) | (cl >> 63); q.n[1] = (a << 1) | (al >> 63); q.n[2] = a; q.n[3] = (a >> 1) | (ar << 63);
-            q.n[4] = (c >> 1) | (cr << 63); q.n[5] = (b >> 1) | (br << 63); q.n[6] = b; q.n[7] = (b << 1) | (bl >> 63);
-        }
-        uint64_t pw[8];
-        pdart_words(q, pw);
+        const uint32_t F = tile_F(s_t, rl, jl, i);
+        uint32_t P = pdart_mask(F);
         const uint64_t below = (1ull << i) - 1ull;
-        uint32_t F = 0, P = 0, off = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            F |= (uint32_t)((q.n[k] >> i) & 1ull) << k;
-            P |= (uint32_t)((pw[k] >> i) & 1ull) << k;
-            off += (uint32_t)__popcll(pw[k] & below);   // darts of the word's earlier border pixels
-        }
+        // darts of the word's earlier border pixels
+        const uint32_t off = (uint32_t)__popcll(s_c0[w] & below) + 2u * (uint32_t)__popcll(s_c1[w] & below) + 4u * (uint32_t)__popcll(s_c2[w] & below);
         const int x = 64 * wj + i;
         uint32_t cur = dart0 + s_dbase[w] + off;
         // only pixels on the rim of the tile can be the target of a successor pointer from another tile
@@ -255,77 +268,69 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
             const int k = __ffs(P) - 1;
             P &= P - 1;
             const uint32_t info = (uint32_t)k | (k == kW ? kInfoW : 0u) | (k == kE ? kInfoE : 0u);
-            d_rec[cur] = dart_rec(xy, F, info);   // one 8-byte store per dart
+            d_rec[cur] = dart_rec(xy, F, info, f);   // one 8-byte store per dart
             // successor: next foreground neighbour counter-clockwise after k; resolved here when the target pixel lies in
             // this tile (its dart indices follow from the tile's prefix sums), otherwise left to k_dart_link
             const uint32_t rr = ((F >> k) | (F << (8 - k))) & 0xFFu;   // bit t <-> direction (k + t) & 7
             const int ko = (k + (31 - __clz(rr))) & 7, kin = (ko + 4) & 7;
-            const int lx = jl * 64 + i + kDX[ko], ly = rl + kDY[ko];
+            const int lx = jl * 64 + i + dir_dx(ko), ly = rl + dir_dy(ko);
             uint32_t succ;
             if (lx >= 0 && lx < kTileWords * 64 && ly >= 0 && ly < kTileRows) {
                 const int j2 = lx >> 6, i2 = lx & 63, w2 = ly * kTileWords + j2;
-                Nb8 t;
-                const uint64_t al = s_t[ly][j2], a = s_t[ly][j2 + 1], ar = s_t[ly][j2 + 2];
-                const uint64_t cl = s_t[ly + 1][j2], c = s_t[ly + 1][j2 + 1], cr = s_t[ly + 1][j2 + 2];
-                const uint64_t bl = s_t[ly + 2][j2], b = s_t[ly + 2][j2 + 1], br = s_t[ly + 2][j2 + 2];
-                t.c = c;
-                t.n[0] = (c << 1) | (cl >> 63); t.n[1] = (a << 1) | (al >> 63); t.n[2] = a; t.n[3] = (a >> 1) | (ar << 63);
-                t.n[4] = (c >> 1) | (cr << 63); t.n[5] = (b >> 1) | (br << 63); t.n[6] = b; t.n[7] = (b << 1) | (bl >> 63);
-                uint64_t tw[8];
-                pdart_words(t, tw);
-                const uint64_t below2 = (1ull << i2) - 1ull;
-                uint32_t P2 = 0, off2 = 0;
-#pragma unroll
-                for (int kk = 0; kk < 8; kk++) { P2 |= (uint32_t)((tw[kk] >> i2) & 1ull) << kk; off2 += (uint32_t)__popcll(tw[kk] & below2); }
-                succ = ((P2 >> kin) & 1u) ? dart0 + s_dbase[w2] + off2 + (uint32_t)__popc(P2 & ((1u << kin) - 1u)) : cur;   // cur = chain end
+                const uint32_t P2 = pdart_mask(tile_F(s_t, ly, j2, i2));
+                succ = cur;   // chain end unless the target dart exists
+                if ((P2 >> kin) & 1u) {
+                    const uint64_t below2 = (1ull << i2) - 1ull;
+                    const uint32_t off2 = (uint32_t)__popcll(s_c0[w2] & below2) + 2u * (uint32_t)__popcll(s_c1[w2] & below2) +
+                                          4u * (uint32_t)__popcll(s_c2[w2] & below2);
+                    succ = dart0 + s_dbase[w2] + off2 + (uint32_t)__popc(P2 & ((1u << kin) - 1u));
+                }
             } else {
-                succ = kNone;
-                s_cross[atomicAdd(&s_cross_n, 1u)] = cur;   // only rim pixels get here: at most 640 pixels x 4 darts
+                succ = kNone;   // only rim pixels get here; k_dart_link fills these in
             }
             d_succ[cur] = succ;
             cur++;
         }
     }
-    // the darts whose successor lies in another tile go on a list for k_dart_link: one global atomic per tile
-    __syncthreads();
-    if (threadIdx.x == 0) s_cross_base = s_cross_n ? atomicAdd(cross_count, s_cross_n) : 0u;
-    __syncthreads();
-    for (uint32_t c = threadIdx.x; c < s_cross_n; c += 256) cross_list[s_cross_base + c] = s_cross[c];
 }
 
-// successors that leave their tile (listed by k_dart_assign): looked up through the target pixel's first-dart index
-// (pix_base, written for tile-rim pixels) and its node bit.
-__global__ __launch_bounds__(256) void k_dart_link(int W, int H, uint32_t first_dart_frame0, const uint32_t* __restrict__ frame_base,
-                                                   uint32_t n_frames, const uint32_t* __restrict__ pix_base,
-                                                   const uint64_t* __restrict__ node_bits, const uint64_t* __restrict__ d_rec,
-                                                   uint32_t* __restrict__ d_succ, const uint32_t* __restrict__ cross_list,
-                                                   const unsigned int* __restrict__ cross_count) {
+// neighbour mask of one pixel straight from the packed image (ring order W NW N NE E SE S SW)
+__device__ __forceinline__ uint32_t pixel_F(const uint64_t* __restrict__ img, int wpr, int H, int x, int y) {
+    auto px = [&](int xx, int yy) -> uint32_t {
+        return xx < 0 ? 0u : (uint32_t)((ldw(img, wpr, H, xx >> 6, yy) >> (xx & 63)) & 1ull);   // columns >= W hold zeros
+    };
+    return px(x - 1, y) | (px(x - 1, y - 1) << 1) | (px(x, y - 1) << 2) | (px(x + 1, y - 1) << 3) | (px(x + 1, y) << 4) |
+           (px(x + 1, y + 1) << 5) | (px(x, y + 1) << 6) | (px(x - 1, y + 1) << 7);
+}
+
+// A successor that leaves its tile (k_dart_assign left kNone): looked up through the target pixel's first-dart index
+// (pix_base, written for tile-rim pixels that own darts); whether it owns the wanted dart follows from its neighbour mask.
+// A compact list of these darts would need one same-address atomic per tile (~11 ns each, serialised); sweeping d_succ
+// is cheaper (32 us).  Resolving them inside k_local_contract's load phase was tried: the dependent loads of the few
+// cross-tile darts stall every tile's first barrier (+47 us).
+__device__ __forceinline__ uint32_t cross_tile_succ(uint32_t d, uint64_t rec, int W, int H, int wpr, uint32_t first_frame,
+                                                    const uint32_t* __restrict__ pix_base, const uint64_t* __restrict__ bits) {
+    const uint32_t f = rec_frame(rec);
+    const uint64_t* img = bits + (size_t)(first_frame + f) * wpr * H;
+    const uint32_t* pb = pix_base + (size_t)f * W * H;
+    const uint32_t xy = rec_xy(rec);
+    const int x = xy & 0xFFFF, y = xy >> 16;
+    const uint32_t F = rec_F(rec);
+    const int k = rec_info(rec) & 7;
+    const uint32_t r = ((F >> k) | (F << (8 - k))) & 0xFFu;  // bit t <-> direction (k + t) & 7
+    const int ko = (k + (31 - __clz(r))) & 7;
+    const int nx = x + dir_dx(ko), ny = y + dir_dy(ko);
+    const uint32_t tP = pdart_mask(pixel_F(img, wpr, H, nx, ny));   // the target is a foreground pixel by construction
+    const int kin = (ko + 4) & 7;
+    return ((tP >> kin) & 1u) ? pb[(size_t)ny * W + nx] + __popc(tP & ((1u << kin) - 1u)) : d;  // d = chain end
+}
+
+__global__ __launch_bounds__(256) void k_dart_link(int W, int H, uint32_t first_frame, const uint32_t* __restrict__ pix_base,
+                                                   const uint64_t* __restrict__ bits, const uint64_t* __restrict__ d_rec,
+                                                   uint32_t* __restrict__ d_succ, uint32_t n_darts) {
     const int wpr = (int)words_per_row((uint32_t)W);
-    const uint32_t n = *cross_count;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t d = cross_list[i];
-        uint32_t lo = 0, hi = n_frames;   // frame of this dart
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (frame_base[mid] <= d) lo = mid; else hi = mid; }
-        const uint32_t f = lo;
-        const uint64_t* nbits = node_bits + (size_t)f * wpr * H;
-        const uint32_t* pb = pix_base + (size_t)f * W * H;
-        const uint64_t rec = d_rec[d];
-        const uint32_t xy = rec_xy(rec);
-        const int x = xy & 0xFFFF, y = xy >> 16;
-        const uint32_t F = rec_F(rec);
-        const int k = rec_info(rec) & 7;
-        const uint32_t r = ((F >> k) | (F << (8 - k))) & 0xFFu;  // bit t <-> direction (k + t) & 7
-        const int ko = (k + (31 - __clz(r))) & 7;
-        const int nx = x + kDX[ko], ny = y + kDY[ko];
-        uint32_t succ = d;  // chain end unless the target dart exists
-        if ((nbits[(size_t)ny * wpr + (nx >> 6)] >> (nx & 63)) & 1ull) {
-            const uint32_t tb = pb[(size_t)ny * W + nx];
-            const uint32_t tP = pdart_mask(rec_F(d_rec[tb]));
-            const int kin = (ko + 4) & 7;
-            if ((tP >> kin) & 1u) succ = tb + __popc(tP & ((1u << kin) - 1u));
-        }
-        d_succ[d] = succ;
-    }
+    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x)
+        if (d_succ[d] == kNone) d_succ[d] = cross_tile_succ(d, d_rec[d], W, H, wpr, first_frame, pix_base, bits);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -335,6 +340,33 @@ __global__ __launch_bounds__(256) void k_dart_link(int W, int H, uint32_t first_
 // dart.  Joining window(d) with window(ptr) doubles the path; once a window wraps a whole cycle its key is the cycle's
 // leader and off the hop distance to it.
 constexpr int kLT = 2048;                     // darts per local tile (consecutive indices = neighbouring pixels)
+// Entry slots are handed out from 16 counters (one same-address atomic costs ~11 ns and they serialise): tile t uses
+// shard t & 15, whose slots are [shard * cap, shard * cap + count[shard]); a tile holds at most kLT entries, so
+// cap = ceil(tiles / 16) * kLT can never overflow.
+constexpr uint32_t kEntryShards = 16;
+__host__ __device__ inline uint32_t entry_shard_cap(uint32_t n_darts) {
+    const uint32_t tiles = (n_darts + kLT - 1) / kLT;
+    return ((tiles + kEntryShards - 1) / kEntryShards) * kLT;
+}
+// the sparse slot space as a dense loop index: shard-major, every shard padded to the largest count
+struct EntrySpace {
+    uint32_t cnt[kEntryShards], span, total;
+    __device__ explicit EntrySpace(const unsigned int* __restrict__ entry_count) {
+        uint32_t m = 0;
+#pragma unroll
+        for (uint32_t sh = 0; sh < kEntryShards; sh++) { cnt[sh] = entry_count[sh]; m = max(m, cnt[sh]); }
+        span = max((m + 63u) & ~63u, 64u);
+        total = span * kEntryShards;
+    }
+    // -> slot, or kNone for padding
+    __device__ uint32_t slot(uint32_t i0, uint32_t cap) const {
+        const uint32_t sh = i0 / span, i = i0 - sh * span;
+        uint32_t c = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kEntryShards; k++) c = (k == sh) ? cnt[k] : c;
+        return i < c ? sh * cap + i : kNone;
+    }
+};
 constexpr uint32_t kFrozen = 0x80000000u;     // dist flag: the window reached a dart outside the tile
 
 // Phase 1: 11 doubling rounds inside one tile, entirely in LDS.  A window stops growing ("freezes") when its end leaves
@@ -408,7 +440,10 @@ __global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W,
         if ((s0 - lo) >= cnt) { my_e[u] = s0; my_slot[u] = atomicAdd(&s_new_count, 1u); }
     }
     __syncthreads();
-    if (threadIdx.x == 0) s_new_base = s_new_count ? atomicAdd(entry_count, s_new_count) : 0u;
+    if (threadIdx.x == 0) {
+        const uint32_t shard = blockIdx.x & (kEntryShards - 1);
+        s_new_base = shard * entry_shard_cap(n_darts) + (s_new_count ? atomicAdd(&entry_count[shard], s_new_count) : 0u);
+    }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < kLT / 256; u++)
@@ -425,9 +460,11 @@ struct __attribute__((aligned(8))) EntryState { uint64_t key; uint32_t ptr; uint
 // tile, so it cannot sit on a tile-local cycle) unless its chain dead-ends inside the tile; then it points at itself.
 __global__ void k_entry_init(const uint32_t* __restrict__ entry_list, const unsigned int* __restrict__ entry_count,
                              const JumpState* __restrict__ loc, const uint32_t* __restrict__ loc_dist,
-                             const uint32_t* __restrict__ entry_pos, EntryState* __restrict__ es) {
-    const uint32_t n = *entry_count;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+                             const uint32_t* __restrict__ entry_pos, EntryState* __restrict__ es, uint32_t cap) {
+    const EntrySpace sp(entry_count);
+    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < sp.total; i0 += gridDim.x * blockDim.x) {
+        const uint32_t i = sp.slot(i0, cap);
+        if (i == kNone) continue;
         const uint32_t e = entry_list[i];
         const JumpState l = loc[e];
         const uint32_t dd = loc_dist[e];
@@ -440,12 +477,15 @@ __global__ void k_entry_init(const uint32_t* __restrict__ entry_list, const unsi
 
 // Phase 2: doubling over entries (hop counts double per round; `dist` carries the real path length)
 __global__ __launch_bounds__(256) void k_entry_jump(const EntryState* __restrict__ in, EntryState* __restrict__ out,
-                                                    const unsigned int* __restrict__ entry_count, int round, DeviceCounters* __restrict__ ctr) {
+                                                    const unsigned int* __restrict__ entry_count, uint32_t cap, int round,
+                                                    DeviceCounters* __restrict__ ctr) {
     // no key moved in the previous round => every window already wraps its cycle; both buffers hold final key/off
     if (round > 0 && ctr->jump_changed[round - 1] == 0) return;
-    const uint32_t n = *entry_count;
+    const EntrySpace sp(entry_count);
     uint32_t changed = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < sp.total; i0 += gridDim.x * blockDim.x) {
+        const uint32_t i = sp.slot(i0, cap);
+        if (i == kNone) continue;
         EntryState s = in[i];
         const EntryState t = in[s.ptr];
         if (t.key < s.key) { s.key = t.key; s.off = s.dist + t.off; changed++; }
@@ -453,8 +493,8 @@ __global__ __launch_bounds__(256) void k_entry_jump(const EntryState* __restrict
         s.ptr = t.ptr;
         out[i] = s;
     }
-    for (int o = 32; o > 0; o >>= 1) changed += __shfl_down(changed, o);
-    if ((threadIdx.x & 63) == 0 && changed) atomicAdd(&ctr->jump_changed[round], changed);
+    // a flag, not a count: same-address atomics serialise (~11 ns each), plain stores of the same value do not
+    if (__ballot(changed != 0) && (threadIdx.x & 63) == 0) ctr->jump_changed[round] = 1u;
 }
 
 // Phase 3: every dart learns its cycle's leader and its hop distance to it
@@ -869,25 +909,26 @@ static inline int blocks_for(uint64_t n, int per_block, int cap) {
     return (int)b;
 }
 
+size_t tile_darts_bytes(uint32_t W, uint32_t H, uint32_t n_frames) { return (size_t)dart_tiles(W, H) * n_frames * 4; }
+
 hipError_t launch_dart_count(hipStream_t st, const uint64_t* bits, int W, int H, uint32_t first_frame, uint32_t n_frames,
-                             unsigned long long* frame_darts) {
-    hipLaunchKernelGGL(k_dart_count, dim3(dart_tiles((uint32_t)W, (uint32_t)H), n_frames), dim3(256), 0, st, bits, W, H, first_frame, frame_darts);
+                             unsigned long long* frame_darts, uint32_t* tile_darts) {
+    hipLaunchKernelGGL(k_dart_count, dim3(dart_tiles((uint32_t)W, (uint32_t)H), n_frames), dim3(256), 0, st, bits, W, H, first_frame, frame_darts,
+                       tile_darts);
     return hipGetLastError();
 }
 
 hipError_t launch_dart_build(hipStream_t st, const uint64_t* bits, int W, int H, uint32_t first_frame, uint32_t n_frames,
-                             const uint32_t* frame_base, uint32_t* frame_cursor, uint32_t* pix_base, uint64_t* node_bits, uint64_t* d_rec,
-                             uint32_t* d_succ, uint32_t* cross_list, unsigned int* cross_count, uint32_t n_darts) {
-    hipError_t e = hipMemsetAsync(cross_count, 0, 4, st);
-    if (e != hipSuccess) return e;
+                             const uint32_t* frame_base, uint32_t* frame_cursor, uint32_t* pix_base, const uint32_t* tile_darts, uint64_t* d_rec,
+                             uint32_t* d_succ, uint32_t n_darts) {
     hipLaunchKernelGGL(k_dart_assign, dim3(dart_tiles((uint32_t)W, (uint32_t)H), n_frames), dim3(256), 0, st, bits, W, H, first_frame, frame_base, frame_cursor,
-                       pix_base, node_bits, d_rec, d_succ, cross_list, cross_count);
-    hipLaunchKernelGGL(k_dart_link, dim3(blocks_for(n_darts / 16 + 1, 256, 2048)), dim3(256), 0, st, W, H, 0u, frame_base, n_frames, pix_base, node_bits,
-                       d_rec, d_succ, cross_list, cross_count);
+                       pix_base, tile_darts, d_rec, d_succ);
+    hipLaunchKernelGGL(k_dart_link, dim3(blocks_for(n_darts, 256 * 4, 4096)), dim3(256), 0, st, W, H, first_frame, pix_base, bits, d_rec, d_succ, n_darts);
     return hipGetLastError();
 }
 
 size_t entry_state_bytes() { return sizeof(EntryState); }
+size_t entry_slots(uint32_t n_darts) { return (size_t)entry_shard_cap(n_darts) * kEntryShards; }
 size_t leader_list_bytes(uint32_t n_darts) { return (size_t)leader_shard_cap(n_darts) * kLeaderShards * 4; }
 
 // leaders + ranks for every dart of the chunk.  loc/fin: JumpState[n_darts]; es_a/es_b: EntryState[n_darts] (upper bound);
@@ -897,20 +938,18 @@ hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uin
                               unsigned int* entry_count, void* es_a, void* es_b, JumpState* fin, uint32_t* leader_list,
                               unsigned int* leader_count, int max_rounds, DeviceCounters* ctr) {
     (void)entry_bits;
-    hipError_t e = hipMemsetAsync(entry_count, 0, 4, st);
-    if (e != hipSuccess) return e;
+    // entry_count[16] and leader_count[16] arrive zeroed (the caller's per-batch / per-chunk memset)
+    const uint32_t ecap = entry_shard_cap(n_darts);
     hipLaunchKernelGGL(k_local_contract, dim3((n_darts + kLT - 1) / kLT), dim3(256), 0, st, n_darts, W, d_rec, d_succ, loc, loc_dist,
                        entry_list, entry_pos, entry_count);
     EntryState* a = reinterpret_cast<EntryState*>(es_a);
     EntryState* b = reinterpret_cast<EntryState*>(es_b);
-    const dim3 grid(blocks_for(n_darts / 8 + 1, 256, 2048)), block(256);
-    hipLaunchKernelGGL(k_entry_init, grid, block, 0, st, entry_list, entry_count, loc, loc_dist, entry_pos, a);
+    const dim3 grid(blocks_for(n_darts / 16 + 1, 256, 1024)), block(256);   // entries are a few % of the darts on clean frames
+    hipLaunchKernelGGL(k_entry_init, grid, block, 0, st, entry_list, entry_count, loc, loc_dist, entry_pos, a, ecap);
     for (int r = 0; r < max_rounds; r++) {
-        hipLaunchKernelGGL(k_entry_jump, grid, block, 0, st, a, b, entry_count, r, ctr);
+        hipLaunchKernelGGL(k_entry_jump, grid, block, 0, st, a, b, entry_count, ecap, r, ctr);
         EntryState* t = a; a = b; b = t;
     }
-    e = hipMemsetAsync(leader_count, 0, 4 * kLeaderShards, st);
-    if (e != hipSuccess) return e;
     const int fin_blocks = std::max(blocks_for(n_darts, 256, 8192), (int)(((uint64_t)n_darts + 256ull * 32 - 1) / (256ull * 32)));
     hipLaunchKernelGGL(k_jump_finalize, dim3(fin_blocks), block, 0, st, n_darts, loc, loc_dist, entry_pos, a, fin,
                        leader_list, leader_count, leader_shard_cap(n_darts));
@@ -922,6 +961,7 @@ hipError_t launch_resolve(hipStream_t st, const JumpState* fin, uint32_t n_darts
     const dim3 grid(blocks_for(n_darts, 256, 4096)), block(256);
     hipLaunchKernelGGL(k_resolve_fast, dim3(blocks_for(n_darts / 16 + 1, 256, 1024)), block, 0, st, fin, leader_list, leader_count,
                        leader_shard_cap(n_darts), W, d_rec, t_cur, ctr);
+    if (max_iters <= 0) return hipGetLastError();   // the caller re-runs the batch with the full passes if k_resolve_fast asks for them
     hipLaunchKernelGGL(k_resolve_init, grid, block, 0, st, fin, n_darts, t_cur, t_next, ctr);
     for (int it = 0; it < max_iters; it++) {
         hipLaunchKernelGGL(k_resolve_eval, grid, block, 0, st, fin, n_darts, W, d_rec, t_cur, t_next, it, ctr);
