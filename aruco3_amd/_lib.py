@@ -20,7 +20,7 @@ STAGE_THRESHOLD, STAGE_CONTOUR, STAGE_DECODE = 0, 1, 2
 # every symbol include/aruco3_hip.h declares
 SYMBOLS = [
     "a3_abi_version", "a3_default_config", "a3_create", "a3_destroy", "a3_last_error", "a3_set_stream", "a3_set_pool_limits",
-    "a3_get_tau", "a3_set_debug_taps", "a3_detect_batch", "a3_detect_batch_pose", "a3_get_stats", "a3_download_grey", "a3_download_thresholded",
+    "a3_get_tau", "a3_set_debug_taps", "a3_detect_batch", "a3_detect_batch_pose", "a3_get_stats", "a3_debug_kernel_time", "a3_download_grey", "a3_download_thresholded",
     "a3_candidate_count", "a3_download_candidates", "a3_download_homographies", "a3_estimate_pose", "a3_estimate_pose_normalized",
     "a3_find_nearest", "a3_calculate_tau", "a3_set_profiling", "a3_get_profile", "a3_selftest_ieee",
 ]
@@ -121,6 +121,8 @@ def load():
     L.a3_detect_batch_pose.restype = C.c_int
     L.a3_detect_batch_pose.argtypes = [vp, vp, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_size_t, C.c_size_t, C.c_uint32, C.c_float,
                                        C.POINTER(Intrinsics), vp, vp, C.c_size_t, u32p, C.POINTER(C.c_size_t)]
+    L.a3_debug_kernel_time.restype = C.c_int
+    L.a3_debug_kernel_time.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.a3_get_stats.restype = C.c_int
     L.a3_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.a3_download_grey.restype = C.c_int
@@ -212,6 +214,11 @@ class Context:
         ms, n = C.c_double(), C.c_uint64()
         check(load().a3_get_profile(self.handle, stage, C.byref(ms), C.byref(n), int(reset)), self.handle)
         return float(ms.value), int(n.value)
+
+    def debug_kernel_time(self, kernel: int, dbg: int = 0, reps: int = 5) -> float:
+        ms = C.c_float()
+        check(load().a3_debug_kernel_time(self.handle, kernel, dbg, reps, C.byref(ms)), self.handle)
+        return ms.value
 
     def stats(self) -> dict:
         s = Stats()

@@ -18,12 +18,12 @@ hipError_t launch_grey_threshold(hipStream_t, const uint8_t*, int, size_t, size_
 hipError_t launch_dart_count(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, unsigned long long*, uint32_t*);
 size_t tile_darts_bytes(uint32_t W, uint32_t H, uint32_t n_frames);
 hipError_t launch_dart_build(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, const uint32_t*, uint32_t*, uint32_t*, const uint32_t*,
-                             uint64_t*, uint32_t*, uint32_t);
+                             uint64_t*, uint32_t*, uint32_t, int);
 size_t entry_state_bytes();
 size_t entry_slots(uint32_t);
 size_t leader_list_bytes(uint32_t);
 hipError_t launch_rank_cycles(hipStream_t, uint32_t, int, const uint64_t*, const uint32_t*, JumpState*, uint32_t*, uint32_t*,
-                              uint32_t*, uint32_t*, unsigned int*, void*, void*, JumpState*, uint32_t*, unsigned int*, int, DeviceCounters*);
+                              uint32_t*, uint32_t*, unsigned int*, void*, void*, JumpState*, uint32_t*, unsigned int*, int, DeviceCounters*, int);
 hipError_t launch_resolve(hipStream_t, const JumpState*, uint32_t, int, const uint64_t*, const uint32_t*, const unsigned int*, uint64_t*, uint64_t*,
                           DeviceCounters*, int);
 hipError_t launch_select_scatter(hipStream_t, const JumpState*, uint32_t, const uint32_t*, const unsigned int*, const uint32_t*, const uint64_t*,
@@ -38,7 +38,7 @@ size_t decode_out_bytes();
 hipError_t launch_frame_candidates(hipStream_t, const CandRec*, const uint32_t*, uint32_t, uint32_t, float, uint16_t*, uint16_t*, uint32_t*,
                                    uint32_t*, unsigned int*);
 size_t proj_rec_bytes();
-hipError_t launch_decode(hipStream_t, const uint8_t*, int, int, uint32_t, const uint16_t*, const uint32_t*, const unsigned int*, uint32_t,
+hipError_t launch_decode(hipStream_t, PixelSrc, int, int, uint32_t, const uint16_t*, const uint32_t*, const unsigned int*, uint32_t,
                          uint32_t, uint32_t, uint32_t, const uint64_t*, uint32_t, uint32_t, int, void*, void*, uint8_t*, int);
 hipError_t launch_compact_markers(hipStream_t, const void*, const uint16_t*, const uint32_t*, uint32_t, uint32_t, uint32_t, a3_marker*,
                                   uint32_t, uint32_t*, unsigned int*, unsigned int*);
@@ -96,6 +96,7 @@ struct a3_ctx {
     // launch-count hints (every pass past convergence is an empty launch of ~5 us): start low, retry the batch with the
     // maximum if a pass count turns out too small
     int jump_rounds_hint = 10, resolve_iters_hint = 4;
+    uint32_t dbg_nd = 0, dbg_frames = 0, dbg_chunks = 0;   // a3_debug_kernel_time: shape of the last batch's contour graph
     int resolve_full_ttl = 0;   // > 0: launch the fixpoint passes over all darts too (a recent batch needed them); else only k_resolve_fast
     // a3_detect_batch_pose: poses of every marker are computed on the device right after detection
     bool want_pose = false;
@@ -104,6 +105,7 @@ struct a3_ctx {
     a3_intrinsics pose_intr{};
     a3_pose* pose_out = nullptr;
     bool debug_taps = false;
+    bool grey_valid = false;   // the last batch wrote the grey plane
     bool profiling = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double prof_ms[A3_STAGE_COUNT] = {0, 0, 0};
@@ -186,7 +188,11 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     const float min_corner_separation = (float)minwh * ctx->cfg.min_corner_separation_factor;       // src/aruco.rs:56
     const uint32_t S = ctx->cfg.homography_sample_size;
 
-    A3_HIP(ctx->grey.ensure(npx * n));
+    // the grey plane is materialised only for readers outside the fused path: Detection.grey (debug taps) and the generic
+    // threshold kernels of other window sizes; the decode stage otherwise samples the caller's frames directly
+    const bool need_grey = ctx->debug_taps || ctx->cfg.threshold_window != 7;
+    if (need_grey) A3_HIP(ctx->grey.ensure(npx * n));
+    ctx->grey_valid = need_grey;
     const size_t bits_per_frame = (size_t)words_per_row(W) * 8 * H;   // packed thresholded image
     A3_HIP(ctx->bin.ensure(bits_per_frame * n));
     A3_HIP(ctx->frame_darts.ensure((size_t)n * 8));
@@ -206,7 +212,7 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     // ---- K1 ----
     if (ctx->profiling) A3_HIP(hipEventRecord(ctx->ev[0], st));
     A3_HIP(launch_grey_threshold(st, pixels, fmt, row_stride, frame_stride, (int)W, (int)H, n, ctx->cfg.threshold_window,
-                                 ctx->grey.as<uint8_t>(), ctx->bin.as<uint64_t>()));
+                                 need_grey ? ctx->grey.as<uint8_t>() : nullptr, ctx->bin.as<uint64_t>()));
     if (ctx->profiling) A3_HIP(hipEventRecord(ctx->ev[1], st));
 
     // ---- contour graph size per frame -> chunk plan ----
@@ -290,7 +296,7 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
             A3_HIP(hipMemsetAsync(d_leader_count, 0, 4 * 32, st));   // leader + entry counters, adjacent
         }
         A3_HIP(launch_dart_build(st, d_bin, (int)W, (int)H, c.first, c.count, fb, ctx->frame_cursor, ctx->pix_base.as<uint32_t>(),
-                                 ctx->tile_darts.as<uint32_t>(), ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), nd));
+                                 ctx->tile_darts.as<uint32_t>(), ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), nd, 0));
         int rounds = 1;
         while ((1ull << rounds) < (uint64_t)c.max_frame_darts && rounds < 31) rounds++;
         rounds += 1;  // the round that observes "nothing moved"
@@ -299,7 +305,8 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
         A3_HIP(launch_rank_cycles(st, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(),
                                   ctx->stA.as<JumpState>(), ctx->loc_dist.as<uint32_t>(), ctx->entry_bits.as<uint32_t>(),
                                   ctx->entry_list.as<uint32_t>(), ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
-                                  ctx->stB.as<JumpState>(), ctx->entry_bits.as<uint32_t>(), d_leader_count, rounds, ctr));
+                                  ctx->stB.as<JumpState>(), ctx->entry_bits.as<uint32_t>(), d_leader_count, rounds, ctr, 0));
+        ctx->dbg_nd = nd; ctx->dbg_frames = c.count; ctx->dbg_chunks = (uint32_t)chunks.size();
         const JumpState* fin = ctx->stB.as<JumpState>();
         A3_HIP(launch_resolve(st, fin, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->entry_bits.as<uint32_t>(), d_leader_count,
                               ctx->t_cur.as<uint64_t>(), ctx->t_next.as<uint64_t>(), ctr, ctx->resolve_full_ttl > 0 ? ctx->resolve_iters_hint : 0));
@@ -318,7 +325,9 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     A3_HIP(launch_frame_candidates(st, ctx->cands.as<CandRec>(), ctx->cand_count, n, kMaxCand, min_corner_separation,
                                    ctx->pre_xy.as<uint16_t>(), ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(),
                                    ctx->work.as<uint32_t>(), d_work_count));
-    A3_HIP(launch_decode(st, ctx->grey.as<uint8_t>(), (int)W, (int)H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), d_work_count,
+    const PixelSrc src = need_grey ? PixelSrc{ctx->grey.as<uint8_t>(), W, (unsigned long long)npx, kFmtGreyPlane}
+                                   : PixelSrc{pixels, row_stride, frame_stride, fmt};
+    A3_HIP(launch_decode(st, src, (int)W, (int)H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), d_work_count,
                          kMaxCand, S, ctx->mark_size, S, ctx->dict.as<uint64_t>(), ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors,
                          ctx->proj.p, ctx->outs.p, ctx->debug_taps ? ctx->patches.as<uint8_t>() : nullptr, 4096));
     A3_HIP(launch_compact_markers(st, ctx->outs.p, ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(), n, 0, kMaxCand,
@@ -576,6 +585,48 @@ int a3_detect_batch_pose(a3_ctx* ctx, const void* pixels, int memory, int fmt, u
     return rc;
 }
 
+// Re-runs one contour kernel on the buffers of the last batch (single-chunk batches only) and returns its average device
+// time; dbg selects a truncated variant (see the kernels).  The contour graph buffers hold garbage afterwards, which the
+// next a3_detect_batch overwrites; nothing reads them in between.
+int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_ms) {
+    if (!ctx || !avg_ms || reps <= 0) return A3_ERR_INVALID;
+    if (ctx->dbg_chunks != 1 || ctx->dbg_nd == 0) return fail(ctx, A3_ERR_INVALID, "needs a preceding single-chunk batch");
+    A3_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    hipEvent_t e0, e1;
+    A3_HIP(hipEventCreate(&e0)); A3_HIP(hipEventCreate(&e1));
+    double total = 0.0;
+    unsigned int* d_entry_count = ctx->scratch_u32 + 32;
+    unsigned int* d_leader_count = ctx->scratch_u32 + 16;
+    for (int r = 0; r < reps; r++) {
+        A3_HIP(hipMemsetAsync(ctx->frame_cursor, 0, (size_t)ctx->dbg_frames * 4, st));
+        A3_HIP(hipMemsetAsync(d_leader_count, 0, 4 * 32, st));
+        A3_HIP(hipEventRecord(e0, st));
+        if (kernel == 0) {
+            A3_HIP(hipMemsetAsync(ctx->frame_darts.p, 0, (size_t)ctx->frames * 8, st));
+            A3_HIP(launch_dart_count(st, ctx->bin.as<uint64_t>(), (int)ctx->W, (int)ctx->H, 0, ctx->frames, ctx->frame_darts.as<unsigned long long>(),
+                                     ctx->tile_darts.as<uint32_t>()));
+        } else if (kernel == 1) {
+            A3_HIP(launch_dart_build(st, ctx->bin.as<uint64_t>(), (int)ctx->W, (int)ctx->H, 0, ctx->dbg_frames, ctx->frame_base.as<uint32_t>(),
+                                     ctx->frame_cursor, ctx->pix_base.as<uint32_t>(), ctx->tile_darts.as<uint32_t>(), ctx->d_xy.as<uint64_t>(),
+                                     ctx->d_succ.as<uint32_t>(), ctx->dbg_nd, dbg ? dbg : 5));
+        } else if (kernel == 2) {
+            A3_HIP(launch_rank_cycles(st, ctx->dbg_nd, (int)ctx->W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), ctx->stA.as<JumpState>(),
+                                      ctx->loc_dist.as<uint32_t>(), ctx->entry_bits.as<uint32_t>(), ctx->entry_list.as<uint32_t>(),
+                                      ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p, ctx->stB.as<JumpState>(),
+                                      ctx->entry_bits.as<uint32_t>(), d_leader_count, 0, ctx->counters, dbg ? dbg : 11));
+        } else return fail(ctx, A3_ERR_INVALID, "kernel: 0 dart_count, 1 dart_assign, 2 local_contract");
+        A3_HIP(hipEventRecord(e1, st));
+        A3_HIP(hipStreamSynchronize(st));
+        float ms = 0;
+        A3_HIP(hipEventElapsedTime(&ms, e0, e1));
+        total += ms;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_ms = (float)(total / reps);
+    return A3_OK;
+}
+
 int a3_get_stats(const a3_ctx* ctx, a3_stats* stats) {
     if (!ctx || !stats) return A3_ERR_INVALID;
     *stats = ctx->stats;
@@ -591,7 +642,11 @@ static int download_plane(a3_ctx* ctx, const DevBuf& buf, uint32_t frame, uint8_
     return A3_OK;
 }
 
-int a3_download_grey(a3_ctx* ctx, uint32_t frame, uint8_t* dst) { return ctx ? download_plane(ctx, ctx->grey, frame, dst) : A3_ERR_INVALID; }
+int a3_download_grey(a3_ctx* ctx, uint32_t frame, uint8_t* dst) {
+    if (!ctx) return A3_ERR_INVALID;
+    if (!ctx->grey_valid) return fail(ctx, A3_ERR_INVALID, "the grey plane is only kept when debug taps are enabled before the batch");
+    return download_plane(ctx, ctx->grey, frame, dst);
+}
 int a3_download_thresholded(a3_ctx* ctx, uint32_t frame, uint8_t* dst) {
     if (!ctx || !dst) return A3_ERR_INVALID;
     if (frame >= ctx->frames) return fail(ctx, A3_ERR_INVALID, "frame index outside the last batch");

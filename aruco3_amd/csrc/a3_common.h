@@ -58,6 +58,18 @@ __host__ __device__ inline uint32_t pdart_mask(uint32_t F) {
     return F & ~rot1 & (0xAAu | ~rot2) & 0xFFu;
 }
 
+// Where the decode stage reads grey levels from: the caller's frames (grey is recomputed per tap, so K1 need not write a
+// grey plane at all) or, with debug taps / other threshold windows, the grey plane K1 wrote (fmt = kFmtGreyPlane).
+constexpr int kFmtGreyPlane = 4;
+struct PixelSrc {
+    const uint8_t* base;
+    unsigned long long row_stride, frame_stride;
+    int fmt;   // A3_FMT_* or kFmtGreyPlane
+};
+
+// image::DynamicImage::into_luma8 for one pixel: (2126 R + 7152 G + 722 B) / 10000, truncating
+__host__ __device__ inline uint32_t luma_of(uint32_t r, uint32_t g, uint32_t b) { return (2126u * r + 7152u * g + 722u * b) / 10000u; }
+
 // one border that survived the size pruning and gets its points written out
 struct ContourRec {
     uint32_t frame;

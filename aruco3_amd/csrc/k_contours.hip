@@ -190,7 +190,9 @@ __device__ __forceinline__ int dir_dy(int k) { return (int)((0xA901u >> (2 * k))
 __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict__ bits, int W, int H, uint32_t first_frame,
                                                      const uint32_t* __restrict__ frame_base, uint32_t* __restrict__ frame_cursor,
                                                      uint32_t* __restrict__ pix_base, const uint32_t* __restrict__ tile_darts,
-                                                     uint64_t* __restrict__ d_rec, uint32_t* __restrict__ d_succ) {
+                                                     uint64_t* __restrict__ d_rec, uint32_t* __restrict__ d_succ, int dbg) {
+    // dbg (a3_debug_kernel_time only; 0 in the product path): stop after 1 = the empty-tile test, 2 = phase 1 and its scans,
+    // 3 = the range allocation; 4 = run phase 2 without its global stores
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_base;
     __shared__ uint64_t s_t[kTileRows + 2][kTileWords + 2];
@@ -200,6 +202,7 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
     const int wpr = (int)words_per_row((uint32_t)W);
     const uint32_t f = blockIdx.y;
     if (tile_darts[(size_t)(first_frame + f) * gridDim.x + blockIdx.x] == 0u) return;   // uniform for the workgroup
+    if (dbg == 1) return;
     int j, y;
     bool active;
     const Nb8 nb = tile_nb8(bits + (size_t)(first_frame + f) * wpr * H, W, H, s_t, &active, &j, &y);
@@ -228,8 +231,10 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
     s_c0[threadIdx.x] = c0; s_c1[threadIdx.x] = c1; s_c2[threadIdx.x] = c2;
     s_dbase[threadIdx.x] = excl_d;
     s_nbase[threadIdx.x] = excl_n;
+    if (dbg == 2) return;
     if (threadIdx.x == 0) { s_base = total_d ? atomicAdd(&frame_cursor[f], total_d) : 0u; s_nbase[256] = total_n; }
     __syncthreads();
+    if (dbg == 3) return;
     const uint32_t dart0 = frame_base[f] + s_base;
     const int tx = blockIdx.x % dart_tiles_x((uint32_t)W), ty = blockIdx.x / dart_tiles_x((uint32_t)W);
     uint32_t* pbf = pix_base + (size_t)f * W * H;
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
         const int x = 64 * wj + i;
         uint32_t cur = dart0 + s_dbase[w] + off;
         // only pixels on the rim of the tile can be the target of a successor pointer from another tile
-        if (i == 0 || i == 63 || rl == 0 || rl == kTileRows - 1) pbf[(size_t)wy * W + x] = cur;
+        if ((i == 0 || i == 63 || rl == 0 || rl == kTileRows - 1) && dbg != 4) pbf[(size_t)wy * W + x] = cur;
         // event darts: first foreground neighbour clockwise from W (resp. E) when that side is background
         int kW = -1, kE = -1;
         if (x > 0 && !(F & 1u)) kW = __ffs(F >> 1);  // 1-based position in F>>1 == direction index
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
             const int k = __ffs(P) - 1;
             P &= P - 1;
             const uint32_t info = (uint32_t)k | (k == kW ? kInfoW : 0u) | (k == kE ? kInfoE : 0u);
-            d_rec[cur] = dart_rec(xy, F, info, f);   // one 8-byte store per dart
+            if (dbg != 4) d_rec[cur] = dart_rec(xy, F, info, f);   // one 8-byte store per dart
             // successor: next foreground neighbour counter-clockwise after k; resolved here when the target pixel lies in
             // this tile (its dart indices follow from the tile's prefix sums), otherwise left to k_dart_link
             const uint32_t rr = ((F >> k) | (F << (8 - k))) & 0xFFu;   // bit t <-> direction (k + t) & 7
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
             } else {
                 succ = kNone;   // only rim pixels get here; k_dart_link fills these in
             }
-            d_succ[cur] = succ;
+            if (dbg != 4 || succ == 0x12345678u) d_succ[cur] = succ;
             cur++;
         }
     }
@@ -375,7 +380,8 @@ __global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W,
                                                         const uint32_t* __restrict__ d_succ,
                                                         JumpState* __restrict__ loc, uint32_t* __restrict__ loc_dist,
                                                         uint32_t* __restrict__ entry_list,
-                                                        uint32_t* __restrict__ entry_pos, unsigned int* __restrict__ entry_count) {
+                                                        uint32_t* __restrict__ entry_pos, unsigned int* __restrict__ entry_count, int dbg) {
+    // dbg (a3_debug_kernel_time only; 0 in the product path): n > 0 runs n doubling rounds instead of 11; -1 = none
     __shared__ uint64_t s_key[kLT];
     __shared__ uint32_t s_ptr[kLT], s_off[kLT], s_dist[kLT];
     const uint32_t lo = blockIdx.x * kLT;
@@ -393,7 +399,8 @@ __global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W,
     }
     __syncthreads();
     constexpr int PER = kLT / 256;
-    for (int round = 0; round < 11; round++) {
+    const int n_rounds = dbg == 0 ? 11 : (dbg < 0 ? 0 : dbg);
+    for (int round = 0; round < n_rounds; round++) {
         uint64_t nk[PER]; uint32_t np[PER], no[PER], nd[PER];
 #pragma unroll
         for (int u = 0; u < PER; u++) {
@@ -920,9 +927,10 @@ hipError_t launch_dart_count(hipStream_t st, const uint64_t* bits, int W, int H,
 
 hipError_t launch_dart_build(hipStream_t st, const uint64_t* bits, int W, int H, uint32_t first_frame, uint32_t n_frames,
                              const uint32_t* frame_base, uint32_t* frame_cursor, uint32_t* pix_base, const uint32_t* tile_darts, uint64_t* d_rec,
-                             uint32_t* d_succ, uint32_t n_darts) {
+                             uint32_t* d_succ, uint32_t n_darts, int dbg) {
     hipLaunchKernelGGL(k_dart_assign, dim3(dart_tiles((uint32_t)W, (uint32_t)H), n_frames), dim3(256), 0, st, bits, W, H, first_frame, frame_base, frame_cursor,
-                       pix_base, tile_darts, d_rec, d_succ);
+                       pix_base, tile_darts, d_rec, d_succ, dbg);
+    if (dbg && dbg != 5) return hipGetLastError();   // 5 = everything (the probe's reference point), others leave d_succ alone
     hipLaunchKernelGGL(k_dart_link, dim3(blocks_for(n_darts, 256 * 4, 4096)), dim3(256), 0, st, W, H, first_frame, pix_base, bits, d_rec, d_succ, n_darts);
     return hipGetLastError();
 }
@@ -936,12 +944,13 @@ size_t leader_list_bytes(uint32_t n_darts) { return (size_t)leader_shard_cap(n_d
 hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uint64_t* d_rec, const uint32_t* d_succ,
                               JumpState* loc, uint32_t* loc_dist, uint32_t* entry_bits, uint32_t* entry_list, uint32_t* entry_pos,
                               unsigned int* entry_count, void* es_a, void* es_b, JumpState* fin, uint32_t* leader_list,
-                              unsigned int* leader_count, int max_rounds, DeviceCounters* ctr) {
+                              unsigned int* leader_count, int max_rounds, DeviceCounters* ctr, int dbg) {
     (void)entry_bits;
     // entry_count[16] and leader_count[16] arrive zeroed (the caller's per-batch / per-chunk memset)
     const uint32_t ecap = entry_shard_cap(n_darts);
     hipLaunchKernelGGL(k_local_contract, dim3((n_darts + kLT - 1) / kLT), dim3(256), 0, st, n_darts, W, d_rec, d_succ, loc, loc_dist,
-                       entry_list, entry_pos, entry_count);
+                       entry_list, entry_pos, entry_count, dbg);
+    if (dbg) return hipGetLastError();
     EntryState* a = reinterpret_cast<EntryState*>(es_a);
     EntryState* b = reinterpret_cast<EntryState*>(es_b);
     const dim3 grid(blocks_for(n_darts / 16 + 1, 256, 1024)), block(256);   // entries are a few % of the darts on clean frames

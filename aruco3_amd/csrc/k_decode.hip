@@ -195,16 +195,80 @@ __device__ __forceinline__ uint32_t sat_u32(float x) {  // Rust `as u32`
     return (uint32_t)x;
 }
 
-// imageproc interpolate_bilinear: default (0) outside, the two horizontal lerps truncated to u8 first
-__device__ __forceinline__ uint8_t sample_bilinear(const uint8_t* __restrict__ img, uint32_t w, uint32_t h, float x, float y) {
+// grey level of pixel x in a frame row: the plane K1 wrote, or into_luma8 of the caller's pixel (same integers)
+__device__ __forceinline__ float grey_tap(const uint8_t* __restrict__ row, uint32_t x, int fmt) {
+    if (fmt == A3_FMT_L8 || fmt == kFmtGreyPlane) return (float)row[x];
+    if (fmt == A3_FMT_RGB8) { const uint8_t* p = row + 3u * (size_t)x; return (float)luma_of(p[0], p[1], p[2]); }
+    const uint8_t* p = row + 4u * (size_t)x;
+    return (float)(fmt == A3_FMT_BGRA8 ? luma_of(p[2], p[1], p[0]) : luma_of(p[0], p[1], p[2]));
+}
+
+// grey of one pixel in the low bytes of px (byte 0 = R, or B when bgr): byte-wise dot products with the split weights
+// 2126 = 8*256+78, 7152 = 27*256+240, 722 = 2*256+210 and the exact /10000 (same integers as luma_of, as in K1)
+__device__ __forceinline__ uint32_t luma_px(uint32_t px, bool bgr) {
+    const uint32_t lo = __builtin_amdgcn_udot4(px, bgr ? 0x004EF0D2u : 0x00D2F04Eu, 0u, false);
+    const uint32_t hi = __builtin_amdgcn_udot4(px, bgr ? 0x00081B02u : 0x00021B08u, 0u, false);
+    const uint32_t l = lo + (hi << 8);
+    return (uint32_t)(((uint64_t)l * 13743896ull) >> 37);
+}
+
+// imageproc interpolate_bilinear: default (0) outside, the two horizontal lerps truncated to u8 first.
+// Split in two so that a lane can have the loads of several samples in flight before it converts any of them:
+// issue() decides the case and starts the two 12-byte row reads, finish() turns them into the sample.
+struct TapLoad {
+    uint32_t top[3], bot[3];
+    float rw, bw;
+    uint32_t sh;         // byte misalignment of the first tap, in bits
+    int mode;            // 0 outside (sample = 0), 1 wide loads issued, 2 near the end of the frame: byte loads in finish()
+    uint32_t l, t;       // first tap (mode 2 only)
+};
+
+__device__ __forceinline__ void sample_issue(TapLoad& tl, const uint8_t* __restrict__ img, size_t row_stride, uint32_t bpp, uint32_t w, uint32_t h,
+                                             float x, float y, bool valid) {
     const float left = floorf(x), right = left + 1.0f, top = floorf(y), bottom = top + 1.0f;
-    const float rw = x - left, bw = y - top;
-    if (left < 0.0f || right >= (float)w || top < 0.0f || bottom >= (float)h) return 0;
-    const uint32_t l = sat_u32(left), r = sat_u32(right), t = sat_u32(top), b = sat_u32(bottom);
-    const float tl = img[(size_t)t * w + l], tr = img[(size_t)t * w + r], bl = img[(size_t)b * w + l], br = img[(size_t)b * w + r];
-    const uint8_t tv = clamp_u8((1.0f - rw) * tl + rw * tr);
-    const uint8_t bv = clamp_u8((1.0f - rw) * bl + rw * br);
-    return clamp_u8((1.0f - bw) * (float)tv + bw * (float)bv);
+    tl.rw = x - left; tl.bw = y - top;
+    tl.mode = 0;
+    if (!valid || left < 0.0f || right >= (float)w || top < 0.0f || bottom >= (float)h) return;
+    const uint32_t l = sat_u32(left), t = sat_u32(top), b = sat_u32(bottom);
+    const uint8_t* rt = img + (size_t)t * row_stride;
+    const uint8_t* rb = img + (size_t)b * row_stride;
+    tl.l = l; tl.t = t;
+    // the wide read of the bottom row must end inside this frame (running on into the next row is fine)
+    if ((size_t)b * row_stride + (size_t)bpp * l + 12u <= (size_t)(h - 1u) * row_stride + (size_t)w * bpp) {
+        const uintptr_t pt = reinterpret_cast<uintptr_t>(rt) + (size_t)bpp * l, pb = reinterpret_cast<uintptr_t>(rb) + (size_t)bpp * l;
+        const uint32_t* qt = reinterpret_cast<const uint32_t*>(pt & ~(uintptr_t)3);
+        const uint32_t* qb = reinterpret_cast<const uint32_t*>(pb & ~(uintptr_t)3);
+        tl.top[0] = qt[0]; tl.top[1] = qt[1]; tl.top[2] = qt[2];
+        tl.bot[0] = qb[0]; tl.bot[1] = qb[1]; tl.bot[2] = qb[2];
+        // both rows start at the same misalignment only if row_stride % 4 == 0; keep one shift per row in sh's halves
+        tl.sh = ((uint32_t)(pt & 3u) * 8u) | (((uint32_t)(pb & 3u) * 8u) << 8);
+        tl.mode = 1;
+    } else tl.mode = 2;
+}
+
+__device__ __forceinline__ void pair_from(const uint32_t d[3], uint32_t sh, int fmt, uint32_t bpp, float* g0, float* g1) {
+    const uint32_t w0 = __builtin_amdgcn_alignbit(d[1], d[0], sh), w1 = __builtin_amdgcn_alignbit(d[2], d[1], sh);   // bytes p .. p+7
+    if (bpp == 1u) { *g0 = (float)(w0 & 0xFFu); *g1 = (float)((w0 >> 8) & 0xFFu); return; }
+    const bool bgr = fmt == A3_FMT_BGRA8;
+    const uint32_t px1 = bpp == 3u ? ((w0 >> 24) | (w1 << 8)) : w1;   // the dot products ignore byte 3
+    *g0 = (float)luma_px(w0, bgr);
+    *g1 = (float)luma_px(px1, bgr);
+}
+
+__device__ __forceinline__ uint8_t sample_finish(const TapLoad& tl, const uint8_t* __restrict__ img, size_t row_stride, int fmt, uint32_t bpp) {
+    if (tl.mode == 0) return 0;
+    float a, b, c, d;
+    if (tl.mode == 1) {
+        pair_from(tl.top, tl.sh & 0xFFu, fmt, bpp, &a, &b);
+        pair_from(tl.bot, tl.sh >> 8, fmt, bpp, &c, &d);
+    } else {
+        const uint8_t* rt = img + (size_t)tl.t * row_stride;
+        const uint8_t* rb = rt + row_stride;
+        a = grey_tap(rt, tl.l, fmt); b = grey_tap(rt, tl.l + 1u, fmt); c = grey_tap(rb, tl.l, fmt); d = grey_tap(rb, tl.l + 1u, fmt);
+    }
+    const uint8_t tv = clamp_u8((1.0f - tl.rw) * a + tl.rw * b);
+    const uint8_t bv = clamp_u8((1.0f - tl.rw) * c + tl.rw * d);
+    return clamp_u8((1.0f - tl.bw) * (float)tv + tl.bw * (float)bv);
 }
 
 __device__ __forceinline__ float triangle_kernel(float x) { return fabsf(x) < 1.0f ? 1.0f - fabsf(x) : 0.0f; }
@@ -252,7 +316,7 @@ __global__ __launch_bounds__(64) void k_projection(const uint16_t* __restrict__ 
 
 // grid-stride over the work list; block = 256 threads; dynamic LDS:
 //   patch S*S | tmp n*S f32 | wtab n*max_taps f32 | wleft n u32 | wcnt n u32 | bits n*n
-__global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ grey, int W, int H, uint32_t first_frame,
+__global__ __launch_bounds__(256) void k_decode(PixelSrc src, int W, int H, uint32_t first_frame,
                                                 const uint16_t* __restrict__ fin_xy, const uint32_t* __restrict__ work,
                                                 const unsigned int* __restrict__ work_count, uint32_t max_cand, uint32_t S, uint32_t n,
                                                 uint32_t max_taps, const uint64_t* __restrict__ dict, uint32_t n_codes, uint32_t tau,
@@ -281,7 +345,7 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ grey
     for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
         const uint32_t slot = work[wi];
         const uint32_t fl = slot / max_cand;
-        const uint8_t* img = grey + (size_t)(first_frame + fl) * W * H;
+        const uint8_t* img = src.base + (size_t)(first_frame + fl) * src.frame_stride;
         __syncthreads();
         if (tid < 9) s_inv[tid] = proj[wi].inv[tid];
         if (tid == 9) s_ok = proj[wi].ok;
@@ -293,14 +357,30 @@ __global__ __launch_bounds__(256) void k_decode(const uint8_t* __restrict__ grey
         if (ok) {
             const float t0 = s_inv[0], t1 = s_inv[1], t2 = s_inv[2], t3 = s_inv[3], t4 = s_inv[4], t5 = s_inv[5], t6 = s_inv[6],
                         t7 = s_inv[7], t8 = s_inv[8];
-            for (uint32_t i = tid; i < S * S; i += 256) {
-                const float fx = (float)(i % S), fy = (float)(i / S);
-                const float d = t6 * fx + t7 * fy + t8;
-                const float px = (t0 * fx + t1 * fy + t2) / d;
-                const float py = (t3 * fx + t4 * fy + t5) / d;
-                const uint8_t v = sample_bilinear(img, (uint32_t)W, (uint32_t)H, px, py);
-                s_patch[i] = v;
-                atomicAdd(&s_hist[v], 1u);
+            // kU samples per lane per trip: all their row reads (one 12-byte load per row and sample: the two taps of a row
+            // are adjacent) are in flight before the first is converted
+            constexpr int kU = 4;
+            const uint32_t bpp = (src.fmt == A3_FMT_RGB8) ? 3u : ((src.fmt == A3_FMT_RGBA8 || src.fmt == A3_FMT_BGRA8) ? 4u : 1u);
+            for (uint32_t i0 = tid; i0 < S * S; i0 += 256 * kU) {
+                TapLoad tl[kU];
+#pragma unroll
+                for (int u = 0; u < kU; u++) {
+                    const uint32_t i = i0 + 256u * u;
+                    const float fx = (float)(i % S), fy = (float)(i / S);
+                    const float d = t6 * fx + t7 * fy + t8;
+                    const float px = (t0 * fx + t1 * fy + t2) / d;
+                    const float py = (t3 * fx + t4 * fy + t5) / d;
+                    sample_issue(tl[u], img, (size_t)src.row_stride, bpp, (uint32_t)W, (uint32_t)H, px, py, i < S * S);
+                }
+#pragma unroll
+                for (int u = 0; u < kU; u++) {
+                    const uint32_t i = i0 + 256u * u;
+                    if (i < S * S) {
+                        const uint8_t v = sample_finish(tl[u], img, (size_t)src.row_stride, src.fmt, bpp);
+                        s_patch[i] = v;
+                        atomicAdd(&s_hist[v], 1u);
+                    }
+                }
             }
         } else if (tid == 0) {  // GrayImage::new(1, 1): one black pixel (quirk Q4)
             s_patch[0] = 0;
@@ -751,11 +831,11 @@ hipError_t launch_frame_candidates(hipStream_t st, const CandRec* cands, const u
 
 size_t proj_rec_bytes() { return sizeof(ProjRec); }
 
-hipError_t launch_decode(hipStream_t st, const uint8_t* grey, int W, int H, uint32_t first_frame, const uint16_t* fin_xy, const uint32_t* work,
+hipError_t launch_decode(hipStream_t st, PixelSrc src, int W, int H, uint32_t first_frame, const uint16_t* fin_xy, const uint32_t* work,
                          const unsigned int* work_count, uint32_t max_cand, uint32_t S, uint32_t n, uint32_t max_taps, const uint64_t* dict,
                          uint32_t n_codes, uint32_t tau, int filter, void* proj, void* outs, uint8_t* patches, int grid_blocks) {
     hipLaunchKernelGGL(k_projection, dim3(256), dim3(64), 0, st, fin_xy, work, work_count, S, reinterpret_cast<ProjRec*>(proj));
-    hipLaunchKernelGGL(k_decode, dim3(grid_blocks), dim3(256), decode_lds_bytes(S, n, max_taps), st, grey, W, H, first_frame, fin_xy, work,
+    hipLaunchKernelGGL(k_decode, dim3(grid_blocks), dim3(256), decode_lds_bytes(S, n, max_taps), st, src, W, H, first_frame, fin_xy, work,
                        work_count, max_cand, S, n, max_taps, dict, n_codes, tau, filter, reinterpret_cast<const ProjRec*>(proj),
                        reinterpret_cast<DecodeOut*>(outs), patches);
     return hipGetLastError();

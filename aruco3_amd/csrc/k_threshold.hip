@@ -33,9 +33,6 @@ constexpr int T_OUT = 62 * T_LPX;    // 992 output columns per wave (lanes 0 and
 #endif
 constexpr int T_PF = A3_T_PF;        // rows of loads kept in flight per lane
 
-__device__ __forceinline__ uint32_t luma_of(uint32_t r, uint32_t g, uint32_t b) {
-    return (2126u * r + 7152u * g + 722u * b) / 10000u;
-}
 
 // grey of one RGB(A) pixel held in the low 3 bytes of `px` (4th byte ignored): two byte-wise dot products with
 // the split weights 2126 = 8*256+78, 7152 = 27*256+240, 722 = 2*256+210, then the exact /10000.
@@ -168,6 +165,7 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
     const uint32_t f = pair / strips_x;
     const uint8_t* frame = pixels + (size_t)f * frame_stride;
     uint8_t* gout = grey + (size_t)f * W * H;
+    const bool write_grey = grey != nullptr;
     const size_t bpr = (size_t)words_per_row((uint32_t)W) * 8;
     uint8_t* bout = bits + (size_t)f * bpr * H;
 
@@ -238,8 +236,9 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
             if constexpr (FAST) {
                 if (!(lane_in && r >= 0 && r < H)) { g[0] = 0u; g[1] = 0u; g[2] = 0u; g[3] = 0u; }
             }
-            // Detection.grey of the rows this wave owns
-            if (owner && r >= y_begin && r < y_end) {
+            // Detection.grey of the rows this wave owns -- only when somebody reads the plane (debug taps); the decode stage
+            // otherwise recomputes the few grey levels it samples from the frame itself
+            if (write_grey && owner && r >= y_begin && r < y_end) {
                 uint8_t* dst = gout + (size_t)r * W + x0;
                 if (FAST || (aligned_out && x0 + T_LPX <= W)) *reinterpret_cast<uint4*>(dst) = make_uint4(g[0], g[1], g[2], g[3]);
                 else {

@@ -146,6 +146,11 @@ enum { A3_STAGE_THRESHOLD = 0, A3_STAGE_CONTOUR = 1, A3_STAGE_DECODE = 2, A3_STA
 int  a3_set_profiling(a3_ctx *ctx, int enabled);
 int  a3_get_profile(a3_ctx *ctx, int stage, double *total_ms, uint64_t *launches, int reset);
 
+/* kernel-level timing for tuning (tools/kernel_probe.py): re-runs one contour-stage kernel (0 dart_count, 1 dart_assign,
+ * 2 local_contract) on the buffers of the last single-chunk batch, optionally truncated (dbg), and returns the
+ * average device time.  The internal contour buffers hold garbage afterwards; results already returned are unaffected. */
+int  a3_debug_kernel_time(a3_ctx *ctx, int kernel, int dbg, int reps, float *avg_ms);
+
 /* numerics self-check used by the GPU tests: evaluates the IEEE operations the kernels rely on
  * (f64 sqrt/div, f32 sqrt/div) for n inputs so that the host can compare them bit for bit */
 int  a3_selftest_ieee(a3_ctx *ctx, const double *a, const double *b, size_t n, double *sqrt_a, double *a_div_b,

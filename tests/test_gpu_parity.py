@@ -43,7 +43,11 @@ def _run(det, frames, populate=True, out_cap=0):
 
 def _check(det, oracle, frames, check_patches=True):
     d = det.dictionary
+    # product path first (no debug taps: K1 writes no grey plane, the decode stage samples the caller's frames), then the
+    # tapped run whose intermediate stages are compared below; both must return the same markers
+    _, markers0, per0 = _run(det, frames, populate=False)
     ctx, markers, per = _run(det, frames)
+    assert np.array_equal(per0, per) and np.array_equal(markers0, markers)
     frames = np.asarray(frames)
     if frames.ndim == 3 and frames.shape[-1] in (3, 4):
         frames = frames[None]
@@ -109,12 +113,22 @@ def test_threshold_stage_bit_exact(dicts, oracle, shape, channels):
     flat = np.full((h, w, channels), 200, np.uint8)
     det = _detector(dicts)
     frames = np.stack([noise, ramp, flat])
-    ctx, _, _ = _run(det, frames if channels > 1 else frames[..., 0][..., None], populate=False)
+    batch = frames if channels > 1 else frames[..., 0][..., None]
+    ctx, _, _ = _run(det, batch, populate=True)
+    want = []
     for f in range(3):
         img = frames[f] if channels > 1 else frames[f][..., 0]
         grey = oracle.to_luma8(img)
+        want.append(oracle.adaptive_threshold(grey, 7))
         assert np.array_equal(ctx.download_grey(f, w, h), grey)
-        assert np.array_equal(ctx.download_grey(f, w, h, thresholded=True), oracle.adaptive_threshold(grey, 7))
+        assert np.array_equal(ctx.download_grey(f, w, h, thresholded=True), want[f])
+    # without debug taps K1 writes no grey plane; the thresholded image must not change, and asking for grey is an error
+    ctx, _, _ = _run(det, batch, populate=False)
+    for f in range(3):
+        assert np.array_equal(ctx.download_grey(f, w, h, thresholded=True), want[f])
+    from aruco3_amd._lib import A3Error
+    with pytest.raises(A3Error):
+        ctx.download_grey(0, w, h)
 
 
 def test_other_threshold_window(dicts, oracle):
@@ -329,7 +343,11 @@ def test_strided_and_offset_input(hip, dicts, oracle):
         if mem == hip.MEM_DEVICE:
             keep = torch.from_numpy(buf).cuda()
             ptr = keep.data_ptr() + off
+        ctx.set_debug_taps(False)   # product path: the decode stage samples the strided frames themselves
+        markers0, per0 = ctx.detect_batch(ptr, mem, hip.FMT_RGB8, w, h, row_stride, frame_stride, n)
+        ctx.set_debug_taps(True)
         markers, per = ctx.detect_batch(ptr, mem, hip.FMT_RGB8, w, h, row_stride, frame_stride, n)
+        assert np.array_equal(per0, per) and np.array_equal(markers0, markers)
         pos = 0
         for f in range(n):
             res = oracle.detect(frames[f], d.code_list, d.num_bits, d._tau)
@@ -393,8 +411,11 @@ def test_bgra_webcam_byte_order(hip, dicts, oracle):
         bgra = np.ascontiguousarray(rgba[..., [2, 1, 0, 3]])
         det = _detector(dicts, "ARUCO_DEFAULT")
         ctx = det._context()
+        ctx.set_debug_taps(False)
+        markers0, per0 = ctx.detect_batch(bgra.ctypes.data, hip.MEM_HOST, hip.FMT_BGRA8, w, h, w * 4, w * h * 4, 1)
         ctx.set_debug_taps(True)
         markers, per = ctx.detect_batch(bgra.ctypes.data, hip.MEM_HOST, hip.FMT_BGRA8, w, h, w * 4, w * h * 4, 1)
+        assert np.array_equal(per0, per) and np.array_equal(markers0, markers)
         res = oracle.detect(rgba, d.code_list, d.num_bits, d._tau)
         assert_frame_parity(ctx, 0, rgba, res, w, h)
         assert markers_of_hip(markers) == markers_of_oracle(res)
