@@ -229,7 +229,7 @@ class Context:
                      out_cap: int = 0):
         """-> (markers structured array, per-frame counts)"""
         cap = out_cap or max(64 * n_frames, 64)
-        out = np.zeros(cap, dtype=MARKER_DTYPE)
+        out = np.empty(cap, dtype=MARKER_DTYPE)   # only the first n records are written and returned
         per = np.zeros(max(n_frames, 1), dtype=np.uint32)
         n = C.c_size_t()
         rc = load().a3_detect_batch(self.handle, C.c_void_p(pixels_ptr), memory, fmt, width, height, row_stride, frame_stride, n_frames,

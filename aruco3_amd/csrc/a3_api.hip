@@ -3,6 +3,7 @@
 // a3_create fails with A3_ERR_NO_DEVICE.
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
@@ -17,19 +18,20 @@ hipError_t launch_grey_threshold(hipStream_t, const uint8_t*, int, size_t, size_
 // k_contours.hip
 hipError_t launch_dart_count(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, unsigned long long*, uint32_t*);
 size_t tile_darts_bytes(uint32_t W, uint32_t H, uint32_t n_frames);
-hipError_t launch_dart_build(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, const uint32_t*, uint32_t*, uint32_t*, const uint32_t*,
-                             uint64_t*, uint32_t*, uint32_t, int);
+hipError_t launch_dart_build(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*, const uint32_t*,
+                             uint64_t*, uint32_t*, uint32_t, const uint32_t*, int);
+hipError_t launch_plan(hipStream_t, const unsigned long long*, uint32_t, uint64_t, uint32_t*, uint32_t*);
 size_t entry_state_bytes();
 size_t entry_slots(uint32_t);
 size_t leader_list_bytes(uint32_t);
 hipError_t launch_rank_cycles(hipStream_t, uint32_t, int, const uint64_t*, const uint32_t*, JumpState*, uint32_t*, uint32_t*,
-                              uint32_t*, uint32_t*, unsigned int*, void*, void*, JumpState*, uint32_t*, unsigned int*, int, DeviceCounters*, int);
+                              uint32_t*, uint32_t*, unsigned int*, void*, void*, JumpState*, uint32_t*, unsigned int*, int, DeviceCounters*, const uint32_t*, int);
 hipError_t launch_resolve(hipStream_t, const JumpState*, uint32_t, int, const uint64_t*, const uint32_t*, const unsigned int*, uint64_t*, uint64_t*,
-                          DeviceCounters*, int);
+                          DeviceCounters*, int, const uint32_t*);
 hipError_t launch_select_scatter(hipStream_t, const JumpState*, uint32_t, const uint32_t*, const unsigned int*, const uint32_t*, const uint64_t*,
                                  const uint32_t*, uint32_t, uint32_t,
                                  uint32_t, double, double, uint32_t*, ContourRec*, uint32_t*, uint32_t, uint64_t, DeviceCounters*,
-                                 const uint64_t*, uint32_t*);
+                                 const uint64_t*, uint32_t*, const uint32_t*);
 hipError_t launch_unpack_bits(hipStream_t, const uint64_t*, int, int, uint8_t*);
 hipError_t launch_contour_quads(hipStream_t, const ContourRec*, const DeviceCounters*, uint32_t, const uint32_t*, double, uint32_t, uint32_t,
                                 uint32_t, CandRec*, uint32_t*, unsigned int*);
@@ -97,7 +99,12 @@ struct a3_ctx {
     // maximum if a pass count turns out too small
     int jump_rounds_hint = 10, resolve_iters_hint = 4;
     uint32_t dbg_nd = 0, dbg_frames = 0, dbg_chunks = 0;   // a3_debug_kernel_time: shape of the last batch's contour graph
-    int resolve_full_ttl = 0;   // > 0: launch the fixpoint passes over all darts too (a recent batch needed them); else only k_resolve_fast
+    int resolve_full_ttl = 0;
+    // device-side planning: the previous batch of this shape fitted one chunk with plan_darts darts, so this one is enqueued
+    // without reading the dart counts back first (k_plan); an overflow falls back to the host plan once (force_host_plan)
+    bool plan_valid = false, force_host_plan = false;
+    uint32_t plan_n = 0, plan_W = 0, plan_H = 0;
+    uint64_t plan_darts = 0;   // > 0: launch the fixpoint passes over all darts too (a recent batch needed them); else only k_resolve_fast
     // a3_detect_batch_pose: poses of every marker are computed on the device right after detection
     bool want_pose = false;
     float pose_size_mm = 0.0f;
@@ -144,6 +151,17 @@ int fail(a3_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
         hipError_t e_ = (call);                                             \
         if (e_ != hipSuccess) return fail(ctx, A3_ERR_HIP, #call, e_);      \
     } while (0)
+
+// Waiting for a batch that takes about a millisecond: a blocking hipStreamSynchronize wakes the host tens of microseconds
+// late, so poll first and only block when the work is long.
+hipError_t wait_stream(hipStream_t st) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) return hipStreamSynchronize(st);
+    }
+}
 
 int ensure_pinned(a3_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->pinned_cap) return A3_OK;
@@ -220,16 +238,27 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     A3_HIP(ctx->tile_darts.ensure(tile_darts_bytes(W, H, n)));
     A3_HIP(launch_dart_count(st, ctx->bin.as<uint64_t>(), (int)W, (int)H, 0, n, ctx->frame_darts.as<unsigned long long>(),
                              ctx->tile_darts.as<uint32_t>()));
-    if (int rc = ensure_pinned(ctx, std::max<size_t>((size_t)n * 8, 1 << 16))) return rc;
-    A3_HIP(hipMemcpyAsync(ctx->pinned, ctx->frame_darts.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-    A3_HIP(hipStreamSynchronize(st));
-    std::vector<uint64_t> fd((uint64_t*)ctx->pinned, (uint64_t*)ctx->pinned + n);
-    uint64_t biggest = 0;
-    for (uint64_t v : fd) { biggest = std::max(biggest, v); ctx->stats.darts += v; }
-    if (biggest > kHardMaxDarts) return fail(ctx, A3_ERR_CAPACITY, "a frame needs more contour-graph nodes than 32-bit indices allow");
-    if (biggest > ctx->max_darts) ctx->max_darts = biggest;  // one frame must fit; grow the pool
+    // A batch shaped like the previous one is planned on the device: no read-back, no idle GPU while the host thinks.
+    uint64_t cap_d = 0;
+    bool device_plan = ctx->plan_valid && !ctx->force_host_plan && ctx->plan_n == n && ctx->plan_W == W && ctx->plan_H == H &&
+                       n <= kMaxChunkFrames;
+    if (device_plan) {
+        cap_d = ctx->plan_darts + ctx->plan_darts / 4 + 65536;
+        if (cap_d > ctx->max_darts) device_plan = false;
+    }
     std::vector<Chunk> chunks;
-    {
+    std::vector<uint64_t> fd;
+    if (device_plan) {
+        chunks.push_back(Chunk{0, n, cap_d, (uint32_t)std::min<uint64_t>(cap_d, 0xFFFFFFFFu)});
+    } else {
+        if (int rc = ensure_pinned(ctx, std::max<size_t>((size_t)n * 8, 1 << 16))) return rc;
+        A3_HIP(hipMemcpyAsync(ctx->pinned, ctx->frame_darts.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+        A3_HIP(wait_stream(st));
+        fd.assign((uint64_t*)ctx->pinned, (uint64_t*)ctx->pinned + n);
+        uint64_t biggest = 0;
+        for (uint64_t v : fd) { biggest = std::max(biggest, v); ctx->stats.darts += v; }
+        if (biggest > kHardMaxDarts) return fail(ctx, A3_ERR_CAPACITY, "a frame needs more contour-graph nodes than 32-bit indices allow");
+        if (biggest > ctx->max_darts) ctx->max_darts = biggest;  // one frame must fit; grow the pool
         Chunk c{0, 0, 0, 0};
         for (uint32_t f = 0; f < n; f++) {
             if (c.count && (c.darts + fd[f] > ctx->max_darts || c.count >= kMaxChunkFrames)) { chunks.push_back(c); c = Chunk{f, 0, 0, 0}; }
@@ -266,20 +295,27 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     unsigned int* d_entry_count = ctx->scratch_u32 + 32;    // [32..47]
     unsigned int* d_leader_count = ctx->scratch_u32 + 16;   // [16..31]
 
-    // frame bases of every chunk, uploaded once
-    std::vector<uint32_t> bases;
-    for (auto& c : chunks) {
-        uint32_t acc = 0;
-        for (uint32_t i = 0; i < max_chunk_frames + 1; i++) {
-            bases.push_back(acc);
-            if (i < c.count) acc += (uint32_t)fd[c.first + i];
+    const uint32_t* n_live = nullptr;
+    if (device_plan) {
+        // frame bases and the dart total come from k_plan (scratch words 8..11, read back with the results)
+        A3_HIP(launch_plan(st, ctx->frame_darts.as<unsigned long long>(), n, cap_d, ctx->frame_base.as<uint32_t>(), ctx->scratch_u32 + 8));
+        n_live = ctx->scratch_u32 + 8;
+    } else {
+        // frame bases of every chunk, uploaded once
+        std::vector<uint32_t> bases;
+        for (auto& c : chunks) {
+            uint32_t acc = 0;
+            for (uint32_t i = 0; i < max_chunk_frames + 1; i++) {
+                bases.push_back(acc);
+                if (i < c.count) acc += (uint32_t)fd[c.first + i];
+            }
         }
+        // the pinned buffer still holds fd; stage the bases behind it
+        if (int rc = ensure_pinned(ctx, (size_t)n * 8 + bases.size() * 4 + (1 << 16))) return rc;
+        uint32_t* h_bases = reinterpret_cast<uint32_t*>((uint8_t*)ctx->pinned + (size_t)n * 8);
+        memcpy(h_bases, bases.data(), bases.size() * 4);
+        A3_HIP(hipMemcpyAsync(ctx->frame_base.p, h_bases, bases.size() * 4, hipMemcpyHostToDevice, st));
     }
-    // the pinned buffer still holds fd; stage the bases behind it
-    if (int rc = ensure_pinned(ctx, (size_t)n * 8 + bases.size() * 4 + (1 << 16))) return rc;
-    uint32_t* h_bases = reinterpret_cast<uint32_t*>((uint8_t*)ctx->pinned + (size_t)n * 8);
-    memcpy(h_bases, bases.data(), bases.size() * 4);
-    A3_HIP(hipMemcpyAsync(ctx->frame_base.p, h_bases, bases.size() * 4, hipMemcpyHostToDevice, st));
 
     // ---- contour stage, chunk by chunk ----
     const uint64_t* d_bin = ctx->bin.as<uint64_t>();
@@ -291,12 +327,10 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
         const uint32_t* fb = ctx->frame_base.as<uint32_t>() + ci * (max_chunk_frames + 1);
         const uint32_t nd = (uint32_t)c.darts;
         if (nd == 0) continue;
-        if (ci > 0) {   // the batch-wide memset covered the first chunk
-            A3_HIP(hipMemsetAsync(ctx->frame_cursor, 0, (size_t)c.count * 4, st));
-            A3_HIP(hipMemsetAsync(d_leader_count, 0, 4 * 32, st));   // leader + entry counters, adjacent
-        }
-        A3_HIP(launch_dart_build(st, d_bin, (int)W, (int)H, c.first, c.count, fb, ctx->frame_cursor, ctx->pix_base.as<uint32_t>(),
-                                 ctx->tile_darts.as<uint32_t>(), ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), nd, 0));
+        if (ci > 0) A3_HIP(hipMemsetAsync(d_leader_count, 0, 4 * 32, st));   // leader + entry counters, adjacent (the batch-wide memset covered chunk 0)
+        const uint32_t* tile_off = ctx->tile_darts.as<uint32_t>() + tile_darts_bytes(W, H, n) / 8;
+        A3_HIP(launch_dart_build(st, d_bin, (int)W, (int)H, c.first, c.count, fb, tile_off, ctx->pix_base.as<uint32_t>(),
+                                 ctx->tile_darts.as<uint32_t>(), ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), nd, n_live, 0));
         int rounds = 1;
         while ((1ull << rounds) < (uint64_t)c.max_frame_darts && rounds < 31) rounds++;
         rounds += 1;  // the round that observes "nothing moved"
@@ -305,16 +339,16 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
         A3_HIP(launch_rank_cycles(st, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(),
                                   ctx->stA.as<JumpState>(), ctx->loc_dist.as<uint32_t>(), ctx->entry_bits.as<uint32_t>(),
                                   ctx->entry_list.as<uint32_t>(), ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
-                                  ctx->stB.as<JumpState>(), ctx->entry_bits.as<uint32_t>(), d_leader_count, rounds, ctr, 0));
+                                  ctx->stB.as<JumpState>(), ctx->entry_bits.as<uint32_t>(), d_leader_count, rounds, ctr, n_live, 0));
         ctx->dbg_nd = nd; ctx->dbg_frames = c.count; ctx->dbg_chunks = (uint32_t)chunks.size();
         const JumpState* fin = ctx->stB.as<JumpState>();
         A3_HIP(launch_resolve(st, fin, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->entry_bits.as<uint32_t>(), d_leader_count,
-                              ctx->t_cur.as<uint64_t>(), ctx->t_next.as<uint64_t>(), ctr, ctx->resolve_full_ttl > 0 ? ctx->resolve_iters_hint : 0));
+                              ctx->t_cur.as<uint64_t>(), ctx->t_next.as<uint64_t>(), ctr, ctx->resolve_full_ttl > 0 ? ctx->resolve_iters_hint : 0, n_live));
         A3_HIP(launch_select_scatter(st, fin, nd, ctx->entry_bits.as<uint32_t>(), d_leader_count, ctx->d_succ.as<uint32_t>(), ctx->t_cur.as<uint64_t>(), fb, c.count, c.first, min_edge_length,
                                      ctx->cfg.contour_simplification_epsilon, image_diag, ctx->cyc_slot.as<uint32_t>(),
                                      ctx->contours.as<ContourRec>(),
                                      ctx->cyc_start_off.as<uint32_t>(), ctx->max_contours, ctx->max_points, ctr, ctx->d_xy.as<uint64_t>(),
-                                     ctx->points.as<uint32_t>()));
+                                     ctx->points.as<uint32_t>(), n_live));
         A3_HIP(launch_contour_quads(st, ctx->contours.as<ContourRec>(), ctr, ctx->max_contours, ctx->points.as<uint32_t>(),
                                     ctx->cfg.contour_simplification_epsilon, min_edge_length, c.first, kMaxCand,
                                     ctx->cands.as<CandRec>() + (size_t)c.first * kMaxCand, ctx->cand_count + c.first, d_err));
@@ -352,9 +386,19 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     A3_HIP(hipMemcpyAsync(hp, ctx->zero_blk.p, head_bytes, hipMemcpyDeviceToHost, st));
     A3_HIP(hipMemcpyAsync(h_markers, ctx->markers.p, (size_t)guess * sizeof(a3_marker), hipMemcpyDeviceToHost, st));
     if (pose_bytes) A3_HIP(hipMemcpyAsync(h_poses, ctx->tmp_b.p, (size_t)guess * pose_bytes, hipMemcpyDeviceToHost, st));
-    A3_HIP(hipStreamSynchronize(st));
+    A3_HIP(wait_stream(st));
     const unsigned int* hs = reinterpret_cast<const unsigned int*>(hp);
     const DeviceCounters* hc = reinterpret_cast<const DeviceCounters*>(hp + 256);
+    if (device_plan) {
+        if (hs[9]) { ctx->force_host_plan = true; return 1; }   // the graph outgrew the hint: plan on the host this once
+        ctx->stats.darts = hs[8];
+        ctx->dbg_nd = hs[8];
+        ctx->plan_darts = hs[8];
+    } else {
+        ctx->plan_valid = chunks.size() == 1;
+        ctx->plan_n = n; ctx->plan_W = W; ctx->plan_H = H;
+        ctx->plan_darts = chunks.size() == 1 ? chunks[0].darts : 0;
+    }
     unsigned int flags = hs[4];
     uint64_t need_points = 0; uint32_t need_contours = 0;
     bool jump_short = false, resolve_needed = false;
@@ -563,6 +607,7 @@ int a3_detect_batch(a3_ctx* ctx, const void* pixels, int memory, int fmt, uint32
         A3_HIP(hipMemcpyAsync(ctx->in.p, pixels, bytes, hipMemcpyHostToDevice, ctx->stream));
         d_pixels = ctx->in.as<uint8_t>();
     } else if (memory != A3_MEM_DEVICE) return fail(ctx, A3_ERR_INVALID, "memory must be A3_MEM_HOST or A3_MEM_DEVICE");
+    ctx->force_host_plan = false;
     for (int attempt = 0; attempt < 8; attempt++) {
         const int rc = run_batch(ctx, d_pixels, fmt, width, height, row_stride, frame_stride, n_frames, out, out_cap, per_frame_count, out_n);
         if (rc != 1) return rc;
@@ -599,7 +644,6 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
     unsigned int* d_entry_count = ctx->scratch_u32 + 32;
     unsigned int* d_leader_count = ctx->scratch_u32 + 16;
     for (int r = 0; r < reps; r++) {
-        A3_HIP(hipMemsetAsync(ctx->frame_cursor, 0, (size_t)ctx->dbg_frames * 4, st));
         A3_HIP(hipMemsetAsync(d_leader_count, 0, 4 * 32, st));
         A3_HIP(hipEventRecord(e0, st));
         if (kernel == 0) {
@@ -608,13 +652,14 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
                                      ctx->tile_darts.as<uint32_t>()));
         } else if (kernel == 1) {
             A3_HIP(launch_dart_build(st, ctx->bin.as<uint64_t>(), (int)ctx->W, (int)ctx->H, 0, ctx->dbg_frames, ctx->frame_base.as<uint32_t>(),
-                                     ctx->frame_cursor, ctx->pix_base.as<uint32_t>(), ctx->tile_darts.as<uint32_t>(), ctx->d_xy.as<uint64_t>(),
-                                     ctx->d_succ.as<uint32_t>(), ctx->dbg_nd, dbg ? dbg : 5));
+                                     ctx->tile_darts.as<uint32_t>() + tile_darts_bytes(ctx->W, ctx->H, ctx->frames) / 8, ctx->pix_base.as<uint32_t>(),
+                                     ctx->tile_darts.as<uint32_t>(), ctx->d_xy.as<uint64_t>(),
+                                     ctx->d_succ.as<uint32_t>(), ctx->dbg_nd, nullptr, dbg ? dbg : 5));
         } else if (kernel == 2) {
             A3_HIP(launch_rank_cycles(st, ctx->dbg_nd, (int)ctx->W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), ctx->stA.as<JumpState>(),
                                       ctx->loc_dist.as<uint32_t>(), ctx->entry_bits.as<uint32_t>(), ctx->entry_list.as<uint32_t>(),
                                       ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p, ctx->stB.as<JumpState>(),
-                                      ctx->entry_bits.as<uint32_t>(), d_leader_count, 0, ctx->counters, dbg ? dbg : 11));
+                                      ctx->entry_bits.as<uint32_t>(), d_leader_count, 0, ctx->counters, nullptr, dbg ? dbg : 11));
         } else return fail(ctx, A3_ERR_INVALID, "kernel: 0 dart_count, 1 dart_assign, 2 local_contract");
         A3_HIP(hipEventRecord(e1, st));
         A3_HIP(hipStreamSynchronize(st));

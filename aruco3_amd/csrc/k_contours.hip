@@ -138,31 +138,77 @@ __device__ __forceinline__ Nb8 tile_nb8(const uint64_t* __restrict__ img, int W,
     return r;
 }
 
-// grid: (dart_tiles(W,H), frames)
+// grid: (tiles_x * ceil(tiles_y / 4), frames).  A workgroup counts four vertically stacked tiles: their 258 x 6 words are
+// staged with all loads in flight at once (a tile per workgroup was bound by one load latency + barriers per tile: 86 us).
+constexpr int kCountStack = 4;
 __global__ __launch_bounds__(256) void k_dart_count(const uint64_t* __restrict__ bits, int W, int H, uint32_t first_frame,
                                                     unsigned long long* __restrict__ frame_darts, uint32_t* __restrict__ tile_darts) {
-    __shared__ uint32_t s_wave[4];
-    __shared__ uint64_t s_t[kTileRows + 2][kTileWords + 2];
+    __shared__ uint64_t s_t[kCountStack * kTileRows + 2][kTileWords + 2];
+    __shared__ uint32_t s_tot[kCountStack];
     const int wpr = (int)words_per_row((uint32_t)W);
     const uint32_t f = blockIdx.y;
-    uint32_t nd = 0;
-    int j, y;
-    bool active;
-    // (nine direct loads per lane instead of the staged tile were tried: 121 us instead of 86 us)
-    const Nb8 nb = tile_nb8(bits + (size_t)(first_frame + f) * wpr * H, W, H, s_t, &active, &j, &y);
-    if (active) {
-        if (nb.c) {
+    const uint32_t tiles_x = dart_tiles_x((uint32_t)W), tiles_y = ((uint32_t)H + kTileRows - 1) / kTileRows;
+    const int tx = blockIdx.x % tiles_x, sy = blockIdx.x / tiles_x;       // sy: stack index
+    const uint64_t* img = bits + (size_t)(first_frame + f) * wpr * H;
+    const int j0 = tx * kTileWords - 1, y0 = sy * kCountStack * kTileRows - 1;
+    if (threadIdx.x < kCountStack) s_tot[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < (kCountStack * kTileRows + 2) * (kTileWords + 2); i += 256) {
+        const int r = i / (kTileWords + 2), c = i - r * (kTileWords + 2);
+        s_t[r][c] = ldw(img, wpr, H, j0 + c, y0 + r);
+    }
+    __syncthreads();
+    const int jl = threadIdx.x & (kTileWords - 1), rl0 = threadIdx.x >> 2;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < kCountStack; q++) {
+        const int rl = q * kTileRows + rl0;
+        uint32_t nd = 0;
+        const uint64_t c = s_t[rl + 1][jl + 1];
+        if (c) {   // rows / words outside the image were staged as zeros
+            const uint64_t al = s_t[rl][jl], a = s_t[rl][jl + 1], ar = s_t[rl][jl + 2];
+            const uint64_t cl = s_t[rl + 1][jl], cr = s_t[rl + 1][jl + 2];
+            const uint64_t bl = s_t[rl + 2][jl], b = s_t[rl + 2][jl + 1], br = s_t[rl + 2][jl + 2];
+            Nb8 nb;
+            nb.c = c;
+            nb.n[0] = (c << 1) | (cl >> 63); nb.n[1] = (a << 1) | (al >> 63); nb.n[2] = a; nb.n[3] = (a >> 1) | (ar << 63);
+            nb.n[4] = (c >> 1) | (cr << 63); nb.n[5] = (b >> 1) | (br << 63); nb.n[6] = b; nb.n[7] = (b << 1) | (bl >> 63);
             uint64_t p[8];
             pdart_words(nb, p);
 #pragma unroll
             for (int k = 0; k < 8; k++) nd += __popcll(p[k]);
         }
+        for (int o = 32; o > 0; o >>= 1) nd += __shfl_down(nd, o);
+        if (lane == 0 && nd) atomicAdd(&s_tot[q], nd);
     }
-    uint32_t total;
-    block_excl_scan_256(nd, s_wave, &total);
+    __syncthreads();
+    if (threadIdx.x < kCountStack) {
+        const uint32_t ty = sy * kCountStack + threadIdx.x;
+        if (ty < tiles_y) tile_darts[(size_t)(first_frame + f) * (tiles_x * tiles_y) + ty * tiles_x + tx] = s_tot[threadIdx.x];   // lets k_dart_assign skip empty tiles
+    }
     if (threadIdx.x == 0) {
-        tile_darts[(size_t)(first_frame + f) * gridDim.x + blockIdx.x] = total;   // lets k_dart_assign skip empty tiles outright
+        const uint32_t total = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
         if (total) atomicAdd(&frame_darts[f], (unsigned long long)total);
+    }
+}
+
+// Per frame: exclusive prefix sums of its tiles' dart counts, so that every tile knows its dart range without an atomic
+// (and dart numbering no longer depends on scheduling).  grid: frames; tiles per frame is a few hundred.
+__global__ __launch_bounds__(256) void k_tile_scan(const uint32_t* __restrict__ tile_darts, uint32_t tiles, uint32_t first_frame,
+                                                   uint32_t* __restrict__ tile_off) {
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_run;
+    const size_t base = (size_t)(first_frame + blockIdx.x) * tiles;
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < tiles; t0 += 256) {
+        const uint32_t t = t0 + threadIdx.x;
+        const uint32_t v = t < tiles ? tile_darts[base + t] : 0u;
+        uint32_t total;
+        const uint32_t excl = block_excl_scan_256(v, s_wave, &total);
+        if (t < tiles) tile_off[base + t] = s_run + excl;
+        __syncthreads();
+        if (threadIdx.x == 0) s_run += total;
+        __syncthreads();
     }
 }
 
@@ -188,13 +234,13 @@ __device__ __forceinline__ int dir_dx(int k) { return (int)((0x1A90u >> (2 * k))
 __device__ __forceinline__ int dir_dy(int k) { return (int)((0xA901u >> (2 * k)) & 3u) - 1; }
 
 __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict__ bits, int W, int H, uint32_t first_frame,
-                                                     const uint32_t* __restrict__ frame_base, uint32_t* __restrict__ frame_cursor,
+                                                     const uint32_t* __restrict__ frame_base, const uint32_t* __restrict__ tile_off,
                                                      uint32_t* __restrict__ pix_base, const uint32_t* __restrict__ tile_darts,
-                                                     uint64_t* __restrict__ d_rec, uint32_t* __restrict__ d_succ, int dbg) {
+                                                     uint64_t* __restrict__ d_rec, uint32_t* __restrict__ d_succ,
+                                                     const uint32_t* __restrict__ n_live, int dbg) {
     // dbg (a3_debug_kernel_time only; 0 in the product path): stop after 1 = the empty-tile test, 2 = phase 1 and its scans,
     // 3 = the range allocation; 4 = run phase 2 without its global stores
     __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_base;
     __shared__ uint64_t s_t[kTileRows + 2][kTileWords + 2];
     __shared__ uint64_t s_nodes[256];
     __shared__ uint64_t s_c0[256], s_c1[256], s_c2[256];   // darts per pixel (0..4) as three bit planes
@@ -202,6 +248,8 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
     const int wpr = (int)words_per_row((uint32_t)W);
     const uint32_t f = blockIdx.y;
     if (tile_darts[(size_t)(first_frame + f) * gridDim.x + blockIdx.x] == 0u) return;   // uniform for the workgroup
+    if (n_live && *n_live == 0u) return;   // device-side plan: the graph does not fit the pool, the host re-plans
+    const uint32_t dart0 = frame_base[f] + tile_off[(size_t)(first_frame + f) * gridDim.x + blockIdx.x];
     if (dbg == 1) return;
     int j, y;
     bool active;
@@ -223,19 +271,18 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
         c1 = t ^ k4;
         c2 = q1 | (t & k4);
     }
-    uint32_t total_d, total_n;
-    const uint32_t excl_d = block_excl_scan_256(nd, s_wave, &total_d);
-    __syncthreads();
-    const uint32_t excl_n = block_excl_scan_256((uint32_t)__popcll(nodes), s_wave, &total_n);
+    // one block scan for both counts: darts (<= 65536 per tile) in the low 17 bits, border pixels (<= 16384) above
+    uint32_t total_p;
+    const uint32_t excl_p = block_excl_scan_256(nd | ((uint32_t)__popcll(nodes) << 17), s_wave, &total_p);
+    const uint32_t excl_d = excl_p & 0x1FFFFu, excl_n = excl_p >> 17, total_n = total_p >> 17;
     s_nodes[threadIdx.x] = nodes;
     s_c0[threadIdx.x] = c0; s_c1[threadIdx.x] = c1; s_c2[threadIdx.x] = c2;
     s_dbase[threadIdx.x] = excl_d;
     s_nbase[threadIdx.x] = excl_n;
     if (dbg == 2) return;
-    if (threadIdx.x == 0) { s_base = total_d ? atomicAdd(&frame_cursor[f], total_d) : 0u; s_nbase[256] = total_n; }
+    if (threadIdx.x == 0) s_nbase[256] = total_n;
     __syncthreads();
     if (dbg == 3) return;
-    const uint32_t dart0 = frame_base[f] + s_base;
     const int tx = blockIdx.x % dart_tiles_x((uint32_t)W), ty = blockIdx.x / dart_tiles_x((uint32_t)W);
     uint32_t* pbf = pix_base + (size_t)f * W * H;
     for (uint32_t n = threadIdx.x; n < total_n; n += 256) {
@@ -332,7 +379,8 @@ __device__ __forceinline__ uint32_t cross_tile_succ(uint32_t d, uint64_t rec, in
 
 __global__ __launch_bounds__(256) void k_dart_link(int W, int H, uint32_t first_frame, const uint32_t* __restrict__ pix_base,
                                                    const uint64_t* __restrict__ bits, const uint64_t* __restrict__ d_rec,
-                                                   uint32_t* __restrict__ d_succ, uint32_t n_darts) {
+                                                   uint32_t* __restrict__ d_succ, uint32_t n_darts, const uint32_t* __restrict__ n_live) {
+    if (n_live) n_darts = min(n_darts, *n_live);
     const int wpr = (int)words_per_row((uint32_t)W);
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x)
         if (d_succ[d] == kNone) d_succ[d] = cross_tile_succ(d, d_rec[d], W, H, wpr, first_frame, pix_base, bits);
@@ -380,11 +428,14 @@ __global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W,
                                                         const uint32_t* __restrict__ d_succ,
                                                         JumpState* __restrict__ loc, uint32_t* __restrict__ loc_dist,
                                                         uint32_t* __restrict__ entry_list,
-                                                        uint32_t* __restrict__ entry_pos, unsigned int* __restrict__ entry_count, int dbg) {
+                                                        uint32_t* __restrict__ entry_pos, unsigned int* __restrict__ entry_count, uint32_t ecap,
+                                                        const uint32_t* __restrict__ n_live, int dbg) {
     // dbg (a3_debug_kernel_time only; 0 in the product path): n > 0 runs n doubling rounds instead of 11; -1 = none
     __shared__ uint64_t s_key[kLT];
     __shared__ uint32_t s_ptr[kLT], s_off[kLT], s_dist[kLT];
+    if (n_live) n_darts = min(n_darts, *n_live);
     const uint32_t lo = blockIdx.x * kLT;
+    if (lo >= n_darts) return;   // the grid covers the pool's capacity, the graph may be smaller
     const uint32_t cnt = min((uint32_t)kLT, n_darts - lo);
     for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
         const uint32_t d = lo + i;
@@ -449,7 +500,7 @@ __global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W,
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t shard = blockIdx.x & (kEntryShards - 1);
-        s_new_base = shard * entry_shard_cap(n_darts) + (s_new_count ? atomicAdd(&entry_count[shard], s_new_count) : 0u);
+        s_new_base = shard * ecap + (s_new_count ? atomicAdd(&entry_count[shard], s_new_count) : 0u);
     }
     __syncthreads();
 #pragma unroll
@@ -514,7 +565,9 @@ __host__ __device__ inline uint32_t leader_shard_cap(uint32_t n_darts) { return 
 __global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const JumpState* __restrict__ loc, const uint32_t* __restrict__ loc_dist,
                                                        const uint32_t* __restrict__ entry_pos, const EntryState* __restrict__ es,
                                                        JumpState* __restrict__ fin, uint32_t* __restrict__ leader_list,
-                                                       unsigned int* __restrict__ leader_count /*[kLeaderShards]*/, uint32_t shard_cap) {
+                                                       unsigned int* __restrict__ leader_count /*[kLeaderShards]*/, uint32_t shard_cap,
+                                                       const uint32_t* __restrict__ n_live) {
+    if (n_live) n_darts = min(n_darts, *n_live);
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_base;
     const uint32_t shard = blockIdx.x & (kLeaderShards - 1);   // spread the slot counter over 16 addresses
@@ -598,8 +651,9 @@ __global__ __launch_bounds__(256) void k_resolve_fast(const JumpState* __restric
 
 // leaders get their natural start (their own key: the smallest event on the cycle); every other slot is "never"
 __global__ void k_resolve_init(const JumpState* __restrict__ st, uint32_t n_darts, uint64_t* __restrict__ t_cur,
-                               uint64_t* __restrict__ t_next, const DeviceCounters* __restrict__ ctr) {
+                               uint64_t* __restrict__ t_next, const DeviceCounters* __restrict__ ctr, const uint32_t* __restrict__ n_live) {
     if (!ctr->resolve_needed) return;
+    if (n_live) n_darts = min(n_darts, *n_live);
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
         const uint64_t key = st[d].key;
         const bool natural = (uint32_t)key == d && (uint32_t)(key >> 32) != kNoKey;
@@ -615,8 +669,10 @@ __global__ void k_resolve_init(const JumpState* __restrict__ st, uint32_t n_dart
 // and propose T'(cycle) = min key of its firing events.
 __global__ __launch_bounds__(256) void k_resolve_eval(const JumpState* __restrict__ st, uint32_t n_darts, int W,
                                                       const uint64_t* __restrict__ d_rec, const uint64_t* __restrict__ t_cur,
-                                                      uint64_t* __restrict__ t_next, int iter, DeviceCounters* __restrict__ ctr) {
+                                                      uint64_t* __restrict__ t_next, int iter, DeviceCounters* __restrict__ ctr,
+                                                      const uint32_t* __restrict__ n_live) {
     if (!ctr->resolve_needed || (iter > 0 && ctr->resolve_changed[iter - 1] == 0)) return;
+    if (n_live) n_darts = min(n_darts, *n_live);
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
         const uint64_t rec = d_rec[d];
         const uint32_t info = rec_info(rec);
@@ -648,8 +704,10 @@ __global__ __launch_bounds__(256) void k_resolve_eval(const JumpState* __restric
 
 // adopt T' as T, count the cycles whose start moved (into this pass's slot), clear T' for the next pass
 __global__ void k_resolve_commit(const JumpState* __restrict__ st, uint32_t n_darts, uint64_t* __restrict__ t_cur,
-                                 uint64_t* __restrict__ t_next, int iter, int last, DeviceCounters* __restrict__ ctr) {
+                                 uint64_t* __restrict__ t_next, int iter, int last, DeviceCounters* __restrict__ ctr,
+                                 const uint32_t* __restrict__ n_live) {
     if (!ctr->resolve_needed || (iter > 0 && ctr->resolve_changed[iter - 1] == 0)) return;
+    if (n_live) n_darts = min(n_darts, *n_live);
     uint32_t changed = 0;
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
         if ((uint32_t)st[d].key != d) continue;
@@ -750,7 +808,9 @@ __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restric
 
 __global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restrict__ st, uint32_t n_darts, const uint64_t* __restrict__ d_rec,
                                                         const uint32_t* __restrict__ cyc_slot, const ContourRec* __restrict__ contours,
-                                                        const uint32_t* __restrict__ cyc_start_off, uint32_t* __restrict__ points) {
+                                                        const uint32_t* __restrict__ cyc_start_off, uint32_t* __restrict__ points,
+                                                        const uint32_t* __restrict__ n_live) {
+    if (n_live) n_darts = min(n_darts, *n_live);
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
         const JumpState s = st[d];
         if ((uint32_t)(s.key >> 32) == kNoKey) continue;   // no start event anywhere on this cycle: never traced
@@ -916,22 +976,69 @@ static inline int blocks_for(uint64_t n, int per_block, int cap) {
     return (int)b;
 }
 
-size_t tile_darts_bytes(uint32_t W, uint32_t H, uint32_t n_frames) { return (size_t)dart_tiles(W, H) * n_frames * 4; }
+// Device-side plan for a batch whose contour graph is expected to fit one chunk (the host learnt its size from the previous
+// batch): exclusive prefix sums of the per-frame dart counts -> frame_base[0..n], total -> plan[0] (0 and plan[1] = 1 when
+// the total exceeds `cap`, which makes every later kernel a no-op; the host then re-plans with a read-back), largest
+// frame -> plan[2].  One workgroup; n_frames is small.
+__global__ __launch_bounds__(1024) void k_plan(const unsigned long long* __restrict__ frame_darts, uint32_t n_frames, unsigned long long cap,
+                                               uint32_t* __restrict__ frame_base, uint32_t* __restrict__ plan) {
+    __shared__ unsigned long long s_wave[16];
+    __shared__ unsigned long long s_run;
+    __shared__ unsigned int s_max;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { s_run = 0; s_max = 0; }
+    __syncthreads();
+    for (uint32_t base = 0; base < n_frames; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const unsigned long long v = i < n_frames ? frame_darts[i] : 0ull;
+        unsigned long long inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned long long t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        if (lane == 63) s_wave[wave] = inc;
+        atomicMax(&s_max, (unsigned int)min(v, 0xFFFFFFFFull));
+        __syncthreads();
+        unsigned long long before = s_run, tot = 0;
+        for (int w = 0; w < 16; w++) { const unsigned long long t = s_wave[w]; if (w < wave) before += t; tot += t; }
+        if (i < n_frames) frame_base[i] = (uint32_t)min(before + inc - v, 0xFFFFFFFFull);
+        __syncthreads();
+        if (threadIdx.x == 0) s_run += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const unsigned long long total = s_run;
+        const bool fits = total <= cap;
+        frame_base[n_frames] = fits ? (uint32_t)total : 0u;
+        plan[0] = fits ? (uint32_t)total : 0u;
+        plan[1] = fits ? 0u : 1u;
+        plan[2] = s_max;
+        plan[3] = (uint32_t)min(total, 0xFFFFFFFFull);
+    }
+}
+
+hipError_t launch_plan(hipStream_t st, const unsigned long long* frame_darts, uint32_t n_frames, uint64_t cap, uint32_t* frame_base, uint32_t* plan) {
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, st, frame_darts, n_frames, (unsigned long long)cap, frame_base, plan);
+    return hipGetLastError();
+}
+
+// tile_darts[frames * tiles] followed by tile_off[frames * tiles]
+size_t tile_darts_bytes(uint32_t W, uint32_t H, uint32_t n_frames) { return (size_t)dart_tiles(W, H) * n_frames * 4 * 2; }
 
 hipError_t launch_dart_count(hipStream_t st, const uint64_t* bits, int W, int H, uint32_t first_frame, uint32_t n_frames,
                              unsigned long long* frame_darts, uint32_t* tile_darts) {
-    hipLaunchKernelGGL(k_dart_count, dim3(dart_tiles((uint32_t)W, (uint32_t)H), n_frames), dim3(256), 0, st, bits, W, H, first_frame, frame_darts,
-                       tile_darts);
+    const uint32_t tiles_x = dart_tiles_x((uint32_t)W), tiles_y = ((uint32_t)H + kTileRows - 1) / kTileRows;
+    hipLaunchKernelGGL(k_dart_count, dim3(tiles_x * ((tiles_y + kCountStack - 1) / kCountStack), n_frames), dim3(256), 0, st, bits, W, H, first_frame,
+                       frame_darts, tile_darts);
+    hipLaunchKernelGGL(k_tile_scan, dim3(n_frames), dim3(256), 0, st, tile_darts, tiles_x * tiles_y, first_frame, tile_darts + (size_t)tiles_x * tiles_y * n_frames);
     return hipGetLastError();
 }
 
 hipError_t launch_dart_build(hipStream_t st, const uint64_t* bits, int W, int H, uint32_t first_frame, uint32_t n_frames,
-                             const uint32_t* frame_base, uint32_t* frame_cursor, uint32_t* pix_base, const uint32_t* tile_darts, uint64_t* d_rec,
-                             uint32_t* d_succ, uint32_t n_darts, int dbg) {
-    hipLaunchKernelGGL(k_dart_assign, dim3(dart_tiles((uint32_t)W, (uint32_t)H), n_frames), dim3(256), 0, st, bits, W, H, first_frame, frame_base, frame_cursor,
-                       pix_base, tile_darts, d_rec, d_succ, dbg);
+                             const uint32_t* frame_base, const uint32_t* tile_off, uint32_t* pix_base, const uint32_t* tile_darts, uint64_t* d_rec,
+                             uint32_t* d_succ, uint32_t n_darts, const uint32_t* n_live, int dbg) {
+    hipLaunchKernelGGL(k_dart_assign, dim3(dart_tiles((uint32_t)W, (uint32_t)H), n_frames), dim3(256), 0, st, bits, W, H, first_frame, frame_base, tile_off,
+                       pix_base, tile_darts, d_rec, d_succ, n_live, dbg);
     if (dbg && dbg != 5) return hipGetLastError();   // 5 = everything (the probe's reference point), others leave d_succ alone
-    hipLaunchKernelGGL(k_dart_link, dim3(blocks_for(n_darts, 256 * 4, 4096)), dim3(256), 0, st, W, H, first_frame, pix_base, bits, d_rec, d_succ, n_darts);
+    hipLaunchKernelGGL(k_dart_link, dim3(blocks_for(n_darts, 256 * 4, 4096)), dim3(256), 0, st, W, H, first_frame, pix_base, bits, d_rec, d_succ, n_darts, n_live);
     return hipGetLastError();
 }
 
@@ -944,12 +1051,12 @@ size_t leader_list_bytes(uint32_t n_darts) { return (size_t)leader_shard_cap(n_d
 hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uint64_t* d_rec, const uint32_t* d_succ,
                               JumpState* loc, uint32_t* loc_dist, uint32_t* entry_bits, uint32_t* entry_list, uint32_t* entry_pos,
                               unsigned int* entry_count, void* es_a, void* es_b, JumpState* fin, uint32_t* leader_list,
-                              unsigned int* leader_count, int max_rounds, DeviceCounters* ctr, int dbg) {
+                              unsigned int* leader_count, int max_rounds, DeviceCounters* ctr, const uint32_t* n_live, int dbg) {
     (void)entry_bits;
     // entry_count[16] and leader_count[16] arrive zeroed (the caller's per-batch / per-chunk memset)
     const uint32_t ecap = entry_shard_cap(n_darts);
     hipLaunchKernelGGL(k_local_contract, dim3((n_darts + kLT - 1) / kLT), dim3(256), 0, st, n_darts, W, d_rec, d_succ, loc, loc_dist,
-                       entry_list, entry_pos, entry_count, dbg);
+                       entry_list, entry_pos, entry_count, ecap, n_live, dbg);
     if (dbg) return hipGetLastError();
     EntryState* a = reinterpret_cast<EntryState*>(es_a);
     EntryState* b = reinterpret_cast<EntryState*>(es_b);
@@ -961,20 +1068,21 @@ hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uin
     }
     const int fin_blocks = std::max(blocks_for(n_darts, 256, 8192), (int)(((uint64_t)n_darts + 256ull * 32 - 1) / (256ull * 32)));
     hipLaunchKernelGGL(k_jump_finalize, dim3(fin_blocks), block, 0, st, n_darts, loc, loc_dist, entry_pos, a, fin,
-                       leader_list, leader_count, leader_shard_cap(n_darts));
+                       leader_list, leader_count, leader_shard_cap(n_darts), n_live);
     return hipGetLastError();
 }
 
 hipError_t launch_resolve(hipStream_t st, const JumpState* fin, uint32_t n_darts, int W, const uint64_t* d_rec, const uint32_t* leader_list,
-                          const unsigned int* leader_count, uint64_t* t_cur, uint64_t* t_next, DeviceCounters* ctr, int max_iters) {
+                          const unsigned int* leader_count, uint64_t* t_cur, uint64_t* t_next, DeviceCounters* ctr, int max_iters,
+                          const uint32_t* n_live) {
     const dim3 grid(blocks_for(n_darts, 256, 4096)), block(256);
     hipLaunchKernelGGL(k_resolve_fast, dim3(blocks_for(n_darts / 16 + 1, 256, 1024)), block, 0, st, fin, leader_list, leader_count,
                        leader_shard_cap(n_darts), W, d_rec, t_cur, ctr);
     if (max_iters <= 0) return hipGetLastError();   // the caller re-runs the batch with the full passes if k_resolve_fast asks for them
-    hipLaunchKernelGGL(k_resolve_init, grid, block, 0, st, fin, n_darts, t_cur, t_next, ctr);
+    hipLaunchKernelGGL(k_resolve_init, grid, block, 0, st, fin, n_darts, t_cur, t_next, ctr, n_live);
     for (int it = 0; it < max_iters; it++) {
-        hipLaunchKernelGGL(k_resolve_eval, grid, block, 0, st, fin, n_darts, W, d_rec, t_cur, t_next, it, ctr);
-        hipLaunchKernelGGL(k_resolve_commit, grid, block, 0, st, fin, n_darts, t_cur, t_next, it, it == max_iters - 1 ? 1 : 0, ctr);
+        hipLaunchKernelGGL(k_resolve_eval, grid, block, 0, st, fin, n_darts, W, d_rec, t_cur, t_next, it, ctr, n_live);
+        hipLaunchKernelGGL(k_resolve_commit, grid, block, 0, st, fin, n_darts, t_cur, t_next, it, it == max_iters - 1 ? 1 : 0, ctr, n_live);
     }
     return hipGetLastError();
 }
@@ -983,12 +1091,13 @@ hipError_t launch_select_scatter(hipStream_t st, const JumpState* fin, uint32_t 
                                  const unsigned int* leader_count, const uint32_t* d_succ, const uint64_t* t_cur,
                                  const uint32_t* frame_base, uint32_t n_frames, uint32_t first_frame, uint32_t min_edge_length,
                                  double eps_factor, double image_diag, uint32_t* cyc_slot, ContourRec* contours, uint32_t* cyc_start_off,
-                                 uint32_t max_contours, uint64_t max_points, DeviceCounters* ctr, const uint64_t* d_rec, uint32_t* points) {
+                                 uint32_t max_contours, uint64_t max_points, DeviceCounters* ctr, const uint64_t* d_rec, uint32_t* points,
+                                 const uint32_t* n_live) {
     const dim3 grid(blocks_for(n_darts, 256, 4096)), block(256);
     hipLaunchKernelGGL(k_cycle_select, dim3(blocks_for(n_darts / 64 + 1, 256, 1024)), block, 0, st, fin, leader_list, leader_count, d_succ, t_cur,
                        frame_base, n_frames, first_frame, min_edge_length,
                        eps_factor, image_diag, cyc_slot, contours, cyc_start_off, max_contours, max_points, ctr, leader_shard_cap(n_darts));
-    hipLaunchKernelGGL(k_scatter_points, grid, block, 0, st, fin, n_darts, d_rec, cyc_slot, contours, cyc_start_off, points);
+    hipLaunchKernelGGL(k_scatter_points, grid, block, 0, st, fin, n_darts, d_rec, cyc_slot, contours, cyc_start_off, points, n_live);
     return hipGetLastError();
 }
 

@@ -510,3 +510,20 @@ def test_start_resolution_fast_and_full_paths(dicts, oracle):
     rng = np.random.default_rng(5)
     noise = rng.integers(0, 256, size=(2, 200, 320, 3), dtype=np.uint8)
     _check(det, oracle, noise)
+
+
+def test_device_side_plan_and_its_fallback(dicts, oracle):
+    """A batch shaped like the previous one is planned on the device from the previous dart total (no read-back in the
+    middle of the pipeline).  Same-shape batches with a graph that is suddenly ~50x larger must fall back to the host
+    plan and still match the oracle; so must the batches after it."""
+    from aruco3_amd import synth
+
+    det = _detector(dicts, "ARUCO_DEFAULT")
+    clean, _ = synth.config_frames(1, 2)                      # 640x480, few thousand darts
+    rng = np.random.default_rng(11)
+    noise = rng.integers(0, 256, size=clean.shape, dtype=np.uint8)
+    darts = []
+    for frames in (clean, clean, noise, noise, clean, clean):
+        _check(det, oracle, frames)
+        darts.append(det._context().stats()["darts"])
+    assert darts[0] == darts[1] == darts[4] == darts[5] and darts[2] == darts[3] and darts[2] > 20 * darts[0]
