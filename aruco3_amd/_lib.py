@@ -20,7 +20,7 @@ STAGE_THRESHOLD, STAGE_CONTOUR, STAGE_DECODE = 0, 1, 2
 # every symbol include/aruco3_hip.h declares
 SYMBOLS = [
     "a3_abi_version", "a3_default_config", "a3_create", "a3_destroy", "a3_last_error", "a3_set_stream", "a3_set_pool_limits",
-    "a3_get_tau", "a3_set_debug_taps", "a3_detect_batch", "a3_detect_batch_pose", "a3_get_stats", "a3_debug_kernel_time", "a3_download_grey", "a3_download_thresholded",
+    "a3_get_tau", "a3_set_debug_taps", "a3_detect_batch", "a3_detect_batch_pose", "a3_detect_batch_submit", "a3_detect_batch_collect", "a3_get_stats", "a3_debug_kernel_time", "a3_download_grey", "a3_download_thresholded",
     "a3_candidate_count", "a3_download_candidates", "a3_download_homographies", "a3_estimate_pose", "a3_estimate_pose_normalized",
     "a3_find_nearest", "a3_calculate_tau", "a3_set_profiling", "a3_get_profile", "a3_selftest_ieee",
 ]
@@ -118,6 +118,10 @@ def load():
     L.a3_detect_batch.restype = C.c_int
     L.a3_detect_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_size_t, C.c_size_t, C.c_uint32, vp, C.c_size_t, u32p,
                                   C.POINTER(C.c_size_t)]
+    L.a3_detect_batch_submit.restype = C.c_int
+    L.a3_detect_batch_submit.argtypes = [vp, vp, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_size_t, C.c_size_t, C.c_uint32, C.c_size_t]
+    L.a3_detect_batch_collect.restype = C.c_int
+    L.a3_detect_batch_collect.argtypes = [vp, vp, C.c_size_t, u32p, C.POINTER(C.c_size_t)]
     L.a3_detect_batch_pose.restype = C.c_int
     L.a3_detect_batch_pose.argtypes = [vp, vp, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_size_t, C.c_size_t, C.c_uint32, C.c_float,
                                        C.POINTER(Intrinsics), vp, vp, C.c_size_t, u32p, C.POINTER(C.c_size_t)]
@@ -235,6 +239,21 @@ class Context:
         rc = load().a3_detect_batch(self.handle, C.c_void_p(pixels_ptr), memory, fmt, width, height, row_stride, frame_stride, n_frames,
                                     out.ctypes.data_as(C.c_void_p), cap, _p(per, C.c_uint32), C.byref(n))
         check(rc, self.handle)
+        return out[: n.value], per[:n_frames]
+
+    def submit(self, pixels_ptr: int, memory: int, fmt: int, width: int, height: int, row_stride: int, frame_stride: int, n_frames: int,
+               out_cap: int = 0):
+        """Enqueue a batch without waiting (a3_detect_batch_submit); `collect()` returns what detect_batch would."""
+        self._pending = (out_cap or max(64 * n_frames, 64), n_frames)
+        check(load().a3_detect_batch_submit(self.handle, C.c_void_p(pixels_ptr), memory, fmt, width, height, row_stride, frame_stride, n_frames,
+                                            self._pending[0]), self.handle)
+
+    def collect(self):
+        cap, n_frames = self._pending
+        out = np.empty(cap, dtype=MARKER_DTYPE)
+        per = np.zeros(max(n_frames, 1), dtype=np.uint32)
+        n = C.c_size_t()
+        check(load().a3_detect_batch_collect(self.handle, out.ctypes.data_as(C.c_void_p), cap, _p(per, C.c_uint32), C.byref(n)), self.handle)
         return out[: n.value], per[:n_frames]
 
     def detect_batch_pose(self, pixels_ptr: int, memory: int, fmt: int, width: int, height: int, row_stride: int, frame_stride: int,

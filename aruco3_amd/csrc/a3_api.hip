@@ -41,7 +41,7 @@ hipError_t launch_frame_candidates(hipStream_t, const CandRec*, const uint32_t*,
                                    uint32_t*, unsigned int*);
 size_t proj_rec_bytes();
 hipError_t launch_decode(hipStream_t, PixelSrc, int, int, uint32_t, const uint16_t*, const uint32_t*, const unsigned int*, uint32_t,
-                         uint32_t, uint32_t, uint32_t, const uint64_t*, uint32_t, uint32_t, int, void*, void*, uint8_t*, int);
+                         uint32_t, uint32_t, uint32_t, const uint64_t*, uint32_t, uint32_t, int, void*, void*, uint8_t*, int, int);
 hipError_t launch_compact_markers(hipStream_t, const void*, const uint16_t*, const uint32_t*, uint32_t, uint32_t, uint32_t, a3_marker*,
                                   uint32_t, uint32_t*, unsigned int*, unsigned int*);
 hipError_t launch_pose(hipStream_t, const uint32_t*, uint32_t, const float*, uint32_t, const unsigned int*, int, float, float, float, float,
@@ -82,6 +82,16 @@ struct DevBuf {
 };
 
 struct Chunk { uint32_t first, count; uint64_t darts; uint32_t max_frame_darts; };
+// what finish_batch needs to know about the batch enqueue_batch put on the stream
+struct Pending {
+    bool active = false, device_plan = false;
+    size_t n_chunks = 0, ctr_bytes = 0, head_pad = 0, pose_bytes = 0;
+    uint64_t chunk0_darts = 0;
+    uint32_t marker_cap = 0, guess = 0, n = 0, W = 0, H = 0;
+    int rounds_max = 0;
+    // the submitted call, for the synchronous re-run when the device asks for one
+    const uint8_t* pixels = nullptr; int fmt = 0; size_t row_stride = 0, frame_stride = 0;
+};
 
 }  // namespace
 
@@ -98,7 +108,10 @@ struct a3_ctx {
     // launch-count hints (every pass past convergence is an empty launch of ~5 us): start low, retry the batch with the
     // maximum if a pass count turns out too small
     int jump_rounds_hint = 10, resolve_iters_hint = 4;
-    uint32_t dbg_nd = 0, dbg_frames = 0, dbg_chunks = 0;   // a3_debug_kernel_time: shape of the last batch's contour graph
+    uint32_t dbg_nd = 0, dbg_frames = 0, dbg_chunks = 0;
+    PixelSrc dbg_src{};
+    Pending pending;
+    bool pending_trivial = false;   // a submitted batch with no frames / empty images   // a3_debug_kernel_time: shape of the last batch's contour graph
     int resolve_full_ttl = 0;
     // device-side planning: the previous batch of this shape fitted one chunk with plan_darts darts, so this one is enqueued
     // without reading the dart counts back first (k_plan); an overflow falls back to the host plan once (force_host_plan)
@@ -163,6 +176,16 @@ hipError_t wait_stream(hipStream_t st) {
     }
 }
 
+hipError_t wait_event(hipEvent_t ev, hipStream_t st) {
+    (void)hipStreamQuery(st);   // makes the runtime hand everything queued so far to the GPU; the event poll alone may not
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) return hipEventSynchronize(ev);
+    }
+}
+
 int ensure_pinned(a3_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->pinned_cap) return A3_OK;
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -197,8 +220,11 @@ int ensure_dart_pool(a3_ctx* ctx, uint64_t darts) {
 }
 
 // the whole pipeline for one batch; `pixels` is a device pointer here
-int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t H, size_t row_stride, size_t frame_stride, uint32_t n,
-              a3_marker* out, size_t out_cap, uint32_t* per_frame_count, size_t* out_n) {
+// One batch = enqueue_batch (every launch and the read-back copies, then an event) + finish_batch (wait for the event, check
+// the device's verdict, hand out the markers).  a3_detect_batch runs them back to back; a3_detect_batch_submit / _collect
+// let the caller enqueue the next batch (on another context) before collecting this one, so the GPU never waits for the host.
+int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t H, size_t row_stride, size_t frame_stride, uint32_t n,
+                  size_t out_cap) {
     hipStream_t st = ctx->stream;
     const size_t npx = (size_t)W * H;
     const uint32_t minwh = W < H ? W : H;
@@ -269,7 +295,10 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     uint32_t max_chunk_frames = 0; uint64_t max_chunk_darts = 0;
     for (auto& c : chunks) { max_chunk_frames = std::max(max_chunk_frames, c.count); max_chunk_darts = std::max(max_chunk_darts, c.darts); }
     ctx->stats.chunks = (uint32_t)chunks.size();
-    if (int rc = ensure_dart_pool(ctx, std::max<uint64_t>(max_chunk_darts, 1))) return rc;
+    // a single-chunk batch is followed by device-planned ones sized darts * 1.25 + 64k: allocate that now, not inside batch 2
+    uint64_t pool_darts = std::max<uint64_t>(max_chunk_darts, 1);
+    if (chunks.size() == 1) pool_darts = std::min<uint64_t>(std::max<uint64_t>(ctx->max_darts, pool_darts), pool_darts + pool_darts / 2 + 131072);
+    if (int rc = ensure_dart_pool(ctx, pool_darts)) return rc;
     A3_HIP(ctx->pix_base.ensure((size_t)max_chunk_frames * npx * 4));
     A3_HIP(ctx->frame_base.ensure((size_t)(max_chunk_frames + 1) * 4 * chunks.size()));
     const size_t ctr_bytes = sizeof(DeviceCounters) * chunks.size();
@@ -363,7 +392,8 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
                                    : PixelSrc{pixels, row_stride, frame_stride, fmt};
     A3_HIP(launch_decode(st, src, (int)W, (int)H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), d_work_count,
                          kMaxCand, S, ctx->mark_size, S, ctx->dict.as<uint64_t>(), ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors,
-                         ctx->proj.p, ctx->outs.p, ctx->debug_taps ? ctx->patches.as<uint8_t>() : nullptr, 4096));
+                         ctx->proj.p, ctx->outs.p, ctx->debug_taps ? ctx->patches.as<uint8_t>() : nullptr, 4096, 0));
+    ctx->dbg_src = src;
     A3_HIP(launch_compact_markers(st, ctx->outs.p, ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(), n, 0, kMaxCand,
                                   ctx->markers.as<a3_marker>(), marker_cap, ctx->per_frame, d_marker_total, d_err));
     if (ctx->want_pose) {   // IPPE on the device-resident marker list (src/pose.rs:52-81), no extra round trip
@@ -386,7 +416,27 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
     A3_HIP(hipMemcpyAsync(hp, ctx->zero_blk.p, head_bytes, hipMemcpyDeviceToHost, st));
     A3_HIP(hipMemcpyAsync(h_markers, ctx->markers.p, (size_t)guess * sizeof(a3_marker), hipMemcpyDeviceToHost, st));
     if (pose_bytes) A3_HIP(hipMemcpyAsync(h_poses, ctx->tmp_b.p, (size_t)guess * pose_bytes, hipMemcpyDeviceToHost, st));
-    A3_HIP(wait_stream(st));
+    A3_HIP(hipEventRecord(ctx->ev[4], st));
+    Pending& pd = ctx->pending;
+    pd.active = true; pd.n_chunks = chunks.size(); pd.chunk0_darts = chunks.empty() ? 0 : chunks[0].darts; pd.ctr_bytes = ctr_bytes;
+    pd.head_pad = head_pad; pd.marker_cap = marker_cap; pd.guess = guess; pd.pose_bytes = pose_bytes; pd.device_plan = device_plan;
+    pd.rounds_max = rounds_max; pd.n = n; pd.W = W; pd.H = H;
+    return A3_OK;
+}
+
+int finish_batch(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_frame_count, size_t* out_n) {
+    Pending& pd = ctx->pending;
+    if (!pd.active) return fail(ctx, A3_ERR_INVALID, "no batch was submitted");
+    pd.active = false;
+    hipStream_t st = ctx->stream;
+    const size_t ctr_bytes = pd.ctr_bytes, head_pad = pd.head_pad, pose_bytes = pd.pose_bytes, n_chunks = pd.n_chunks;
+    const uint32_t marker_cap = pd.marker_cap, guess = pd.guess, n = pd.n, W = pd.W, H = pd.H;
+    const bool device_plan = pd.device_plan;
+    const int rounds_max = pd.rounds_max;
+    uint8_t* hp = (uint8_t*)ctx->pinned;
+    a3_marker* h_markers = reinterpret_cast<a3_marker*>(hp + head_pad);
+    a3_pose* h_poses = reinterpret_cast<a3_pose*>(hp + head_pad + (size_t)marker_cap * sizeof(a3_marker));
+    A3_HIP(wait_event(ctx->ev[4], st));
     const unsigned int* hs = reinterpret_cast<const unsigned int*>(hp);
     const DeviceCounters* hc = reinterpret_cast<const DeviceCounters*>(hp + 256);
     if (device_plan) {
@@ -395,14 +445,14 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
         ctx->dbg_nd = hs[8];
         ctx->plan_darts = hs[8];
     } else {
-        ctx->plan_valid = chunks.size() == 1;
+        ctx->plan_valid = n_chunks == 1;
         ctx->plan_n = n; ctx->plan_W = W; ctx->plan_H = H;
-        ctx->plan_darts = chunks.size() == 1 ? chunks[0].darts : 0;
+        ctx->plan_darts = n_chunks == 1 ? pd.chunk0_darts : 0;
     }
     unsigned int flags = hs[4];
     uint64_t need_points = 0; uint32_t need_contours = 0;
     bool jump_short = false, resolve_needed = false;
-    for (size_t ci = 0; ci < chunks.size(); ci++) {
+    for (size_t ci = 0; ci < n_chunks; ci++) {
         flags |= hc[ci].err_flags;
         resolve_needed |= hc[ci].resolve_needed != 0;
         need_points = std::max<uint64_t>(need_points, hc[ci].points);
@@ -455,6 +505,12 @@ int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t 
         A3_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->prof_ms[A3_STAGE_DECODE] += ms; ctx->prof_n[A3_STAGE_DECODE]++;
     }
     return A3_OK;
+}
+
+int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t H, size_t row_stride, size_t frame_stride, uint32_t n,
+              a3_marker* out, size_t out_cap, uint32_t* per_frame_count, size_t* out_n) {
+    if (int rc = enqueue_batch(ctx, pixels, fmt, W, H, row_stride, frame_stride, n, out_cap)) return rc;
+    return finish_batch(ctx, out, out_cap, per_frame_count, out_n);
 }
 
 }  // namespace
@@ -580,39 +636,89 @@ int a3_get_tau(const a3_ctx* ctx, uint8_t* tau) {
     return A3_OK;
 }
 
-int a3_detect_batch(a3_ctx* ctx, const void* pixels, int memory, int fmt, uint32_t width, uint32_t height, size_t row_stride,
-                    size_t frame_stride, uint32_t n_frames, a3_marker* out, size_t out_cap, uint32_t* per_frame_count, size_t* out_n) {
-    if (!ctx) return A3_ERR_INVALID;
-    if (!out_n || (!out && out_cap)) return fail(ctx, A3_ERR_INVALID, "a3_detect_batch: null output");
-    *out_n = 0;
-    if (n_frames == 0) return A3_OK;
+// argument checks + H2D staging shared by the synchronous and the split entry points.  -> A3_OK, an error, or
+// kNothingToDo (no frames / empty images: the answer is "no markers").
+static constexpr int kNothingToDo = 2;
+static int stage_input(a3_ctx* ctx, const void* pixels, int memory, int fmt, uint32_t width, uint32_t height, size_t* row_stride,
+                       size_t* frame_stride, uint32_t n_frames, const uint8_t** d_pixels) {
+    if (n_frames == 0) return kNothingToDo;
     if (!pixels) return fail(ctx, A3_ERR_INVALID, "a3_detect_batch: null pixels");
     if (fmt != A3_FMT_RGB8 && fmt != A3_FMT_RGBA8 && fmt != A3_FMT_L8 && fmt != A3_FMT_BGRA8) return fail(ctx, A3_ERR_INVALID, "unknown pixel format");
-    if (width == 0 || height == 0) {  // an empty image has no contours
-        if (per_frame_count) memset(per_frame_count, 0, (size_t)n_frames * 4);
-        return A3_OK;
-    }
+    if (width == 0 || height == 0) return kNothingToDo;   // an empty image has no contours
     if (width > 65535 || height > 65535 || (uint64_t)width * height >= (1ull << 30))
         return fail(ctx, A3_ERR_INVALID, "image dimensions above 65535 (or 2^30 pixels) are not supported");
     const size_t bpp = fmt == A3_FMT_RGB8 ? 3 : (fmt == A3_FMT_L8 ? 1 : 4);
-    if (row_stride == 0) row_stride = (size_t)width * bpp;
-    if (row_stride < (size_t)width * bpp) return fail(ctx, A3_ERR_INVALID, "row_stride smaller than a row");
-    if (frame_stride == 0) frame_stride = row_stride * height;
-    if (frame_stride < row_stride * (height - 1) + (size_t)width * bpp) return fail(ctx, A3_ERR_INVALID, "frame_stride smaller than a frame");
+    if (*row_stride == 0) *row_stride = (size_t)width * bpp;
+    if (*row_stride < (size_t)width * bpp) return fail(ctx, A3_ERR_INVALID, "row_stride smaller than a row");
+    if (*frame_stride == 0) *frame_stride = *row_stride * height;
+    if (*frame_stride < *row_stride * (height - 1) + (size_t)width * bpp) return fail(ctx, A3_ERR_INVALID, "frame_stride smaller than a frame");
     A3_HIP(hipSetDevice(ctx->device));
-    const uint8_t* d_pixels = reinterpret_cast<const uint8_t*>(pixels);
+    *d_pixels = reinterpret_cast<const uint8_t*>(pixels);
     if (memory == A3_MEM_HOST) {
-        const size_t bytes = frame_stride * (n_frames - 1) + row_stride * (height - 1) + (size_t)width * bpp;
+        const size_t bytes = *frame_stride * (n_frames - 1) + *row_stride * (height - 1) + (size_t)width * bpp;
         A3_HIP(ctx->in.ensure(bytes));
         A3_HIP(hipMemcpyAsync(ctx->in.p, pixels, bytes, hipMemcpyHostToDevice, ctx->stream));
-        d_pixels = ctx->in.as<uint8_t>();
+        *d_pixels = ctx->in.as<uint8_t>();
     } else if (memory != A3_MEM_DEVICE) return fail(ctx, A3_ERR_INVALID, "memory must be A3_MEM_HOST or A3_MEM_DEVICE");
-    ctx->force_host_plan = false;
+    return A3_OK;
+}
+
+static int run_batch_with_retries(a3_ctx* ctx, const uint8_t* d_pixels, int fmt, uint32_t width, uint32_t height, size_t row_stride,
+                                  size_t frame_stride, uint32_t n_frames, a3_marker* out, size_t out_cap, uint32_t* per_frame_count, size_t* out_n) {
     for (int attempt = 0; attempt < 8; attempt++) {
         const int rc = run_batch(ctx, d_pixels, fmt, width, height, row_stride, frame_stride, n_frames, out, out_cap, per_frame_count, out_n);
         if (rc != 1) return rc;
     }
     return fail(ctx, A3_ERR_CAPACITY, "contour pools kept overflowing");
+}
+
+int a3_detect_batch(a3_ctx* ctx, const void* pixels, int memory, int fmt, uint32_t width, uint32_t height, size_t row_stride,
+                    size_t frame_stride, uint32_t n_frames, a3_marker* out, size_t out_cap, uint32_t* per_frame_count, size_t* out_n) {
+    if (!ctx) return A3_ERR_INVALID;
+    if (!out_n || (!out && out_cap)) return fail(ctx, A3_ERR_INVALID, "a3_detect_batch: null output");
+    *out_n = 0;
+    if (ctx->pending.active) return fail(ctx, A3_ERR_INVALID, "a submitted batch has not been collected");
+    const uint8_t* d_pixels = nullptr;
+    const int rc = stage_input(ctx, pixels, memory, fmt, width, height, &row_stride, &frame_stride, n_frames, &d_pixels);
+    if (rc == kNothingToDo) {
+        if (per_frame_count && n_frames) memset(per_frame_count, 0, (size_t)n_frames * 4);
+        return A3_OK;
+    }
+    if (rc != A3_OK) return rc;
+    ctx->force_host_plan = false;
+    return run_batch_with_retries(ctx, d_pixels, fmt, width, height, row_stride, frame_stride, n_frames, out, out_cap, per_frame_count, out_n);
+}
+
+int a3_detect_batch_submit(a3_ctx* ctx, const void* pixels, int memory, int fmt, uint32_t width, uint32_t height, size_t row_stride,
+                           size_t frame_stride, uint32_t n_frames, size_t out_cap) {
+    if (!ctx) return A3_ERR_INVALID;
+    if (ctx->pending.active || ctx->pending_trivial) return fail(ctx, A3_ERR_INVALID, "a submitted batch has not been collected");
+    const uint8_t* d_pixels = nullptr;
+    const int rc = stage_input(ctx, pixels, memory, fmt, width, height, &row_stride, &frame_stride, n_frames, &d_pixels);
+    if (rc == kNothingToDo) { ctx->pending_trivial = true; ctx->pending.n = n_frames; return A3_OK; }
+    if (rc != A3_OK) return rc;
+    ctx->force_host_plan = false;
+    ctx->want_pose = false;
+    Pending& pd = ctx->pending;
+    pd.pixels = d_pixels; pd.fmt = fmt; pd.row_stride = row_stride; pd.frame_stride = frame_stride;
+    return enqueue_batch(ctx, d_pixels, fmt, width, height, row_stride, frame_stride, n_frames, out_cap);
+}
+
+int a3_detect_batch_collect(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_frame_count, size_t* out_n) {
+    if (!ctx) return A3_ERR_INVALID;
+    if (!out_n || (!out && out_cap)) return fail(ctx, A3_ERR_INVALID, "a3_detect_batch_collect: null output");
+    *out_n = 0;
+    if (ctx->pending_trivial) {
+        ctx->pending_trivial = false;
+        if (per_frame_count && ctx->pending.n) memset(per_frame_count, 0, (size_t)ctx->pending.n * 4);
+        return A3_OK;
+    }
+    A3_HIP(hipSetDevice(ctx->device));
+    const Pending pd = ctx->pending;   // finish_batch clears .active
+    const int rc = finish_batch(ctx, out, out_cap, per_frame_count, out_n);
+    if (rc != 1) return rc;
+    // the device asked for a re-run (pool growth, more passes, host-side plan): do it synchronously
+    return run_batch_with_retries(ctx, pd.pixels, pd.fmt, pd.W, pd.H, pd.row_stride, pd.frame_stride, pd.n, out, out_cap, per_frame_count, out_n);
 }
 
 int a3_detect_batch_pose(a3_ctx* ctx, const void* pixels, int memory, int fmt, uint32_t width, uint32_t height, size_t row_stride,
@@ -660,7 +766,11 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
                                       ctx->loc_dist.as<uint32_t>(), ctx->entry_bits.as<uint32_t>(), ctx->entry_list.as<uint32_t>(),
                                       ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p, ctx->stB.as<JumpState>(),
                                       ctx->entry_bits.as<uint32_t>(), d_leader_count, 0, ctx->counters, nullptr, dbg ? dbg : 11));
-        } else return fail(ctx, A3_ERR_INVALID, "kernel: 0 dart_count, 1 dart_assign, 2 local_contract");
+        } else if (kernel == 3) {   // dbg < 0: k_decode alone (variant -dbg), dbg >= 0: k_projection + k_decode
+            A3_HIP(launch_decode(st, ctx->dbg_src, (int)ctx->W, (int)ctx->H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), ctx->scratch_u32,
+                                 kMaxCand, ctx->cfg.homography_sample_size, ctx->mark_size, ctx->cfg.homography_sample_size, ctx->dict.as<uint64_t>(),
+                                 ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors, ctx->proj.p, ctx->outs.p, nullptr, 4096, dbg));
+        } else return fail(ctx, A3_ERR_INVALID, "kernel: 0 dart_count, 1 dart_assign, 2 local_contract, 3 decode");
         A3_HIP(hipEventRecord(e1, st));
         A3_HIP(hipStreamSynchronize(st));
         float ms = 0;

@@ -31,6 +31,7 @@
 // Border pixels are found 64 at a time with word-wide bit operations on the packed image;
 // dart ranges are handed out with a block scan and one atomic per workgroup.
 #include <algorithm>
+#include <cstdlib>
 
 #include "a3_common.h"
 
@@ -969,6 +970,8 @@ __global__ void k_unpack_bits(const uint64_t* __restrict__ bits, int W, int H, u
 // ---------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------
+// grid caps of the per-dart sweeps, overridable for tuning (tools/sweep_grids.sh)
+static inline int env_cap(const char* name, int dflt) { const char* v = getenv(name); return v && atoi(v) > 0 ? atoi(v) : dflt; }
 static inline int blocks_for(uint64_t n, int per_block, int cap) {
     uint64_t b = (n + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -1038,7 +1041,7 @@ hipError_t launch_dart_build(hipStream_t st, const uint64_t* bits, int W, int H,
     hipLaunchKernelGGL(k_dart_assign, dim3(dart_tiles((uint32_t)W, (uint32_t)H), n_frames), dim3(256), 0, st, bits, W, H, first_frame, frame_base, tile_off,
                        pix_base, tile_darts, d_rec, d_succ, n_live, dbg);
     if (dbg && dbg != 5) return hipGetLastError();   // 5 = everything (the probe's reference point), others leave d_succ alone
-    hipLaunchKernelGGL(k_dart_link, dim3(blocks_for(n_darts, 256 * 4, 4096)), dim3(256), 0, st, W, H, first_frame, pix_base, bits, d_rec, d_succ, n_darts, n_live);
+    hipLaunchKernelGGL(k_dart_link, dim3(blocks_for(n_darts, 256, env_cap("A3_LINK_BLOCKS", 4096))), dim3(256), 0, st, W, H, first_frame, pix_base, bits, d_rec, d_succ, n_darts, n_live);
     return hipGetLastError();
 }
 
@@ -1066,7 +1069,7 @@ hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uin
         hipLaunchKernelGGL(k_entry_jump, grid, block, 0, st, a, b, entry_count, ecap, r, ctr);
         EntryState* t = a; a = b; b = t;
     }
-    const int fin_blocks = std::max(blocks_for(n_darts, 256, 8192), (int)(((uint64_t)n_darts + 256ull * 32 - 1) / (256ull * 32)));
+    const int fin_blocks = std::max(blocks_for(n_darts, 256, env_cap("A3_FIN_BLOCKS", 8192)), (int)(((uint64_t)n_darts + 256ull * 32 - 1) / (256ull * 32)));
     hipLaunchKernelGGL(k_jump_finalize, dim3(fin_blocks), block, 0, st, n_darts, loc, loc_dist, entry_pos, a, fin,
                        leader_list, leader_count, leader_shard_cap(n_darts), n_live);
     return hipGetLastError();
@@ -1093,7 +1096,7 @@ hipError_t launch_select_scatter(hipStream_t st, const JumpState* fin, uint32_t 
                                  double eps_factor, double image_diag, uint32_t* cyc_slot, ContourRec* contours, uint32_t* cyc_start_off,
                                  uint32_t max_contours, uint64_t max_points, DeviceCounters* ctr, const uint64_t* d_rec, uint32_t* points,
                                  const uint32_t* n_live) {
-    const dim3 grid(blocks_for(n_darts, 256, 4096)), block(256);
+    const dim3 grid(blocks_for(n_darts, 256, env_cap("A3_SCATTER_BLOCKS", 4096))), block(256);
     hipLaunchKernelGGL(k_cycle_select, dim3(blocks_for(n_darts / 64 + 1, 256, 1024)), block, 0, st, fin, leader_list, leader_count, d_succ, t_cur,
                        frame_base, n_frames, first_frame, min_edge_length,
                        eps_factor, image_diag, cyc_slot, contours, cyc_start_off, max_contours, max_points, ctr, leader_shard_cap(n_darts));

@@ -321,7 +321,8 @@ __global__ __launch_bounds__(256) void k_decode(PixelSrc src, int W, int H, uint
                                                 const unsigned int* __restrict__ work_count, uint32_t max_cand, uint32_t S, uint32_t n,
                                                 uint32_t max_taps, const uint64_t* __restrict__ dict, uint32_t n_codes, uint32_t tau,
                                                 int filter, const ProjRec* __restrict__ proj, DecodeOut* __restrict__ outs,
-                                                uint8_t* __restrict__ patches /*nullable*/) {
+                                                uint8_t* __restrict__ patches /*nullable*/, int dbg) {
+    // dbg (a3_debug_kernel_time only, 0 in the product path): 1 = no sampling, 2 / 3 / 4 = stop after sampling / Otsu / bits
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* s_patch = smem;
     size_t o = ((size_t)S * S + 15) & ~(size_t)15;
@@ -354,7 +355,9 @@ __global__ __launch_bounds__(256) void k_decode(PixelSrc src, int W, int H, uint
         const bool ok = s_ok != 0;
         const uint32_t pw = ok ? S : 1u, ph = pw;
         // warp_into: integer output coordinates, no centre offset, mapping = the projection's inverse
-        if (ok) {
+        if (ok && dbg == 1) {
+            for (uint32_t i = tid; i < S * S; i += 256) { s_patch[i] = (uint8_t)(i * 7u); atomicAdd(&s_hist[(i * 7u) & 255u], 1u); }
+        } else if (ok) {
             const float t0 = s_inv[0], t1 = s_inv[1], t2 = s_inv[2], t3 = s_inv[3], t4 = s_inv[4], t5 = s_inv[5], t6 = s_inv[6],
                         t7 = s_inv[7], t8 = s_inv[8];
             // kU samples per lane per trip: all their row reads (one 12-byte load per row and sample: the two taps of a row
@@ -387,6 +390,7 @@ __global__ __launch_bounds__(256) void k_decode(PixelSrc src, int W, int H, uint
             s_hist[0] = 1;
         }
         __syncthreads();
+        if (dbg == 2) continue;
         if (patches) {
             uint8_t* dst = patches + (size_t)slot * S * S;
             for (uint32_t i = tid; i < S * S; i += 256) dst[i] = ok ? s_patch[i] : 0;
@@ -437,6 +441,7 @@ __global__ __launch_bounds__(256) void k_decode(PixelSrc src, int W, int H, uint
                 s_otsu = bv > 0.0 ? (uint32_t)bt : 0u;
             }
         }
+        if (dbg == 3) continue;
         // resize weights (same table for both passes: the patch and the grid are square)
         if (tid >= 64 && tid < 64 + (int)n) {
             const uint32_t oi = tid - 64;
@@ -471,6 +476,7 @@ __global__ __launch_bounds__(256) void k_decode(PixelSrc src, int W, int H, uint
             }
         }
         __syncthreads();
+        if (dbg == 4) continue;
         // border test + 4 rotated codes, src/aruco.rs:287-310
         if (tid == 0) {
             int have = 1;
@@ -833,11 +839,11 @@ size_t proj_rec_bytes() { return sizeof(ProjRec); }
 
 hipError_t launch_decode(hipStream_t st, PixelSrc src, int W, int H, uint32_t first_frame, const uint16_t* fin_xy, const uint32_t* work,
                          const unsigned int* work_count, uint32_t max_cand, uint32_t S, uint32_t n, uint32_t max_taps, const uint64_t* dict,
-                         uint32_t n_codes, uint32_t tau, int filter, void* proj, void* outs, uint8_t* patches, int grid_blocks) {
-    hipLaunchKernelGGL(k_projection, dim3(256), dim3(64), 0, st, fin_xy, work, work_count, S, reinterpret_cast<ProjRec*>(proj));
+                         uint32_t n_codes, uint32_t tau, int filter, void* proj, void* outs, uint8_t* patches, int grid_blocks, int dbg) {
+    if (dbg >= 0) hipLaunchKernelGGL(k_projection, dim3(256), dim3(64), 0, st, fin_xy, work, work_count, S, reinterpret_cast<ProjRec*>(proj));
     hipLaunchKernelGGL(k_decode, dim3(grid_blocks), dim3(256), decode_lds_bytes(S, n, max_taps), st, src, W, H, first_frame, fin_xy, work,
                        work_count, max_cand, S, n, max_taps, dict, n_codes, tau, filter, reinterpret_cast<const ProjRec*>(proj),
-                       reinterpret_cast<DecodeOut*>(outs), patches);
+                       reinterpret_cast<DecodeOut*>(outs), patches, dbg < 0 ? -dbg : dbg);
     return hipGetLastError();
 }
 

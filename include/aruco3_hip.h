@@ -118,6 +118,14 @@ int  a3_detect_batch_pose(a3_ctx *ctx, const void *pixels, int memory, int fmt, 
                           size_t row_stride, size_t frame_stride, uint32_t n_frames, float marker_size_mm,
                           const a3_intrinsics *intr, a3_marker *out, a3_pose *poses, size_t out_cap,
                           uint32_t *per_frame_count, size_t *out_n);
+/* The same call in two halves, for callers that keep the GPU fed: submit enqueues the whole batch and returns without
+ * waiting; collect waits for it and hands out the results (re-running the batch synchronously in the rare cases a
+ *3_detect_batch would).  One batch may be in flight per context; with two contexts on one stream, batch i+1 is
+ * submitted before batch i is collected.  Device-resident frames must stay valid until collect; host frames are
+ * copied during submit.  out_cap of submit bounds the marker list; collect's must not be smaller than what was found. */
+int  a3_detect_batch_submit(a3_ctx *ctx, const void *pixels, int memory, int fmt, uint32_t width, uint32_t height,
+                            size_t row_stride, size_t frame_stride, uint32_t n_frames, size_t out_cap);
+int  a3_detect_batch_collect(a3_ctx *ctx, a3_marker *out, size_t out_cap, uint32_t *per_frame_count, size_t *out_n);
 int  a3_get_stats(const a3_ctx *ctx, a3_stats *stats);
 
 /* Detection.grey / .candidates / .homographies of the last batch (src/aruco.rs:16-21,115-120),

@@ -527,3 +527,44 @@ def test_device_side_plan_and_its_fallback(dicts, oracle):
         _check(det, oracle, frames)
         darts.append(det._context().stats()["darts"])
     assert darts[0] == darts[1] == darts[4] == darts[5] and darts[2] == darts[3] and darts[2] > 20 * darts[0]
+
+
+def test_submit_collect_equals_detect_batch(hip, dicts, oracle):
+    """a3_detect_batch_submit / _collect (two contexts on one stream, the next batch submitted before the previous one is
+    collected) return exactly what a3_detect_batch returns, including when the device asks for a synchronous re-run
+    (first use of a shape; a graph that outgrows the device-side plan)."""
+    import torch
+
+    from aruco3_amd import synth
+
+    frames, _ = synth.config_frames(1, 3)
+    rng = np.random.default_rng(3)
+    noise = rng.integers(0, 256, size=frames.shape, dtype=np.uint8)
+    n, h, w, c = frames.shape
+    ref = _detector(dicts, "ARUCO_DEFAULT")._context()
+    ref.set_debug_taps(False)
+    want = {}
+    for name, fr in (("clean", frames), ("noise", noise)):
+        want[name] = ref.detect_batch(fr.ctypes.data, hip.MEM_HOST, hip.FMT_RGB8, w, h, w * c, h * w * c, n)
+    stream = torch.cuda.Stream()
+    dev = {"clean": torch.from_numpy(frames).cuda(), "noise": torch.from_numpy(noise).cuda()}
+    torch.cuda.synchronize()
+    ctxs = [_detector(dicts, "ARUCO_DEFAULT")._context() for _ in range(2)]
+    for cx in ctxs:
+        cx.set_stream(stream.cuda_stream)
+        cx.set_debug_taps(False)
+    order = ["clean", "clean", "clean", "noise", "noise", "clean", "clean", "noise", "clean"]
+    args = lambda name: (dev[name].data_ptr(), hip.MEM_DEVICE, hip.FMT_RGB8, w, h, w * c, h * w * c, n)
+    ctxs[0].submit(*args(order[0]))
+    for i, name in enumerate(order):
+        if i + 1 < len(order):
+            ctxs[(i + 1) % 2].submit(*args(order[i + 1]))
+        markers, per = ctxs[i % 2].collect()
+        assert np.array_equal(per, want[name][1]) and np.array_equal(markers, want[name][0]), (i, name)
+    with pytest.raises(hip.A3Error):
+        ctxs[0].collect()            # nothing in flight
+    ctxs[0].submit(*args("clean"))
+    with pytest.raises(hip.A3Error):
+        ctxs[0].submit(*args("clean"))   # one batch per context
+    markers, per = ctxs[0].collect()
+    assert np.array_equal(markers, want["clean"][0])
