@@ -735,78 +735,106 @@ __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restric
                                                       double image_diag, uint32_t* __restrict__ cyc_slot, ContourRec* __restrict__ contours,
                                                       uint32_t* __restrict__ cyc_start_off, uint32_t max_contours, uint64_t max_points,
                                                       DeviceCounters* __restrict__ ctr, uint32_t shard_cap) {
-    const int lane = threadIdx.x & 63;
-    uint32_t n_traced = 0;
+    __shared__ uint32_t s_wave[4], s_wave_t[4];
+    __shared__ unsigned long long s_wave_p[4];
+    __shared__ uint32_t s_cbase;
+    __shared__ unsigned long long s_pbase;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // the leader list is 16 segments of shard_cap slots; segment s holds leader_count[s] entries
     uint32_t n_max = 0;
     for (uint32_t sh = 0; sh < kLeaderShards; sh++) n_max = max(n_max, leader_count[sh]);
-    const uint32_t span = (n_max + 63u) & ~63u;           // per-shard index space, padded so a wave never straddles shards
+    const uint32_t span = (n_max + 63u) & ~63u;           // per-shard index space
     const uint32_t n_leaders = span * kLeaderShards;
     const uint32_t stride = gridDim.x * blockDim.x;
-    // every lane of a wave runs the same number of iterations: the allocation below is wave-collective
-    for (uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; i0 < n_leaders; i0 += stride) {
-        const uint32_t sh = i0 / span, i = i0 - sh * span + lane;
-        const bool valid = i < leader_count[sh];
-        bool traced = false, keep = false, broken = false;
-        uint32_t n = 0, d = 0;
-        uint64_t t = kInf64;
-        if (valid) {
-            d = leader_list[(size_t)sh * shard_cap + i];
-            t = t_cur[d];
-            traced = t != kInf64;
-            if (traced) {
-                // the successor's window must have wrapped around to this leader, else this is a chain, not a cycle
-                const uint32_t sl = d_succ[d];
-                if (sl == d || (uint32_t)st[sl].key != d) broken = true;
-                else {
-                    n = st[sl].off + 1u;
-                    // Parity-safe pruning (src/aruco.rs:133-158):
-                    //  (1) a candidate keeps 4 points whose hull-adjacent pairs are >= sqrt(min_edge_length) apart; two
-                    //      border points i < j are at most min(j-i, n-(j-i)) 8-connected steps apart, i.e.
-                    //      dist^2 <= 2*(n/2)^2, so n^2 >= 2*min_edge_length is necessary;
-                    //  (2) Douglas-Peucker splits only when a point is further than eps = eps_factor*n from a chord,
-                    //      and no two pixels are further apart than the image diagonal (+1 slack for rounding).
-                    const double eps = (double)n * eps_factor;
-                    keep = n >= 5u && (uint64_t)n * n >= 2ull * min_edge_length && eps < image_diag + 1.0;
-                }
-            }
-        }
-        if (broken) atomicOr(&ctr->err_flags, kErrBrokenEvent);
-        // one atomic per wave and counter
-        const unsigned long long m_traced = __ballot(traced), m_keep = __ballot(keep);
-        n_traced += (uint32_t)__popcll(m_traced);   // wave-uniform; added to the global statistic once per wave at the end
-        uint32_t slot = kNone;
-        if (m_keep) {
-            uint32_t inc = keep ? n : 0u;   // wave inclusive scan of the point counts
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
-            const uint32_t total = __shfl(inc, 63);
-            uint32_t cbase = 0; unsigned long long pbase = 0;
-            if (lane == 0) { cbase = atomicAdd(&ctr->contours, (unsigned int)__popcll(m_keep)); pbase = atomicAdd(&ctr->points, (unsigned long long)total); }
-            cbase = __shfl(cbase, 0);
-            pbase = __shfl(pbase, 0);
-            if (keep) {
-                const uint32_t c = cbase + (uint32_t)__popcll(m_keep & ((1ull << lane) - 1ull));
-                const unsigned long long pb = pbase + (inc - n);
-                if (c >= max_contours) atomicOr(&ctr->err_flags, kErrContourTable);
-                else if (pb + n > max_points) atomicOr(&ctr->err_flags, kErrPointPool);
-                else {
-                    uint32_t lo = 0, hi = n_frames;  // frame of this dart: binary search in frame_base
-                    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (frame_base[mid] <= d) lo = mid; else hi = mid; }
-                    ContourRec r;
-                    r.frame = first_frame + lo;
-                    r.start_key = (uint32_t)(t >> 32);
-                    r.point_base = (uint32_t)pb;
-                    r.n = n;
-                    contours[c] = r;
-                    cyc_start_off[c] = st[(uint32_t)t].off;
-                    slot = c;
-                }
-            }
-        }
-        if (valid) cyc_slot[d] = slot;
+
+    // one leader: is its border traced, how long is it, is it worth materialising
+    struct Eval { bool valid, traced, keep, broken; uint32_t n, d; uint64_t t; };
+    auto eval = [&](uint32_t i0) -> Eval {
+        Eval e{false, false, false, false, 0u, 0u, kInf64};
+        const uint32_t sh = i0 / span, i = i0 - sh * span;
+        e.valid = i < leader_count[sh];
+        if (!e.valid) return e;
+        e.d = leader_list[(size_t)sh * shard_cap + i];
+        e.t = t_cur[e.d];
+        e.traced = e.t != kInf64;
+        if (!e.traced) return e;
+        // the successor's window must have wrapped around to this leader, else this is a chain, not a cycle
+        const uint32_t sl = d_succ[e.d];
+        if (sl == e.d || (uint32_t)st[sl].key != e.d) { e.broken = true; return e; }
+        e.n = st[sl].off + 1u;
+        // Parity-safe pruning (src/aruco.rs:133-158):
+        //  (1) a candidate keeps 4 points whose hull-adjacent pairs are >= sqrt(min_edge_length) apart; two
+        //      border points i < j are at most min(j-i, n-(j-i)) 8-connected steps apart, i.e.
+        //      dist^2 <= 2*(n/2)^2, so n^2 >= 2*min_edge_length is necessary;
+        //  (2) Douglas-Peucker splits only when a point is further than eps = eps_factor*n from a chord,
+        //      and no two pixels are further apart than the image diagonal (+1 slack for rounding).
+        const double eps = (double)e.n * eps_factor;
+        e.keep = e.n >= 5u && (uint64_t)e.n * e.n >= 2ull * min_edge_length && eps < image_diag + 1.0;
+        return e;
+    };
+
+    // Pass 1: what this workgroup will allocate.  Pass 2 re-evaluates (the loads hit the cache) and fills the slots.  The
+    // two global counters are bumped once per workgroup: per-wave bumps of one address serialise at ~11 ns each, which on
+    // noise frames (140 k borders per frame) was 1.6 ms of a 1.75 ms kernel.
+    uint32_t my_keep = 0, my_traced = 0;
+    unsigned long long my_points = 0;
+    bool broken = false;
+    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n_leaders; i0 += stride) {
+        const Eval e = eval(i0);
+        my_traced += e.traced; my_keep += e.keep; my_points += e.keep ? e.n : 0u;
+        broken |= e.broken;
     }
-    if (lane == 0 && n_traced) atomicAdd(&ctr->traced, n_traced);
+    if (broken) atomicOr(&ctr->err_flags, kErrBrokenEvent);
+    // exclusive scans of (keep count, point count) over the workgroup
+    uint32_t inc_k = my_keep, inc_t = my_traced;
+    unsigned long long inc_p = my_points;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t a = __shfl_up(inc_k, o), c = __shfl_up(inc_t, o);
+        const unsigned long long b2 = __shfl_up(inc_p, o);
+        if (lane >= o) { inc_k += a; inc_p += b2; inc_t += c; }
+    }
+    if (lane == 63) { s_wave[wave] = inc_k; s_wave_p[wave] = inc_p; s_wave_t[wave] = inc_t; }
+    __syncthreads();
+    uint32_t base_k = 0, tot_k = 0;
+    unsigned long long base_p = 0, tot_p = 0;
+    for (int w = 0; w < 4; w++) {
+        if (w < wave) { base_k += s_wave[w]; base_p += s_wave_p[w]; }
+        tot_k += s_wave[w]; tot_p += s_wave_p[w];
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t tot_t = s_wave_t[0] + s_wave_t[1] + s_wave_t[2] + s_wave_t[3];
+        if (tot_t) atomicAdd(&ctr->traced, tot_t);
+        s_cbase = tot_k ? atomicAdd(&ctr->contours, tot_k) : 0u;
+        s_pbase = tot_k ? atomicAdd(&ctr->points, tot_p) : 0ull;
+    }
+    __syncthreads();
+    uint32_t c = s_cbase + base_k + (inc_k - my_keep);
+    unsigned long long pb = s_pbase + base_p + (inc_p - my_points);
+
+    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n_leaders; i0 += stride) {
+        const Eval e = eval(i0);
+        if (!e.valid) continue;
+        uint32_t slot = kNone;
+        if (e.keep) {
+            if (c >= max_contours) atomicOr(&ctr->err_flags, kErrContourTable);
+            else if (pb + e.n > max_points) atomicOr(&ctr->err_flags, kErrPointPool);
+            else {
+                uint32_t lo = 0, hi = n_frames;  // frame of this dart: binary search in frame_base
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (frame_base[mid] <= e.d) lo = mid; else hi = mid; }
+                ContourRec r;
+                r.frame = first_frame + lo;
+                r.start_key = (uint32_t)(e.t >> 32);
+                r.point_base = (uint32_t)pb;
+                r.n = e.n;
+                contours[c] = r;
+                cyc_start_off[c] = st[(uint32_t)e.t].off;
+                slot = c;
+            }
+            c++; pb += e.n;
+        }
+        cyc_slot[e.d] = slot;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restrict__ st, uint32_t n_darts, const uint64_t* __restrict__ d_rec,
@@ -880,16 +908,22 @@ __device__ bool hull4(const int* __restrict__ in /*8*/, int* __restrict__ out /*
     return true;
 }
 
+// G lanes work on one border: 64 for long ones, 16 (four borders per wave) for the short ones that noisy frames produce by
+// the hundred thousand -- a full wave per 20-point border is latency with 60 idle lanes.  Control flow is uniform inside a
+// group and the shuffles stay inside it.
+constexpr uint32_t kSmallBorder = 64;
+template <int G>
 __global__ __launch_bounds__(256) void k_contour_quads(const ContourRec* __restrict__ contours, const DeviceCounters* __restrict__ ctr,
                                                        uint32_t max_contours, const uint32_t* __restrict__ points, double eps_factor,
                                                        uint32_t min_edge_length, uint32_t first_frame, uint32_t max_cand,
                                                        CandRec* __restrict__ cands, uint32_t* __restrict__ cand_count,
                                                        unsigned int* __restrict__ err_flags) {
     const uint32_t n_contours = min(ctr->contours, max_contours);
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & (G - 1);
+    const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) / G, n_waves = (gridDim.x * blockDim.x) / G;
     for (uint32_t c = wave_global; c < n_contours; c += n_waves) {
         const ContourRec r = contours[c];
+        if ((r.n <= kSmallBorder) != (G == 16)) continue;   // the other instantiation's share
         const uint32_t* P = points + r.point_base;
         const uint32_t n = r.n;
         const double eps = (double)n * eps_factor;  // c.points.len() as f64 * epsilon, src/aruco.rs:133
@@ -906,14 +940,15 @@ __global__ __launch_bounds__(256) void k_contour_quads(const ContourRec* __restr
             const long long ax = pa & 0xFFFF, ay = pa >> 16, bx = pb & 0xFFFF, by = pb >> 16;
             const long long la = ay - by, lb = bx - ax, lc = ax * by - bx * ay;
             unsigned long long best = 0;  // (|num| << 32) | ~index : max picks largest num, then smallest index
-            for (uint32_t i = a + 1 + lane; i <= b; i += 64) {
+            for (uint32_t i = a + 1 + lane; i <= b; i += G) {
                 const uint32_t p = P[i];
                 long long num = la * (long long)(p & 0xFFFF) + lb * (long long)(p >> 16) + lc;
                 if (num < 0) num = -num;
                 const unsigned long long cand = ((unsigned long long)num << 32) | (unsigned long long)(~i);
                 if (cand > best) best = cand;
             }
-            for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) {
                 const unsigned long long other = __shfl_xor(best, o);
                 if (other > best) best = other;
             }
@@ -1109,7 +1144,9 @@ hipError_t launch_select_scatter(hipStream_t st, const JumpState* fin, uint32_t 
 hipError_t launch_contour_quads(hipStream_t st, const ContourRec* contours, const DeviceCounters* ctr, uint32_t max_contours,
                                 const uint32_t* points, double eps_factor, uint32_t min_edge_length, uint32_t first_frame, uint32_t max_cand,
                                 CandRec* cands, uint32_t* cand_count, unsigned int* err_flags) {
-    hipLaunchKernelGGL(k_contour_quads, dim3(1024), dim3(256), 0, st, contours, ctr, max_contours, points, eps_factor, min_edge_length,
+    hipLaunchKernelGGL(k_contour_quads<16>, dim3(1024), dim3(256), 0, st, contours, ctr, max_contours, points, eps_factor, min_edge_length,
+                       first_frame, max_cand, cands, cand_count, err_flags);
+    hipLaunchKernelGGL(k_contour_quads<64>, dim3(1024), dim3(256), 0, st, contours, ctr, max_contours, points, eps_factor, min_edge_length,
                        first_frame, max_cand, cands, cand_count, err_flags);
     return hipGetLastError();
 }

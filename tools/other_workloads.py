@@ -14,13 +14,16 @@ def timeit(fn, iters):
     for _ in range(iters): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / iters
 
-def gpu_vs_cpu(name, frames, dname, iters=5, extra=None):
+def gpu_vs_cpu(name, frames, dname, iters=5, extra=None, pose_mm=None):
     d = ARDictionary.new_from_named_dict(dname)
     det = Detector(DetectorConfig(), d); ctx = det._context(); ctx.set_profiling(True)
     t = torch.from_numpy(frames).cuda(); n, h, w, c = frames.shape
     res = {}
     def step():
-        res['m'], res['p'] = ctx.detect_batch(t.data_ptr(), _lib.MEM_DEVICE, _lib.FMT_RGB8, w, h, w * c, h * w * c, n, out_cap=n * 64)
+        if pose_mm:   # detect + IPPE pose of every marker in one device pass (a3_detect_batch_pose)
+            res['m'], res['p'], res['poses'] = ctx.detect_batch_pose(t.data_ptr(), _lib.MEM_DEVICE, _lib.FMT_RGB8, w, h, w * c, h * w * c, n, pose_mm, None, n * 64)
+        else:
+            res['m'], res['p'] = ctx.detect_batch(t.data_ptr(), _lib.MEM_DEVICE, _lib.FMT_RGB8, w, h, w * c, h * w * c, n, out_cap=n * 64)
         if extra: extra(res['m'])
     dt = timeit(step, iters)
     k = min(n, 8); t0 = time.perf_counter()
@@ -35,4 +38,8 @@ gpu_vs_cpu('C0 noise 1920x1080 x32', noise, 'ARUCO', iters=3)
 f4, _ = synth.config_frames(4, 32)
 gpu_vs_cpu('C4 apriltag36h11 1280x720 sigma8 x32', f4, 'APRILTAG_36H11', iters=3)
 f5, _ = synth.config_frames(5, 8)
-gpu_vs_cpu('C5 3840x2160 x8 detect+pose', f5, 'ARUCO', iters=5, extra=lambda m: pose.solve_batch(m['corners'], 40.0, (3840, 2160)) if len(m) else None)
+gpu_vs_cpu('C5 3840x2160 x8 detect+pose', f5, 'ARUCO', iters=5, pose_mm=40.0)
+f5b, _ = synth.config_frames(5, 32)
+gpu_vs_cpu('C5 3840x2160 x32 detect+pose', f5b, 'ARUCO', iters=5, pose_mm=40.0)
+f1, _ = synth.config_frames(1, 1)
+gpu_vs_cpu('C1 640x480 x1 (latency of one small frame)', f1, 'ARUCO_DEFAULT', iters=20)
