@@ -53,14 +53,14 @@ def pack_detections(markers: np.ndarray, per_frame: np.ndarray, first_frame: int
     head[:, 0] = np.minimum(per_frame, MAXM)
     head[:, 1] = np.arange(first_frame, first_frame + n, dtype=np.uint32)
     body = rec[:, 8:].reshape(n, MAXM, _REC_BYTES)
-    raw = markers.view(np.uint8).reshape(-1, _REC_BYTES)
-    pos = 0
-    for f in range(n):
-        c = int(per_frame[f])
-        k = min(c, MAXM)
-        if k:
-            body[f, :k] = raw[pos: pos + k]
-        pos += c
+    total = int(per_frame.sum())
+    if total:
+        raw = np.ascontiguousarray(markers[:total]).view(np.uint8).reshape(total, _REC_BYTES)
+        counts = per_frame.astype(np.int64)
+        frame_of = np.repeat(np.arange(n), counts)                      # frame of every marker (markers are frame-major)
+        rank_in_frame = np.arange(total) - np.repeat(np.cumsum(counts) - counts, counts)
+        keep = rank_in_frame < MAXM
+        body[frame_of[keep], rank_in_frame[keep]] = raw[keep]
     return rec
 
 
