@@ -41,7 +41,7 @@ hipError_t launch_frame_candidates(hipStream_t, const CandRec*, const uint32_t*,
                                    uint32_t*, unsigned int*);
 size_t proj_rec_bytes();
 hipError_t launch_decode(hipStream_t, PixelSrc, int, int, uint32_t, const uint16_t*, const uint32_t*, const unsigned int*, uint32_t,
-                         uint32_t, uint32_t, uint32_t, const uint64_t*, uint32_t, uint32_t, int, void*, void*, uint8_t*, int, int);
+                         uint32_t, uint32_t, uint32_t, const uint64_t*, uint32_t, uint32_t, int, void*, void*, uint8_t*, uint32_t*, int, int);
 hipError_t launch_compact_markers(hipStream_t, const void*, const uint16_t*, const uint32_t*, uint32_t, uint32_t, uint32_t, a3_marker*,
                                   uint32_t, uint32_t*, unsigned int*, unsigned int*);
 hipError_t launch_pose(hipStream_t, const uint32_t*, uint32_t, const float*, uint32_t, const unsigned int*, int, float, float, float, float,
@@ -392,7 +392,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
                                    : PixelSrc{pixels, row_stride, frame_stride, fmt};
     A3_HIP(launch_decode(st, src, (int)W, (int)H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), d_work_count,
                          kMaxCand, S, ctx->mark_size, S, ctx->dict.as<uint64_t>(), ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors,
-                         ctx->proj.p, ctx->outs.p, ctx->debug_taps ? ctx->patches.as<uint8_t>() : nullptr, 4096, 0));
+                         ctx->proj.p, ctx->outs.p, ctx->debug_taps ? ctx->patches.as<uint8_t>() : nullptr, ctx->per_frame, 4096, 0));
     ctx->dbg_src = src;
     A3_HIP(launch_compact_markers(st, ctx->outs.p, ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(), n, 0, kMaxCand,
                                   ctx->markers.as<a3_marker>(), marker_cap, ctx->per_frame, d_marker_total, d_err));
@@ -472,7 +472,7 @@ int finish_batch(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_fram
         if (!ran) return 1;                // they were not launched this time: re-run
     } else if (ctx->resolve_full_ttl > 0) ctx->resolve_full_ttl--;
     if ((flags & kErrResolve) && ctx->resolve_iters_hint < kResolveItersMax) { ctx->resolve_iters_hint = kResolveItersMax; return 1; }
-    ctx->jump_rounds_hint = std::max(4, std::min(32, (int)ctx->stats.jump_rounds + 2));   // follow the workload, both ways
+    ctx->jump_rounds_hint = std::max(4, std::min(32, (int)ctx->stats.jump_rounds + 2));   // follow the workload, both ways (one round of slack: a short launch costs a re-run)
     if (flags & (kErrPointPool | kErrContourTable)) {
         // grow and let the caller loop re-run the batch
         if (need_points > ctx->max_points) ctx->max_points = std::min<uint64_t>(kHardMaxPoints, std::max(need_points, ctx->max_points * 2));
@@ -769,7 +769,7 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
         } else if (kernel == 3) {   // dbg < 0: k_decode alone (variant -dbg), dbg >= 0: k_projection + k_decode
             A3_HIP(launch_decode(st, ctx->dbg_src, (int)ctx->W, (int)ctx->H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), ctx->scratch_u32,
                                  kMaxCand, ctx->cfg.homography_sample_size, ctx->mark_size, ctx->cfg.homography_sample_size, ctx->dict.as<uint64_t>(),
-                                 ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors, ctx->proj.p, ctx->outs.p, nullptr, 4096, dbg));
+                                 ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors, ctx->proj.p, ctx->outs.p, nullptr, nullptr, 4096, dbg));
         } else return fail(ctx, A3_ERR_INVALID, "kernel: 0 dart_count, 1 dart_assign, 2 local_contract, 3 decode");
         A3_HIP(hipEventRecord(e1, st));
         A3_HIP(hipStreamSynchronize(st));

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void k_decode(PixelSrc src, int W, int H, uint
                                                 const unsigned int* __restrict__ work_count, uint32_t max_cand, uint32_t S, uint32_t n,
                                                 uint32_t max_taps, const uint64_t* __restrict__ dict, uint32_t n_codes, uint32_t tau,
                                                 int filter, const ProjRec* __restrict__ proj, DecodeOut* __restrict__ outs,
-                                                uint8_t* __restrict__ patches /*nullable*/, int dbg) {
+                                                uint8_t* __restrict__ patches /*nullable*/, uint32_t* __restrict__ per_frame /*nullable*/, int dbg) {
     // dbg (a3_debug_kernel_time only, 0 in the product path): 1 = no sampling, 2 / 3 / 4 = stop after sampling / Otsu / bits
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* s_patch = smem;
@@ -559,11 +559,60 @@ __global__ __launch_bounds__(256) void k_decode(PixelSrc src, int W, int H, uint
                 out.hamming = (uint8_t)min_code_distance;
             }
             outs[slot] = out;
+            if (out.valid && per_frame) atomicAdd(&per_frame[first_frame + fl], 1u);   // one address per frame: no contention to speak of
         }
     }
 }
 
-// gather the accepted markers, frame by frame, candidate order preserved.  Single block.
+// gather the accepted markers, frame by frame, candidate order preserved: one wave per frame.  per_frame[] already holds
+// the number of accepted candidates of every frame (k_decode counted them), so a frame's first output slot is a sum over
+// the frames before it, which every wave forms for itself (n_frames is a few hundred; the single-workgroup kernel below
+// takes over beyond kCompactParMax frames).
+constexpr uint32_t kCompactParMax = 4096;
+__global__ __launch_bounds__(256) void k_compact_markers_par(const DecodeOut* __restrict__ outs, const uint16_t* __restrict__ fin_xy,
+                                                             const uint32_t* __restrict__ fin_count, uint32_t n_frames, uint32_t max_cand,
+                                                             a3_marker* __restrict__ markers, uint32_t marker_cap,
+                                                             const uint32_t* __restrict__ per_frame, unsigned int* __restrict__ marker_total,
+                                                             unsigned int* __restrict__ err_flags) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t f = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (f >= n_frames) return;
+    uint32_t base = 0;
+    for (uint32_t g = lane; g < f; g += 64) base += per_frame[g];
+    for (int o = 32; o > 0; o >>= 1) base += __shfl_xor(base, o);
+    if (f + 1 == n_frames && lane == 0) *marker_total = base + per_frame[f];
+    const uint32_t c = fin_count[f];
+    uint32_t pos = base;
+    for (uint32_t k0 = 0; k0 < c; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        DecodeOut o;
+        o.valid = 0;
+        if (k < c) o = outs[(size_t)f * max_cand + k];
+        const unsigned long long m = __ballot(o.valid != 0);
+        if (o.valid) {
+            const uint32_t p = pos + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (p < marker_cap) {
+                a3_marker mk;
+                mk.frame = f;
+                mk.id = o.id;
+                mk.code = o.code;
+                const uint16_t* q = fin_xy + ((size_t)f * max_cand + k) * 8;
+                for (int i = 0; i < 4; i++) {  // corners.rotate_left(min_rotation), src/aruco.rs:103
+                    const int s2 = (i + o.rotation) & 3;
+                    mk.corners[2 * i] = q[2 * s2];
+                    mk.corners[2 * i + 1] = q[2 * s2 + 1];
+                }
+                mk.hamming_distance = o.hamming;
+                mk.rotation = o.rotation;
+                mk.candidate_index = (uint16_t)k;
+                markers[p] = mk;
+            } else atomicOr(err_flags, kErrCandTable);
+        }
+        pos += (uint32_t)__popcll(m);
+    }
+}
+
+// The same with one workgroup and no pre-computed counts (any number of frames).
 __global__ __launch_bounds__(256) void k_compact_markers(const DecodeOut* __restrict__ outs, const uint16_t* __restrict__ fin_xy,
                                                          const uint32_t* __restrict__ fin_count, uint32_t n_frames, uint32_t first_frame,
                                                          uint32_t max_cand, a3_marker* __restrict__ markers, uint32_t marker_cap,
@@ -839,11 +888,11 @@ size_t proj_rec_bytes() { return sizeof(ProjRec); }
 
 hipError_t launch_decode(hipStream_t st, PixelSrc src, int W, int H, uint32_t first_frame, const uint16_t* fin_xy, const uint32_t* work,
                          const unsigned int* work_count, uint32_t max_cand, uint32_t S, uint32_t n, uint32_t max_taps, const uint64_t* dict,
-                         uint32_t n_codes, uint32_t tau, int filter, void* proj, void* outs, uint8_t* patches, int grid_blocks, int dbg) {
+                         uint32_t n_codes, uint32_t tau, int filter, void* proj, void* outs, uint8_t* patches, uint32_t* per_frame, int grid_blocks, int dbg) {
     if (dbg >= 0) hipLaunchKernelGGL(k_projection, dim3(256), dim3(64), 0, st, fin_xy, work, work_count, S, reinterpret_cast<ProjRec*>(proj));
     hipLaunchKernelGGL(k_decode, dim3(grid_blocks), dim3(256), decode_lds_bytes(S, n, max_taps), st, src, W, H, first_frame, fin_xy, work,
                        work_count, max_cand, S, n, max_taps, dict, n_codes, tau, filter, reinterpret_cast<const ProjRec*>(proj),
-                       reinterpret_cast<DecodeOut*>(outs), patches, dbg < 0 ? -dbg : dbg);
+                       reinterpret_cast<DecodeOut*>(outs), patches, per_frame, dbg < 0 ? -dbg : dbg);
     return hipGetLastError();
 }
 
@@ -852,8 +901,12 @@ size_t decode_out_bytes() { return sizeof(DecodeOut); }
 hipError_t launch_compact_markers(hipStream_t st, const void* outs, const uint16_t* fin_xy, const uint32_t* fin_count, uint32_t n_frames,
                                   uint32_t first_frame, uint32_t max_cand, a3_marker* markers, uint32_t marker_cap, uint32_t* per_frame,
                                   unsigned int* marker_total, unsigned int* err_flags) {
-    hipLaunchKernelGGL(k_compact_markers, dim3(1), dim3(256), 0, st, reinterpret_cast<const DecodeOut*>(outs), fin_xy, fin_count, n_frames,
-                       first_frame, max_cand, markers, marker_cap, per_frame, marker_total, err_flags);
+    if (first_frame == 0 && n_frames <= kCompactParMax)
+        hipLaunchKernelGGL(k_compact_markers_par, dim3((n_frames + 3) / 4), dim3(256), 0, st, reinterpret_cast<const DecodeOut*>(outs), fin_xy, fin_count,
+                           n_frames, max_cand, markers, marker_cap, per_frame, marker_total, err_flags);
+    else
+        hipLaunchKernelGGL(k_compact_markers, dim3(1), dim3(256), 0, st, reinterpret_cast<const DecodeOut*>(outs), fin_xy, fin_count, n_frames,
+                           first_frame, max_cand, markers, marker_cap, per_frame, marker_total, err_flags);
     return hipGetLastError();
 }
 
