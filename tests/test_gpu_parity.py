@@ -568,3 +568,71 @@ def test_submit_collect_equals_detect_batch(hip, dicts, oracle):
         ctxs[0].submit(*args("clean"))   # one batch per context
     markers, per = ctxs[0].collect()
     assert np.array_equal(markers, want["clean"][0])
+
+
+def _fuzz_frame(rng, h, w, kind):
+    """Structured random content: rectangles / rotated quads / strokes / speckle on a gradient, optional noise."""
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = (120 + 60 * np.sin(xx / max(w, 1) * rng.uniform(1, 9)) + 40 * np.cos(yy / max(h, 1) * rng.uniform(1, 9))).astype(np.float32)
+    img = base.copy()
+    for _ in range(int(rng.integers(1, 9))):
+        if kind == "quads" and min(h, w) > 24:
+            cx, cy = rng.uniform(0, w), rng.uniform(0, h)
+            a, s = rng.uniform(0, np.pi), rng.uniform(4, min(h, w) / 2)
+            u = (xx - cx) * np.cos(a) + (yy - cy) * np.sin(a)
+            v = -(xx - cx) * np.sin(a) + (yy - cy) * np.cos(a)
+            m = (np.abs(u) < s) & (np.abs(v) < s * rng.uniform(0.3, 1.0))
+            img[m] = rng.choice([15.0, 240.0])
+            if rng.random() < 0.6:
+                img[(np.abs(u) < s * 0.6) & (np.abs(v) < s * 0.3)] = rng.choice([15.0, 240.0])
+        elif kind == "strokes":
+            x0, y0, x1, y1 = rng.uniform(0, w), rng.uniform(0, h), rng.uniform(0, w), rng.uniform(0, h)
+            t = np.linspace(0, 1, 4 * max(h, w))
+            xs, ys = np.clip((x0 + (x1 - x0) * t).astype(int), 0, w - 1), np.clip((y0 + (y1 - y0) * t).astype(int), 0, h - 1)
+            img[ys, xs] = 20.0
+        else:
+            x0, y0 = int(rng.integers(0, w)), int(rng.integers(0, h))
+            x1, y1 = min(w, x0 + int(rng.integers(1, max(2, w // 2)))), min(h, y0 + int(rng.integers(1, max(2, h // 2))))
+            img[y0:y1, x0:x1] = rng.choice([10.0, 245.0])
+    if rng.random() < 0.5:
+        img += rng.normal(0, rng.uniform(1, 25), img.shape)
+    if rng.random() < 0.3:
+        sp = rng.random(img.shape) < 0.02
+        img[sp] = rng.choice([0.0, 255.0])
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_randomised_structured_frames_full_parity(dicts, oracle, seed):
+    """Fuzz: odd sizes (not multiples of 16 / 64, narrower than a lane, taller than wide), 1 / 3 / 4 channels, shapes cut by
+    every image edge, thin strokes, speckle and noise -- every stage against the oracle, product path and tapped path."""
+    rng = np.random.default_rng(1000 + seed)
+    det = _detector(dicts, ["ARUCO", "ARUCO_MIP_36H12", "APRILTAG_16H5"][seed % 3])
+    for case in range(5):
+        h = int(rng.choice([1, 2, 7, 16, 33, 64, 65, 127, 200, 311]))
+        w = int(rng.choice([1, 3, 15, 16, 17, 63, 64, 65, 130, 257, 400]))
+        c = int(rng.choice([1, 3, 4]))
+        n = int(rng.integers(1, 5))
+        kind = ["rects", "quads", "strokes"][int(rng.integers(0, 3))]
+        frames = np.stack([np.repeat(_fuzz_frame(rng, h, w, kind)[..., None], c, axis=2) for _ in range(n)])
+        if c >= 3:   # decorrelate the channels a little so that the luma weights matter
+            frames[..., 1] = np.clip(frames[..., 1].astype(np.int16) + rng.integers(-20, 21), 0, 255).astype(np.uint8)
+        _check(det, oracle, frames if c > 1 else frames[..., 0][..., None])
+
+
+def test_many_small_frames_in_one_batch(dicts, oracle):
+    """Per-frame bookkeeping under load: 600 frames of 96x80 (several per wave everywhere), a sample checked in full,
+    every frame's marker list against the oracle."""
+    from aruco3_amd import synth
+
+    d = dicts.new_from_named_dict("ARUCO_DEFAULT")
+    det = _detector(dicts, "ARUCO_DEFAULT")
+    spec = synth.SynthSpec(96, 80, n_markers=(0, 1), side=(40.0, 60.0), min_center_sep=60.0)
+    frames = np.stack([synth.render_frame(spec, d.code_list, d.num_bits, 5000 + i)[0] for i in range(600)])
+    ctx, markers, per = _run(det, frames, populate=False)
+    pos, found = 0, 0
+    for f in range(len(frames)):
+        res = oracle.detect(frames[f], d.code_list, d.num_bits, d._tau)
+        assert markers_of_hip(markers[pos: pos + int(per[f])]) == markers_of_oracle(res), f
+        pos += int(per[f]); found += int(per[f])
+    assert pos == len(markers) and found > 100
