@@ -20,7 +20,7 @@ STAGE_THRESHOLD, STAGE_CONTOUR, STAGE_DECODE = 0, 1, 2
 # every symbol include/aruco3_hip.h declares
 SYMBOLS = [
     "a3_abi_version", "a3_default_config", "a3_create", "a3_destroy", "a3_last_error", "a3_set_stream", "a3_set_pool_limits",
-    "a3_get_tau", "a3_set_debug_taps", "a3_detect_batch", "a3_detect_batch_pose", "a3_detect_batch_submit", "a3_detect_batch_collect", "a3_get_stats", "a3_debug_kernel_time", "a3_download_grey", "a3_download_thresholded",
+    "a3_get_tau", "a3_set_debug_taps", "a3_detect_batch", "a3_detect_batch_pose", "a3_detect_batch_submit", "a3_detect_batch_collect", "a3_get_stats", "a3_debug_kernel_time", "a3_synth_render", "a3_download_grey", "a3_download_thresholded",
     "a3_candidate_count", "a3_download_candidates", "a3_download_homographies", "a3_estimate_pose", "a3_estimate_pose_normalized",
     "a3_find_nearest", "a3_calculate_tau", "a3_set_profiling", "a3_get_profile", "a3_selftest_ieee",
 ]
@@ -125,6 +125,9 @@ def load():
     L.a3_detect_batch_pose.restype = C.c_int
     L.a3_detect_batch_pose.argtypes = [vp, vp, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_size_t, C.c_size_t, C.c_uint32, C.c_float,
                                        C.POINTER(Intrinsics), vp, vp, C.c_size_t, u32p, C.POINTER(C.c_size_t)]
+    L.a3_synth_render.restype = C.c_int
+    L.a3_synth_render.argtypes = [C.c_int, vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_float, C.c_float, C.c_int,
+                                  vp, C.c_size_t, C.c_size_t]
     L.a3_debug_kernel_time.restype = C.c_int
     L.a3_debug_kernel_time.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.a3_get_stats.restype = C.c_int
@@ -170,6 +173,18 @@ def default_config() -> Config:
     cfg = Config()
     load().a3_default_config(C.byref(cfg))
     return cfg
+
+
+def synth_render(device: int, frames: np.ndarray, markers: np.ndarray, width: int, height: int, paper: bool, black: float, white: float,
+                 supersample: int, out_ptr: int, row_stride: int = 0, frame_stride: int = 0, stream: int = 0) -> None:
+    """a3_synth_render: frames / markers are the record arrays of aruco3_amd.synth.device_layout, out_ptr a device pointer."""
+    frames = np.ascontiguousarray(frames)
+    markers = np.ascontiguousarray(markers)
+    rc = load().a3_synth_render(device, C.c_void_p(stream), frames.ctypes.data_as(C.c_void_p), len(frames),
+                                markers.ctypes.data_as(C.c_void_p) if len(markers) else None, len(markers), width, height, int(paper),
+                                black, white, supersample, C.c_void_p(out_ptr), row_stride, frame_stride)
+    if rc != 0:
+        raise A3Error(f"a3_synth_render failed ({rc})")
 
 
 class Context:

@@ -48,6 +48,8 @@ hipError_t launch_pose(hipStream_t, const uint32_t*, uint32_t, const float*, uin
                        float, float, float, a3_pose*);
 hipError_t launch_find_nearest(hipStream_t, const uint64_t*, uint32_t, const uint64_t*, uint32_t, uint32_t*, uint8_t*);
 hipError_t launch_calc_tau(hipStream_t, const uint64_t*, uint32_t, unsigned int*);
+hipError_t launch_synth_render(hipStream_t, const a3_synth_frame*, uint32_t, const a3_synth_marker*, uint32_t, uint32_t, int, float, float, int,
+                               uint8_t*, size_t, size_t);
 hipError_t launch_selftest(hipStream_t, const double*, const double*, uint32_t, double*, double*, float*, float*);
 }  // namespace a3
 
@@ -780,6 +782,34 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *avg_ms = (float)(total / reps);
     return A3_OK;
+}
+
+int a3_synth_render(int device, void* hip_stream, const a3_synth_frame* frames, uint32_t n_frames, const a3_synth_marker* markers,
+                    uint32_t n_markers, uint32_t width, uint32_t height, int paper, float black, float white, int supersample,
+                    void* out_rgb_device, size_t row_stride, size_t frame_stride) {
+    if (!frames || !out_rgb_device || (n_markers && !markers) || supersample < 1 || supersample > 8) return A3_ERR_INVALID;
+    if (n_frames == 0 || width == 0 || height == 0) return A3_OK;
+    if (row_stride == 0) row_stride = (size_t)width * 3;
+    if (frame_stride == 0) frame_stride = row_stride * height;
+    if (row_stride < (size_t)width * 3 || frame_stride < row_stride * (height - 1) + (size_t)width * 3 || height > 65535 || n_frames > 65535)
+        return A3_ERR_INVALID;
+    for (uint32_t f = 0; f < n_frames; f++)
+        if ((uint64_t)frames[f].first_marker + frames[f].n_markers > n_markers) return A3_ERR_INVALID;
+    for (uint32_t m = 0; m < n_markers; m++)
+        if (markers[m].n == 0 || markers[m].n > 8) return A3_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return A3_ERR_NO_DEVICE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    a3_synth_frame* d_frames = nullptr; a3_synth_marker* d_markers = nullptr;
+    hipError_t e = hipMalloc(&d_frames, sizeof(a3_synth_frame) * n_frames);
+    if (e == hipSuccess && n_markers) e = hipMalloc(&d_markers, sizeof(a3_synth_marker) * n_markers);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_frames, frames, sizeof(a3_synth_frame) * n_frames, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && n_markers) e = hipMemcpyAsync(d_markers, markers, sizeof(a3_synth_marker) * n_markers, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = launch_synth_render(st, d_frames, n_frames, d_markers, width, height, paper, black, white, supersample,
+                                                 reinterpret_cast<uint8_t*>(out_rgb_device), row_stride, frame_stride);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (d_frames) (void)hipFree(d_frames);
+    if (d_markers) (void)hipFree(d_markers);
+    return e == hipSuccess ? A3_OK : A3_ERR_HIP;
 }
 
 int a3_get_stats(const a3_ctx* ctx, a3_stats* stats) {

@@ -138,21 +138,18 @@ def _draw_marker(gray: np.ndarray, cells: np.ndarray, quad: np.ndarray, spec: Sy
     region[...] = (region * (k - cov) + acc) / k
 
 
-def render_frame(spec: SynthSpec, codes: np.ndarray, num_bits: int, seed: int):
-    """-> (HxWx3 uint8 RGB frame, [TruthMarker])"""
+def frame_layout(spec: SynthSpec, codes: np.ndarray, num_bits: int, seed: int):
+    """Every random choice of one frame (the only consumer of the seed): background (base, gx, gy) and, per marker,
+    (quad 4x2 in image coordinates, dictionary index, n x n cells).  Shared by the host and the device renderer."""
     rng = SplitMix64(seed)
     w, h = spec.width, spec.height
     if spec.background == "gradient":
         gx = rng.uniform(-12.0, 12.0)
         gy = rng.uniform(-12.0, 12.0)
         base = rng.uniform(185.0, 215.0)
-        xs = np.linspace(-1.0, 1.0, w, dtype=np.float32)[None, :]
-        ys = np.linspace(-1.0, 1.0, h, dtype=np.float32)[:, None]
-        gray = (base + gx * xs + gy * ys).astype(np.float32)
     else:
-        gray = np.full((h, w), 200.0, dtype=np.float32)
-
-    truth: List[TruthMarker] = []
+        gx, gy, base = 0.0, 0.0, 200.0
+    markers = []
     centers: List[Tuple[float, float]] = []
     gc, gr = spec.grid
     count = gc * gr if gc and gr else rng.randint(*spec.n_markers)
@@ -187,7 +184,22 @@ def render_frame(spec: SynthSpec, codes: np.ndarray, num_bits: int, seed: int):
         rot = np.array([[ca, -sa], [sa, ca]])
         quad = sq @ rot.T + np.array([cx, cy])
         mid_ = rng.randint(0, len(codes) - 1)
-        cells = marker_cells(int(codes[mid_]), num_bits, spec.cell_order)
+        markers.append((quad, mid_, marker_cells(int(codes[mid_]), num_bits, spec.cell_order)))
+    return base, gx, gy, markers
+
+
+def render_frame(spec: SynthSpec, codes: np.ndarray, num_bits: int, seed: int):
+    """-> (HxWx3 uint8 RGB frame, [TruthMarker])"""
+    w, h = spec.width, spec.height
+    base, gx, gy, markers = frame_layout(spec, codes, num_bits, seed)
+    if spec.background == "gradient":
+        xs = np.linspace(-1.0, 1.0, w, dtype=np.float32)[None, :]
+        ys = np.linspace(-1.0, 1.0, h, dtype=np.float32)[:, None]
+        gray = (base + gx * xs + gy * ys).astype(np.float32)
+    else:
+        gray = np.full((h, w), 200.0, dtype=np.float32)
+    truth: List[TruthMarker] = []
+    for quad, mid_, cells in markers:
         _draw_marker(gray, cells, quad, spec)
         truth.append(TruthMarker(mid_, quad))
 
@@ -201,6 +213,59 @@ def render_frame(spec: SynthSpec, codes: np.ndarray, num_bits: int, seed: int):
         rgb += g.standard_normal(rgb.shape, dtype=np.float32) * np.float32(spec.noise_sigma)
     np.clip(rgb, 0.0, 255.0, out=rgb)
     return np.rint(rgb).astype(np.uint8), truth
+
+
+SYNTH_MARKER_DTYPE = np.dtype([("hinv", np.float32, 9), ("x0", np.int32), ("y0", np.int32), ("x1", np.int32), ("y1", np.int32),
+                               ("cells", np.uint64), ("n", np.uint32), ("reserved", np.uint32)], align=True)   # C layout: 72 bytes
+SYNTH_FRAME_DTYPE = np.dtype([("base", np.float32), ("gx", np.float32), ("gy", np.float32), ("noise_sigma", np.float32),
+                              ("first_marker", np.uint32), ("n_markers", np.uint32), ("seed", np.uint64)], align=True)       # 32 bytes
+
+
+def device_layout(spec: SynthSpec, codes: np.ndarray, num_bits: int, seeds):
+    """The layouts of `frame_layout` for a list of seeds as the two record arrays a3_synth_render takes
+    (include/aruco3_hip.h) -> (frames, markers, [[TruthMarker]])."""
+    w, h = spec.width, spec.height
+    frames = np.zeros(len(seeds), dtype=SYNTH_FRAME_DTYPE)
+    recs, truths = [], []
+    for fi, seed in enumerate(seeds):
+        base, gx, gy, markers = frame_layout(spec, codes, num_bits, seed)
+        frames[fi] = (base, gx, gy, spec.noise_sigma, len(recs), len(markers), seed & _M64)
+        truth = []
+        for quad, mid_, cells in markers:
+            n = cells.shape[0]
+            src = np.array([[0, 0], [n, 0], [n, n], [0, n]], dtype=np.float64)
+            H = _homography(src, quad)
+            outer = (H @ np.array([[-1, -1, 1], [n + 1, -1, 1], [n + 1, n + 1, 1], [-1, n + 1, 1]], dtype=np.float64).T).T
+            outer = outer[:, :2] / outer[:, 2:3]
+            x0 = max(int(math.floor(outer[:, 0].min())) - 1, 0); x1 = min(int(math.ceil(outer[:, 0].max())) + 2, w)
+            y0 = max(int(math.floor(outer[:, 1].min())) - 1, 0); y1 = min(int(math.ceil(outer[:, 1].max())) + 2, h)
+            bits = 0
+            for r in range(n):
+                for c in range(n):
+                    bits |= int(cells[r, c]) << (r * n + c)
+            recs.append((np.linalg.inv(H).astype(np.float32).reshape(9), x0, y0, x1, y1, bits, n, 0))
+            truth.append(TruthMarker(mid_, quad))
+        truths.append(truth)
+    marr = np.zeros(max(len(recs), 1), dtype=SYNTH_MARKER_DTYPE)
+    for i, r in enumerate(recs):
+        marr[i] = r
+    return frames, marr[: len(recs)] if recs else marr[:0], truths
+
+
+def render_frames_device(spec: SynthSpec, codes: np.ndarray, num_bits: int, seeds, out=None, device: int = 0):
+    """Render the frames of `seeds` on the GPU (a3_synth_render) into a CUDA uint8 tensor (N,H,W,3) -> (tensor, truths).
+    Same layouts (markers, ids, positions) as render_frame; pixel values may differ by a grey level (f32 vs f64 painting) and
+    the noise, if any, comes from a different generator."""
+    import torch
+
+    from . import _lib
+
+    frames, markers, truths = device_layout(spec, codes, num_bits, seeds)
+    if out is None:
+        out = torch.empty((len(seeds), spec.height, spec.width, 3), dtype=torch.uint8, device=torch.device("cuda", device))
+    _lib.synth_render(device, frames, markers, spec.width, spec.height, spec.paper, float(spec.black), float(spec.white), spec.supersample,
+                      out.data_ptr(), spec.width * 3, spec.width * spec.height * 3)
+    return out, truths
 
 
 def noise_frame(width: int, height: int, seed: int) -> np.ndarray:

@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--device-synth", action="store_true", help="render the frames on the GPU (a3_synth_render) instead of on the host: no "
+                                                                  "host rendering, no H2D copy (same layouts and ids; pixels may differ by "
+                                                                  "a grey level at cell edges)")
     ap.add_argument("--no-pipeline", action="store_true", help="one context, a3_detect_batch per step (the GPU idles while the host "
                                                                 "collects a batch); default: two contexts on one stream, step i+1 is "
                                                                 "submitted before step i is collected")
@@ -79,7 +82,9 @@ def main():
     workers = args.synth_workers or max(1, min(16, (os.cpu_count() or 8) // max(1, world)))
     t0 = time.time()
     cache = Path(f"{args.frames_cache}.r{rank}.npz") if args.frames_cache else None
-    if cache is not None and cache.exists():
+    if args.device_synth:
+        frames, truth_ids = None, None        # rendered below, once the device is set up
+    elif cache is not None and cache.exists():
         z = np.load(cache, allow_pickle=True)
         frames, truth_ids = z["frames"], [list(t) for t in z["truth"]]
         assert frames.shape[0] == args.frames
@@ -122,7 +127,17 @@ def main():
         ctx.set_profiling(True)
     ctx = ctxs[0]
 
-    d_frames = torch.from_numpy(frames).to(dev)      # inputs resident in HBM before the timed region
+    if args.device_synth:
+        from aruco3_amd import synth
+        spec, _ = synth.config_spec(2)
+        seeds = [synth.frame_seed(2, rank * args.frames + i) for i in range(args.frames)]
+        t0 = time.time()
+        d_frames, truths = synth.render_frames_device(spec, d.code_list, d.num_bits, seeds, device=local_rank)
+        truth_ids = [[t.id for t in tr] for tr in truths]
+        t_gen = time.time() - t0
+        frames = d_frames.cpu().numpy() if (rank == 0 and not args.no_cpu_baseline and world == 1) else None   # only the CPU baseline reads them
+    else:
+        d_frames = torch.from_numpy(frames).to(dev)      # inputs resident in HBM before the timed region
     torch.cuda.synchronize()
     n, h, w, c = d_frames.shape
     first_frame = rank * args.frames
@@ -202,7 +217,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": "synthetic",
+            "data": "synthetic" + (" (rendered on the device)" if args.device_synth else ""),
             "config": {
                 "workload": "BASELINE config 2: batch of 256 x 1920x1080 synthetic RGB frames per GPU, ARUCO dict, 4-8 markers per frame, "
                             "frames resident in HBM; Detector::detect end to end (grey, threshold, contours, quads, warp+decode, lookup) "

@@ -159,6 +159,26 @@ int  a3_get_profile(a3_ctx *ctx, int stage, double *total_ms, uint64_t *launches
  * average device time.  The internal contour buffers hold garbage afterwards; results already returned are unaffected. */
 int  a3_debug_kernel_time(a3_ctx *ctx, int kernel, int dbg, int reps, float *avg_ms);
 
+/* Synthetic frames rendered on the device (the reference's counterparts are its test renderer
+ * and ARDictionary::make_binary_image, src/dictionaries.rs:209-232).  The caller lays the frames out -- background
+ * gradient, and per marker the inverse homography image -> cell coordinates, a bounding box and the n x n cell bitmap
+ * (bit r*n+c = 1: white; n = code side + 2 <= 8) -- and the kernel paints RGB8 frames into device memory `out`. */
+typedef struct a3_synth_marker {
+    float    hinv[9];            /* image (x, y, 1) -> marker cells (u, v, w), row-major */
+    int32_t  x0, y0, x1, y1;     /* pixels the marker (with its one-cell quiet zone) can touch: [x0,x1) x [y0,y1) */
+    uint64_t cells;
+    uint32_t n, reserved;
+} a3_synth_marker;
+typedef struct a3_synth_frame {
+    float    base, gx, gy;       /* background = base + gx * xs + gy * ys, xs, ys in [-1, 1] */
+    float    noise_sigma;        /* additive Gaussian noise per channel, 0 = none */
+    uint32_t first_marker, n_markers;
+    uint64_t seed;               /* of the noise */
+} a3_synth_frame;
+int  a3_synth_render(int device, void *hip_stream, const a3_synth_frame *frames, uint32_t n_frames, const a3_synth_marker *markers,
+                     uint32_t n_markers, uint32_t width, uint32_t height, int paper, float black, float white, int supersample,
+                     void *out_rgb_device, size_t row_stride, size_t frame_stride);
+
 /* numerics self-check used by the GPU tests: evaluates the IEEE operations the kernels rely on
  * (f64 sqrt/div, f32 sqrt/div) for n inputs so that the host can compare them bit for bit */
 int  a3_selftest_ieee(a3_ctx *ctx, const double *a, const double *b, size_t n, double *sqrt_a, double *a_div_b,

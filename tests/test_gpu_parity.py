@@ -636,3 +636,34 @@ def test_many_small_frames_in_one_batch(dicts, oracle):
         assert markers_of_hip(markers[pos: pos + int(per[f])]) == markers_of_oracle(res), f
         pos += int(per[f]); found += int(per[f])
     assert pos == len(markers) and found > 100
+
+
+def test_device_side_frame_generator(dicts, oracle):
+    """frames rendered on the GPU (a3_synth_render) from the host renderer's layouts.  They are
+    (nearly) the host renderer's frames, decode to the ids that were drawn, and -- downloaded -- give the oracle exactly
+    what the HIP path finds in them in place."""
+    import torch
+
+    from aruco3_amd import synth
+
+    for config, count in ((1, 2), (2, 2), (4, 2)):
+        spec, name = synth.config_spec(config)
+        d = dicts.new_from_named_dict(name)
+        seeds = [synth.frame_seed(config, i) for i in range(count)]
+        dev, truths = synth.render_frames_device(spec, d.code_list, d.num_bits, seeds)
+        frames = dev.cpu().numpy()
+        host = np.stack([synth.render_frame(spec, d.code_list, d.num_bits, s)[0] for s in seeds])
+        if spec.noise_sigma == 0.0:
+            diff = np.abs(frames.astype(np.int16) - host.astype(np.int16))
+            # f32 painting vs f64 painting: a sub-sample on a cell edge may fall on the other side (one ninth of black-white)
+            assert diff.max() <= 30 and (diff > 1).mean() < 0.002 and (diff > 0).mean() < 0.02
+        det = _detector(dicts, name)
+        in_place = det.detect_batch(dev)                              # device-resident tensor, no copy
+        for f in range(count):
+            res = oracle.detect(frames[f], d.code_list, d.num_bits, d._tau)
+            assert [(m.id, m.corners) for m in in_place[f].markers] == [(m["id"], [tuple(c) for c in m["corners"]]) for m in res["markers"]]
+            drawn = sorted(t.id for t in truths[f])
+            found = sorted(m.id for m in in_place[f].markers)
+            assert len(set(found) & set(drawn)) >= len(set(drawn)) - 1     # (noisy frames may add a false positive: the oracle's too)
+            if spec.noise_sigma == 0.0:
+                assert set(found) <= set(drawn)
