@@ -14,22 +14,27 @@
 //              counter-clockwise after k.  Darts fall into cycles (plus open chains that
 //              belong to no border), and every border the reference traces is one cycle,
 //              rotated to its start dart.
-//   doubling   log2(longest cycle) rounds of pointer jumping give every dart its cycle's
-//              leader (the dart holding the smallest start-event key) and its hop distance
-//              to the leader (=> cycle length and rank along the border).
+//   doubling   pointer jumping gives every dart its cycle's leader (the dart holding the smallest
+//              start-event key) and its hop distance to the leader (=> cycle length and rank
+//              along the border): 11 rounds inside 2048-dart tiles in LDS, then only the darts
+//              whose predecessor lies in another tile ("entries") are doubled globally.
 //   events     a W-event at pixel q (x>0, west neighbour background) can start a border as
 //              "outer", an E-event (x+1<W, east neighbour background) as "hole"; which event
 //              starts a cycle is the fixpoint of the rule in k_resolve_eval (the reference's
-//              label tests `== 1` / `> 0`, restated on cycles).  Start keys give the
-//              reference's contour order.
+//              label tests `== 1` / `> 0`, restated on cycles); k_resolve_fast confirms the
+//              usual answer (every border starts at its smallest event) from the leaders alone.
+//              Start keys give the reference's contour order.
 //   pruning    only parity-safe (see k_cycle_select): a border too short to hold one
 //              candidate edge, or so long that epsilon = 0.05*len exceeds the image
 //              diagonal, can never yield a 4-point candidate (src/aruco.rs:133-158).
 //   DP         one wave per surviving border: Douglas-Peucker with a wave arg-max, split
 //              count capped at 3 (exactly 4 points are needed), hull + winding + edge test.
 //
-// Border pixels are found 64 at a time with word-wide bit operations on the packed image;
-// dart ranges are handed out with a block scan and one atomic per workgroup.
+// Border pixels are found 64 at a time with word-wide bit operations on the packed image; dart
+// ranges come from prefix sums over per-tile counts (k_dart_count -> k_tile_scan -> k_plan), so
+// numbering is deterministic and no hot path bumps one address from many workgroups: a returning
+// atomic on one address costs ~11 ns and they serialise (12 k tiles = 140 us).  Counters that
+// remain are sharded 16 ways (entry and leader lists) or bumped once per workgroup.
 #include <algorithm>
 #include <cstdlib>
 
