@@ -647,6 +647,7 @@ static int stage_input(a3_ctx* ctx, const void* pixels, int memory, int fmt, uin
     if (!pixels) return fail(ctx, A3_ERR_INVALID, "a3_detect_batch: null pixels");
     if (fmt != A3_FMT_RGB8 && fmt != A3_FMT_RGBA8 && fmt != A3_FMT_L8 && fmt != A3_FMT_BGRA8) return fail(ctx, A3_ERR_INVALID, "unknown pixel format");
     if (width == 0 || height == 0) return kNothingToDo;   // an empty image has no contours
+    if (n_frames > 65535) return fail(ctx, A3_ERR_INVALID, "more than 65535 frames in one call (split the batch)");
     if (width > 65535 || height > 65535 || (uint64_t)width * height >= (1ull << 30))
         return fail(ctx, A3_ERR_INVALID, "image dimensions above 65535 (or 2^30 pixels) are not supported");
     const size_t bpp = fmt == A3_FMT_RGB8 ? 3 : (fmt == A3_FMT_L8 ? 1 : 4);

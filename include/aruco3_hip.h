@@ -102,12 +102,14 @@ int  a3_set_stream(a3_ctx *ctx, void *hip_stream);
 /* total darts / contour points the device pools may hold (0 keeps the default); call before detect */
 int  a3_set_pool_limits(a3_ctx *ctx, uint64_t max_darts, uint64_t max_points);
 int  a3_get_tau(const a3_ctx *ctx, uint8_t *tau);
-/* keep the warped 49x49 patches (Detection.homographies) of the next batches for a3_download_homographies */
+/* debug taps: keep the grey plane (Detection.grey -- not even computed otherwise, the decode stage samples the frames
+ * themselves) and the warped 49x49 patches (Detection.homographies) of the next batches for a3_download_* */
 int  a3_set_debug_taps(a3_ctx *ctx, int enabled);
 
 /* Detector::detect over a batch of independent frames (src/aruco.rs:52-121).
  * pixels: n_frames images, `frame_stride` bytes apart, rows `row_stride` bytes apart.
- * out: markers of frame 0 first, in the reference's order; per_frame_count[n_frames] optional. */
+ * out: markers of frame 0 first, in the reference's order; per_frame_count[n_frames] optional.
+ * Limits: width, height <= 65535, width * height < 2^30, n_frames <= 65535 per call. */
 int  a3_detect_batch(a3_ctx *ctx, const void *pixels, int memory, int fmt, uint32_t width, uint32_t height,
                      size_t row_stride, size_t frame_stride, uint32_t n_frames,
                      a3_marker *out, size_t out_cap, uint32_t *per_frame_count, size_t *out_n);
