@@ -25,7 +25,8 @@ size_t entry_state_bytes();
 size_t entry_slots(uint32_t);
 size_t leader_list_bytes(uint32_t);
 hipError_t launch_rank_cycles(hipStream_t, uint32_t, int, const uint64_t*, const uint32_t*, JumpState*, uint32_t*, uint32_t*,
-                              uint32_t*, uint32_t*, unsigned int*, void*, void*, JumpState*, uint32_t*, unsigned int*, int, DeviceCounters*, const uint32_t*, int);
+                              uint32_t*, uint32_t*, unsigned int*, void*, void*, JumpState*, uint32_t*, unsigned int*, int, DeviceCounters*, const uint32_t*, int,
+                              const uint32_t*, uint32_t*, uint32_t);
 hipError_t launch_resolve(hipStream_t, const JumpState*, uint32_t, int, const uint64_t*, const uint32_t*, const unsigned int*, uint64_t*, uint64_t*,
                           DeviceCounters*, int, const uint32_t*);
 hipError_t launch_select_scatter(hipStream_t, const JumpState*, uint32_t, const uint32_t*, const unsigned int*, const uint32_t*, const uint64_t*,
@@ -115,6 +116,7 @@ struct a3_ctx {
     Pending pending;
     bool pending_trivial = false;   // a submitted batch with no frames / empty images   // a3_debug_kernel_time: shape of the last batch's contour graph
     int resolve_full_ttl = 0;
+    int entry_global_ttl = 0;   // > 0: a recent batch had a frame whose entry list did not fit LDS: use the global doubling rounds
     // device-side planning: the previous batch of this shape fitted one chunk with plan_darts darts, so this one is enqueued
     // without reading the dart counts back first (k_plan); an overflow falls back to the host plan once (force_host_plan)
     bool plan_valid = false, force_host_plan = false;
@@ -358,7 +360,10 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
         const uint32_t* fb = ctx->frame_base.as<uint32_t>() + ci * (max_chunk_frames + 1);
         const uint32_t nd = (uint32_t)c.darts;
         if (nd == 0) continue;
-        if (ci > 0) A3_HIP(hipMemsetAsync(d_leader_count, 0, 4 * 32, st));   // leader + entry counters, adjacent (the batch-wide memset covered chunk 0)
+        if (ci > 0) {   // the batch-wide memset covered chunk 0
+            A3_HIP(hipMemsetAsync(d_leader_count, 0, 4 * 32, st));   // leader + entry counters, adjacent
+            A3_HIP(hipMemsetAsync(ctx->frame_cursor, 0, (size_t)c.count * 4, st));   // per-frame entry counts
+        }
         const uint32_t* tile_off = ctx->tile_darts.as<uint32_t>() + tile_darts_bytes(W, H, n) / 8;
         A3_HIP(launch_dart_build(st, d_bin, (int)W, (int)H, c.first, c.count, fb, tile_off, ctx->pix_base.as<uint32_t>(),
                                  ctx->tile_darts.as<uint32_t>(), ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), nd, n_live, 0));
@@ -370,7 +375,8 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
         A3_HIP(launch_rank_cycles(st, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(),
                                   ctx->stA.as<JumpState>(), ctx->loc_dist.as<uint32_t>(), ctx->entry_bits.as<uint32_t>(),
                                   ctx->entry_list.as<uint32_t>(), ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
-                                  ctx->stB.as<JumpState>(), ctx->entry_bits.as<uint32_t>(), d_leader_count, rounds, ctr, n_live, 0));
+                                  ctx->stB.as<JumpState>(), ctx->entry_bits.as<uint32_t>(), d_leader_count, rounds, ctr, n_live, 0, fb,
+                                  ctx->entry_global_ttl > 0 ? nullptr : ctx->frame_cursor /* per-frame entry counts */, c.count));
         ctx->dbg_nd = nd; ctx->dbg_frames = c.count; ctx->dbg_chunks = (uint32_t)chunks.size();
         const JumpState* fin = ctx->stB.as<JumpState>();
         A3_HIP(launch_resolve(st, fin, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->entry_bits.as<uint32_t>(), d_leader_count,
@@ -453,10 +459,11 @@ int finish_batch(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_fram
     }
     unsigned int flags = hs[4];
     uint64_t need_points = 0; uint32_t need_contours = 0;
-    bool jump_short = false, resolve_needed = false;
+    bool jump_short = false, resolve_needed = false, entry_overflow = false;
     for (size_t ci = 0; ci < n_chunks; ci++) {
         flags |= hc[ci].err_flags;
         resolve_needed |= hc[ci].resolve_needed != 0;
+        entry_overflow |= hc[ci].entry_overflow != 0;
         need_points = std::max<uint64_t>(need_points, hc[ci].points);
         need_contours = std::max(need_contours, hc[ci].contours);
         ctx->stats.contours_traced += hc[ci].traced;
@@ -467,6 +474,8 @@ int finish_batch(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_fram
         ctx->stats.resolve_iterations = std::max(ctx->stats.resolve_iterations, it);
         if (rounds_max > 0 && rounds_max < 32 && hc[ci].jump_changed[rounds_max - 1] != 0) jump_short = true;
     }
+    if (entry_overflow) { ctx->entry_global_ttl = 64; ctx->jump_rounds_hint = std::max(ctx->jump_rounds_hint, 12); return 1; }     // a frame's entry list outgrew LDS: re-run with the global rounds
+    if (ctx->entry_global_ttl > 0) ctx->entry_global_ttl--;
     if (jump_short && ctx->jump_rounds_hint < 32) { ctx->jump_rounds_hint = 32; return 1; }             // re-run with all rounds
     if (resolve_needed) {
         const bool ran = ctx->resolve_full_ttl > 0;
@@ -768,7 +777,7 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
             A3_HIP(launch_rank_cycles(st, ctx->dbg_nd, (int)ctx->W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), ctx->stA.as<JumpState>(),
                                       ctx->loc_dist.as<uint32_t>(), ctx->entry_bits.as<uint32_t>(), ctx->entry_list.as<uint32_t>(),
                                       ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p, ctx->stB.as<JumpState>(),
-                                      ctx->entry_bits.as<uint32_t>(), d_leader_count, 0, ctx->counters, nullptr, dbg ? dbg : 11));
+                                      ctx->entry_bits.as<uint32_t>(), d_leader_count, 0, ctx->counters, nullptr, dbg ? dbg : 11, ctx->frame_base.as<uint32_t>(), nullptr, ctx->dbg_frames));
         } else if (kernel == 3) {   // dbg < 0: k_decode alone (variant -dbg), dbg >= 0: k_projection + k_decode
             A3_HIP(launch_decode(st, ctx->dbg_src, (int)ctx->W, (int)ctx->H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), ctx->scratch_u32,
                                  kMaxCand, ctx->cfg.homography_sample_size, ctx->mark_size, ctx->cfg.homography_sample_size, ctx->dict.as<uint64_t>(),

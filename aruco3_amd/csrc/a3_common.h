@@ -94,7 +94,8 @@ struct DeviceCounters {
     unsigned int resolve_needed;    // set by k_resolve_fast: some border's first start event does not fire -> run the fixpoint passes
     unsigned int jump_changed[32];     // per doubling round: darts whose key changed
     unsigned int resolve_changed[16];  // per start-resolution pass: cycles whose start moved
-    unsigned int pad[2];
+    unsigned int entry_overflow;    // k_entry_frame: a frame has more entries than fit in LDS -> re-run with the global doubling rounds
+    unsigned int pad[1];
 };
 
 constexpr unsigned kErrBrokenEvent = 1u, kErrPointPool = 2u, kErrContourTable = 4u, kErrCandTable = 8u, kErrResolve = 16u;

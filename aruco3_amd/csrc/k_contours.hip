@@ -437,7 +437,10 @@ __global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W,
                                                         JumpState* __restrict__ loc, uint32_t* __restrict__ loc_dist,
                                                         uint32_t* __restrict__ entry_list,
                                                         uint32_t* __restrict__ entry_pos, unsigned int* __restrict__ entry_count, uint32_t ecap,
+                                                        const uint32_t* __restrict__ frame_base, uint32_t* __restrict__ frame_entries,
                                                         const uint32_t* __restrict__ n_live, int dbg) {
+    // frame_entries != nullptr: entries get slots grouped by frame (slot = frame_base[f] + running count of the frame: a
+    // frame has at most as many entries as darts), for k_entry_frame; else the 16-shard allocation of the global rounds
     // dbg (a3_debug_kernel_time only; 0 in the product path): n > 0 runs n doubling rounds instead of 11; -1 = none
     __shared__ uint64_t s_key[kLT];
     __shared__ uint32_t s_ptr[kLT], s_off[kLT], s_dist[kLT];
@@ -489,9 +492,13 @@ __global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W,
     // predecessor's tile; succ is injective, so each is registered once, by that predecessor, with no global dedupe.
     // Slots are counted per workgroup: one global atomic per tile.
     __shared__ uint32_t s_new_count, s_new_base;
+    constexpr uint32_t kFrameWin = 64;               // frames a tile may span with block-aggregated counting (beyond: direct atomics)
+    __shared__ uint32_t s_fcnt[kFrameWin], s_fbase[kFrameWin];
     if (threadIdx.x == 0) s_new_count = 0;
+    if (threadIdx.x < kFrameWin) s_fcnt[threadIdx.x] = 0;
+    const uint32_t f0 = frame_entries ? rec_frame(d_rec[lo]) : 0u;   // darts are frame-major: the tile's frames are f0, f0+1, ...
     __syncthreads();
-    uint32_t my_e[kLT / 256], my_slot[kLT / 256];
+    uint32_t my_e[kLT / 256], my_slot[kLT / 256], my_f[kLT / 256];
 #pragma unroll
     for (int u = 0; u < kLT / 256; u++) {
         const uint32_t i = threadIdx.x + u * 256;
@@ -505,9 +512,34 @@ __global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W,
         loc[d] = r;
         loc_dist[d] = s_dist[i] | (frozen ? kFrozen : 0u);
         const uint32_t s0 = d_succ[d];
-        if ((s0 - lo) >= cnt) { my_e[u] = s0; my_slot[u] = atomicAdd(&s_new_count, 1u); }
+        if ((s0 - lo) >= cnt) {
+            my_e[u] = s0;
+            if (frame_entries) {   // a border never leaves its frame: the successor's frame is this dart's
+                const uint32_t f = rec_frame(d_rec[d]);
+                my_f[u] = f;
+                if (f - f0 < kFrameWin) my_slot[u] = atomicAdd(&s_fcnt[f - f0], 1u);          // rank inside (tile, frame)
+                else {                                                                           // a tile over > 64 tiny frames
+                    const uint32_t slot = frame_base[f] + atomicAdd(&frame_entries[f], 1u);
+                    entry_list[slot] = s0;
+                    entry_pos[s0] = slot;
+                }
+            } else my_slot[u] = atomicAdd(&s_new_count, 1u);
+        }
     }
     __syncthreads();
+    if (frame_entries) {
+        // one global bump per frame the tile touches (slot = frame_base[f] + running count of the frame)
+        if (threadIdx.x < kFrameWin && s_fcnt[threadIdx.x]) s_fbase[threadIdx.x] = atomicAdd(&frame_entries[f0 + threadIdx.x], s_fcnt[threadIdx.x]);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kLT / 256; u++)
+            if (my_slot[u] != kNone) {
+                const uint32_t slot = frame_base[my_f[u]] + s_fbase[my_f[u] - f0] + my_slot[u];
+                entry_list[slot] = my_e[u];
+                entry_pos[my_e[u]] = slot;
+            }
+        return;
+    }
     if (threadIdx.x == 0) {
         const uint32_t shard = blockIdx.x & (kEntryShards - 1);
         s_new_base = shard * ecap + (s_new_count ? atomicAdd(&entry_count[shard], s_new_count) : 0u);
@@ -523,6 +555,62 @@ __global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W,
 }
 
 struct __attribute__((aligned(8))) EntryState { uint64_t key; uint32_t ptr; uint32_t off; uint32_t dist; uint32_t pad; };
+
+// Phase 2, one workgroup per frame, all rounds in LDS: the entries of a clean frame number a few hundred, and a border never
+// leaves its frame, so the reduced list of a frame closes on itself.  Replaces k_entry_init + ~8 k_entry_jump launches (each
+// is mostly launch latency).  A frame with more than kEntryLdsCap entries raises ctr->entry_overflow: the batch is re-run
+// with the global rounds below (noise-like frames).
+constexpr uint32_t kEntryLdsCap = 2048;
+__global__ __launch_bounds__(256) void k_entry_frame(const uint32_t* __restrict__ entry_list, const uint32_t* __restrict__ frame_entries,
+                                                     const uint32_t* __restrict__ frame_base, const JumpState* __restrict__ loc,
+                                                     const uint32_t* __restrict__ loc_dist, const uint32_t* __restrict__ entry_pos,
+                                                     EntryState* __restrict__ es, DeviceCounters* __restrict__ ctr) {
+    __shared__ uint64_t s_key[kEntryLdsCap];
+    __shared__ uint32_t s_ptr[kEntryLdsCap], s_off[kEntryLdsCap], s_dist[kEntryLdsCap];
+    const uint32_t f = blockIdx.x;
+    const uint32_t cnt = frame_entries[f], base = frame_base[f];
+    if (cnt == 0) return;
+    if (cnt > kEntryLdsCap) { if (threadIdx.x == 0) ctr->entry_overflow = 1u; return; }
+    for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
+        const uint32_t e = entry_list[base + i];
+        const JumpState l = loc[e];
+        const uint32_t dd = loc_dist[e];
+        s_key[i] = l.key; s_off[i] = l.off; s_dist[i] = dd & ~kFrozen;
+        // an entry's local window always freezes (its predecessor lies in another tile) unless its chain dead-ends in the tile
+        s_ptr[i] = (dd & kFrozen) ? entry_pos[l.ptr] - base : i;
+    }
+    __syncthreads();
+    constexpr int PER = kEntryLdsCap / 256;
+    for (int round = 0; round < 12; round++) {   // 2^11 = kEntryLdsCap hops, + the round that sees nothing move
+        uint64_t nk[PER]; uint32_t np[PER], no[PER], nd[PER];
+        int changed = 0;
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const uint32_t i = threadIdx.x + u * 256;
+            if (i < cnt) {
+                nk[u] = s_key[i]; np[u] = s_ptr[i]; no[u] = s_off[i]; nd[u] = s_dist[i];
+                const uint32_t t = np[u] < cnt ? np[u] : i;   // (a corrupt pointer cannot leave the frame's slots)
+                const uint64_t tk = s_key[t];
+                if (tk < nk[u]) { nk[u] = tk; no[u] = nd[u] + s_off[t]; changed = 1; }
+                nd[u] += s_dist[t];
+                np[u] = s_ptr[t];
+            }
+        }
+        const int any = __syncthreads_or(changed);
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const uint32_t i = threadIdx.x + u * 256;
+            if (i < cnt) { s_key[i] = nk[u]; s_ptr[i] = np[u]; s_off[i] = no[u]; s_dist[i] = nd[u]; }
+        }
+        __syncthreads();
+        if (!any) break;   // no key moved: every window wraps its cycle
+    }
+    for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
+        EntryState o;
+        o.key = s_key[i]; o.ptr = base + s_ptr[i]; o.off = s_off[i]; o.dist = s_dist[i]; o.pad = 0;
+        es[base + i] = o;
+    }
+}
 
 // Phase 2 set-up: the reduced list over entries.  An entry's local window always freezes (its predecessor lies in another
 // tile, so it cannot sit on a tile-local cycle) unless its chain dead-ends inside the tile; then it points at itself.
@@ -576,7 +664,10 @@ __global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const J
                                                        const uint32_t* __restrict__ entry_pos, const EntryState* __restrict__ es,
                                                        JumpState* __restrict__ fin, uint32_t* __restrict__ leader_list,
                                                        unsigned int* __restrict__ leader_count /*[kLeaderShards]*/, uint32_t shard_cap,
-                                                       const uint32_t* __restrict__ n_live) {
+                                                       const uint32_t* __restrict__ n_live, const DeviceCounters* __restrict__ ctr) {
+    // a frame's entries did not fit k_entry_frame's LDS: their states were never written and the batch is re-run; with no
+    // leaders listed and no points scattered everything downstream is a no-op
+    if (ctr->entry_overflow) return;
     if (n_live) n_darts = min(n_darts, *n_live);
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_base;
@@ -847,7 +938,8 @@ __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restric
 __global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restrict__ st, uint32_t n_darts, const uint64_t* __restrict__ d_rec,
                                                         const uint32_t* __restrict__ cyc_slot, const ContourRec* __restrict__ contours,
                                                         const uint32_t* __restrict__ cyc_start_off, uint32_t* __restrict__ points,
-                                                        const uint32_t* __restrict__ n_live) {
+                                                        const uint32_t* __restrict__ n_live, const DeviceCounters* __restrict__ ctr) {
+    if (ctr->entry_overflow) return;
     if (n_live) n_darts = min(n_darts, *n_live);
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
         const JumpState s = st[d];
@@ -920,14 +1012,14 @@ __device__ bool hull4(const int* __restrict__ in /*8*/, int* __restrict__ out /*
 // group and the shuffles stay inside it.
 constexpr uint32_t kSmallBorder = 64;
 template <int G>
-__global__ __launch_bounds__(256) void k_contour_quads(const ContourRec* __restrict__ contours, const DeviceCounters* __restrict__ ctr,
+__device__ __forceinline__ void contour_quads_body(uint32_t block, uint32_t n_blocks, const ContourRec* __restrict__ contours, const DeviceCounters* __restrict__ ctr,
                                                        uint32_t max_contours, const uint32_t* __restrict__ points, double eps_factor,
                                                        uint32_t min_edge_length, uint32_t first_frame, uint32_t max_cand,
                                                        CandRec* __restrict__ cands, uint32_t* __restrict__ cand_count,
                                                        unsigned int* __restrict__ err_flags) {
     const uint32_t n_contours = min(ctr->contours, max_contours);
     const int lane = threadIdx.x & (G - 1);
-    const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) / G, n_waves = (gridDim.x * blockDim.x) / G;
+    const uint32_t wave_global = (block * blockDim.x + threadIdx.x) / G, n_waves = (n_blocks * blockDim.x) / G;
     for (uint32_t c = wave_global; c < n_contours; c += n_waves) {
         const ContourRec r = contours[c];
         if ((r.n <= kSmallBorder) != (G == 16)) continue;   // the other instantiation's share
@@ -1001,6 +1093,20 @@ __global__ __launch_bounds__(256) void k_contour_quads(const ContourRec* __restr
         for (int i = 0; i < 8; i++) cr.xy[i] = (uint16_t)hq[i];
         cands[(size_t)fl * max_cand + slot] = cr;
     }
+}
+
+// one launch for both group widths: the first `blocks64` workgroups take the long borders, the rest the short ones
+__global__ __launch_bounds__(256) void k_contour_quads(uint32_t blocks64, const ContourRec* __restrict__ contours, const DeviceCounters* __restrict__ ctr,
+                                                       uint32_t max_contours, const uint32_t* __restrict__ points, double eps_factor,
+                                                       uint32_t min_edge_length, uint32_t first_frame, uint32_t max_cand,
+                                                       CandRec* __restrict__ cands, uint32_t* __restrict__ cand_count,
+                                                       unsigned int* __restrict__ err_flags) {
+    if (blockIdx.x < blocks64)
+        contour_quads_body<64>(blockIdx.x, blocks64, contours, ctr, max_contours, points, eps_factor, min_edge_length, first_frame, max_cand, cands,
+                               cand_count, err_flags);
+    else
+        contour_quads_body<16>(blockIdx.x - blocks64, gridDim.x - blocks64, contours, ctr, max_contours, points, eps_factor, min_edge_length,
+                               first_frame, max_cand, cands, cand_count, err_flags);
 }
 
 // expand the packed thresholded image to 0/255 bytes (debug tap a3_download_thresholded)
@@ -1098,15 +1204,23 @@ size_t leader_list_bytes(uint32_t n_darts) { return (size_t)leader_shard_cap(n_d
 hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uint64_t* d_rec, const uint32_t* d_succ,
                               JumpState* loc, uint32_t* loc_dist, uint32_t* entry_bits, uint32_t* entry_list, uint32_t* entry_pos,
                               unsigned int* entry_count, void* es_a, void* es_b, JumpState* fin, uint32_t* leader_list,
-                              unsigned int* leader_count, int max_rounds, DeviceCounters* ctr, const uint32_t* n_live, int dbg) {
+                              unsigned int* leader_count, int max_rounds, DeviceCounters* ctr, const uint32_t* n_live, int dbg,
+                              const uint32_t* frame_base, uint32_t* frame_entries /*nullptr: global rounds*/, uint32_t n_frames) {
     (void)entry_bits;
     // entry_count[16] and leader_count[16] arrive zeroed (the caller's per-batch / per-chunk memset)
     const uint32_t ecap = entry_shard_cap(n_darts);
     hipLaunchKernelGGL(k_local_contract, dim3((n_darts + kLT - 1) / kLT), dim3(256), 0, st, n_darts, W, d_rec, d_succ, loc, loc_dist,
-                       entry_list, entry_pos, entry_count, ecap, n_live, dbg);
+                       entry_list, entry_pos, entry_count, ecap, frame_base, frame_entries, n_live, dbg);
     if (dbg) return hipGetLastError();
     EntryState* a = reinterpret_cast<EntryState*>(es_a);
     EntryState* b = reinterpret_cast<EntryState*>(es_b);
+    if (frame_entries) {   // clean frames: every frame's entry list fits LDS, one launch instead of ~9
+        hipLaunchKernelGGL(k_entry_frame, dim3(n_frames), dim3(256), 0, st, entry_list, frame_entries, frame_base, loc, loc_dist, entry_pos, a, ctr);
+        const int fin_blocks = std::max(blocks_for(n_darts, 256, env_cap("A3_FIN_BLOCKS", 2048)), (int)(((uint64_t)n_darts + 256ull * 32 - 1) / (256ull * 32)));
+        hipLaunchKernelGGL(k_jump_finalize, dim3(fin_blocks), dim3(256), 0, st, n_darts, loc, loc_dist, entry_pos, a, fin,
+                           leader_list, leader_count, leader_shard_cap(n_darts), n_live, ctr);
+        return hipGetLastError();
+    }
     const dim3 grid(blocks_for(n_darts / 16 + 1, 256, 1024)), block(256);   // entries are a few % of the darts on clean frames
     hipLaunchKernelGGL(k_entry_init, grid, block, 0, st, entry_list, entry_count, loc, loc_dist, entry_pos, a, ecap);
     for (int r = 0; r < max_rounds; r++) {
@@ -1115,7 +1229,7 @@ hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uin
     }
     const int fin_blocks = std::max(blocks_for(n_darts, 256, env_cap("A3_FIN_BLOCKS", 2048)), (int)(((uint64_t)n_darts + 256ull * 32 - 1) / (256ull * 32)));
     hipLaunchKernelGGL(k_jump_finalize, dim3(fin_blocks), block, 0, st, n_darts, loc, loc_dist, entry_pos, a, fin,
-                       leader_list, leader_count, leader_shard_cap(n_darts), n_live);
+                       leader_list, leader_count, leader_shard_cap(n_darts), n_live, ctr);
     return hipGetLastError();
 }
 
@@ -1144,16 +1258,14 @@ hipError_t launch_select_scatter(hipStream_t st, const JumpState* fin, uint32_t 
     hipLaunchKernelGGL(k_cycle_select, dim3(blocks_for(n_darts / 64 + 1, 256, 1024)), block, 0, st, fin, leader_list, leader_count, d_succ, t_cur,
                        frame_base, n_frames, first_frame, min_edge_length,
                        eps_factor, image_diag, cyc_slot, contours, cyc_start_off, max_contours, max_points, ctr, leader_shard_cap(n_darts));
-    hipLaunchKernelGGL(k_scatter_points, grid, block, 0, st, fin, n_darts, d_rec, cyc_slot, contours, cyc_start_off, points, n_live);
+    hipLaunchKernelGGL(k_scatter_points, grid, block, 0, st, fin, n_darts, d_rec, cyc_slot, contours, cyc_start_off, points, n_live, ctr);
     return hipGetLastError();
 }
 
 hipError_t launch_contour_quads(hipStream_t st, const ContourRec* contours, const DeviceCounters* ctr, uint32_t max_contours,
                                 const uint32_t* points, double eps_factor, uint32_t min_edge_length, uint32_t first_frame, uint32_t max_cand,
                                 CandRec* cands, uint32_t* cand_count, unsigned int* err_flags) {
-    hipLaunchKernelGGL(k_contour_quads<16>, dim3(1024), dim3(256), 0, st, contours, ctr, max_contours, points, eps_factor, min_edge_length,
-                       first_frame, max_cand, cands, cand_count, err_flags);
-    hipLaunchKernelGGL(k_contour_quads<64>, dim3(1024), dim3(256), 0, st, contours, ctr, max_contours, points, eps_factor, min_edge_length,
+    hipLaunchKernelGGL(k_contour_quads, dim3(1024 + 512), dim3(256), 0, st, 1024u, contours, ctr, max_contours, points, eps_factor, min_edge_length,
                        first_frame, max_cand, cands, cand_count, err_flags);
     return hipGetLastError();
 }

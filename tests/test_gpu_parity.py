@@ -667,3 +667,18 @@ def test_device_side_frame_generator(dicts, oracle):
             assert len(set(found) & set(drawn)) >= len(set(drawn)) - 1     # (noisy frames may add a false positive: the oracle's too)
             if spec.noise_sigma == 0.0:
                 assert set(found) <= set(drawn)
+
+
+def test_entry_resolution_per_frame_and_global(dicts, oracle):
+    """Cross-tile border pieces are joined per frame in LDS when a frame has few of them (clean frames) and by the global
+    doubling rounds otherwise; a batch that mixes both kinds must take the global path, and going back and forth between
+    the two must not change any result."""
+    from aruco3_amd import synth
+
+    det = _detector(dicts, "ARUCO")
+    clean, _ = synth.config_frames(2, 2)                     # 1920x1080: borders cross many 2048-dart tiles
+    rng = np.random.default_rng(21)
+    noise = rng.integers(0, 256, size=clean.shape, dtype=np.uint8)
+    mixed = np.stack([clean[0], noise[0]])
+    for frames in (clean, mixed, clean, noise, clean):
+        _check(det, oracle, frames, check_patches=False)
