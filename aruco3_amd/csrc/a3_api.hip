@@ -32,7 +32,7 @@ hipError_t launch_resolve(hipStream_t, const JumpState*, uint32_t, int, const ui
 hipError_t launch_select_scatter(hipStream_t, const JumpState*, uint32_t, const uint32_t*, const unsigned int*, const uint32_t*, const uint64_t*,
                                  const uint32_t*, uint32_t, uint32_t,
                                  uint32_t, double, double, uint32_t*, ContourRec*, uint32_t*, uint32_t, uint64_t, DeviceCounters*,
-                                 const uint64_t*, uint32_t*, const uint32_t*);
+                                 const uint64_t*, uint32_t*, const uint32_t*, int);
 hipError_t launch_unpack_bits(hipStream_t, const uint64_t*, int, int, uint8_t*);
 hipError_t launch_contour_quads(hipStream_t, const ContourRec*, const DeviceCounters*, uint32_t, const uint32_t*, double, uint32_t, uint32_t,
                                 uint32_t, CandRec*, uint32_t*, unsigned int*);
@@ -146,6 +146,7 @@ struct a3_ctx {
     DevBuf cands, pre_xy, fin_xy, fin_count, work, outs, proj, patches, markers;
     // one allocation zeroed by one memset per batch and read back with one copy: [scratch 256 B | counters | per_frame | frame_cursor | cand_count]
     DevBuf zero_blk;
+    unsigned long long* frame_darts_ptr = nullptr;   // inside the zero block (device plan) or the frame_darts buffer (host plan)
     unsigned int* scratch_u32 = nullptr; DeviceCounters* counters = nullptr; uint32_t* per_frame = nullptr; uint32_t* frame_cursor = nullptr; uint32_t* cand_count = nullptr;
     uint32_t last_marker_total = 0;   // sizes the speculative marker read-back of the next batch
     DevBuf tmp_a, tmp_b, tmp_c, tmp_d;
@@ -264,10 +265,6 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     if (ctx->profiling) A3_HIP(hipEventRecord(ctx->ev[1], st));
 
     // ---- contour graph size per frame -> chunk plan ----
-    A3_HIP(hipMemsetAsync(ctx->frame_darts.p, 0, (size_t)n * 8, st));
-    A3_HIP(ctx->tile_darts.ensure(tile_darts_bytes(W, H, n)));
-    A3_HIP(launch_dart_count(st, ctx->bin.as<uint64_t>(), (int)W, (int)H, 0, n, ctx->frame_darts.as<unsigned long long>(),
-                             ctx->tile_darts.as<uint32_t>()));
     // A batch shaped like the previous one is planned on the device: no read-back, no idle GPU while the host thinks.
     uint64_t cap_d = 0;
     bool device_plan = ctx->plan_valid && !ctx->force_host_plan && ctx->plan_n == n && ctx->plan_W == W && ctx->plan_H == H &&
@@ -276,11 +273,37 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
         cap_d = ctx->plan_darts + ctx->plan_darts / 4 + 65536;
         if (cap_d > ctx->max_darts) device_plan = false;
     }
+    // the zero block: [scratch 256 B | counters | per_frame | frame_cursor | cand_count | (device plan: frame_darts)], one memset
+    size_t ctr_bytes = 0, head_bytes = 0, zero_bytes = 0;
+    auto layout_zero_block = [&](size_t n_chunks, uint32_t chunk_frames, bool with_frame_darts) -> hipError_t {
+        ctr_bytes = sizeof(DeviceCounters) * n_chunks;
+        head_bytes = 256 + ctr_bytes + (size_t)n * 4;                       // what the host reads back
+        const size_t fd_off = (head_bytes + (size_t)chunk_frames * 4 + (size_t)n * 4 + 15) & ~(size_t)15;
+        zero_bytes = fd_off + (with_frame_darts ? (size_t)n * 8 : 0);
+        zero_bytes = (zero_bytes + 15) & ~(size_t)15;
+        const hipError_t e = ctx->zero_blk.ensure(zero_bytes);
+        if (e != hipSuccess) return e;
+        uint8_t* z = ctx->zero_blk.as<uint8_t>();
+        ctx->scratch_u32 = reinterpret_cast<unsigned int*>(z);
+        ctx->counters = reinterpret_cast<DeviceCounters*>(z + 256);
+        ctx->per_frame = reinterpret_cast<uint32_t*>(z + 256 + ctr_bytes);
+        ctx->frame_cursor = ctx->per_frame + n;
+        ctx->cand_count = ctx->frame_cursor + chunk_frames;
+        ctx->frame_darts_ptr = with_frame_darts ? reinterpret_cast<unsigned long long*>(z + fd_off) : ctx->frame_darts.as<unsigned long long>();
+        return hipMemsetAsync(z, 0, zero_bytes, st);
+    };
     std::vector<Chunk> chunks;
     std::vector<uint64_t> fd;
+    A3_HIP(ctx->tile_darts.ensure(tile_darts_bytes(W, H, n)));
     if (device_plan) {
         chunks.push_back(Chunk{0, n, cap_d, (uint32_t)std::min<uint64_t>(cap_d, 0xFFFFFFFFu)});
+        A3_HIP(layout_zero_block(1, n, true));
     } else {
+        ctx->frame_darts_ptr = ctx->frame_darts.as<unsigned long long>();
+        A3_HIP(hipMemsetAsync(ctx->frame_darts.p, 0, (size_t)n * 8, st));
+    }
+    A3_HIP(launch_dart_count(st, ctx->bin.as<uint64_t>(), (int)W, (int)H, 0, n, ctx->frame_darts_ptr, ctx->tile_darts.as<uint32_t>()));
+    if (!device_plan) {
         if (int rc = ensure_pinned(ctx, std::max<size_t>((size_t)n * 8, 1 << 16))) return rc;
         A3_HIP(hipMemcpyAsync(ctx->pinned, ctx->frame_darts.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
         A3_HIP(wait_stream(st));
@@ -305,23 +328,11 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     if (int rc = ensure_dart_pool(ctx, pool_darts)) return rc;
     A3_HIP(ctx->pix_base.ensure((size_t)max_chunk_frames * npx * 4));
     A3_HIP(ctx->frame_base.ensure((size_t)(max_chunk_frames + 1) * 4 * chunks.size()));
-    const size_t ctr_bytes = sizeof(DeviceCounters) * chunks.size();
-    const size_t head_bytes = 256 + ctr_bytes + (size_t)n * 4;                       // what the host reads back
-    const size_t zero_bytes = head_bytes + (size_t)max_chunk_frames * 4 + (size_t)n * 4;
-    A3_HIP(ctx->zero_blk.ensure(zero_bytes));
-    {
-        uint8_t* z = ctx->zero_blk.as<uint8_t>();
-        ctx->scratch_u32 = reinterpret_cast<unsigned int*>(z);
-        ctx->counters = reinterpret_cast<DeviceCounters*>(z + 256);
-        ctx->per_frame = reinterpret_cast<uint32_t*>(z + 256 + ctr_bytes);
-        ctx->frame_cursor = ctx->per_frame + n;
-        ctx->cand_count = ctx->frame_cursor + max_chunk_frames;
-    }
+    if (!device_plan) A3_HIP(layout_zero_block(chunks.size(), max_chunk_frames, false));
     A3_HIP(ctx->contours.ensure((size_t)ctx->max_contours * sizeof(ContourRec)));
     A3_HIP(ctx->cyc_start_off.ensure((size_t)ctx->max_contours * 4));
     A3_HIP(ctx->points.ensure(ctx->max_points * 4));
 
-    A3_HIP(hipMemsetAsync(ctx->zero_blk.p, 0, zero_bytes, st));
     unsigned int* d_work_count = ctx->scratch_u32 + 0;
     unsigned int* d_marker_total = ctx->scratch_u32 + 1;
     unsigned int* d_err = ctx->scratch_u32 + 4;
@@ -331,7 +342,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     const uint32_t* n_live = nullptr;
     if (device_plan) {
         // frame bases and the dart total come from k_plan (scratch words 8..11, read back with the results)
-        A3_HIP(launch_plan(st, ctx->frame_darts.as<unsigned long long>(), n, cap_d, ctx->frame_base.as<uint32_t>(), ctx->scratch_u32 + 8));
+        A3_HIP(launch_plan(st, ctx->frame_darts_ptr, n, cap_d, ctx->frame_base.as<uint32_t>(), ctx->scratch_u32 + 8));
         n_live = ctx->scratch_u32 + 8;
     } else {
         // frame bases of every chunk, uploaded once
@@ -385,7 +396,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
                                      ctx->cfg.contour_simplification_epsilon, image_diag, ctx->cyc_slot.as<uint32_t>(),
                                      ctx->contours.as<ContourRec>(),
                                      ctx->cyc_start_off.as<uint32_t>(), ctx->max_contours, ctx->max_points, ctr, ctx->d_xy.as<uint64_t>(),
-                                     ctx->points.as<uint32_t>(), n_live));
+                                     ctx->points.as<uint32_t>(), n_live, ctx->resolve_full_ttl > 0 ? 0 : (int)W));
         A3_HIP(launch_contour_quads(st, ctx->contours.as<ContourRec>(), ctr, ctx->max_contours, ctx->points.as<uint32_t>(),
                                     ctx->cfg.contour_simplification_epsilon, min_edge_length, c.first, kMaxCand,
                                     ctx->cands.as<CandRec>() + (size_t)c.first * kMaxCand, ctx->cand_count + c.first, d_err));

@@ -708,6 +708,35 @@ constexpr uint64_t kInf64 = ~0ull;
 // step of k_resolve_eval maps T0 to itself (T'(c) = min firing event >= min event = T0(c)), so T0 is the fixpoint and the
 // passes over all darts below are skipped; this is the case unless a component's first pixel lies in column 0.
 // T0 is written for the listed leaders only -- the only slots k_cycle_select reads.
+// does the smallest event of the border led by dart d (key0 = st[d].key) fire under the natural assignment?
+__device__ __forceinline__ bool natural_start_fires(uint32_t d, uint64_t key0, const JumpState* __restrict__ st, const uint64_t* __restrict__ d_rec,
+                                                    int W) {
+    const uint64_t rec = d_rec[d];
+    const uint32_t info = rec_info(rec);
+    const uint32_t xy = rec_xy(rec);
+    const uint32_t x = xy & 0xFFFF, y = xy >> 16;
+    const uint32_t q = y * (uint32_t)W + x;
+    const uint32_t F = rec_F(rec), P = pdart_mask(F);
+    const int k = info & 7;
+    const uint32_t base = d - __popc(P & ((1u << k) - 1u));
+    const int cnt = __popc(P);
+    bool wfires = true;
+    for (int j = 0; j < cnt; j++) {
+        const uint64_t kj = st[base + j].key;
+        const uint32_t leader = (uint32_t)kj;
+        // T0 of the border through this dart: its key, provided the dart sits on an intact cycle with an event
+        uint32_t t = (uint32_t)(kj >> 32);
+        if (leader != d && (uint32_t)st[leader].key != leader) t = kNoKey;
+        if (t < 2u * q) { wfires = false; break; }
+    }
+    const bool has_w = x > 0 && !(F & 1u);
+    uint32_t key = kNoKey;
+    if ((info & kInfoW) && wfires) key = 2u * q;
+    else if ((info & kInfoE) && !(has_w && wfires)) key = 2u * q + 1u;
+    return key == (uint32_t)(key0 >> 32);
+}
+
+// (Launched only when the full passes below are in the launch sequence; otherwise k_cycle_select does this check itself.)
 __global__ __launch_bounds__(256) void k_resolve_fast(const JumpState* __restrict__ st, const uint32_t* __restrict__ leader_list,
                                                       const unsigned int* __restrict__ leader_count, uint32_t shard_cap, int W,
                                                       const uint64_t* __restrict__ d_rec, uint64_t* __restrict__ t_cur,
@@ -723,29 +752,7 @@ __global__ __launch_bounds__(256) void k_resolve_fast(const JumpState* __restric
         const uint32_t d = leader_list[(size_t)sh * shard_cap + i];
         const uint64_t key0 = st[d].key;            // (smallest event key << 32) | d
         t_cur[d] = key0;
-        const uint64_t rec = d_rec[d];
-        const uint32_t info = rec_info(rec);
-        const uint32_t xy = rec_xy(rec);
-        const uint32_t x = xy & 0xFFFF, y = xy >> 16;
-        const uint32_t q = y * (uint32_t)W + x;
-        const uint32_t F = rec_F(rec), P = pdart_mask(F);
-        const int k = info & 7;
-        const uint32_t base = d - __popc(P & ((1u << k) - 1u));
-        const int cnt = __popc(P);
-        bool wfires = true;
-        for (int j = 0; j < cnt; j++) {
-            const uint64_t kj = st[base + j].key;
-            const uint32_t leader = (uint32_t)kj;
-            // T0 of the border through this dart: its key, provided the dart sits on an intact cycle with an event
-            uint32_t t = (uint32_t)(kj >> 32);
-            if (leader != d && (uint32_t)st[leader].key != leader) t = kNoKey;
-            if (t < 2u * q) { wfires = false; break; }
-        }
-        const bool has_w = x > 0 && !(F & 1u);
-        uint32_t key = kNoKey;
-        if ((info & kInfoW) && wfires) key = 2u * q;
-        else if ((info & kInfoE) && !(has_w && wfires)) key = 2u * q + 1u;
-        if (key != (uint32_t)(key0 >> 32)) moved = true;
+        if (!natural_start_fires(d, key0, st, d_rec, W)) moved = true;
     }
     if (moved) ctr->resolve_needed = 1u;
 }
@@ -832,7 +839,8 @@ __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restric
                                                       uint32_t n_frames, uint32_t first_frame, uint32_t min_edge_length, double eps_factor,
                                                       double image_diag, uint32_t* __restrict__ cyc_slot, ContourRec* __restrict__ contours,
                                                       uint32_t* __restrict__ cyc_start_off, uint32_t max_contours, uint64_t max_points,
-                                                      DeviceCounters* __restrict__ ctr, uint32_t shard_cap) {
+                                                      DeviceCounters* __restrict__ ctr, uint32_t shard_cap, const uint64_t* __restrict__ d_rec,
+                                                      int W /* > 0: no resolve kernel ran; borders start naturally, checked here */) {
     __shared__ uint32_t s_wave[4], s_wave_t[4];
     __shared__ unsigned long long s_wave_p[4];
     __shared__ uint32_t s_cbase;
@@ -853,7 +861,7 @@ __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restric
         e.valid = i < leader_count[sh];
         if (!e.valid) return e;
         e.d = leader_list[(size_t)sh * shard_cap + i];
-        e.t = t_cur[e.d];
+        e.t = W > 0 ? st[e.d].key : t_cur[e.d];   // listed leaders carry a start event: their natural start is their key
         e.traced = e.t != kInf64;
         if (!e.traced) return e;
         // the successor's window must have wrapped around to this leader, else this is a chain, not a cycle
@@ -876,12 +884,16 @@ __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restric
     // noise frames (140 k borders per frame) was 1.6 ms of a 1.75 ms kernel.
     uint32_t my_keep = 0, my_traced = 0;
     unsigned long long my_points = 0;
-    bool broken = false;
+    bool broken = false, moved = false;
     for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n_leaders; i0 += stride) {
         const Eval e = eval(i0);
         my_traced += e.traced; my_keep += e.keep; my_points += e.keep ? e.n : 0u;
         broken |= e.broken;
+        // the k_resolve_fast test, folded in: if some border's smallest event does not fire the batch is re-run with the
+        // fixpoint passes (what is selected below is then discarded)
+        if (W > 0 && e.valid && !natural_start_fires(e.d, e.t, st, d_rec, W)) moved = true;
     }
+    if (moved) ctr->resolve_needed = 1u;
     if (broken) atomicOr(&ctr->err_flags, kErrBrokenEvent);
     // exclusive scans of (keep count, point count) over the workgroup
     uint32_t inc_k = my_keep, inc_t = my_traced;
@@ -1236,10 +1248,10 @@ hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uin
 hipError_t launch_resolve(hipStream_t st, const JumpState* fin, uint32_t n_darts, int W, const uint64_t* d_rec, const uint32_t* leader_list,
                           const unsigned int* leader_count, uint64_t* t_cur, uint64_t* t_next, DeviceCounters* ctr, int max_iters,
                           const uint32_t* n_live) {
+    if (max_iters <= 0) return hipSuccess;   // k_cycle_select checks the natural starts itself; the caller re-runs the batch if they do not hold
     const dim3 grid(blocks_for(n_darts, 256, 4096)), block(256);
     hipLaunchKernelGGL(k_resolve_fast, dim3(blocks_for(n_darts / 16 + 1, 256, 1024)), block, 0, st, fin, leader_list, leader_count,
                        leader_shard_cap(n_darts), W, d_rec, t_cur, ctr);
-    if (max_iters <= 0) return hipGetLastError();   // the caller re-runs the batch with the full passes if k_resolve_fast asks for them
     hipLaunchKernelGGL(k_resolve_init, grid, block, 0, st, fin, n_darts, t_cur, t_next, ctr, n_live);
     for (int it = 0; it < max_iters; it++) {
         hipLaunchKernelGGL(k_resolve_eval, grid, block, 0, st, fin, n_darts, W, d_rec, t_cur, t_next, it, ctr, n_live);
@@ -1253,11 +1265,12 @@ hipError_t launch_select_scatter(hipStream_t st, const JumpState* fin, uint32_t 
                                  const uint32_t* frame_base, uint32_t n_frames, uint32_t first_frame, uint32_t min_edge_length,
                                  double eps_factor, double image_diag, uint32_t* cyc_slot, ContourRec* contours, uint32_t* cyc_start_off,
                                  uint32_t max_contours, uint64_t max_points, DeviceCounters* ctr, const uint64_t* d_rec, uint32_t* points,
-                                 const uint32_t* n_live) {
+                                 const uint32_t* n_live, int inline_resolve_W) {
     const dim3 grid(blocks_for(n_darts, 256, env_cap("A3_SCATTER_BLOCKS", 4096))), block(256);
     hipLaunchKernelGGL(k_cycle_select, dim3(blocks_for(n_darts / 64 + 1, 256, 1024)), block, 0, st, fin, leader_list, leader_count, d_succ, t_cur,
                        frame_base, n_frames, first_frame, min_edge_length,
-                       eps_factor, image_diag, cyc_slot, contours, cyc_start_off, max_contours, max_points, ctr, leader_shard_cap(n_darts));
+                       eps_factor, image_diag, cyc_slot, contours, cyc_start_off, max_contours, max_points, ctr, leader_shard_cap(n_darts), d_rec,
+                       inline_resolve_W);
     hipLaunchKernelGGL(k_scatter_points, grid, block, 0, st, fin, n_darts, d_rec, cyc_slot, contours, cyc_start_off, points, n_live, ctr);
     return hipGetLastError();
 }
