@@ -24,7 +24,7 @@ hipError_t launch_plan(hipStream_t, const unsigned long long*, uint32_t, uint64_
 size_t entry_state_bytes();
 size_t entry_slots(uint32_t);
 size_t leader_list_bytes(uint32_t);
-hipError_t launch_rank_cycles(hipStream_t, uint32_t, int, const uint64_t*, const uint32_t*, JumpState*, uint32_t*, uint32_t*,
+hipError_t launch_rank_cycles(hipStream_t, uint32_t, int, const uint64_t*, const uint32_t*, JumpState*, uint32_t*,
                               uint32_t*, uint32_t*, unsigned int*, void*, void*, JumpState*, uint32_t*, unsigned int*, int, DeviceCounters*, const uint32_t*, int,
                               const uint32_t*, uint32_t*, uint32_t);
 hipError_t launch_resolve(hipStream_t, const JumpState*, uint32_t, int, const uint64_t*, const uint32_t*, const unsigned int*, uint64_t*, uint64_t*,
@@ -140,8 +140,8 @@ struct a3_ctx {
     uint32_t W = 0, H = 0, frames = 0;
 
     DevBuf dict, in, grey, bin, frame_darts, frame_base, pix_base, tile_darts;
-    DevBuf d_xy, d_info, d_F, d_succ, stA, stB, t_cur, t_next, cyc_slot;
-    DevBuf loc_dist, entry_bits, entry_list, entry_pos, es_a, es_b;
+    DevBuf d_xy, d_succ, stA, stB, t_cur, t_next, cyc_slot;
+    DevBuf loc_dist, leader_list, entry_list, entry_pos, es_a, es_b;
     DevBuf contours, cyc_start_off, points;
     DevBuf cands, pre_xy, fin_xy, fin_count, work, outs, proj, patches, markers;
     // one allocation zeroed by one memset per batch and read back with one copy: [scratch 256 B | counters | per_frame | frame_cursor | cand_count]
@@ -213,7 +213,7 @@ int ensure_dart_pool(a3_ctx* ctx, uint64_t darts) {
     A3_HIP(ctx->t_next.ensure(darts * 8));
     A3_HIP(ctx->cyc_slot.ensure(darts * 4));
     A3_HIP(ctx->loc_dist.ensure(darts * 4));
-    A3_HIP(ctx->entry_bits.ensure(leader_list_bytes((uint32_t)darts)));   // leader list (cycles with a start event), 16 shards
+    A3_HIP(ctx->leader_list.ensure(leader_list_bytes((uint32_t)darts)));   // leaders of cycles with a start event, 16 shards
     const size_t eslots = entry_slots((uint32_t)darts);   // sharded slot space: darts + at most 16 tiles of padding
     A3_HIP(ctx->entry_list.ensure(eslots * 4));
     A3_HIP(ctx->entry_pos.ensure(darts * 4));
@@ -384,15 +384,15 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
         rounds = std::min(rounds, ctx->jump_rounds_hint);
         rounds_max = std::max(rounds_max, rounds);
         A3_HIP(launch_rank_cycles(st, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(),
-                                  ctx->stA.as<JumpState>(), ctx->loc_dist.as<uint32_t>(), ctx->entry_bits.as<uint32_t>(),
+                                  ctx->stA.as<JumpState>(), ctx->loc_dist.as<uint32_t>(),
                                   ctx->entry_list.as<uint32_t>(), ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
-                                  ctx->stB.as<JumpState>(), ctx->entry_bits.as<uint32_t>(), d_leader_count, rounds, ctr, n_live, 0, fb,
+                                  ctx->stB.as<JumpState>(), ctx->leader_list.as<uint32_t>(), d_leader_count, rounds, ctr, n_live, 0, fb,
                                   ctx->entry_global_ttl > 0 ? nullptr : ctx->frame_cursor /* per-frame entry counts */, c.count));
         ctx->dbg_nd = nd; ctx->dbg_frames = c.count; ctx->dbg_chunks = (uint32_t)chunks.size();
         const JumpState* fin = ctx->stB.as<JumpState>();
-        A3_HIP(launch_resolve(st, fin, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->entry_bits.as<uint32_t>(), d_leader_count,
+        A3_HIP(launch_resolve(st, fin, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->leader_list.as<uint32_t>(), d_leader_count,
                               ctx->t_cur.as<uint64_t>(), ctx->t_next.as<uint64_t>(), ctr, ctx->resolve_full_ttl > 0 ? ctx->resolve_iters_hint : 0, n_live));
-        A3_HIP(launch_select_scatter(st, fin, nd, ctx->entry_bits.as<uint32_t>(), d_leader_count, ctx->d_succ.as<uint32_t>(), ctx->t_cur.as<uint64_t>(), fb, c.count, c.first, min_edge_length,
+        A3_HIP(launch_select_scatter(st, fin, nd, ctx->leader_list.as<uint32_t>(), d_leader_count, ctx->d_succ.as<uint32_t>(), ctx->t_cur.as<uint64_t>(), fb, c.count, c.first, min_edge_length,
                                      ctx->cfg.contour_simplification_epsilon, image_diag, ctx->cyc_slot.as<uint32_t>(),
                                      ctx->contours.as<ContourRec>(),
                                      ctx->cyc_start_off.as<uint32_t>(), ctx->max_contours, ctx->max_points, ctr, ctx->d_xy.as<uint64_t>(),
@@ -621,8 +621,8 @@ void a3_destroy(a3_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     DevBuf* bufs[] = {&ctx->dict, &ctx->in, &ctx->grey, &ctx->bin, &ctx->frame_darts, &ctx->frame_base, &ctx->pix_base,
-                      &ctx->tile_darts, &ctx->d_xy, &ctx->d_info, &ctx->d_F, &ctx->d_succ, &ctx->stA, &ctx->stB, &ctx->t_cur, &ctx->t_next, &ctx->cyc_slot,
-                      &ctx->loc_dist, &ctx->entry_bits, &ctx->entry_list, &ctx->entry_pos, &ctx->es_a, &ctx->es_b,
+                      &ctx->tile_darts, &ctx->d_xy, &ctx->d_succ, &ctx->stA, &ctx->stB, &ctx->t_cur, &ctx->t_next, &ctx->cyc_slot,
+                      &ctx->loc_dist, &ctx->leader_list, &ctx->entry_list, &ctx->entry_pos, &ctx->es_a, &ctx->es_b,
                       &ctx->contours, &ctx->cyc_start_off, &ctx->points, &ctx->zero_blk, &ctx->cands,
                       &ctx->pre_xy, &ctx->fin_xy, &ctx->fin_count, &ctx->work, &ctx->outs, &ctx->proj, &ctx->patches, &ctx->markers,
                       &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_d};
@@ -786,9 +786,9 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
                                      ctx->d_succ.as<uint32_t>(), ctx->dbg_nd, nullptr, dbg ? dbg : 5));
         } else if (kernel == 2) {
             A3_HIP(launch_rank_cycles(st, ctx->dbg_nd, (int)ctx->W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), ctx->stA.as<JumpState>(),
-                                      ctx->loc_dist.as<uint32_t>(), ctx->entry_bits.as<uint32_t>(), ctx->entry_list.as<uint32_t>(),
+                                      ctx->loc_dist.as<uint32_t>(), ctx->entry_list.as<uint32_t>(),
                                       ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p, ctx->stB.as<JumpState>(),
-                                      ctx->entry_bits.as<uint32_t>(), d_leader_count, 0, ctx->counters, nullptr, dbg ? dbg : 11, ctx->frame_base.as<uint32_t>(), nullptr, ctx->dbg_frames));
+                                      ctx->leader_list.as<uint32_t>(), d_leader_count, 0, ctx->counters, nullptr, dbg ? dbg : 11, ctx->frame_base.as<uint32_t>(), nullptr, ctx->dbg_frames));
         } else if (kernel == 3) {   // dbg < 0: k_decode alone (variant -dbg), dbg >= 0: k_projection + k_decode
             A3_HIP(launch_decode(st, ctx->dbg_src, (int)ctx->W, (int)ctx->H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), ctx->scratch_u32,
                                  kMaxCand, ctx->cfg.homography_sample_size, ctx->mark_size, ctx->cfg.homography_sample_size, ctx->dict.as<uint64_t>(),

@@ -51,23 +51,6 @@ __device__ __forceinline__ uint64_t ldw(const uint64_t* __restrict__ img, int wp
     return (y >= 0 && y < H && j >= 0 && j < wpr) ? img[(size_t)y * wpr + j] : 0ull;
 }
 
-__device__ __forceinline__ Nb8 load_nb8(const uint64_t* __restrict__ img, int wpr, int H, int j, int y) {
-    Nb8 r;
-    const uint64_t al = ldw(img, wpr, H, j - 1, y - 1), a = ldw(img, wpr, H, j, y - 1), ar = ldw(img, wpr, H, j + 1, y - 1);
-    const uint64_t cl = ldw(img, wpr, H, j - 1, y), c = ldw(img, wpr, H, j, y), cr = ldw(img, wpr, H, j + 1, y);
-    const uint64_t bl = ldw(img, wpr, H, j - 1, y + 1), b = ldw(img, wpr, H, j, y + 1), br = ldw(img, wpr, H, j + 1, y + 1);
-    r.c = c;
-    r.n[0] = (c << 1) | (cl >> 63);   // W : pixel x-1
-    r.n[1] = (a << 1) | (al >> 63);   // NW
-    r.n[2] = a;                       // N
-    r.n[3] = (a >> 1) | (ar << 63);   // NE
-    r.n[4] = (c >> 1) | (cr << 63);   // E
-    r.n[5] = (b >> 1) | (br << 63);   // SE
-    r.n[6] = b;                       // S
-    r.n[7] = (b << 1) | (bl >> 63);   // SW
-    return r;
-}
-
 // per direction: the pixels of this word that own a dart in that direction (pdart_mask, 64 pixels at once)
 __device__ __forceinline__ void pdart_words(const Nb8& nb, uint64_t p[8]) {
 #pragma unroll
@@ -1212,13 +1195,12 @@ size_t entry_slots(uint32_t n_darts) { return (size_t)entry_shard_cap(n_darts) *
 size_t leader_list_bytes(uint32_t n_darts) { return (size_t)leader_shard_cap(n_darts) * kLeaderShards * 4; }
 
 // leaders + ranks for every dart of the chunk.  loc/fin: JumpState[n_darts]; es_a/es_b: EntryState[n_darts] (upper bound);
-// entry_bits: ceil(n_darts/32) words, zeroed here.
+// entry_count[16] and leader_count[16] arrive zeroed.
 hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uint64_t* d_rec, const uint32_t* d_succ,
-                              JumpState* loc, uint32_t* loc_dist, uint32_t* entry_bits, uint32_t* entry_list, uint32_t* entry_pos,
+                              JumpState* loc, uint32_t* loc_dist, uint32_t* entry_list, uint32_t* entry_pos,
                               unsigned int* entry_count, void* es_a, void* es_b, JumpState* fin, uint32_t* leader_list,
                               unsigned int* leader_count, int max_rounds, DeviceCounters* ctr, const uint32_t* n_live, int dbg,
                               const uint32_t* frame_base, uint32_t* frame_entries /*nullptr: global rounds*/, uint32_t n_frames) {
-    (void)entry_bits;
     // entry_count[16] and leader_count[16] arrive zeroed (the caller's per-batch / per-chunk memset)
     const uint32_t ecap = entry_shard_cap(n_darts);
     hipLaunchKernelGGL(k_local_contract, dim3((n_darts + kLT - 1) / kLT), dim3(256), 0, st, n_darts, W, d_rec, d_succ, loc, loc_dist,
