@@ -425,41 +425,45 @@ __global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W,
     // frame_entries != nullptr: entries get slots grouped by frame (slot = frame_base[f] + running count of the frame: a
     // frame has at most as many entries as darts), for k_entry_frame; else the 16-shard allocation of the global rounds
     // dbg (a3_debug_kernel_time only; 0 in the product path): n > 0 runs n doubling rounds instead of 11; -1 = none
-    __shared__ uint64_t s_key[kLT];
-    __shared__ uint32_t s_ptr[kLT], s_off[kLT], s_dist[kLT];
+    // one 16-byte record per dart (a single ds_read_b128 fetches the next window): off <= 2047 and dist <= 2048 share a word
+    struct __attribute__((aligned(16))) Win { uint64_t key; uint32_t ptr; uint32_t offdist; };
+    __shared__ Win s_win[kLT];
     if (n_live) n_darts = min(n_darts, *n_live);
     const uint32_t lo = blockIdx.x * kLT;
     if (lo >= n_darts) return;   // the grid covers the pool's capacity, the graph may be smaller
     const uint32_t cnt = min((uint32_t)kLT, n_darts - lo);
-    for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
-        const uint32_t d = lo + i;
-        const uint64_t rec = d_rec[d];
-        const uint32_t xy = rec_xy(rec), info = rec_info(rec);
-        const uint32_t q = (xy >> 16) * (uint32_t)W + (xy & 0xFFFF);
-        const uint32_t ek = (info & kInfoW) ? 2u * q : ((info & kInfoE) ? 2u * q + 1u : kNoKey);
-        s_key[i] = ((uint64_t)ek << 32) | d;
-        s_ptr[i] = d_succ[d];
-        s_off[i] = 0;
-        s_dist[i] = 1;
+    // every lane owns 8 darts (i = lane + 256 u) and keeps their window state in registers across the rounds; LDS holds the
+    // copy the other lanes read (per dart and round: one 16-byte read of the next window, one 16-byte write)
+    constexpr int PER = kLT / 256;
+    uint64_t nk[PER]; uint32_t np[PER], no[PER], nd[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const uint32_t i = threadIdx.x + u * 256;
+        if (i < cnt) {
+            const uint32_t d = lo + i;
+            const uint64_t rec = d_rec[d];
+            const uint32_t xy = rec_xy(rec), info = rec_info(rec);
+            const uint32_t q = (xy >> 16) * (uint32_t)W + (xy & 0xFFFF);
+            const uint32_t ek = (info & kInfoW) ? 2u * q : ((info & kInfoE) ? 2u * q + 1u : kNoKey);
+            nk[u] = ((uint64_t)ek << 32) | d; np[u] = d_succ[d]; no[u] = 0; nd[u] = 1;
+            s_win[i] = Win{nk[u], np[u], 1u << 16};
+        }
     }
     __syncthreads();
     // (Skipping windows that are already final -- frozen, or wrapped, visible as "the next window has the same minimum" --
     // was tried: most windows of a clean frame only become final in the last rounds, and the extra flags made it 20 % slower.)
-    constexpr int PER = kLT / 256;
     const int n_rounds = dbg == 0 ? 11 : (dbg < 0 ? 0 : dbg);
     for (int round = 0; round < n_rounds; round++) {
-        uint64_t nk[PER]; uint32_t np[PER], no[PER], nd[PER];
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             const uint32_t i = threadIdx.x + u * 256;
             if (i < cnt) {
-                nk[u] = s_key[i]; np[u] = s_ptr[i]; no[u] = s_off[i]; nd[u] = s_dist[i];
                 const uint32_t t = np[u] - lo;          // unsigned: also catches ptr < lo
                 if (t < cnt) {
-                    const uint64_t tk = s_key[t];
-                    if (tk < nk[u]) { nk[u] = tk; no[u] = nd[u] + s_off[t]; }
-                    nd[u] += s_dist[t];
-                    np[u] = s_ptr[t];
+                    const Win w = s_win[t];
+                    if (w.key < nk[u]) { nk[u] = w.key; no[u] = nd[u] + (w.offdist & 0xFFFFu); }
+                    nd[u] += w.offdist >> 16;
+                    np[u] = w.ptr;
                 }
             }
         }
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W,
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             const uint32_t i = threadIdx.x + u * 256;
-            if (i < cnt) { s_key[i] = nk[u]; s_ptr[i] = np[u]; s_off[i] = no[u]; s_dist[i] = nd[u]; }
+            if (i < cnt) s_win[i] = Win{nk[u], np[u], no[u] | (nd[u] << 16)};
         }
         __syncthreads();
     }
@@ -488,12 +492,12 @@ __global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W,
         my_slot[u] = kNone;
         if (i >= cnt) continue;
         const uint32_t d = lo + i;
-        const uint32_t e = s_ptr[i];
+        const uint32_t e = np[u];
         const bool frozen = (e - lo) >= cnt;
         JumpState r;
-        r.key = s_key[i]; r.ptr = e; r.off = s_off[i];
+        r.key = nk[u]; r.ptr = e; r.off = no[u];
         loc[d] = r;
-        loc_dist[d] = s_dist[i] | (frozen ? kFrozen : 0u);
+        loc_dist[d] = nd[u] | (frozen ? kFrozen : 0u);
         const uint32_t s0 = d_succ[d];
         if ((s0 - lo) >= cnt) {
             my_e[u] = s0;
