@@ -24,7 +24,7 @@ hipError_t launch_plan(hipStream_t, const unsigned long long*, uint32_t, uint64_
 size_t entry_state_bytes();
 size_t entry_slots(uint32_t);
 size_t leader_list_bytes(uint32_t);
-hipError_t launch_rank_cycles(hipStream_t, uint32_t, int, const uint64_t*, const uint32_t*, JumpState*, uint32_t*,
+hipError_t launch_rank_cycles(hipStream_t, uint32_t, int, const uint64_t*, const uint32_t*, JumpState*,
                               uint32_t*, uint32_t*, unsigned int*, void*, void*, JumpState*, uint32_t*, unsigned int*, int, DeviceCounters*, const uint32_t*, int,
                               const uint32_t*, uint32_t*, uint32_t);
 hipError_t launch_resolve(hipStream_t, const JumpState*, uint32_t, int, const uint64_t*, const uint32_t*, const unsigned int*, uint64_t*, uint64_t*,
@@ -141,7 +141,7 @@ struct a3_ctx {
 
     DevBuf dict, in, grey, bin, frame_darts, frame_base, pix_base, tile_darts;
     DevBuf d_xy, d_succ, stA, stB, t_cur, t_next, cyc_slot;
-    DevBuf loc_dist, leader_list, entry_list, entry_pos, es_a, es_b;
+    DevBuf leader_list, entry_list, entry_pos, es_a, es_b;
     DevBuf contours, cyc_start_off, points;
     DevBuf cands, pre_xy, fin_xy, fin_count, work, outs, proj, patches, markers;
     // one allocation zeroed by one memset per batch and read back with one copy: [scratch 256 B | counters | per_frame | frame_cursor | cand_count]
@@ -212,7 +212,6 @@ int ensure_dart_pool(a3_ctx* ctx, uint64_t darts) {
     A3_HIP(ctx->t_cur.ensure(darts * 8));
     A3_HIP(ctx->t_next.ensure(darts * 8));
     A3_HIP(ctx->cyc_slot.ensure(darts * 4));
-    A3_HIP(ctx->loc_dist.ensure(darts * 4));
     A3_HIP(ctx->leader_list.ensure(leader_list_bytes((uint32_t)darts)));   // leaders of cycles with a start event, 16 shards
     const size_t eslots = entry_slots((uint32_t)darts);   // sharded slot space: darts + at most 16 tiles of padding
     A3_HIP(ctx->entry_list.ensure(eslots * 4));
@@ -384,7 +383,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
         rounds = std::min(rounds, ctx->jump_rounds_hint);
         rounds_max = std::max(rounds_max, rounds);
         A3_HIP(launch_rank_cycles(st, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(),
-                                  ctx->stA.as<JumpState>(), ctx->loc_dist.as<uint32_t>(),
+                                  ctx->stA.as<JumpState>(),
                                   ctx->entry_list.as<uint32_t>(), ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
                                   ctx->stB.as<JumpState>(), ctx->leader_list.as<uint32_t>(), d_leader_count, rounds, ctr, n_live, 0, fb,
                                   ctx->entry_global_ttl > 0 ? nullptr : ctx->frame_cursor /* per-frame entry counts */, c.count));
@@ -622,7 +621,7 @@ void a3_destroy(a3_ctx* ctx) {
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     DevBuf* bufs[] = {&ctx->dict, &ctx->in, &ctx->grey, &ctx->bin, &ctx->frame_darts, &ctx->frame_base, &ctx->pix_base,
                       &ctx->tile_darts, &ctx->d_xy, &ctx->d_succ, &ctx->stA, &ctx->stB, &ctx->t_cur, &ctx->t_next, &ctx->cyc_slot,
-                      &ctx->loc_dist, &ctx->leader_list, &ctx->entry_list, &ctx->entry_pos, &ctx->es_a, &ctx->es_b,
+                      &ctx->leader_list, &ctx->entry_list, &ctx->entry_pos, &ctx->es_a, &ctx->es_b,
                       &ctx->contours, &ctx->cyc_start_off, &ctx->points, &ctx->zero_blk, &ctx->cands,
                       &ctx->pre_xy, &ctx->fin_xy, &ctx->fin_count, &ctx->work, &ctx->outs, &ctx->proj, &ctx->patches, &ctx->markers,
                       &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_d};
@@ -786,7 +785,7 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
                                      ctx->d_succ.as<uint32_t>(), ctx->dbg_nd, nullptr, dbg ? dbg : 5));
         } else if (kernel == 2) {
             A3_HIP(launch_rank_cycles(st, ctx->dbg_nd, (int)ctx->W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), ctx->stA.as<JumpState>(),
-                                      ctx->loc_dist.as<uint32_t>(), ctx->entry_list.as<uint32_t>(),
+                                      ctx->entry_list.as<uint32_t>(),
                                       ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p, ctx->stB.as<JumpState>(),
                                       ctx->leader_list.as<uint32_t>(), d_leader_count, 0, ctx->counters, nullptr, dbg ? dbg : 11, ctx->frame_base.as<uint32_t>(), nullptr, ctx->dbg_frames));
         } else if (kernel == 3) {   // dbg < 0: k_decode alone (variant -dbg), dbg >= 0: k_projection + k_decode

@@ -411,13 +411,18 @@ struct EntrySpace {
         return i < c ? sh * cap + i : kNone;
     }
 };
-constexpr uint32_t kFrozen = 0x80000000u;     // dist flag: the window reached a dart outside the tile
+constexpr uint32_t kFrozen = 0x80000000u;     // the window reached a dart outside the tile
+// k_local_contract's result per dart is one JumpState whose `off` word carries three things: hops to the window's minimum
+// (bits 0-11, <= 2047), window length in hops (bits 12-24, <= 2048) and kFrozen
+__device__ __forceinline__ uint32_t loc_pack(uint32_t off, uint32_t dist, bool frozen) { return off | (dist << 12) | (frozen ? kFrozen : 0u); }
+__device__ __forceinline__ uint32_t loc_off(uint32_t w) { return w & 0xFFFu; }
+__device__ __forceinline__ uint32_t loc_dist(uint32_t w) { return (w >> 12) & 0x1FFFu; }
 
 // Phase 1: 11 doubling rounds inside one tile, entirely in LDS.  A window stops growing ("freezes") when its end leaves
 // the tile; cycles that close inside the tile finish here.  Darts that some frozen window ends on become "entries".
 __global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W, const uint64_t* __restrict__ d_rec,
                                                         const uint32_t* __restrict__ d_succ,
-                                                        JumpState* __restrict__ loc, uint32_t* __restrict__ loc_dist,
+                                                        JumpState* __restrict__ loc,
                                                         uint32_t* __restrict__ entry_list,
                                                         uint32_t* __restrict__ entry_pos, unsigned int* __restrict__ entry_count, uint32_t ecap,
                                                         const uint32_t* __restrict__ frame_base, uint32_t* __restrict__ frame_entries,
@@ -495,9 +500,8 @@ __global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W,
         const uint32_t e = np[u];
         const bool frozen = (e - lo) >= cnt;
         JumpState r;
-        r.key = nk[u]; r.ptr = e; r.off = no[u];
+        r.key = nk[u]; r.ptr = e; r.off = loc_pack(no[u], nd[u], frozen);
         loc[d] = r;
-        loc_dist[d] = nd[u] | (frozen ? kFrozen : 0u);
         const uint32_t s0 = d_succ[d];
         if ((s0 - lo) >= cnt) {
             my_e[u] = s0;
@@ -550,7 +554,7 @@ struct __attribute__((aligned(8))) EntryState { uint64_t key; uint32_t ptr; uint
 constexpr uint32_t kEntryLdsCap = 2048;
 __global__ __launch_bounds__(256) void k_entry_frame(const uint32_t* __restrict__ entry_list, const uint32_t* __restrict__ frame_entries,
                                                      const uint32_t* __restrict__ frame_base, const JumpState* __restrict__ loc,
-                                                     const uint32_t* __restrict__ loc_dist, const uint32_t* __restrict__ entry_pos,
+                                                     const uint32_t* __restrict__ entry_pos,
                                                      EntryState* __restrict__ es, DeviceCounters* __restrict__ ctr) {
     __shared__ uint64_t s_key[kEntryLdsCap];
     __shared__ uint32_t s_ptr[kEntryLdsCap], s_off[kEntryLdsCap], s_dist[kEntryLdsCap];
@@ -561,10 +565,9 @@ __global__ __launch_bounds__(256) void k_entry_frame(const uint32_t* __restrict_
     for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
         const uint32_t e = entry_list[base + i];
         const JumpState l = loc[e];
-        const uint32_t dd = loc_dist[e];
-        s_key[i] = l.key; s_off[i] = l.off; s_dist[i] = dd & ~kFrozen;
+        s_key[i] = l.key; s_off[i] = loc_off(l.off); s_dist[i] = loc_dist(l.off);
         // an entry's local window always freezes (its predecessor lies in another tile) unless its chain dead-ends in the tile
-        s_ptr[i] = (dd & kFrozen) ? entry_pos[l.ptr] - base : i;
+        s_ptr[i] = (l.off & kFrozen) ? entry_pos[l.ptr] - base : i;
     }
     __syncthreads();
     constexpr int PER = kEntryLdsCap / 256;
@@ -602,7 +605,7 @@ __global__ __launch_bounds__(256) void k_entry_frame(const uint32_t* __restrict_
 // Phase 2 set-up: the reduced list over entries.  An entry's local window always freezes (its predecessor lies in another
 // tile, so it cannot sit on a tile-local cycle) unless its chain dead-ends inside the tile; then it points at itself.
 __global__ void k_entry_init(const uint32_t* __restrict__ entry_list, const unsigned int* __restrict__ entry_count,
-                             const JumpState* __restrict__ loc, const uint32_t* __restrict__ loc_dist,
+                             const JumpState* __restrict__ loc,
                              const uint32_t* __restrict__ entry_pos, EntryState* __restrict__ es, uint32_t cap) {
     const EntrySpace sp(entry_count);
     for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < sp.total; i0 += gridDim.x * blockDim.x) {
@@ -610,10 +613,9 @@ __global__ void k_entry_init(const uint32_t* __restrict__ entry_list, const unsi
         if (i == kNone) continue;
         const uint32_t e = entry_list[i];
         const JumpState l = loc[e];
-        const uint32_t dd = loc_dist[e];
         EntryState s;
-        s.key = l.key; s.off = l.off; s.dist = dd & ~kFrozen; s.pad = 0;
-        s.ptr = (dd & kFrozen) ? entry_pos[l.ptr] : i;
+        s.key = l.key; s.off = loc_off(l.off); s.dist = loc_dist(l.off); s.pad = 0;
+        s.ptr = (l.off & kFrozen) ? entry_pos[l.ptr] : i;
         es[i] = s;
     }
 }
@@ -647,7 +649,7 @@ __host__ __device__ inline uint32_t leader_shard_cap(uint32_t n_darts) { return 
 
 // ... and the leaders of cycles that carry at least one start event are collected (one atomic per wave) for the
 // per-border kernels that follow.
-__global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const JumpState* __restrict__ loc, const uint32_t* __restrict__ loc_dist,
+__global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const JumpState* __restrict__ loc,
                                                        const uint32_t* __restrict__ entry_pos, const EntryState* __restrict__ es,
                                                        JumpState* __restrict__ fin, uint32_t* __restrict__ leader_list,
                                                        unsigned int* __restrict__ leader_count /*[kLeaderShards]*/, uint32_t shard_cap,
@@ -664,10 +666,11 @@ __global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const J
     int it = 0;
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += stride, it++) {
         JumpState s = loc[d];
-        const uint32_t dd = loc_dist[d];
-        if (dd & kFrozen) {
+        const uint32_t od = s.off;
+        s.off = loc_off(od);
+        if (od & kFrozen) {
             const EntryState g = es[entry_pos[s.ptr]];
-            if (g.key < s.key) { s.key = g.key; s.off = (dd & ~kFrozen) + g.off; }
+            if (g.key < s.key) { s.key = g.key; s.off = loc_dist(od) + g.off; }
         }
         fin[d] = s;
         if ((uint32_t)s.key == d && (uint32_t)(s.key >> 32) != kNoKey) mask |= 1u << it;
@@ -1201,32 +1204,32 @@ size_t leader_list_bytes(uint32_t n_darts) { return (size_t)leader_shard_cap(n_d
 // leaders + ranks for every dart of the chunk.  loc/fin: JumpState[n_darts]; es_a/es_b: EntryState[n_darts] (upper bound);
 // entry_count[16] and leader_count[16] arrive zeroed.
 hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uint64_t* d_rec, const uint32_t* d_succ,
-                              JumpState* loc, uint32_t* loc_dist, uint32_t* entry_list, uint32_t* entry_pos,
+                              JumpState* loc, uint32_t* entry_list, uint32_t* entry_pos,
                               unsigned int* entry_count, void* es_a, void* es_b, JumpState* fin, uint32_t* leader_list,
                               unsigned int* leader_count, int max_rounds, DeviceCounters* ctr, const uint32_t* n_live, int dbg,
                               const uint32_t* frame_base, uint32_t* frame_entries /*nullptr: global rounds*/, uint32_t n_frames) {
     // entry_count[16] and leader_count[16] arrive zeroed (the caller's per-batch / per-chunk memset)
     const uint32_t ecap = entry_shard_cap(n_darts);
-    hipLaunchKernelGGL(k_local_contract, dim3((n_darts + kLT - 1) / kLT), dim3(256), 0, st, n_darts, W, d_rec, d_succ, loc, loc_dist,
+    hipLaunchKernelGGL(k_local_contract, dim3((n_darts + kLT - 1) / kLT), dim3(256), 0, st, n_darts, W, d_rec, d_succ, loc,
                        entry_list, entry_pos, entry_count, ecap, frame_base, frame_entries, n_live, dbg);
     if (dbg) return hipGetLastError();
     EntryState* a = reinterpret_cast<EntryState*>(es_a);
     EntryState* b = reinterpret_cast<EntryState*>(es_b);
     if (frame_entries) {   // clean frames: every frame's entry list fits LDS, one launch instead of ~9
-        hipLaunchKernelGGL(k_entry_frame, dim3(n_frames), dim3(256), 0, st, entry_list, frame_entries, frame_base, loc, loc_dist, entry_pos, a, ctr);
+        hipLaunchKernelGGL(k_entry_frame, dim3(n_frames), dim3(256), 0, st, entry_list, frame_entries, frame_base, loc, entry_pos, a, ctr);
         const int fin_blocks = std::max(blocks_for(n_darts, 256, env_cap("A3_FIN_BLOCKS", 2048)), (int)(((uint64_t)n_darts + 256ull * 32 - 1) / (256ull * 32)));
-        hipLaunchKernelGGL(k_jump_finalize, dim3(fin_blocks), dim3(256), 0, st, n_darts, loc, loc_dist, entry_pos, a, fin,
+        hipLaunchKernelGGL(k_jump_finalize, dim3(fin_blocks), dim3(256), 0, st, n_darts, loc, entry_pos, a, fin,
                            leader_list, leader_count, leader_shard_cap(n_darts), n_live, ctr);
         return hipGetLastError();
     }
     const dim3 grid(blocks_for(n_darts / 16 + 1, 256, 1024)), block(256);   // entries are a few % of the darts on clean frames
-    hipLaunchKernelGGL(k_entry_init, grid, block, 0, st, entry_list, entry_count, loc, loc_dist, entry_pos, a, ecap);
+    hipLaunchKernelGGL(k_entry_init, grid, block, 0, st, entry_list, entry_count, loc, entry_pos, a, ecap);
     for (int r = 0; r < max_rounds; r++) {
         hipLaunchKernelGGL(k_entry_jump, grid, block, 0, st, a, b, entry_count, ecap, r, ctr);
         EntryState* t = a; a = b; b = t;
     }
     const int fin_blocks = std::max(blocks_for(n_darts, 256, env_cap("A3_FIN_BLOCKS", 2048)), (int)(((uint64_t)n_darts + 256ull * 32 - 1) / (256ull * 32)));
-    hipLaunchKernelGGL(k_jump_finalize, dim3(fin_blocks), block, 0, st, n_darts, loc, loc_dist, entry_pos, a, fin,
+    hipLaunchKernelGGL(k_jump_finalize, dim3(fin_blocks), block, 0, st, n_darts, loc, entry_pos, a, fin,
                        leader_list, leader_count, leader_shard_cap(n_darts), n_live, ctr);
     return hipGetLastError();
 }
