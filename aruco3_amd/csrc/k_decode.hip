@@ -477,35 +477,34 @@ __global__ __launch_bounds__(256) void k_decode(PixelSrc src, int W, int H, uint
         }
         __syncthreads();
         if (dbg == 4) continue;
-        // border test + 4 rotated codes, src/aruco.rs:287-310
-        if (tid == 0) {
+        // border test + 4 rotated codes, src/aruco.rs:287-310.  One lane per (rotation, cell): the bit goes to its place in
+        // the code with an LDS atomic (row-major, first cell = most significant bit).
+        if (tid < 4) s_codes[tid] = 0;
+        if (tid == 4) {
             int have = 1;
             const uint32_t end = n ? n - 1 : 0;
             for (uint32_t i = 0; i < n && have; i++) {
                 if (s_bits[i * n] || s_bits[i * n + end]) have = 0;
                 else if (s_bits[i] || s_bits[end * n + i]) have = 0;
             }
-            if (have) {
-                for (int r = 0; r < 4; r++) {
-                    // rotation r of the bit matrix read row-major: after r applications of rotate_bit_matrix
-                    // (new[a][b] = old[b][n-1-a]) cell (y,x) comes from the original at
-                    //   r=0 (y,x)  r=1 (x,n-1-y)  r=2 (n-1-y,n-1-x)  r=3 (n-1-x,y)
-                    uint64_t v = 0;
-                    for (uint32_t y = 1; y + 1 < n; y++)
-                        for (uint32_t x = 1; x + 1 < n; x++) {
-                            uint32_t sy, sx;
-                            if (r == 0) { sy = y; sx = x; }
-                            else if (r == 1) { sy = x; sx = n - 1 - y; }
-                            else if (r == 2) { sy = n - 1 - y; sx = n - 1 - x; }
-                            else { sy = n - 1 - x; sx = y; }
-                            if (s_bits[sy * n + sx]) v |= 1;
-                            v = (v << 1) | (v >> 63);
-                        }
-                    v = (v >> 1) | (v << 63);
-                    s_codes[r] = v;
-                }
-            }
             s_have = have;
+        }
+        __syncthreads();
+        {
+            const uint32_t inner = n >= 2 ? n - 2 : 0, cells = inner * inner;   // <= 36 cells, 4 rotations <= 144 lanes
+            if (s_have && (uint32_t)tid < 4u * cells) {
+                const uint32_t r = (uint32_t)tid / cells, idx = (uint32_t)tid - r * cells;
+                const uint32_t y = 1 + idx / inner, x = 1 + idx % inner;
+                // rotation r of the bit matrix read row-major: after r applications of rotate_bit_matrix
+                // (new[a][b] = old[b][n-1-a]) cell (y,x) comes from the original at
+                //   r=0 (y,x)  r=1 (x,n-1-y)  r=2 (n-1-y,n-1-x)  r=3 (n-1-x,y)
+                uint32_t sy, sx;
+                if (r == 0) { sy = y; sx = x; }
+                else if (r == 1) { sy = x; sx = n - 1 - y; }
+                else if (r == 2) { sy = n - 1 - y; sx = n - 1 - x; }
+                else { sy = n - 1 - x; sx = y; }
+                if (s_bits[sy * n + sx]) atomicOr(reinterpret_cast<unsigned long long*>(&s_codes[r]), 1ull << (cells - 1 - idx));
+            }
         }
         __syncthreads();
         const int have = s_have;
