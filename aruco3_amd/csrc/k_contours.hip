@@ -337,13 +337,20 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
     }
 }
 
-// neighbour mask of one pixel straight from the packed image (ring order W NW N NE E SE S SW)
+// neighbour mask of one pixel straight from the packed image (ring order W NW N NE E SE S SW): one word per row, plus the
+// neighbouring word only when the pixel sits on a word edge (columns >= W and everything outside the image read as zeros)
 __device__ __forceinline__ uint32_t pixel_F(const uint64_t* __restrict__ img, int wpr, int H, int x, int y) {
-    auto px = [&](int xx, int yy) -> uint32_t {
-        return xx < 0 ? 0u : (uint32_t)((ldw(img, wpr, H, xx >> 6, yy) >> (xx & 63)) & 1ull);   // columns >= W hold zeros
-    };
-    return px(x - 1, y) | (px(x - 1, y - 1) << 1) | (px(x, y - 1) << 2) | (px(x + 1, y - 1) << 3) | (px(x + 1, y) << 4) |
-           (px(x + 1, y + 1) << 5) | (px(x, y + 1) << 6) | (px(x - 1, y + 1) << 7);
+    const int j = x >> 6, i = x & 63;
+    uint32_t rows[3];
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++) {
+        const uint64_t c = ldw(img, wpr, H, j, y + dy);
+        const uint64_t l = i == 0 ? ldw(img, wpr, H, j - 1, y + dy) : 0ull;
+        const uint64_t r = i == 63 ? ldw(img, wpr, H, j + 1, y + dy) : 0ull;
+        rows[dy + 1] = row3(l, c, r, i);
+    }
+    const uint32_t top = rows[0], mid = rows[1], bot = rows[2];
+    return (mid & 1u) | ((top & 7u) << 1) | ((mid & 4u) << 2) | ((bot & 4u) << 3) | ((bot & 2u) << 5) | ((bot & 1u) << 7);
 }
 
 // A successor that leaves its tile (k_dart_assign left kNone): looked up through the target pixel's first-dart index
