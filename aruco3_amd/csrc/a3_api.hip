@@ -32,7 +32,7 @@ hipError_t launch_resolve(hipStream_t, const JumpState*, uint32_t, int, const ui
 hipError_t launch_select_scatter(hipStream_t, const JumpState*, uint32_t, const uint32_t*, const unsigned int*, const uint32_t*, const uint64_t*,
                                  const uint32_t*, uint32_t, uint32_t,
                                  uint32_t, double, double, uint32_t*, ContourRec*, uint32_t*, uint32_t, uint64_t, DeviceCounters*,
-                                 const uint64_t*, uint32_t*, const uint32_t*, int);
+                                 const uint64_t*, uint32_t*, const uint32_t*, int, uint32_t*);
 hipError_t launch_unpack_bits(hipStream_t, const uint64_t*, int, int, uint8_t*);
 hipError_t launch_contour_quads(hipStream_t, const ContourRec*, const DeviceCounters*, uint32_t, const uint32_t*, double, uint32_t, uint32_t,
                                 uint32_t, CandRec*, uint32_t*, unsigned int*);
@@ -141,7 +141,7 @@ struct a3_ctx {
 
     DevBuf dict, in, grey, bin, frame_darts, frame_base, pix_base, tile_darts;
     DevBuf d_xy, d_succ, stA, stB, t_cur, t_next, cyc_slot;
-    DevBuf leader_list, entry_list, entry_pos, es_a, es_b;
+    DevBuf leader_list, leader_keep, entry_list, entry_pos, es_a, es_b;
     DevBuf contours, cyc_start_off, points;
     DevBuf cands, pre_xy, fin_xy, fin_count, work, outs, proj, patches, markers;
     // one allocation zeroed by one memset per batch and read back with one copy: [scratch 256 B | counters | per_frame | frame_cursor | cand_count]
@@ -213,6 +213,7 @@ int ensure_dart_pool(a3_ctx* ctx, uint64_t darts) {
     A3_HIP(ctx->t_next.ensure(darts * 8));
     A3_HIP(ctx->cyc_slot.ensure(darts * 4));
     A3_HIP(ctx->leader_list.ensure(leader_list_bytes((uint32_t)darts)));   // leaders of cycles with a start event, 16 shards
+    A3_HIP(ctx->leader_keep.ensure(leader_list_bytes((uint32_t)darts)));   // k_cycle_select: pass-1 verdict per leader slot
     const size_t eslots = entry_slots((uint32_t)darts);   // sharded slot space: darts + at most 16 tiles of padding
     A3_HIP(ctx->entry_list.ensure(eslots * 4));
     A3_HIP(ctx->entry_pos.ensure(darts * 4));
@@ -395,7 +396,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
                                      ctx->cfg.contour_simplification_epsilon, image_diag, ctx->cyc_slot.as<uint32_t>(),
                                      ctx->contours.as<ContourRec>(),
                                      ctx->cyc_start_off.as<uint32_t>(), ctx->max_contours, ctx->max_points, ctr, ctx->d_xy.as<uint64_t>(),
-                                     ctx->points.as<uint32_t>(), n_live, ctx->resolve_full_ttl > 0 ? 0 : (int)W));
+                                     ctx->points.as<uint32_t>(), n_live, ctx->resolve_full_ttl > 0 ? 0 : (int)W, ctx->leader_keep.as<uint32_t>()));
         A3_HIP(launch_contour_quads(st, ctx->contours.as<ContourRec>(), ctr, ctx->max_contours, ctx->points.as<uint32_t>(),
                                     ctx->cfg.contour_simplification_epsilon, min_edge_length, c.first, kMaxCand,
                                     ctx->cands.as<CandRec>() + (size_t)c.first * kMaxCand, ctx->cand_count + c.first, d_err));
@@ -621,7 +622,7 @@ void a3_destroy(a3_ctx* ctx) {
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     DevBuf* bufs[] = {&ctx->dict, &ctx->in, &ctx->grey, &ctx->bin, &ctx->frame_darts, &ctx->frame_base, &ctx->pix_base,
                       &ctx->tile_darts, &ctx->d_xy, &ctx->d_succ, &ctx->stA, &ctx->stB, &ctx->t_cur, &ctx->t_next, &ctx->cyc_slot,
-                      &ctx->leader_list, &ctx->entry_list, &ctx->entry_pos, &ctx->es_a, &ctx->es_b,
+                      &ctx->leader_list, &ctx->leader_keep, &ctx->entry_list, &ctx->entry_pos, &ctx->es_a, &ctx->es_b,
                       &ctx->contours, &ctx->cyc_start_off, &ctx->points, &ctx->zero_blk, &ctx->cands,
                       &ctx->pre_xy, &ctx->fin_xy, &ctx->fin_count, &ctx->work, &ctx->outs, &ctx->proj, &ctx->patches, &ctx->markers,
                       &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_d};

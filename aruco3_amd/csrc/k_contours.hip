@@ -837,7 +837,8 @@ __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restric
                                                       double image_diag, uint32_t* __restrict__ cyc_slot, ContourRec* __restrict__ contours,
                                                       uint32_t* __restrict__ cyc_start_off, uint32_t max_contours, uint64_t max_points,
                                                       DeviceCounters* __restrict__ ctr, uint32_t shard_cap, const uint64_t* __restrict__ d_rec,
-                                                      int W /* > 0: no resolve kernel ran; borders start naturally, checked here */) {
+                                                      int W /* > 0: no resolve kernel ran; borders start naturally, checked here */,
+                                                      uint32_t* __restrict__ keep_tmp /* one word per leader-list slot */) {
     __shared__ uint32_t s_wave[4], s_wave_t[4];
     __shared__ unsigned long long s_wave_p[4];
     __shared__ uint32_t s_cbase;
@@ -886,6 +887,9 @@ __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restric
         const Eval e = eval(i0);
         my_traced += e.traced; my_keep += e.keep; my_points += e.keep ? e.n : 0u;
         broken |= e.broken;
+        // pass 2 only re-evaluates the borders that are kept (on noise frames one in a hundred); for the others it needs to
+        // know just that, from a coalesced read instead of five scattered ones
+        if (e.valid) { const uint32_t sh = i0 / span; keep_tmp[(size_t)sh * shard_cap + (i0 - sh * span)] = e.keep ? 1u : 0u; }
         // the k_resolve_fast test, folded in: if some border's smallest event does not fire the batch is re-run with the
         // fixpoint passes (what is selected below is then discarded)
         if (W > 0 && e.valid && !natural_start_fires(e.d, e.t, st, d_rec, W)) moved = true;
@@ -920,6 +924,11 @@ __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restric
     unsigned long long pb = s_pbase + base_p + (inc_p - my_points);
 
     for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n_leaders; i0 += stride) {
+        {
+            const uint32_t sh = i0 / span, i = i0 - sh * span;
+            if (i >= leader_count[sh]) continue;
+            if (!keep_tmp[(size_t)sh * shard_cap + i]) { cyc_slot[leader_list[(size_t)sh * shard_cap + i]] = kNone; continue; }
+        }
         const Eval e = eval(i0);
         if (!e.valid) continue;
         uint32_t slot = kNone;
@@ -1261,12 +1270,12 @@ hipError_t launch_select_scatter(hipStream_t st, const JumpState* fin, uint32_t 
                                  const uint32_t* frame_base, uint32_t n_frames, uint32_t first_frame, uint32_t min_edge_length,
                                  double eps_factor, double image_diag, uint32_t* cyc_slot, ContourRec* contours, uint32_t* cyc_start_off,
                                  uint32_t max_contours, uint64_t max_points, DeviceCounters* ctr, const uint64_t* d_rec, uint32_t* points,
-                                 const uint32_t* n_live, int inline_resolve_W) {
+                                 const uint32_t* n_live, int inline_resolve_W, uint32_t* keep_tmp) {
     const dim3 grid(blocks_for(n_darts, 256, env_cap("A3_SCATTER_BLOCKS", 4096))), block(256);
     hipLaunchKernelGGL(k_cycle_select, dim3(blocks_for(n_darts / 64 + 1, 256, 1024)), block, 0, st, fin, leader_list, leader_count, d_succ, t_cur,
                        frame_base, n_frames, first_frame, min_edge_length,
                        eps_factor, image_diag, cyc_slot, contours, cyc_start_off, max_contours, max_points, ctr, leader_shard_cap(n_darts), d_rec,
-                       inline_resolve_W);
+                       inline_resolve_W, keep_tmp);
     hipLaunchKernelGGL(k_scatter_points, grid, block, 0, st, fin, n_darts, d_rec, cyc_slot, contours, cyc_start_off, points, n_live, ctr);
     return hipGetLastError();
 }
