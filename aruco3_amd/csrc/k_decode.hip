@@ -133,36 +133,53 @@ __device__ bool solve_projection(const float* from, float S, float* inv_out) {
         A[2 * i + 1][6] = -x * xf; A[2 * i + 1][7] = -x * yf;
         b[2 * i] = -y; b[2 * i + 1] = x;
     }
-    int perm_i[8], perm_j[8], np = 0;
+    // Every index below is a compile-time constant after unrolling (the pivot row is exchanged by predicated moves over the
+    // candidate rows, b follows its rows instead of replaying the permutation afterwards): A and b live in registers.  With
+    // A[piv][c] indexed at run time they lived in scratch memory and this kernel took 24 us for 2.5 k candidates.
+#pragma unroll
     for (int i = 0; i < 8; i++) {
         int piv = i; double best = fabs(A[i][i]);
+#pragma unroll
         for (int r = i + 1; r < 8; r++) { const double v = fabs(A[r][i]); if (v > best) { best = v; piv = r; } }
-        const double diag = A[piv][i];
+        double diag = A[i][i];
+#pragma unroll
+        for (int r = i + 1; r < 8; r++) diag = piv == r ? A[r][i] : diag;
         if (diag == 0.0) continue;
-        if (piv != i) {
-            perm_i[np] = i; perm_j[np] = piv; np++;
-            for (int c = 0; c < 8; c++) { const double t = A[i][c]; A[i][c] = A[piv][c]; A[piv][c] = t; }
+#pragma unroll
+        for (int r = i + 1; r < 8; r++) {
+            const bool sw = piv == r;
+#pragma unroll
+            for (int c = 0; c < 8; c++) { const double x = A[i][c], y = A[r][c]; A[i][c] = sw ? y : x; A[r][c] = sw ? x : y; }
+            const double x = b[i], y = b[r]; b[i] = sw ? y : x; b[r] = sw ? x : y;
         }
         const double inv_diag = 1.0 / diag;
+#pragma unroll
         for (int r = i + 1; r < 8; r++) A[r][i] *= inv_diag;
+#pragma unroll
         for (int c = i + 1; c < 8; c++) {
             const double pr = -A[i][c];
+#pragma unroll
             for (int r = i + 1; r < 8; r++) A[r][c] = pr * A[r][i] + A[r][c];
         }
     }
-    for (int k = 0; k < np; k++) { const double t = b[perm_i[k]]; b[perm_i[k]] = b[perm_j[k]]; b[perm_j[k]] = t; }
+#pragma unroll
     for (int i = 0; i < 7; i++) {
         const double coeff = -b[i];
+#pragma unroll
         for (int r = i + 1; r < 8; r++) b[r] = coeff * A[r][i] + b[r];
     }
+    bool singular = false;
+#pragma unroll
     for (int i = 7; i >= 0; i--) {
         const double diag = A[i][i];
-        if (diag == 0.0) return false;
+        if (diag == 0.0) singular = true;
         const double coeff = b[i] / diag;
         b[i] = coeff;
         const double nc = -coeff;
+#pragma unroll
         for (int r = 0; r < i; r++) b[r] = nc * A[r][i] + b[r];
     }
+    if (singular) return false;
     float t[9];
     for (int i = 0; i < 8; i++) t[i] = (float)b[i];
     t[8] = 1.0f;
