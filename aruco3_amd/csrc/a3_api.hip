@@ -428,10 +428,11 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     const size_t pose_bytes = (ctx->want_pose && ctx->pose_out) ? 2 * sizeof(a3_pose) : 0;
     const uint32_t guess = (uint32_t)std::min<size_t>(marker_cap, (size_t)ctx->last_marker_total + ctx->last_marker_total / 4 + 64);
     const size_t head_pad = (head_bytes + 255) & ~(size_t)255;
-    if (int rc = ensure_pinned(ctx, head_pad + (size_t)marker_cap * (sizeof(a3_marker) + 2 * sizeof(a3_pose)) + (1 << 16))) return rc;
+    // pinned staging for the head and `guess` markers (+ poses); a longer list is fetched by finish_batch after growing it
+    if (int rc = ensure_pinned(ctx, head_pad + (size_t)guess * (sizeof(a3_marker) + 2 * sizeof(a3_pose)) + (1 << 16))) return rc;
     uint8_t* hp = (uint8_t*)ctx->pinned;
     a3_marker* h_markers = reinterpret_cast<a3_marker*>(hp + head_pad);
-    a3_pose* h_poses = reinterpret_cast<a3_pose*>(hp + head_pad + (size_t)marker_cap * sizeof(a3_marker));
+    a3_pose* h_poses = reinterpret_cast<a3_pose*>(hp + head_pad + (size_t)guess * sizeof(a3_marker));
     A3_HIP(hipMemcpyAsync(hp, ctx->zero_blk.p, head_bytes, hipMemcpyDeviceToHost, st));
     A3_HIP(hipMemcpyAsync(h_markers, ctx->markers.p, (size_t)guess * sizeof(a3_marker), hipMemcpyDeviceToHost, st));
     if (pose_bytes) A3_HIP(hipMemcpyAsync(h_poses, ctx->tmp_b.p, (size_t)guess * pose_bytes, hipMemcpyDeviceToHost, st));
@@ -454,7 +455,8 @@ int finish_batch(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_fram
     const int rounds_max = pd.rounds_max;
     uint8_t* hp = (uint8_t*)ctx->pinned;
     a3_marker* h_markers = reinterpret_cast<a3_marker*>(hp + head_pad);
-    a3_pose* h_poses = reinterpret_cast<a3_pose*>(hp + head_pad + (size_t)marker_cap * sizeof(a3_marker));
+    a3_pose* h_poses = reinterpret_cast<a3_pose*>(hp + head_pad + (size_t)guess * sizeof(a3_marker));
+    (void)marker_cap;
     A3_HIP(wait_event(ctx->ev[4], st));
     const unsigned int* hs = reinterpret_cast<const unsigned int*>(hp);
     const DeviceCounters* hc = reinterpret_cast<const DeviceCounters*>(hp + 256);
@@ -508,9 +510,12 @@ int finish_batch(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_fram
     if (total > out_cap) return fail(ctx, A3_ERR_CAPACITY, "out_cap is smaller than the number of markers found");
     const uint32_t* hpf = reinterpret_cast<const uint32_t*>(hp + 256 + ctr_bytes);
     if (per_frame_count) memcpy(per_frame_count, hpf, (size_t)n * 4);
-    if (total > guess) {   // the guess was short: fetch the rest
-        A3_HIP(hipMemcpyAsync(h_markers + guess, ctx->markers.as<a3_marker>() + guess, (size_t)(total - guess) * sizeof(a3_marker), hipMemcpyDeviceToHost, st));
-        if (pose_bytes) A3_HIP(hipMemcpyAsync(h_poses + 2 * (size_t)guess, ctx->tmp_b.as<a3_pose>() + 2 * (size_t)guess, (size_t)(total - guess) * pose_bytes, hipMemcpyDeviceToHost, st));
+    if (total > guess) {   // the guess was short: the staging area grows (the head has been consumed) and the whole list is fetched
+        if (int rc = ensure_pinned(ctx, (size_t)total * (sizeof(a3_marker) + 2 * sizeof(a3_pose)) + (1 << 16))) return rc;
+        h_markers = reinterpret_cast<a3_marker*>(ctx->pinned);
+        h_poses = reinterpret_cast<a3_pose*>((uint8_t*)ctx->pinned + (size_t)total * sizeof(a3_marker));
+        A3_HIP(hipMemcpyAsync(h_markers, ctx->markers.p, (size_t)total * sizeof(a3_marker), hipMemcpyDeviceToHost, st));
+        if (pose_bytes) A3_HIP(hipMemcpyAsync(h_poses, ctx->tmp_b.p, (size_t)total * pose_bytes, hipMemcpyDeviceToHost, st));
         A3_HIP(hipStreamSynchronize(st));
     }
     if (total) {
