@@ -682,3 +682,35 @@ def test_entry_resolution_per_frame_and_global(dicts, oracle):
     mixed = np.stack([clean[0], noise[0]])
     for frames in (clean, mixed, clean, noise, clean):
         _check(det, oracle, frames, check_patches=False)
+
+
+def test_baseline_config2_full_batch_against_oracle(dicts, oracle):
+    """BASELINE config 2 at its full size -- 256 frames of 1920x1080, rendered on the device -- every frame's marker list
+    (ids, codes, corner integers and order, rotation, Hamming distance) against the oracle, plus idempotence of the batch
+    call and equality of the synchronous and the split entry points on the same device-resident frames."""
+    from aruco3_amd import synth
+
+    spec, name = synth.config_spec(2)
+    d = dicts.new_from_named_dict(name)
+    seeds = [synth.frame_seed(2, i) for i in range(256)]
+    dev, truths = synth.render_frames_device(spec, d.code_list, d.num_bits, seeds)
+    det = _detector(dicts, name)
+    ctx = det._context()
+    ctx.set_debug_taps(False)
+    n, h, w, c = dev.shape
+    args = (dev.data_ptr(), 1, 0, w, h, w * c, h * w * c, n)   # MEM_DEVICE, FMT_RGB8
+    markers, per = ctx.detect_batch(*args)
+    again, per2 = ctx.detect_batch(*args)
+    assert np.array_equal(per, per2) and np.array_equal(markers, again)
+    ctx.submit(*args)
+    split, per3 = ctx.collect()
+    assert np.array_equal(per, per3) and np.array_equal(markers, split)
+    frames = dev.cpu().numpy()
+    pos, all_found = 0, 0
+    for f in range(n):
+        res = oracle.detect(frames[f], d.code_list, d.num_bits, d._tau)
+        got = markers_of_hip(markers[pos: pos + int(per[f])])
+        pos += int(per[f])
+        assert got == markers_of_oracle(res), f
+        all_found += sorted(set(m[0] for m in got)) == sorted(set(t.id for t in truths[f]))
+    assert pos == len(markers) and all_found >= 230      # the remaining frames lose a marker to quirks Q2/Q3, in the oracle too
