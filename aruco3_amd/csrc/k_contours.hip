@@ -212,11 +212,31 @@ __device__ __forceinline__ uint32_t row3(uint64_t l, uint64_t c, uint64_t r, int
     const uint64_t v = i == 0 ? ((c << 1) | (l >> 63)) : (c >> (i - 1));
     return ((uint32_t)v & 7u) | (i == 63 ? ((uint32_t)r & 1u) << 2 : 0u);
 }
+// The staged tile as a bit string: a row is 6 words = 12 dwords; pixel i of tile word jl is bit (jl + 1) * 64 + i of its row,
+// so the pixels i-1, i, i+1 are three consecutive bits of a 64-bit window that one two-dword LDS read delivers (no word-edge
+// cases; this function runs once per border pixel and once per dart, and k_dart_assign is VALU-bound).
 __device__ __forceinline__ uint32_t tile_F(const uint64_t (*s_t)[kTileWords + 2], int rl, int jl, int i) {
-    const uint32_t top = row3(s_t[rl][jl], s_t[rl][jl + 1], s_t[rl][jl + 2], i);
-    const uint32_t mid = row3(s_t[rl + 1][jl], s_t[rl + 1][jl + 1], s_t[rl + 1][jl + 2], i);
-    const uint32_t bot = row3(s_t[rl + 2][jl], s_t[rl + 2][jl + 1], s_t[rl + 2][jl + 2], i);
+    const uint32_t* base = reinterpret_cast<const uint32_t*>(&s_t[0][0]);
+    const int p1 = (jl + 1) * 64 + i - 1, d = p1 >> 5, sh = p1 & 31;
+    constexpr int kRowDwords = 2 * (kTileWords + 2);
+    uint32_t rows[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint32_t* r = base + (rl + k) * kRowDwords + d;
+        rows[k] = __builtin_amdgcn_alignbit(r[1], r[0], (uint32_t)sh) & 7u;
+    }
+    const uint32_t top = rows[0], mid = rows[1], bot = rows[2];
     return (mid & 1u) | ((top & 7u) << 1) | ((mid & 4u) << 2) | ((bot & 4u) << 3) | ((bot & 2u) << 5) | ((bot & 1u) << 7);
+}
+// position of the r-th (0-based) set bit of m; m has more than r bits set
+__device__ __forceinline__ int select_bit(uint64_t m, uint32_t r) {
+    uint32_t w = (uint32_t)m, c = (uint32_t)__popc(w), pos = 0;
+    if (r >= c) { w = (uint32_t)(m >> 32); r -= c; pos = 32; }
+    c = (uint32_t)__popc(w & 0xFFFFu); if (r >= c) { w >>= 16; r -= c; pos += 16; }
+    c = (uint32_t)__popc(w & 0xFFu);   if (r >= c) { w >>= 8;  r -= c; pos += 8; }
+    c = (uint32_t)__popc(w & 0xFu);    if (r >= c) { w >>= 4;  r -= c; pos += 4; }
+    c = (uint32_t)__popc(w & 3u);      if (r >= c) { w >>= 2;  r -= c; pos += 2; }
+    return (int)(pos + (r >= (w & 1u) ? 1u : 0u));
 }
 // kDX / kDY without a table load
 __device__ __forceinline__ int dir_dx(int k) { return (int)((0x1A90u >> (2 * k)) & 3u) - 1; }
@@ -283,11 +303,7 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
         for (int it = 0; it < 8; it++) { const uint32_t mid = (lo + hi) >> 1; if (s_nbase[mid] <= n) lo = mid; else hi = mid; }
         const uint32_t w = lo, r = n - s_nbase[w];
         const uint64_t m = s_nodes[w];
-        // position of the r-th (0-based) set bit of m
-        uint32_t blo = 0, bhi = 63;
-#pragma unroll
-        for (int it = 0; it < 6; it++) { const uint32_t mid = (blo + bhi) >> 1; if ((uint32_t)__popcll(m & ((2ull << mid) - 1ull)) >= r + 1u) bhi = mid; else blo = mid + 1; }
-        const int i = (int)blo;
+        const int i = select_bit(m, r);
         const int jl = w & (kTileWords - 1), rl = w >> 2;
         const int wj = tx * kTileWords + jl, wy = ty * kTileRows + rl;
         const uint32_t F = tile_F(s_t, rl, jl, i);
