@@ -380,13 +380,17 @@ __global__ __launch_bounds__(256) void k_decode(PixelSrc src, int W, int H, uint
             // kU samples per lane per trip: all their row reads (one 12-byte load per row and sample: the two taps of a row
             // are adjacent) are in flight before the first is converted
             constexpr int kU = 4;
+            // i / S and i % S for i < S * S by a multiply-high (S is uniform but not a compile-time constant: the division
+            // would be a ~35-instruction sequence per sample); exact because i * (M * S - 2^32) < 2^32
+            const uint32_t M = S > 1 ? 0xFFFFFFFFu / S + 1u : 0u;
             const uint32_t bpp = (src.fmt == A3_FMT_RGB8) ? 3u : ((src.fmt == A3_FMT_RGBA8 || src.fmt == A3_FMT_BGRA8) ? 4u : 1u);
             for (uint32_t i0 = tid; i0 < S * S; i0 += 256 * kU) {
                 TapLoad tl[kU];
 #pragma unroll
                 for (int u = 0; u < kU; u++) {
                     const uint32_t i = i0 + 256u * u;
-                    const float fx = (float)(i % S), fy = (float)(i / S);
+                    const uint32_t row = S > 1 ? __umulhi(i, M) : i;
+                    const float fx = (float)(i - row * S), fy = (float)row;
                     const float d = t6 * fx + t7 * fy + t8;
                     const float px = (t0 * fx + t1 * fy + t2) / d;
                     const float py = (t3 * fx + t4 * fy + t5) / d;
