@@ -1070,14 +1070,16 @@ __device__ __forceinline__ void contour_quads_body(uint32_t block, uint32_t n_bl
             nseg--;
             const uint32_t a = seg_a[nseg], b = seg_b[nseg];
             const uint32_t pa = P[a], pb = P[b];
-            const long long ax = pa & 0xFFFF, ay = pa >> 16, bx = pb & 0xFFFF, by = pb >> 16;
-            const long long la = ay - by, lb = bx - ax, lc = ax * by - bx * ay;
-            unsigned long long best = 0;  // (|num| << 32) | ~index : max picks largest num, then smallest index
+            const int ax = pa & 0xFFFF, ay = pa >> 16, bx = pb & 0xFFFF, by = pb >> 16;
+            // coordinates < 2^16: the line coefficients fit 17 bits + sign, |num| < 2^34, a border has < 2^30 points
+            const int la = ay - by, lb = bx - ax;
+            const long long lc = (long long)ax * by - (long long)bx * ay;
+            unsigned long long best = 0;  // (|num| << 30) | ~index (30 bits): max picks largest num, then smallest index
             for (uint32_t i = a + 1 + lane; i <= b; i += G) {
                 const uint32_t p = P[i];
-                long long num = la * (long long)(p & 0xFFFF) + lb * (long long)(p >> 16) + lc;
+                long long num = (long long)la * (int)(p & 0xFFFF) + (long long)lb * (int)(p >> 16) + lc;   // 32 x 32 -> 64 multiplies
                 if (num < 0) num = -num;
-                const unsigned long long cand = ((unsigned long long)num << 32) | (unsigned long long)(~i);
+                const unsigned long long cand = ((unsigned long long)num << 30) | (unsigned long long)(~i & 0x3FFFFFFFu);
                 if (cand > best) best = cand;
             }
 #pragma unroll
@@ -1085,11 +1087,11 @@ __device__ __forceinline__ void contour_quads_body(uint32_t block, uint32_t n_bl
                 const unsigned long long other = __shfl_xor(best, o);
                 if (other > best) best = other;
             }
-            const unsigned long long num = best >> 32;
+            const unsigned long long num = best >> 30;
             if (num == 0) continue;
-            const uint32_t index = ~(uint32_t)best;
+            const uint32_t index = ~(uint32_t)best & 0x3FFFFFFFu;
             // d = |a x + b y + c| / sqrt(a^2 + b^2) in f64, compared with `>` (imageproc approximate_polygon_dp)
-            const double dmax = (double)num / sqrt((double)(la * la + lb * lb));
+            const double dmax = (double)num / sqrt((double)((long long)la * la + (long long)lb * lb));
             if (dmax > eps) {
                 if (splits == 3) { reject = true; break; }
                 kept[splits++] = index;
