@@ -157,6 +157,8 @@ __global__ __launch_bounds__(256) void k_dart_count(const uint64_t* __restrict__
             const uint64_t al = s_t[rl][jl], a = s_t[rl][jl + 1], ar = s_t[rl][jl + 2];
             const uint64_t cl = s_t[rl + 1][jl], cr = s_t[rl + 1][jl + 2];
             const uint64_t bl = s_t[rl + 2][jl], b = s_t[rl + 2][jl + 1], br = s_t[rl + 2][jl + 2];
+            // a word in the middle of a white area (all nine words all ones: most words of a frame on white paper) owns no dart
+            if ((c & a & b & al & ar & cl & cr & bl & br) == ~0ull) goto counted;
             Nb8 nb;
             nb.c = c;
             nb.n[0] = (c << 1) | (cl >> 63); nb.n[1] = (a << 1) | (al >> 63); nb.n[2] = a; nb.n[3] = (a >> 1) | (ar << 63);
@@ -166,6 +168,7 @@ __global__ __launch_bounds__(256) void k_dart_count(const uint64_t* __restrict__
 #pragma unroll
             for (int k = 0; k < 8; k++) nd += __popcll(p[k]);
         }
+    counted:
         for (int o = 32; o > 0; o >>= 1) nd += __shfl_down(nd, o);
         if (lane == 0 && nd) atomicAdd(&s_tot[q], nd);
     }
@@ -267,7 +270,8 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
     const Nb8 nb = tile_nb8(bits + (size_t)(first_frame + f) * wpr * H, W, H, s_t, &active, &j, &y);
     uint64_t nodes = 0, c0 = 0, c1 = 0, c2 = 0;
     uint32_t nd = 0;
-    if (active && nb.c) {
+    // only a foreground pixel with a background neighbour can own a dart: most words of a frame on white paper have none
+    if (active && (nb.c & ~(nb.n[0] & nb.n[1] & nb.n[2] & nb.n[3] & nb.n[4] & nb.n[5] & nb.n[6] & nb.n[7]))) {
         uint64_t p[8];
         pdart_words(nb, p);
 #pragma unroll
