@@ -143,9 +143,10 @@ struct a3_ctx {
     DevBuf d_xy, d_succ, stA, stB, t_cur, t_next, cyc_slot;
     DevBuf leader_list, leader_keep, entry_list, entry_pos, es_a, es_b;
     DevBuf contours, cyc_start_off, points;
-    DevBuf cands, pre_xy, fin_xy, fin_count, work, outs, proj, patches, markers;
+    DevBuf cands, pre_xy, fin_xy, fin_count, work, outs, proj, patches;
     // one allocation zeroed by one memset per batch and read back with one copy: [scratch 256 B | counters | per_frame | frame_cursor | cand_count]
     DevBuf zero_blk;
+    a3_marker* markers_ptr = nullptr;                // the compacted marker list, right behind the read-back head in the zero block
     unsigned long long* frame_darts_ptr = nullptr;   // inside the zero block (device plan) or the frame_darts buffer (host plan)
     unsigned int* scratch_u32 = nullptr; DeviceCounters* counters = nullptr; uint32_t* per_frame = nullptr; uint32_t* frame_cursor = nullptr; uint32_t* cand_count = nullptr;
     uint32_t last_marker_total = 0;   // sizes the speculative marker read-back of the next batch
@@ -253,7 +254,6 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     A3_HIP(ctx->outs.ensure((size_t)n * kMaxCand * decode_out_bytes()));
     A3_HIP(ctx->proj.ensure((size_t)n * kMaxCand * proj_rec_bytes()));
     const uint32_t marker_cap = (uint32_t)std::min<size_t>(std::max<size_t>(out_cap, 1), (size_t)n * kMaxCand);
-    A3_HIP(ctx->markers.ensure((size_t)marker_cap * sizeof(a3_marker)));
     if (ctx->debug_taps) A3_HIP(ctx->patches.ensure((size_t)kPatchCap * S * S));
     ctx->W = W; ctx->H = H; ctx->frames = n;
     ctx->stats = a3_stats{};
@@ -273,24 +273,26 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
         cap_d = ctx->plan_darts + ctx->plan_darts / 4 + 65536;
         if (cap_d > ctx->max_darts) device_plan = false;
     }
-    // the zero block: [scratch 256 B | counters | per_frame | frame_cursor | cand_count | (device plan: frame_darts)], one memset
-    size_t ctr_bytes = 0, head_bytes = 0, zero_bytes = 0;
+    // One allocation for everything small: [frame_cursor | cand_count | (device plan: frame_darts) | HEAD | markers].  One
+    // memset zeroes it up to the end of HEAD = [scratch 256 B | counters | per_frame]; HEAD and the marker list that follows it
+    // come back to the host in one copy.
+    size_t ctr_bytes = 0, head_bytes = 0, head_off = 0;
     auto layout_zero_block = [&](size_t n_chunks, uint32_t chunk_frames, bool with_frame_darts) -> hipError_t {
         ctr_bytes = sizeof(DeviceCounters) * n_chunks;
-        head_bytes = 256 + ctr_bytes + (size_t)n * 4;                       // what the host reads back
-        const size_t fd_off = (head_bytes + (size_t)chunk_frames * 4 + (size_t)n * 4 + 15) & ~(size_t)15;
-        zero_bytes = fd_off + (with_frame_darts ? (size_t)n * 8 : 0);
-        zero_bytes = (zero_bytes + 15) & ~(size_t)15;
-        const hipError_t e = ctx->zero_blk.ensure(zero_bytes);
+        head_bytes = (256 + ctr_bytes + (size_t)n * 4 + 7) & ~(size_t)7;     // what the host reads back ahead of the markers
+        const size_t fd_off = ((size_t)chunk_frames * 4 + (size_t)n * 4 + 15) & ~(size_t)15;
+        head_off = (fd_off + (with_frame_darts ? (size_t)n * 8 : 0) + 255) & ~(size_t)255;
+        const hipError_t e = ctx->zero_blk.ensure(head_off + head_bytes + (size_t)marker_cap * sizeof(a3_marker));
         if (e != hipSuccess) return e;
         uint8_t* z = ctx->zero_blk.as<uint8_t>();
-        ctx->scratch_u32 = reinterpret_cast<unsigned int*>(z);
-        ctx->counters = reinterpret_cast<DeviceCounters*>(z + 256);
-        ctx->per_frame = reinterpret_cast<uint32_t*>(z + 256 + ctr_bytes);
-        ctx->frame_cursor = ctx->per_frame + n;
+        ctx->frame_cursor = reinterpret_cast<uint32_t*>(z);
         ctx->cand_count = ctx->frame_cursor + chunk_frames;
         ctx->frame_darts_ptr = with_frame_darts ? reinterpret_cast<unsigned long long*>(z + fd_off) : ctx->frame_darts.as<unsigned long long>();
-        return hipMemsetAsync(z, 0, zero_bytes, st);
+        ctx->scratch_u32 = reinterpret_cast<unsigned int*>(z + head_off);
+        ctx->counters = reinterpret_cast<DeviceCounters*>(z + head_off + 256);
+        ctx->per_frame = reinterpret_cast<uint32_t*>(z + head_off + 256 + ctr_bytes);
+        ctx->markers_ptr = reinterpret_cast<a3_marker*>(z + head_off + head_bytes);
+        return hipMemsetAsync(z, 0, head_off + head_bytes, st);
     };
     std::vector<Chunk> chunks;
     std::vector<uint64_t> fd;
@@ -414,11 +416,11 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
                          ctx->proj.p, ctx->outs.p, ctx->debug_taps ? ctx->patches.as<uint8_t>() : nullptr, ctx->per_frame, 4096, 0));
     ctx->dbg_src = src;
     A3_HIP(launch_compact_markers(st, ctx->outs.p, ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(), n, 0, kMaxCand,
-                                  ctx->markers.as<a3_marker>(), marker_cap, ctx->per_frame, d_marker_total, d_err));
+                                  ctx->markers_ptr, marker_cap, ctx->per_frame, d_marker_total, d_err));
     if (ctx->want_pose) {   // IPPE on the device-resident marker list (src/pose.rs:52-81), no extra round trip
         A3_HIP(ctx->tmp_b.ensure((size_t)marker_cap * 2 * sizeof(a3_pose)));
         const a3_intrinsics& in = ctx->pose_intr;
-        A3_HIP(launch_pose(st, reinterpret_cast<const uint32_t*>(ctx->markers.as<uint8_t>() + offsetof(a3_marker, corners)),
+        A3_HIP(launch_pose(st, reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(ctx->markers_ptr) + offsetof(a3_marker, corners)),
                            (uint32_t)(sizeof(a3_marker) / 4), nullptr, marker_cap, d_marker_total, ctx->pose_has_intr ? 1 : 0, ctx->pose_size_mm,
                            (float)W, (float)H, in.focal_x, in.focal_y, in.principal_x, in.principal_y, ctx->tmp_b.as<a3_pose>()));
     }
@@ -427,14 +429,12 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     // ---- results: one copy of [scratch | counters | per-frame counts], one speculative copy of the marker list ----
     const size_t pose_bytes = (ctx->want_pose && ctx->pose_out) ? 2 * sizeof(a3_pose) : 0;
     const uint32_t guess = (uint32_t)std::min<size_t>(marker_cap, (size_t)ctx->last_marker_total + ctx->last_marker_total / 4 + 64);
-    const size_t head_pad = (head_bytes + 255) & ~(size_t)255;
+    const size_t head_pad = head_bytes;   // the markers follow the head directly, on the device and in the staging buffer
     // pinned staging for the head and `guess` markers (+ poses); a longer list is fetched by finish_batch after growing it
     if (int rc = ensure_pinned(ctx, head_pad + (size_t)guess * (sizeof(a3_marker) + 2 * sizeof(a3_pose)) + (1 << 16))) return rc;
     uint8_t* hp = (uint8_t*)ctx->pinned;
-    a3_marker* h_markers = reinterpret_cast<a3_marker*>(hp + head_pad);
     a3_pose* h_poses = reinterpret_cast<a3_pose*>(hp + head_pad + (size_t)guess * sizeof(a3_marker));
-    A3_HIP(hipMemcpyAsync(hp, ctx->zero_blk.p, head_bytes, hipMemcpyDeviceToHost, st));
-    A3_HIP(hipMemcpyAsync(h_markers, ctx->markers.p, (size_t)guess * sizeof(a3_marker), hipMemcpyDeviceToHost, st));
+    A3_HIP(hipMemcpyAsync(hp, ctx->scratch_u32, head_bytes + (size_t)guess * sizeof(a3_marker), hipMemcpyDeviceToHost, st));
     if (pose_bytes) A3_HIP(hipMemcpyAsync(h_poses, ctx->tmp_b.p, (size_t)guess * pose_bytes, hipMemcpyDeviceToHost, st));
     A3_HIP(hipEventRecord(ctx->ev[4], st));
     Pending& pd = ctx->pending;
@@ -514,7 +514,7 @@ int finish_batch(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_fram
         if (int rc = ensure_pinned(ctx, (size_t)total * (sizeof(a3_marker) + 2 * sizeof(a3_pose)) + (1 << 16))) return rc;
         h_markers = reinterpret_cast<a3_marker*>(ctx->pinned);
         h_poses = reinterpret_cast<a3_pose*>((uint8_t*)ctx->pinned + (size_t)total * sizeof(a3_marker));
-        A3_HIP(hipMemcpyAsync(h_markers, ctx->markers.p, (size_t)total * sizeof(a3_marker), hipMemcpyDeviceToHost, st));
+        A3_HIP(hipMemcpyAsync(h_markers, ctx->markers_ptr, (size_t)total * sizeof(a3_marker), hipMemcpyDeviceToHost, st));
         if (pose_bytes) A3_HIP(hipMemcpyAsync(h_poses, ctx->tmp_b.p, (size_t)total * pose_bytes, hipMemcpyDeviceToHost, st));
         A3_HIP(hipStreamSynchronize(st));
     }
@@ -629,7 +629,7 @@ void a3_destroy(a3_ctx* ctx) {
                       &ctx->tile_darts, &ctx->d_xy, &ctx->d_succ, &ctx->stA, &ctx->stB, &ctx->t_cur, &ctx->t_next, &ctx->cyc_slot,
                       &ctx->leader_list, &ctx->leader_keep, &ctx->entry_list, &ctx->entry_pos, &ctx->es_a, &ctx->es_b,
                       &ctx->contours, &ctx->cyc_start_off, &ctx->points, &ctx->zero_blk, &ctx->cands,
-                      &ctx->pre_xy, &ctx->fin_xy, &ctx->fin_count, &ctx->work, &ctx->outs, &ctx->proj, &ctx->patches, &ctx->markers,
+                      &ctx->pre_xy, &ctx->fin_xy, &ctx->fin_count, &ctx->work, &ctx->outs, &ctx->proj, &ctx->patches,
                       &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_d};
     for (DevBuf* b : bufs) b->release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
