@@ -15,6 +15,7 @@ LIB_PATH = _HERE / "libaruco3_hip.so"
 OK, ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_INTERNAL, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
 FMT_RGB8, FMT_RGBA8, FMT_L8, FMT_BGRA8 = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
+PROFILE_OFF, PROFILE_STAGES, PROFILE_THRESHOLD_ONLY = 0, 1, 2
 STAGE_THRESHOLD, STAGE_CONTOUR, STAGE_DECODE = 0, 1, 2
 
 # every symbol include/aruco3_hip.h declares
@@ -226,8 +227,9 @@ class Context:
     def set_pool_limits(self, max_darts: int = 0, max_points: int = 0):
         check(load().a3_set_pool_limits(self.handle, max_darts, max_points), self.handle)
 
-    def set_profiling(self, on: bool):
-        check(load().a3_set_profiling(self.handle, int(on)), self.handle)
+    def set_profiling(self, mode):
+        """False / 0 off, True / 1 every stage, PROFILE_THRESHOLD_ONLY (2): the threshold stage only (two event records per batch)"""
+        check(load().a3_set_profiling(self.handle, int(mode)), self.handle)
 
     def profile(self, stage: int, reset: bool = False):
         ms, n = C.c_double(), C.c_uint64()

@@ -21,6 +21,7 @@ size_t tile_darts_bytes(uint32_t W, uint32_t H, uint32_t n_frames);
 hipError_t launch_dart_build(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*, const uint32_t*,
                              uint64_t*, uint32_t*, uint32_t, const uint32_t*, int);
 hipError_t launch_plan(hipStream_t, const unsigned long long*, uint32_t, uint64_t, uint32_t*, uint32_t*);
+hipError_t launch_zero(hipStream_t, void*, size_t);
 size_t entry_state_bytes();
 size_t entry_slots(uint32_t);
 size_t leader_list_bytes(uint32_t);
@@ -91,7 +92,7 @@ struct Pending {
     size_t n_chunks = 0, ctr_bytes = 0, head_pad = 0, pose_bytes = 0;
     uint64_t chunk0_darts = 0;
     uint32_t marker_cap = 0, guess = 0, n = 0, W = 0, H = 0;
-    int rounds_max = 0;
+    int rounds_max = 0, profiling = 0;
     // the submitted call, for the synchronous re-run when the device asks for one
     const uint8_t* pixels = nullptr; int fmt = 0; size_t row_stride = 0, frame_stride = 0;
 };
@@ -130,7 +131,7 @@ struct a3_ctx {
     a3_pose* pose_out = nullptr;
     bool debug_taps = false;
     bool grey_valid = false;   // the last batch wrote the grey plane
-    bool profiling = false;
+    int profiling = 0;   // 0 off, 1 threshold stage only, 2 every stage (an event record between kernels costs ~6 us of device time)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double prof_ms[A3_STAGE_COUNT] = {0, 0, 0};
     uint64_t prof_n[A3_STAGE_COUNT] = {0, 0, 0};
@@ -292,7 +293,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
         ctx->counters = reinterpret_cast<DeviceCounters*>(z + head_off + 256);
         ctx->per_frame = reinterpret_cast<uint32_t*>(z + head_off + 256 + ctr_bytes);
         ctx->markers_ptr = reinterpret_cast<a3_marker*>(z + head_off + head_bytes);
-        return hipMemsetAsync(z, 0, head_off + head_bytes, st);
+        return launch_zero(st, z, (head_off + head_bytes + 15) & ~(size_t)15);   // (may run a few bytes into the marker area: not yet written)
     };
     std::vector<Chunk> chunks;
     std::vector<uint64_t> fd;
@@ -403,7 +404,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
                                     ctx->cfg.contour_simplification_epsilon, min_edge_length, c.first, kMaxCand,
                                     ctx->cands.as<CandRec>() + (size_t)c.first * kMaxCand, ctx->cand_count + c.first, d_err));
     }
-    if (ctx->profiling) A3_HIP(hipEventRecord(ctx->ev[2], st));
+    if (ctx->profiling >= 2) A3_HIP(hipEventRecord(ctx->ev[2], st));
 
     // ---- candidates -> markers, all frames at once ----
     A3_HIP(launch_frame_candidates(st, ctx->cands.as<CandRec>(), ctx->cand_count, n, kMaxCand, min_corner_separation,
@@ -424,7 +425,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
                            (uint32_t)(sizeof(a3_marker) / 4), nullptr, marker_cap, d_marker_total, ctx->pose_has_intr ? 1 : 0, ctx->pose_size_mm,
                            (float)W, (float)H, in.focal_x, in.focal_y, in.principal_x, in.principal_y, ctx->tmp_b.as<a3_pose>()));
     }
-    if (ctx->profiling) A3_HIP(hipEventRecord(ctx->ev[3], st));
+    if (ctx->profiling >= 2) A3_HIP(hipEventRecord(ctx->ev[3], st));
 
     // ---- results: one copy of [scratch | counters | per-frame counts], one speculative copy of the marker list ----
     const size_t pose_bytes = (ctx->want_pose && ctx->pose_out) ? 2 * sizeof(a3_pose) : 0;
@@ -440,7 +441,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     Pending& pd = ctx->pending;
     pd.active = true; pd.n_chunks = chunks.size(); pd.chunk0_darts = chunks.empty() ? 0 : chunks[0].darts; pd.ctr_bytes = ctr_bytes;
     pd.head_pad = head_pad; pd.marker_cap = marker_cap; pd.guess = guess; pd.pose_bytes = pose_bytes; pd.device_plan = device_plan;
-    pd.rounds_max = rounds_max; pd.n = n; pd.W = W; pd.H = H;
+    pd.rounds_max = rounds_max; pd.n = n; pd.W = W; pd.H = H; pd.profiling = ctx->profiling;
     return A3_OK;
 }
 
@@ -525,11 +526,13 @@ int finish_batch(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_fram
     ctx->last_marker_total = total;
     *out_n = total;
     ctx->stats.markers = total;
-    if (ctx->profiling) {
+    if (pd.profiling >= 1) {   // the level in force when the batch was enqueued
         float ms;
         A3_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); ctx->prof_ms[A3_STAGE_THRESHOLD] += ms; ctx->prof_n[A3_STAGE_THRESHOLD]++;
-        A3_HIP(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2])); ctx->prof_ms[A3_STAGE_CONTOUR] += ms; ctx->prof_n[A3_STAGE_CONTOUR]++;
-        A3_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->prof_ms[A3_STAGE_DECODE] += ms; ctx->prof_n[A3_STAGE_DECODE]++;
+        if (pd.profiling >= 2) {
+            A3_HIP(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2])); ctx->prof_ms[A3_STAGE_CONTOUR] += ms; ctx->prof_n[A3_STAGE_CONTOUR]++;
+            A3_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->prof_ms[A3_STAGE_DECODE] += ms; ctx->prof_n[A3_STAGE_DECODE]++;
+        }
     }
     return A3_OK;
 }
@@ -968,7 +971,7 @@ int a3_find_nearest(a3_ctx* ctx, const uint64_t* bits, size_t n, uint32_t* idx, 
 
 int a3_set_profiling(a3_ctx* ctx, int enabled) {
     if (!ctx) return A3_ERR_INVALID;
-    ctx->profiling = enabled != 0;
+    ctx->profiling = enabled == A3_PROFILE_STAGES ? 2 : (enabled == A3_PROFILE_THRESHOLD_ONLY ? 1 : 0);
     return A3_OK;
 }
 

@@ -1208,6 +1208,16 @@ __global__ __launch_bounds__(1024) void k_plan(const unsigned long long* __restr
     }
 }
 
+// zeroing as a kernel: a hipMemsetAsync between two kernels costs its own ~4 us plus a ~6 us switch of packet type
+__global__ __launch_bounds__(256) void k_zero(uint4* __restrict__ p, uint32_t n16) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+hipError_t launch_zero(hipStream_t st, void* p, size_t bytes /* multiple of 16, p 16-byte aligned */) {
+    const uint32_t n16 = (uint32_t)(bytes / 16);
+    hipLaunchKernelGGL(k_zero, dim3(blocks_for(n16, 256, 256)), dim3(256), 0, st, reinterpret_cast<uint4*>(p), n16);
+    return hipGetLastError();
+}
+
 hipError_t launch_plan(hipStream_t st, const unsigned long long* frame_darts, uint32_t n_frames, uint64_t cap, uint32_t* frame_base, uint32_t* plan) {
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, st, frame_darts, n_frames, (unsigned long long)cap, frame_base, plan);
     return hipGetLastError();
