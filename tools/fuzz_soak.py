@@ -1,0 +1,32 @@
+"""One-off soak on the GPU box: the randomised structured-frame parity check of tests/test_gpu_parity.py over many more seeds,
+plus random noise / mixed batches of one shape in a row (exercises the device-side plan, its fallback, both entry modes)."""
+import sys, time
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import test_gpu_parity as T
+from oracle import a3oracle
+from aruco3_amd.dictionaries import ARDictionary
+
+class Dicts:
+    new_from_named_dict = staticmethod(ARDictionary.new_from_named_dict)
+
+n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+t0 = time.time(); cases = 0
+for seed in range(100, 100 + n_seeds):
+    T.test_randomised_structured_frames_full_parity.__wrapped__(Dicts, a3oracle, seed) if hasattr(T.test_randomised_structured_frames_full_parity, "__wrapped__") else T.test_randomised_structured_frames_full_parity(Dicts, a3oracle, seed)
+    cases += 5
+    if seed % 25 == 0: print(f"seed {seed} ok, {time.time() - t0:.0f} s", flush=True)
+# same-shape sequences with changing content
+rng = np.random.default_rng(77)
+det = T._detector(Dicts, "ARUCO")
+for it in range(60):
+    h, w = 240, 320
+    kind = rng.integers(0, 3)
+    if kind == 0: frames = rng.integers(0, 256, size=(3, h, w, 3), dtype=np.uint8)
+    elif kind == 1: frames = np.stack([np.repeat(T._fuzz_frame(rng, h, w, "quads")[..., None], 3, axis=2) for _ in range(3)])
+    else: frames = np.stack([np.repeat(T._fuzz_frame(rng, h, w, "rects")[..., None], 3, axis=2), rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8), np.full((h, w, 3), 200, np.uint8)])
+    T._check(det, a3oracle, frames, check_patches=False)
+    cases += 1
+print(f"soak ok: {cases} cases in {time.time() - t0:.0f} s")
