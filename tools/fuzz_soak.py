@@ -30,3 +30,13 @@ for it in range(60):
     T._check(det, a3oracle, frames, check_patches=False)
     cases += 1
 print(f"soak ok: {cases} cases in {time.time() - t0:.0f} s")
+
+# large frames of random sizes (many tiles, long borders crossing tile and word edges)
+t1 = time.time()
+for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
+    h, w = int(rng.integers(300, 1300)), int(rng.integers(300, 2100))
+    kind = ["rects", "quads", "strokes"][int(rng.integers(0, 3))]
+    c = int(rng.choice([1, 3, 4]))
+    fr = np.stack([np.repeat(T._fuzz_frame(rng, h, w, kind)[..., None], c, axis=2) for _ in range(2)])
+    T._check(det, a3oracle, fr if c > 1 else fr[..., 0][..., None], check_patches=False)
+print(f"large frames ok in {time.time() - t1:.0f} s")
