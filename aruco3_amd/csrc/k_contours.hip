@@ -127,55 +127,55 @@ __device__ __forceinline__ Nb8 tile_nb8(const uint64_t* __restrict__ img, int W,
     return r;
 }
 
-// grid: (tiles_x * ceil(tiles_y / 4), frames).  A workgroup counts four vertically stacked tiles: their 258 x 6 words are
-// staged with all loads in flight at once (a tile per workgroup was bound by one load latency + barriers per tile: 86 us).
-constexpr int kCountStack = 4;
+// grid: (ceil(tiles_x / 4) * tiles_y, frames).  A workgroup counts four tiles lying side by side: 66 rows of 18 words are
+// staged with all loads in flight at once, in row segments of 144 bytes (the 48-byte segments of a single tile used a third
+// of every cache line they touched; a tile per workgroup took 86 us, four stacked tiles 61 us).
+constexpr int kCountTiles = 4, kCountWords = kCountTiles * kTileWords;
 __global__ __launch_bounds__(256) void k_dart_count(const uint64_t* __restrict__ bits, int W, int H, uint32_t first_frame,
                                                     unsigned long long* __restrict__ frame_darts, uint32_t* __restrict__ tile_darts) {
-    __shared__ uint64_t s_t[kCountStack * kTileRows + 2][kTileWords + 2];
-    __shared__ uint32_t s_tot[kCountStack];
+    __shared__ uint64_t s_t[kTileRows + 2][kCountWords + 2];
+    __shared__ uint32_t s_tot[kCountTiles];
     const int wpr = (int)words_per_row((uint32_t)W);
     const uint32_t f = blockIdx.y;
     const uint32_t tiles_x = dart_tiles_x((uint32_t)W), tiles_y = ((uint32_t)H + kTileRows - 1) / kTileRows;
-    const int tx = blockIdx.x % tiles_x, sy = blockIdx.x / tiles_x;       // sy: stack index
+    const uint32_t groups_x = (tiles_x + kCountTiles - 1) / kCountTiles;
+    const int gx = blockIdx.x % groups_x, ty = blockIdx.x / groups_x;
     const uint64_t* img = bits + (size_t)(first_frame + f) * wpr * H;
-    const int j0 = tx * kTileWords - 1, y0 = sy * kCountStack * kTileRows - 1;
-    if (threadIdx.x < kCountStack) s_tot[threadIdx.x] = 0;
-    for (int i = threadIdx.x; i < (kCountStack * kTileRows + 2) * (kTileWords + 2); i += 256) {
-        const int r = i / (kTileWords + 2), c = i - r * (kTileWords + 2);
+    const int j0 = gx * kCountWords - 1, y0 = ty * kTileRows - 1;
+    if (threadIdx.x < kCountTiles) s_tot[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < (kTileRows + 2) * (kCountWords + 2); i += 256) {
+        const int r = i / (kCountWords + 2), c = i - r * (kCountWords + 2);
         s_t[r][c] = ldw(img, wpr, H, j0 + c, y0 + r);
     }
     __syncthreads();
-    const int jl = threadIdx.x & (kTileWords - 1), rl0 = threadIdx.x >> 2;
-    const int lane = threadIdx.x & 63;
+    const int jl = threadIdx.x & (kCountWords - 1), rg = threadIdx.x >> 4;   // word of the row, row group (rows rg, rg + 16, ...)
+    uint32_t nd = 0;
 #pragma unroll
-    for (int q = 0; q < kCountStack; q++) {
-        const int rl = q * kTileRows + rl0;
-        uint32_t nd = 0;
+    for (int k = 0; k < kTileRows / 16; k++) {
+        const int rl = rg + 16 * k;
         const uint64_t c = s_t[rl + 1][jl + 1];
-        if (c) {   // rows / words outside the image were staged as zeros
-            const uint64_t al = s_t[rl][jl], a = s_t[rl][jl + 1], ar = s_t[rl][jl + 2];
-            const uint64_t cl = s_t[rl + 1][jl], cr = s_t[rl + 1][jl + 2];
-            const uint64_t bl = s_t[rl + 2][jl], b = s_t[rl + 2][jl + 1], br = s_t[rl + 2][jl + 2];
-            // a word in the middle of a white area (all nine words all ones: most words of a frame on white paper) owns no dart
-            if ((c & a & b & al & ar & cl & cr & bl & br) == ~0ull) goto counted;
-            Nb8 nb;
-            nb.c = c;
-            nb.n[0] = (c << 1) | (cl >> 63); nb.n[1] = (a << 1) | (al >> 63); nb.n[2] = a; nb.n[3] = (a >> 1) | (ar << 63);
-            nb.n[4] = (c >> 1) | (cr << 63); nb.n[5] = (b >> 1) | (br << 63); nb.n[6] = b; nb.n[7] = (b << 1) | (bl >> 63);
-            uint64_t p[8];
-            pdart_words(nb, p);
+        if (c == 0) continue;   // rows / words outside the image were staged as zeros
+        const uint64_t al = s_t[rl][jl], a = s_t[rl][jl + 1], ar = s_t[rl][jl + 2];
+        const uint64_t cl = s_t[rl + 1][jl], cr = s_t[rl + 1][jl + 2];
+        const uint64_t bl = s_t[rl + 2][jl], b = s_t[rl + 2][jl + 1], br = s_t[rl + 2][jl + 2];
+        // a word in the middle of a white area (all nine words all ones: most words of a frame on white paper) owns no dart
+        if ((c & a & b & al & ar & cl & cr & bl & br) == ~0ull) continue;
+        Nb8 nb;
+        nb.c = c;
+        nb.n[0] = (c << 1) | (cl >> 63); nb.n[1] = (a << 1) | (al >> 63); nb.n[2] = a; nb.n[3] = (a >> 1) | (ar << 63);
+        nb.n[4] = (c >> 1) | (cr << 63); nb.n[5] = (b >> 1) | (br << 63); nb.n[6] = b; nb.n[7] = (b << 1) | (bl >> 63);
+        uint64_t p[8];
+        pdart_words(nb, p);
 #pragma unroll
-            for (int k = 0; k < 8; k++) nd += __popcll(p[k]);
-        }
-    counted:
-        for (int o = 32; o > 0; o >>= 1) nd += __shfl_down(nd, o);
-        if (lane == 0 && nd) atomicAdd(&s_tot[q], nd);
+        for (int q = 0; q < 8; q++) nd += __popcll(p[q]);
     }
+    // lanes of one tile inside a wave: same (lane & 15) >> 2; reduce over the word in the tile (xor 1, 2) and the row groups (xor 16, 32)
+    nd += __shfl_xor(nd, 1); nd += __shfl_xor(nd, 2); nd += __shfl_xor(nd, 16); nd += __shfl_xor(nd, 32);
+    if ((threadIdx.x & 0x33) == 0 && nd) atomicAdd(&s_tot[(threadIdx.x & 15) >> 2], nd);
     __syncthreads();
-    if (threadIdx.x < kCountStack) {
-        const uint32_t ty = sy * kCountStack + threadIdx.x;
-        if (ty < tiles_y) tile_darts[(size_t)(first_frame + f) * (tiles_x * tiles_y) + ty * tiles_x + tx] = s_tot[threadIdx.x];   // lets k_dart_assign skip empty tiles
+    if (threadIdx.x < kCountTiles) {
+        const uint32_t tx = gx * kCountTiles + threadIdx.x;
+        if (tx < tiles_x) tile_darts[(size_t)(first_frame + f) * (tiles_x * tiles_y) + ty * tiles_x + tx] = s_tot[threadIdx.x];   // lets k_dart_assign skip empty tiles
     }
     if (threadIdx.x == 0) {
         const uint32_t total = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
@@ -245,7 +245,7 @@ __device__ __forceinline__ int select_bit(uint64_t m, uint32_t r) {
 __device__ __forceinline__ int dir_dx(int k) { return (int)((0x1A90u >> (2 * k)) & 3u) - 1; }
 __device__ __forceinline__ int dir_dy(int k) { return (int)((0xA901u >> (2 * k)) & 3u) - 1; }
 
-// (Staging four stacked tiles per workgroup, as k_dart_count does, was tried here: 138 us instead of 125 us -- the tiles of a
+// (Staging four stacked tiles per workgroup was tried here: 138 us instead of 125 us -- the tiles of a
 // stack are then worked through one after the other and the barriers in between cost more than the shared staging saves.)
 __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict__ bits, int W, int H, uint32_t first_frame,
                                                      const uint32_t* __restrict__ frame_base, const uint32_t* __restrict__ tile_off,
@@ -1229,7 +1229,7 @@ size_t tile_darts_bytes(uint32_t W, uint32_t H, uint32_t n_frames) { return (siz
 hipError_t launch_dart_count(hipStream_t st, const uint64_t* bits, int W, int H, uint32_t first_frame, uint32_t n_frames,
                              unsigned long long* frame_darts, uint32_t* tile_darts) {
     const uint32_t tiles_x = dart_tiles_x((uint32_t)W), tiles_y = ((uint32_t)H + kTileRows - 1) / kTileRows;
-    hipLaunchKernelGGL(k_dart_count, dim3(tiles_x * ((tiles_y + kCountStack - 1) / kCountStack), n_frames), dim3(256), 0, st, bits, W, H, first_frame,
+    hipLaunchKernelGGL(k_dart_count, dim3(((tiles_x + kCountTiles - 1) / kCountTiles) * tiles_y, n_frames), dim3(256), 0, st, bits, W, H, first_frame,
                        frame_darts, tile_darts);
     hipLaunchKernelGGL(k_tile_scan, dim3(n_frames), dim3(256), 0, st, tile_darts, tiles_x * tiles_y, first_frame, tile_darts + (size_t)tiles_x * tiles_y * n_frames);
     return hipGetLastError();
