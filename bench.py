@@ -81,7 +81,7 @@ def main():
     # host-side frame synthesis first (forks a pool; nothing has touched the GPU yet)
     workers = args.synth_workers or max(1, min(16, (os.cpu_count() or 8) // max(1, world)))
     t0 = time.time()
-    cache = Path(f"{args.frames_cache}.r{rank}.npz") if args.frames_cache else None
+    cache = Path(f"{args.frames_cache}.n{args.frames}.r{rank}.npz") if args.frames_cache else None
     if args.device_synth:
         frames, truth_ids = None, None        # rendered below, once the device is set up
     elif cache is not None and cache.exists():
@@ -180,8 +180,9 @@ def main():
         for cx in ctxs:
             a, b = cx.profile(st_id, reset=True); tot += a; cnt += b
         stage_ms[name] = round(tot / cnt, 3) if cnt else None
-    for cx in ctxs:
-        cx.set_profiling(_lib.PROFILE_THRESHOLD_ONLY)
+    if args.warmup > 0:
+        for cx in ctxs:
+            cx.set_profiling(_lib.PROFILE_THRESHOLD_ONLY)
 
     if world > 1:
         dist.barrier()
@@ -207,6 +208,10 @@ def main():
     k1_ms = k1_n = 0
     for cx in ctxs:
         a, b = cx.profile(_lib.STAGE_THRESHOLD); k1_ms += a; k1_n += b
+    if args.warmup == 0:   # no warm-up to take the breakdown from: every stage was timed in the timed steps instead
+        for name, st_id in (("contour", _lib.STAGE_CONTOUR), ("decode", _lib.STAGE_DECODE)):
+            tot = sum(cx.profile(st_id)[0] for cx in ctxs)
+            stage_ms[name] = round(tot / max(k1_n, 1), 3)
     stats = ctx.stats()
 
     if rank == 0:

@@ -8,7 +8,7 @@ from aruco3_amd import _lib
 from aruco3_amd.aruco import Detector, DetectorConfig
 from aruco3_amd.dictionaries import ARDictionary
 
-z = np.load('/tmp/c2frames.r0.npz', allow_pickle=True)['frames']
+z = np.load('/tmp/c2frames.n256.r0.npz', allow_pickle=True)['frames']
 n, h, w, c = z.shape
 t = torch.from_numpy(z).cuda(); torch.cuda.synchronize()
 d = ARDictionary.new_from_named_dict('ARUCO')

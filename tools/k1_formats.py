@@ -9,7 +9,7 @@ from aruco3_amd.aruco import Detector, DetectorConfig
 from aruco3_amd.dictionaries import ARDictionary
 
 n, h, w = 256, 1080, 1920
-z = np.load('/tmp/c2frames.r0.npz', allow_pickle=True)['frames']
+z = np.load('/tmp/c2frames.n256.r0.npz', allow_pickle=True)['frames']
 det = Detector(DetectorConfig(), ARDictionary.new_from_named_dict('ARUCO'))
 ctx = det._context(); ctx.set_profiling(True)
 for name, c in (('L8', 1), ('RGB8', 3), ('RGBA8', 4)):

@@ -13,7 +13,7 @@ from aruco3_amd.aruco import Detector, DetectorConfig
 from aruco3_amd.dictionaries import ARDictionary
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-cache = pathlib.Path("/tmp/c2frames.r0.npz")   # written by bench.py --frames-cache /tmp/c2frames
+cache = pathlib.Path("/tmp/c2frames.n256.r0.npz")   # written by bench.py --frames-cache /tmp/c2frames
 if cache.exists() and n == 256:
     frames = np.load(cache, allow_pickle=True)["frames"]
 else:
