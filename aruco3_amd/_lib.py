@@ -21,10 +21,13 @@ STAGE_THRESHOLD, STAGE_CONTOUR, STAGE_DECODE = 0, 1, 2
 # every symbol include/aruco3_hip.h declares
 SYMBOLS = [
     "a3_abi_version", "a3_default_config", "a3_create", "a3_destroy", "a3_last_error", "a3_set_stream", "a3_set_pool_limits",
-    "a3_get_tau", "a3_set_debug_taps", "a3_detect_batch", "a3_detect_batch_pose", "a3_detect_batch_submit", "a3_detect_batch_collect", "a3_get_stats", "a3_debug_kernel_time", "a3_synth_render", "a3_download_grey", "a3_download_thresholded",
+    "a3_get_tau", "a3_set_debug_taps", "a3_detect_batch", "a3_detect_batch_pose", "a3_detect_batch_submit", "a3_detect_batch_collect", "a3_get_stats", "a3_synth_render", "a3_download_grey", "a3_download_thresholded",
     "a3_candidate_count", "a3_download_candidates", "a3_download_homographies", "a3_estimate_pose", "a3_estimate_pose_normalized",
-    "a3_find_nearest", "a3_calculate_tau", "a3_set_profiling", "a3_get_profile", "a3_selftest_ieee",
+    "a3_find_nearest", "a3_calculate_tau", "a3_set_profiling", "a3_get_profile",
+    "a3_contour_count", "a3_download_contours", "a3_detection_record_bytes", "a3_pack_detections",
 ]
+# aruco3_amd/csrc/a3_internal.h: probes and single-stage hooks for this repository's tests and tools, not for bindings
+INTERNAL_SYMBOLS = ["a3_debug_kernel_time", "a3_selftest_ieee", "a3_debug_clockwise", "a3_debug_rotate_bits", "a3_debug_discard_too_near"]
 
 
 class A3Error(RuntimeError):
@@ -157,6 +160,20 @@ def load():
     L.a3_get_profile.argtypes = [vp, C.c_int, f64p, u64p, C.c_int]
     L.a3_selftest_ieee.restype = C.c_int
     L.a3_selftest_ieee.argtypes = [vp, f64p, f64p, C.c_size_t, f64p, f64p, f32p, f32p]
+    L.a3_contour_count.restype = C.c_int
+    L.a3_contour_count.argtypes = [vp, C.c_uint32, u32p, u64p]
+    L.a3_download_contours.restype = C.c_int
+    L.a3_download_contours.argtypes = [vp, C.c_uint32, u32p, u32p, u32p, C.c_size_t, C.c_size_t]
+    L.a3_detection_record_bytes.restype = C.c_size_t
+    L.a3_detection_record_bytes.argtypes = [C.c_uint32]
+    L.a3_pack_detections.restype = C.c_int
+    L.a3_pack_detections.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_size_t]
+    L.a3_debug_clockwise.restype = C.c_int
+    L.a3_debug_clockwise.argtypes = [vp, C.POINTER(C.c_int32), C.c_size_t, C.POINTER(C.c_int32)]
+    L.a3_debug_rotate_bits.restype = C.c_int
+    L.a3_debug_rotate_bits.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, u8p]
+    L.a3_debug_discard_too_near.restype = C.c_int
+    L.a3_debug_discard_too_near.argtypes = [vp, u32p, C.c_size_t, C.c_float, u32p, C.POINTER(C.c_size_t)]
     _lib = L
     return L
 
@@ -185,7 +202,7 @@ def synth_render(device: int, frames: np.ndarray, markers: np.ndarray, width: in
                                 markers.ctypes.data_as(C.c_void_p) if len(markers) else None, len(markers), width, height, int(paper),
                                 black, white, supersample, C.c_void_p(out_ptr), row_stride, frame_stride)
     if rc != 0:
-        raise A3Error(f"a3_synth_render failed ({rc})")
+        raise A3Error(rc, "a3_synth_render failed")
 
 
 class Context:
@@ -314,6 +331,48 @@ class Context:
                                               _p(codes, C.c_uint64), _p(dec, C.c_int32), max(cnt, 1)), self.handle)
         return patches[:cnt], ok[:cnt], codes[:cnt], dec[:cnt]
 
+    def contours(self, frame: int):
+        """find_contours of one frame of the last batch (debug taps on): -> (start_keys u32[n], list of int32 [len, 2] point arrays)
+        in the reference's discovery order."""
+        nc, npts = C.c_uint32(), C.c_uint64()
+        check(load().a3_contour_count(self.handle, frame, C.byref(nc), C.byref(npts)), self.handle)
+        keys = np.zeros(max(nc.value, 1), dtype=np.uint32)
+        lens = np.zeros(max(nc.value, 1), dtype=np.uint32)
+        pts = np.zeros((max(npts.value, 1), 2), dtype=np.uint32)
+        check(load().a3_download_contours(self.handle, frame, _p(keys, C.c_uint32), _p(lens, C.c_uint32), _p(pts, C.c_uint32),
+                                          max(nc.value, 1), max(npts.value, 1)), self.handle)
+        keys, lens = keys[: nc.value], lens[: nc.value]
+        offs = np.concatenate([[0], np.cumsum(lens, dtype=np.int64)])
+        return keys, [pts[offs[i]: offs[i + 1]].astype(np.int64) for i in range(nc.value)]
+
+    def pack_detections(self, first_frame_global: int, max_markers: int, dst_ptr: int, dst_bytes: int):
+        """a3_pack_detections: the last batch's markers as fixed-capacity per-frame records in device memory at dst_ptr
+        (enqueued on the context's stream)."""
+        check(load().a3_pack_detections(self.handle, first_frame_global, max_markers, C.c_void_p(dst_ptr), dst_bytes), self.handle)
+
+    # ---- a3_internal.h: the reference's small helpers on the device, for its own vectors ----
+    def debug_clockwise(self, quads: np.ndarray) -> np.ndarray:
+        q = np.ascontiguousarray(quads, dtype=np.int32).reshape(-1, 8)
+        out = np.zeros_like(q)
+        check(load().a3_debug_clockwise(self.handle, _p(q, C.c_int32), q.shape[0], _p(out, C.c_int32)), self.handle)
+        return out.reshape(-1, 4, 2)
+
+    def debug_rotate_bits(self, bits: np.ndarray, times: int = 1) -> np.ndarray:
+        b = np.ascontiguousarray(bits, dtype=np.uint8)
+        n = b.shape[0]
+        assert b.shape == (n, n)
+        out = np.zeros_like(b)
+        check(load().a3_debug_rotate_bits(self.handle, _p(b, C.c_uint8), n, times, _p(out, C.c_uint8)), self.handle)
+        return out
+
+    def debug_discard_too_near(self, quads: np.ndarray, min_distance: float) -> np.ndarray:
+        q = np.ascontiguousarray(quads, dtype=np.uint32).reshape(-1, 8)
+        out = np.zeros_like(q)
+        n = C.c_size_t()
+        check(load().a3_debug_discard_too_near(self.handle, _p(q, C.c_uint32), q.shape[0], min_distance, _p(out, C.c_uint32), C.byref(n)),
+              self.handle)
+        return out[: n.value].reshape(-1, 4, 2)
+
     # ---- pose ----
     def estimate_pose(self, corners: np.ndarray, marker_size_mm: float, image_size=None, intrinsics: Intrinsics = None) -> np.ndarray:
         c = np.ascontiguousarray(corners, dtype=np.uint32).reshape(-1, 8)
@@ -352,7 +411,9 @@ _dict_ctx = {}
 
 
 def _ctx_for(codes: np.ndarray) -> Context:
-    key = (codes.ctypes.data, codes.size)
+    # keyed by the table's contents: an address can be re-used by another array once the first one is freed
+    codes = np.ascontiguousarray(codes, dtype=np.uint64)
+    key = codes.tobytes()
     ctx = _dict_ctx.get(key)
     if ctx is None:
         ctx = Context(default_config(), codes, 64, 1)

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "a3_common.h"
+#include "a3_internal.h"
 
 namespace a3 {
 // k_threshold.hip
@@ -33,7 +34,8 @@ hipError_t launch_resolve(hipStream_t, const JumpState*, uint32_t, int, const ui
 hipError_t launch_select_scatter(hipStream_t, const JumpState*, uint32_t, const uint32_t*, const unsigned int*, const uint32_t*, const uint64_t*,
                                  const uint32_t*, uint32_t, uint32_t,
                                  uint32_t, double, double, uint32_t*, ContourRec*, uint32_t*, uint32_t, uint64_t, DeviceCounters*,
-                                 const uint64_t*, uint32_t*, const uint32_t*, int, uint32_t*);
+                                 const uint64_t*, uint32_t*, const uint32_t*, int, uint32_t*, int);
+hipError_t launch_debug_clockwise(hipStream_t, const int32_t*, uint32_t, int32_t*);
 hipError_t launch_unpack_bits(hipStream_t, const uint64_t*, int, int, uint8_t*);
 hipError_t launch_contour_quads(hipStream_t, const ContourRec*, const DeviceCounters*, uint32_t, const uint32_t*, double, uint32_t, uint32_t,
                                 uint32_t, CandRec*, uint32_t*, unsigned int*);
@@ -43,9 +45,11 @@ hipError_t launch_frame_candidates(hipStream_t, const CandRec*, const uint32_t*,
                                    uint32_t*, unsigned int*);
 size_t proj_rec_bytes();
 hipError_t launch_decode(hipStream_t, PixelSrc, int, int, uint32_t, const uint16_t*, const uint32_t*, const unsigned int*, uint32_t,
-                         uint32_t, uint32_t, uint32_t, const uint64_t*, uint32_t, uint32_t, int, void*, void*, uint8_t*, uint32_t*, int, int);
+                         uint32_t, uint32_t, uint32_t, const uint64_t*, uint32_t, uint32_t, int, void*, void*, uint8_t*, uint32_t, uint32_t*, int, int);
 hipError_t launch_compact_markers(hipStream_t, const void*, const uint16_t*, const uint32_t*, uint32_t, uint32_t, uint32_t, a3_marker*,
-                                  uint32_t, uint32_t*, unsigned int*, unsigned int*);
+                                  uint32_t, uint32_t*, unsigned int*, unsigned int*, const uint32_t*, unsigned int*);
+hipError_t launch_pack_detections(hipStream_t, const a3_marker*, const uint32_t*, uint32_t, uint32_t, uint32_t, void*, unsigned int*);
+hipError_t launch_debug_rotate_bits(hipStream_t, const uint8_t*, uint32_t, uint32_t, uint8_t*);
 hipError_t launch_pose(hipStream_t, const uint32_t*, uint32_t, const float*, uint32_t, const unsigned int*, int, float, float, float, float,
                        float, float, float, a3_pose*);
 hipError_t launch_find_nearest(hipStream_t, const uint64_t*, uint32_t, const uint64_t*, uint32_t, uint32_t*, uint8_t*);
@@ -68,7 +72,7 @@ constexpr uint64_t kMaxPointsDefault = 64ull << 20;
 constexpr uint64_t kHardMaxDarts = 3ull << 30;   // 32-bit dart indices
 constexpr uint64_t kHardMaxPoints = 3ull << 30;
 constexpr int kResolveItersMax = 16;        // == DeviceCounters::resolve_changed slots
-constexpr uint32_t kPatchCap = 32768;        // debug taps: warped patches kept per batch
+constexpr uint32_t kPatchCap = 32768;        // debug taps: warped patches kept per batch (one per candidate that reaches the decode stage)
 
 // grow-only device buffer
 struct DevBuf {
@@ -131,6 +135,12 @@ struct a3_ctx {
     a3_pose* pose_out = nullptr;
     bool debug_taps = false;
     bool grey_valid = false;   // the last batch wrote the grey plane
+    // a3_download_contours: the last batch ran with debug taps in one chunk, so its contour table and point pool are whole
+    bool contours_valid = false;
+    uint32_t tap_contours = 0; uint64_t tap_points = 0;
+    // a3_pack_detections: the marker list of the last finished batch is still on the device
+    bool markers_valid = false;
+    uint32_t last_n = 0, last_max_per_frame = 0;
     int profiling = 0;   // 0 off, 1 threshold stage only, 2 every stage (an event record between kernels costs ~6 us of device time)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double prof_ms[A3_STAGE_COUNT] = {0, 0, 0};
@@ -258,6 +268,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     if (ctx->debug_taps) A3_HIP(ctx->patches.ensure((size_t)kPatchCap * S * S));
     ctx->W = W; ctx->H = H; ctx->frames = n;
     ctx->stats = a3_stats{};
+    ctx->contours_valid = false; ctx->markers_valid = false;
 
     // ---- K1 ----
     if (ctx->profiling) A3_HIP(hipEventRecord(ctx->ev[0], st));
@@ -399,7 +410,8 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
                                      ctx->cfg.contour_simplification_epsilon, image_diag, ctx->cyc_slot.as<uint32_t>(),
                                      ctx->contours.as<ContourRec>(),
                                      ctx->cyc_start_off.as<uint32_t>(), ctx->max_contours, ctx->max_points, ctr, ctx->d_xy.as<uint64_t>(),
-                                     ctx->points.as<uint32_t>(), n_live, ctx->resolve_full_ttl > 0 ? 0 : (int)W, ctx->leader_keep.as<uint32_t>()));
+                                     ctx->points.as<uint32_t>(), n_live, ctx->resolve_full_ttl > 0 ? 0 : (int)W, ctx->leader_keep.as<uint32_t>(),
+                                     ctx->debug_taps ? 1 : 0));
         A3_HIP(launch_contour_quads(st, ctx->contours.as<ContourRec>(), ctr, ctx->max_contours, ctx->points.as<uint32_t>(),
                                     ctx->cfg.contour_simplification_epsilon, min_edge_length, c.first, kMaxCand,
                                     ctx->cands.as<CandRec>() + (size_t)c.first * kMaxCand, ctx->cand_count + c.first, d_err));
@@ -414,10 +426,10 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
                                    : PixelSrc{pixels, row_stride, frame_stride, fmt};
     A3_HIP(launch_decode(st, src, (int)W, (int)H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), d_work_count,
                          kMaxCand, S, ctx->mark_size, S, ctx->dict.as<uint64_t>(), ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors,
-                         ctx->proj.p, ctx->outs.p, ctx->debug_taps ? ctx->patches.as<uint8_t>() : nullptr, ctx->per_frame, 4096, 0));
+                         ctx->proj.p, ctx->outs.p, ctx->debug_taps ? ctx->patches.as<uint8_t>() : nullptr, kPatchCap, ctx->per_frame, 4096, 0));
     ctx->dbg_src = src;
     A3_HIP(launch_compact_markers(st, ctx->outs.p, ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(), n, 0, kMaxCand,
-                                  ctx->markers_ptr, marker_cap, ctx->per_frame, d_marker_total, d_err));
+                                  ctx->markers_ptr, marker_cap, ctx->per_frame, d_marker_total, d_err, ctx->cand_count, ctx->scratch_u32 + 2));
     if (ctx->want_pose) {   // IPPE on the device-resident marker list (src/pose.rs:52-81), no extra round trip
         A3_HIP(ctx->tmp_b.ensure((size_t)marker_cap * 2 * sizeof(a3_pose)));
         const a3_intrinsics& in = ctx->pose_intr;
@@ -511,6 +523,10 @@ int finish_batch(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_fram
     if (total > out_cap) return fail(ctx, A3_ERR_CAPACITY, "out_cap is smaller than the number of markers found");
     const uint32_t* hpf = reinterpret_cast<const uint32_t*>(hp + 256 + ctr_bytes);
     if (per_frame_count) memcpy(per_frame_count, hpf, (size_t)n * 4);
+    uint32_t max_per_frame = 0;   // (read now: the staging buffer may be re-allocated below)
+    for (uint32_t f = 0; f < n; f++) max_per_frame = std::max(max_per_frame, hpf[f]);
+    const uint32_t n_work = hs[0], n_pre = hs[2];
+    const uint32_t tap_contours = n_chunks ? hc[0].contours : 0u; const uint64_t tap_points = n_chunks ? hc[0].points : 0ull;
     if (total > guess) {   // the guess was short: the staging area grows (the head has been consumed) and the whole list is fetched
         if (int rc = ensure_pinned(ctx, (size_t)total * (sizeof(a3_marker) + 2 * sizeof(a3_pose)) + (1 << 16))) return rc;
         h_markers = reinterpret_cast<a3_marker*>(ctx->pinned);
@@ -526,6 +542,11 @@ int finish_batch(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_fram
     ctx->last_marker_total = total;
     *out_n = total;
     ctx->stats.markers = total;
+    ctx->stats.candidates = n_work;      // work items = quads that survived discard_too_near
+    ctx->stats.candidates_pre = n_pre;   // quads after contours_to_candidates (k_compact_markers sums the per-frame counts)
+    ctx->markers_valid = true; ctx->last_n = n; ctx->last_max_per_frame = max_per_frame;
+    ctx->contours_valid = ctx->debug_taps && n_chunks == 1;
+    if (ctx->contours_valid) { ctx->tap_contours = tap_contours; ctx->tap_points = tap_points; }
     if (pd.profiling >= 1) {   // the level in force when the batch was enqueued
         float ms;
         A3_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); ctx->prof_ms[A3_STAGE_THRESHOLD] += ms; ctx->prof_n[A3_STAGE_THRESHOLD]++;
@@ -571,14 +592,16 @@ int a3_calculate_tau(int device, const uint64_t* codes, size_t n_codes, uint8_t*
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(ctx, A3_ERR_NO_DEVICE, "no HIP device");
     A3_HIP(hipSetDevice(device));
     uint64_t* d = nullptr; unsigned int* dt = nullptr;
-    A3_HIP(hipMalloc(&d, std::max<size_t>(n_codes, 1) * 8));
-    A3_HIP(hipMalloc(&dt, 4));
     unsigned int init = 255, res = 255;
-    A3_HIP(hipMemcpy(d, codes, n_codes * 8, hipMemcpyHostToDevice));
-    A3_HIP(hipMemcpy(dt, &init, 4, hipMemcpyHostToDevice));
-    A3_HIP(launch_calc_tau(nullptr, d, (uint32_t)n_codes, dt));
-    A3_HIP(hipMemcpy(&res, dt, 4, hipMemcpyDeviceToHost));
-    (void)hipFree(d); (void)hipFree(dt);
+    hipError_t e = hipMalloc(&d, std::max<size_t>(n_codes, 1) * 8);
+    if (e == hipSuccess) e = hipMalloc(&dt, 4);
+    if (e == hipSuccess && n_codes) e = hipMemcpy(d, codes, n_codes * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dt, &init, 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_calc_tau(nullptr, d, (uint32_t)n_codes, dt);
+    if (e == hipSuccess) e = hipMemcpy(&res, dt, 4, hipMemcpyDeviceToHost);
+    if (d) (void)hipFree(d);     // on every path
+    if (dt) (void)hipFree(dt);
+    if (e != hipSuccess) return fail(ctx, A3_ERR_HIP, "a3_calculate_tau", e);
     *tau = (uint8_t)res;
     return A3_OK;
 }
@@ -800,7 +823,7 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
         } else if (kernel == 3) {   // dbg < 0: k_decode alone (variant -dbg), dbg >= 0: k_projection + k_decode
             A3_HIP(launch_decode(st, ctx->dbg_src, (int)ctx->W, (int)ctx->H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), ctx->scratch_u32,
                                  kMaxCand, ctx->cfg.homography_sample_size, ctx->mark_size, ctx->cfg.homography_sample_size, ctx->dict.as<uint64_t>(),
-                                 ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors, ctx->proj.p, ctx->outs.p, nullptr, nullptr, 4096, dbg));
+                                 ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors, ctx->proj.p, ctx->outs.p, nullptr, 0u, nullptr, 4096, dbg));
         } else return fail(ctx, A3_ERR_INVALID, "kernel: 0 dart_count, 1 dart_assign, 2 local_contract, 3 decode");
         A3_HIP(hipEventRecord(e1, st));
         A3_HIP(hipStreamSynchronize(st));
@@ -898,7 +921,7 @@ int a3_download_candidates(a3_ctx* ctx, uint32_t frame, int before_discard, uint
     return A3_OK;
 }
 
-struct DecodeOutHost { uint64_t code; uint64_t codes[4]; uint32_t id; uint8_t valid, rotation, hamming, hom_ok; int32_t decode_ok; uint32_t pad; };
+struct DecodeOutHost { uint64_t code; uint64_t codes[4]; uint32_t id; uint8_t valid, rotation, hamming, hom_ok; int32_t decode_ok; uint32_t patch; };
 
 int a3_download_homographies(a3_ctx* ctx, uint32_t frame, uint8_t* dst, uint8_t* ok, uint64_t* codes4, int32_t* decode_ok, size_t cap) {
     if (!ctx) return A3_ERR_INVALID;
@@ -916,11 +939,143 @@ int a3_download_homographies(a3_ctx* ctx, uint32_t frame, uint8_t* dst, uint8_t*
         if (codes4) for (int r = 0; r < 4; r++) codes4[4 * k + r] = o[k].codes[r];
         if (dst) {
             if (!ctx->debug_taps) return fail(ctx, A3_ERR_INVALID, "patches are only kept after a3_set_debug_taps(ctx, 1)");
-            const size_t slot = (size_t)frame * kMaxCand + k;
-            if (slot >= kPatchCap) return fail(ctx, A3_ERR_CAPACITY, "patch tap holds the first 32768 candidate slots only");
+            const size_t slot = o[k].patch;   // where k_decode kept this candidate's patch (kNone: the tap was full)
+            if (slot >= kPatchCap) return fail(ctx, A3_ERR_CAPACITY, "the patch tap holds 32768 patches per batch; this candidate's was not kept");
             A3_HIP(hipMemcpy(dst + (size_t)k * S * S, ctx->patches.as<uint8_t>() + slot * S * S, (size_t)S * S, hipMemcpyDeviceToHost));
         }
     }
+    return A3_OK;
+}
+
+// ---- Detection gather records on the device (multi-GPU) ----
+size_t a3_detection_record_bytes(uint32_t max_markers_per_frame) { return 8 + (size_t)max_markers_per_frame * sizeof(a3_marker); }
+
+int a3_pack_detections(a3_ctx* ctx, uint32_t first_frame_global, uint32_t max_markers_per_frame, void* dst_device, size_t dst_bytes) {
+    if (!ctx || !dst_device) return A3_ERR_INVALID;
+    if (!ctx->markers_valid) return fail(ctx, A3_ERR_INVALID, "a3_pack_detections: no finished batch on this context");
+    if (max_markers_per_frame == 0) return fail(ctx, A3_ERR_INVALID, "a3_pack_detections: max_markers_per_frame must be > 0");
+    const size_t need = a3_detection_record_bytes(max_markers_per_frame) * ctx->last_n;
+    if (dst_bytes < need) return fail(ctx, A3_ERR_CAPACITY, "a3_pack_detections: dst_bytes smaller than frames x record size");
+    if (reinterpret_cast<uintptr_t>(dst_device) % 4 != 0) return fail(ctx, A3_ERR_INVALID, "a3_pack_detections: dst must be 4-byte aligned");
+    // the host already knows the per-frame counts of that batch: refuse before anything is clipped
+    if (ctx->last_max_per_frame > max_markers_per_frame) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "a3_pack_detections: a frame holds %u markers, the record only %u", ctx->last_max_per_frame, max_markers_per_frame);
+        return fail(ctx, A3_ERR_CAPACITY, msg);
+    }
+    A3_HIP(hipSetDevice(ctx->device));
+    // scratch word 3 is the kernel's overflow flag (cannot fire after the host check; kept as the device-side guard)
+    A3_HIP(launch_pack_detections(ctx->stream, ctx->markers_ptr, ctx->per_frame, ctx->last_n, first_frame_global, max_markers_per_frame, dst_device,
+                                  ctx->scratch_u32 + 3));
+    return A3_OK;
+}
+
+// ---- find_contours output of the last batch (debug taps; src/aruco.rs:64) ----
+namespace {
+int fetch_contours(a3_ctx* ctx, uint32_t frame, std::vector<ContourRec>* recs) {
+    if (!ctx->contours_valid) return fail(ctx, A3_ERR_INVALID, "contours are only kept for a single-chunk batch run after a3_set_debug_taps(ctx, 1)");
+    if (frame >= ctx->frames) return fail(ctx, A3_ERR_INVALID, "frame index outside the last batch");
+    A3_HIP(hipSetDevice(ctx->device));
+    std::vector<ContourRec> all(ctx->tap_contours);
+    if (!all.empty()) A3_HIP(hipMemcpy(all.data(), ctx->contours.p, all.size() * sizeof(ContourRec), hipMemcpyDeviceToHost));
+    recs->clear();
+    for (const ContourRec& r : all) if (r.frame == frame) recs->push_back(r);
+    // the reference's discovery order = ascending start key (2 * raster index of the start pixel, +1 for a hole border)
+    std::sort(recs->begin(), recs->end(), [](const ContourRec& a, const ContourRec& b) { return a.start_key < b.start_key; });
+    return A3_OK;
+}
+}  // namespace
+
+int a3_contour_count(a3_ctx* ctx, uint32_t frame, uint32_t* n_contours, uint64_t* n_points) {
+    if (!ctx) return A3_ERR_INVALID;
+    std::vector<ContourRec> recs;
+    if (int rc = fetch_contours(ctx, frame, &recs)) return rc;
+    uint64_t pts = 0;
+    for (const ContourRec& r : recs) pts += r.n;
+    if (n_contours) *n_contours = (uint32_t)recs.size();
+    if (n_points) *n_points = pts;
+    return A3_OK;
+}
+
+int a3_download_contours(a3_ctx* ctx, uint32_t frame, uint32_t* start_keys, uint32_t* lengths, uint32_t* points_xy, size_t cap_contours,
+                         size_t cap_points) {
+    if (!ctx || !start_keys || !lengths || !points_xy) return A3_ERR_INVALID;
+    std::vector<ContourRec> recs;
+    if (int rc = fetch_contours(ctx, frame, &recs)) return rc;
+    uint64_t pts = 0;
+    for (const ContourRec& r : recs) pts += r.n;
+    if (recs.size() > cap_contours || pts > cap_points) return fail(ctx, A3_ERR_CAPACITY, "a3_download_contours: caps too small");
+    std::vector<uint32_t> pool(ctx->tap_points);
+    if (!pool.empty()) A3_HIP(hipMemcpy(pool.data(), ctx->points.p, pool.size() * 4, hipMemcpyDeviceToHost));
+    size_t o = 0;
+    for (size_t i = 0; i < recs.size(); i++) {
+        start_keys[i] = recs[i].start_key;
+        lengths[i] = recs[i].n;
+        for (uint32_t k = 0; k < recs[i].n; k++) {
+            const uint32_t p = pool[(size_t)recs[i].point_base + k];
+            points_xy[2 * o] = p & 0xFFFFu; points_xy[2 * o + 1] = p >> 16;
+            o++;
+        }
+    }
+    return A3_OK;
+}
+
+// ---- internal (a3_internal.h): the small helpers of src/aruco.rs run on their own, for the reference's vectors ----
+int a3_debug_clockwise(a3_ctx* ctx, const int32_t* quads_xy, size_t n, int32_t* out_xy) {
+    if (!ctx || !quads_xy || !out_xy) return A3_ERR_INVALID;
+    if (n == 0) return A3_OK;
+    A3_HIP(hipSetDevice(ctx->device));
+    A3_HIP(ctx->tmp_a.ensure(n * 32)); A3_HIP(ctx->tmp_c.ensure(n * 32));
+    A3_HIP(hipMemcpyAsync(ctx->tmp_a.p, quads_xy, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    A3_HIP(launch_debug_clockwise(ctx->stream, ctx->tmp_a.as<int32_t>(), (uint32_t)n, ctx->tmp_c.as<int32_t>()));
+    A3_HIP(hipMemcpyAsync(out_xy, ctx->tmp_c.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    A3_HIP(hipStreamSynchronize(ctx->stream));
+    return A3_OK;
+}
+
+int a3_debug_rotate_bits(a3_ctx* ctx, const uint8_t* bits, uint32_t n, uint32_t times, uint8_t* out) {
+    if (!ctx || !bits || !out || n == 0 || n > 16) return A3_ERR_INVALID;
+    A3_HIP(hipSetDevice(ctx->device));
+    A3_HIP(ctx->tmp_a.ensure(256)); A3_HIP(ctx->tmp_c.ensure(256));
+    A3_HIP(hipMemcpyAsync(ctx->tmp_a.p, bits, (size_t)n * n, hipMemcpyHostToDevice, ctx->stream));
+    A3_HIP(launch_debug_rotate_bits(ctx->stream, ctx->tmp_a.as<uint8_t>(), n, times & 3u, ctx->tmp_c.as<uint8_t>()));
+    A3_HIP(hipMemcpyAsync(out, ctx->tmp_c.p, (size_t)n * n, hipMemcpyDeviceToHost, ctx->stream));
+    A3_HIP(hipStreamSynchronize(ctx->stream));
+    return A3_OK;
+}
+
+// quads in the order given (= the reference's candidate order) through k_frame_candidates' discard_too_near
+int a3_debug_discard_too_near(a3_ctx* ctx, const uint32_t* quads_xy, size_t n, float min_distance, uint32_t* out_xy, size_t* n_out) {
+    if (!ctx || !quads_xy || !out_xy || !n_out) return A3_ERR_INVALID;
+    *n_out = 0;
+    if (n == 0) return A3_OK;
+    if (n > kMaxCand) return fail(ctx, A3_ERR_CAPACITY, "a3_debug_discard_too_near: at most 1024 quads");
+    A3_HIP(hipSetDevice(ctx->device));
+    std::vector<CandRec> h(n);
+    for (size_t i = 0; i < n; i++) {
+        h[i].start_key = (uint32_t)i;   // the given order
+        for (int k = 0; k < 8; k++) {
+            if (quads_xy[8 * i + k] > 65535u) return fail(ctx, A3_ERR_INVALID, "coordinates above 65535");
+            h[i].xy[k] = (uint16_t)quads_xy[8 * i + k];
+        }
+    }
+    A3_HIP(ctx->tmp_a.ensure(kMaxCand * sizeof(CandRec)));
+    A3_HIP(ctx->tmp_b.ensure(kMaxCand * 16 * 2));          // pre_xy | fin_xy
+    A3_HIP(ctx->tmp_c.ensure(kMaxCand * 4 + 64));          // work list | cand_count, fin_count, work_count
+    uint32_t* small = ctx->tmp_c.as<uint32_t>() + kMaxCand;
+    const uint32_t init[3] = {(uint32_t)n, 0u, 0u};
+    A3_HIP(hipMemcpyAsync(ctx->tmp_a.p, h.data(), n * sizeof(CandRec), hipMemcpyHostToDevice, ctx->stream));
+    A3_HIP(hipMemcpyAsync(small, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    uint16_t* pre = ctx->tmp_b.as<uint16_t>(); uint16_t* fin = pre + kMaxCand * 8;
+    A3_HIP(launch_frame_candidates(ctx->stream, ctx->tmp_a.as<CandRec>(), small, 1, kMaxCand, min_distance, pre, fin, small + 1,
+                                   ctx->tmp_c.as<uint32_t>(), small + 2));
+    uint32_t cnt = 0;
+    A3_HIP(hipMemcpyAsync(&cnt, small + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    A3_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<uint16_t> o((size_t)cnt * 8);
+    if (cnt) A3_HIP(hipMemcpy(o.data(), fin, o.size() * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < o.size(); i++) out_xy[i] = o[i];
+    *n_out = cnt;
     return A3_OK;
 }
 

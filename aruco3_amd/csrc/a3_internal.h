@@ -1,0 +1,37 @@
+/*
+ * a3_internal.h -- entry points of libaruco3_hip.so that are NOT part of the binding surface (include/aruco3_hip.h):
+ * tuning probes and single-stage hooks used by this repository's tests and tools only.  A Rust/C binding of the detector
+ * has no business calling them; they may change without an ABI version bump.
+ */
+#ifndef ARUCO3_HIP_INTERNAL_H
+#define ARUCO3_HIP_INTERNAL_H
+
+#include "../../include/aruco3_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* kernel-level timing for tuning (tools/kernel_probe.py): re-runs one kernel (0 dart_count, 1 dart_assign, 2 local_contract,
+ * 3 decode) on the buffers of the last single-chunk batch, optionally truncated (dbg), and returns the average device time.
+ * The internal contour buffers hold garbage afterwards; results already returned are unaffected. */
+int  a3_debug_kernel_time(a3_ctx *ctx, int kernel, int dbg, int reps, float *avg_ms);
+
+/* numerics self-check used by the GPU tests: evaluates the IEEE operations the kernels rely on (f64 sqrt/div, f32 sqrt/div)
+ * for n inputs so that the host can compare them bit for bit */
+int  a3_selftest_ieee(a3_ctx *ctx, const double *a, const double *b, size_t n, double *sqrt_a, double *a_div_b,
+                      float *sqrtf_a, float *a_divf_b);
+
+/* The reference's own vectors for its small helpers (src/aruco.rs:400-459), fed through the device code that implements
+ * them inside the pipeline kernels:
+ *   enforce_clockwise_corners (src/aruco.rs:168-185)  -> the winding fix of k_contour_quads, n quads of 4 (x, y) i32 pairs
+ *   rotate_bit_matrix         (src/aruco.rs:315-326)  -> k_decode's rotation mapping applied `times` times to an n x n matrix
+ *   discard_too_near          (src/aruco.rs:187-232)  -> k_frame_candidates on one frame whose candidates are `quads_xy` in order */
+int  a3_debug_clockwise(a3_ctx *ctx, const int32_t *quads_xy, size_t n, int32_t *out_xy);
+int  a3_debug_rotate_bits(a3_ctx *ctx, const uint8_t *bits, uint32_t n, uint32_t times, uint8_t *out);
+int  a3_debug_discard_too_near(a3_ctx *ctx, const uint32_t *quads_xy, size_t n, float min_distance, uint32_t *out_xy, size_t *n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

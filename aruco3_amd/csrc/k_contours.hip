@@ -858,7 +858,8 @@ __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restric
                                                       uint32_t* __restrict__ cyc_start_off, uint32_t max_contours, uint64_t max_points,
                                                       DeviceCounters* __restrict__ ctr, uint32_t shard_cap, const uint64_t* __restrict__ d_rec,
                                                       int W /* > 0: no resolve kernel ran; borders start naturally, checked here */,
-                                                      uint32_t* __restrict__ keep_tmp /* one word per leader-list slot */) {
+                                                      uint32_t* __restrict__ keep_tmp /* one word per leader-list slot */,
+                                                      int keep_all /* debug taps: materialise every traced border (a3_download_contours) */) {
     __shared__ uint32_t s_wave[4], s_wave_t[4];
     __shared__ unsigned long long s_wave_p[4];
     __shared__ uint32_t s_cbase;
@@ -893,7 +894,7 @@ __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restric
         //  (2) Douglas-Peucker splits only when a point is further than eps = eps_factor*n from a chord,
         //      and no two pixels are further apart than the image diagonal (+1 slack for rounding).
         const double eps = (double)e.n * eps_factor;
-        e.keep = e.n >= 5u && (uint64_t)e.n * e.n >= 2ull * min_edge_length && eps < image_diag + 1.0;
+        e.keep = keep_all || (e.n >= 5u && (uint64_t)e.n * e.n >= 2ull * min_edge_length && eps < image_diag + 1.0);
         return e;
     };
 
@@ -1045,6 +1046,22 @@ __device__ bool hull4(const int* __restrict__ in /*8*/, int* __restrict__ out /*
     return true;
 }
 
+// enforce_clockwise_corners for one quad, src/aruco.rs:168-185: (p1-p0) x (p2-p0) < 0 -> swap p1, p3
+__device__ __forceinline__ void enforce_clockwise(int* __restrict__ hq /*8*/) {
+    const int dx1 = hq[2] - hq[0], dy1 = hq[3] - hq[1], dx2 = hq[4] - hq[0], dy2 = hq[5] - hq[1];
+    if (dx1 * dy2 - dy1 * dx2 < 0) { const int tx = hq[2], ty = hq[3]; hq[2] = hq[6]; hq[3] = hq[7]; hq[6] = tx; hq[7] = ty; }
+}
+
+// the winding fix of k_contour_quads on its own (reference vectors: src/aruco.rs:400-412)
+__global__ void k_debug_clockwise(const int32_t* __restrict__ in, uint32_t n, int32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int q[8];
+    for (int k = 0; k < 8; k++) q[k] = in[8 * i + k];
+    enforce_clockwise(q);
+    for (int k = 0; k < 8; k++) out[8 * i + k] = q[k];
+}
+
 // G lanes work on one border: 64 for long ones, 16 (four borders per wave) for the short ones that noisy frames produce by
 // the hundred thousand -- a full wave per 20-point border is latency with 60 idle lanes.  Control flow is uniform inside a
 // group and the shuffles stay inside it.
@@ -1122,9 +1139,7 @@ __device__ __forceinline__ void contour_quads_body(uint32_t block, uint32_t n_bl
             cmin = d2 < cmin ? d2 : cmin;
         }
         if (cmin < min_edge_length) continue;
-        // enforce_clockwise_corners, src/aruco.rs:168-185
-        const int dx1 = hq[2] - hq[0], dy1 = hq[3] - hq[1], dx2 = hq[4] - hq[0], dy2 = hq[5] - hq[1];
-        if (dx1 * dy2 - dy1 * dx2 < 0) { int tx = hq[2], ty = hq[3]; hq[2] = hq[6]; hq[3] = hq[7]; hq[6] = tx; hq[7] = ty; }
+        enforce_clockwise(hq);
         const uint32_t fl = r.frame - first_frame;
         const uint32_t slot = atomicAdd(&cand_count[fl], 1u);
         if (slot >= max_cand) { atomicOr(err_flags, kErrCandTable); continue; }
@@ -1302,12 +1317,12 @@ hipError_t launch_select_scatter(hipStream_t st, const JumpState* fin, uint32_t 
                                  const uint32_t* frame_base, uint32_t n_frames, uint32_t first_frame, uint32_t min_edge_length,
                                  double eps_factor, double image_diag, uint32_t* cyc_slot, ContourRec* contours, uint32_t* cyc_start_off,
                                  uint32_t max_contours, uint64_t max_points, DeviceCounters* ctr, const uint64_t* d_rec, uint32_t* points,
-                                 const uint32_t* n_live, int inline_resolve_W, uint32_t* keep_tmp) {
+                                 const uint32_t* n_live, int inline_resolve_W, uint32_t* keep_tmp, int keep_all) {
     const dim3 grid(blocks_for(n_darts, 256, env_cap("A3_SCATTER_BLOCKS", 4096))), block(256);
     hipLaunchKernelGGL(k_cycle_select, dim3(blocks_for(n_darts / 64 + 1, 256, 1024)), block, 0, st, fin, leader_list, leader_count, d_succ, t_cur,
                        frame_base, n_frames, first_frame, min_edge_length,
                        eps_factor, image_diag, cyc_slot, contours, cyc_start_off, max_contours, max_points, ctr, leader_shard_cap(n_darts), d_rec,
-                       inline_resolve_W, keep_tmp);
+                       inline_resolve_W, keep_tmp, keep_all);
     hipLaunchKernelGGL(k_scatter_points, grid, block, 0, st, fin, n_darts, d_rec, cyc_slot, contours, cyc_start_off, points, n_live, ctr);
     return hipGetLastError();
 }
@@ -1317,6 +1332,11 @@ hipError_t launch_contour_quads(hipStream_t st, const ContourRec* contours, cons
                                 CandRec* cands, uint32_t* cand_count, unsigned int* err_flags) {
     hipLaunchKernelGGL(k_contour_quads, dim3(1024 + 512), dim3(256), 0, st, 1024u, contours, ctr, max_contours, points, eps_factor, min_edge_length,
                        first_frame, max_cand, cands, cand_count, err_flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_debug_clockwise(hipStream_t st, const int32_t* in, uint32_t n, int32_t* out) {
+    hipLaunchKernelGGL(k_debug_clockwise, dim3((n + 63) / 64), dim3(64), 0, st, in, n, out);
     return hipGetLastError();
 }
 

@@ -117,7 +117,7 @@ struct DecodeOut {      // one per final candidate slot
     uint32_t id;
     uint8_t valid, rotation, hamming, hom_ok;
     int32_t decode_ok;
-    uint32_t pad;
+    uint32_t patch;   // debug taps: index of this candidate's warped patch in the patch buffer, kNone if it was not kept
 };
 
 // imageproc Projection::from_control_points: 8x8 system in f64, LU with partial pivoting (nalgebra order of
@@ -331,6 +331,16 @@ __global__ __launch_bounds__(64) void k_projection(const uint16_t* __restrict__ 
     }
 }
 
+// rotate_bit_matrix (src/aruco.rs:315-326: new[a][b] = old[b][n-1-a], 90 degrees counter-clockwise) applied r times:
+// cell (y, x) of the rotated matrix comes from the original at
+//   r=0 (y,x)  r=1 (x,n-1-y)  r=2 (n-1-y,n-1-x)  r=3 (n-1-x,y)
+__device__ __forceinline__ void rotated_source(uint32_t r, uint32_t n, uint32_t y, uint32_t x, uint32_t* sy, uint32_t* sx) {
+    if (r == 0) { *sy = y; *sx = x; }
+    else if (r == 1) { *sy = x; *sx = n - 1 - y; }
+    else if (r == 2) { *sy = n - 1 - y; *sx = n - 1 - x; }
+    else { *sy = n - 1 - x; *sx = y; }
+}
+
 // grid-stride over the work list; block = 256 threads; dynamic LDS:
 //   patch S*S | tmp n*S f32 | wtab n*max_taps f32 | wleft n u32 | wcnt n u32 | bits n*n
 __global__ __launch_bounds__(256) void k_decode(PixelSrc src, int W, int H, uint32_t first_frame,
@@ -338,7 +348,7 @@ __global__ __launch_bounds__(256) void k_decode(PixelSrc src, int W, int H, uint
                                                 const unsigned int* __restrict__ work_count, uint32_t max_cand, uint32_t S, uint32_t n,
                                                 uint32_t max_taps, const uint64_t* __restrict__ dict, uint32_t n_codes, uint32_t tau,
                                                 int filter, const ProjRec* __restrict__ proj, DecodeOut* __restrict__ outs,
-                                                uint8_t* __restrict__ patches /*nullable*/, uint32_t* __restrict__ per_frame /*nullable*/, int dbg) {
+                                                uint8_t* __restrict__ patches /*nullable*/, uint32_t patch_cap, uint32_t* __restrict__ per_frame /*nullable*/, int dbg) {
     // dbg (a3_debug_kernel_time only, 0 in the product path): 1 = no sampling, 2 / 3 / 4 = stop after sampling / Otsu / bits
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* s_patch = smem;
@@ -412,8 +422,11 @@ __global__ __launch_bounds__(256) void k_decode(PixelSrc src, int W, int H, uint
         }
         __syncthreads();
         if (dbg == 2) continue;
-        if (patches) {
-            uint8_t* dst = patches + (size_t)slot * S * S;
+        // debug taps: the patch buffer holds patch_cap patches, one per work item (NOT per candidate slot: slots are
+        // frame * max_cand + k and would run past the buffer for frames beyond patch_cap / max_cand)
+        const bool keep_patch = patches != nullptr && wi < patch_cap;
+        if (keep_patch) {
+            uint8_t* dst = patches + (size_t)wi * S * S;
             for (uint32_t i = tid; i < S * S; i += 256) dst[i] = ok ? s_patch[i] : 0;
         }
         // otsu_level (imageproc): the reference scans thresholds 0..255 keeping running integer sums and the first strict
@@ -516,14 +529,9 @@ __global__ __launch_bounds__(256) void k_decode(PixelSrc src, int W, int H, uint
             if (s_have && (uint32_t)tid < 4u * cells) {
                 const uint32_t r = (uint32_t)tid / cells, idx = (uint32_t)tid - r * cells;
                 const uint32_t y = 1 + idx / inner, x = 1 + idx % inner;
-                // rotation r of the bit matrix read row-major: after r applications of rotate_bit_matrix
-                // (new[a][b] = old[b][n-1-a]) cell (y,x) comes from the original at
-                //   r=0 (y,x)  r=1 (x,n-1-y)  r=2 (n-1-y,n-1-x)  r=3 (n-1-x,y)
+                // rotation r of the bit matrix, read row-major
                 uint32_t sy, sx;
-                if (r == 0) { sy = y; sx = x; }
-                else if (r == 1) { sy = x; sx = n - 1 - y; }
-                else if (r == 2) { sy = n - 1 - y; sx = n - 1 - x; }
-                else { sy = n - 1 - x; sx = y; }
+                rotated_source(r, n, y, x, &sy, &sx);
                 if (s_bits[sy * n + sx]) atomicOr(reinterpret_cast<unsigned long long*>(&s_codes[r]), 1ull << (cells - 1 - idx));
             }
         }
@@ -556,7 +564,7 @@ __global__ __launch_bounds__(256) void k_decode(PixelSrc src, int W, int H, uint
         __syncthreads();
         if (tid == 0) {
             DecodeOut out;
-            out.valid = 0; out.id = 0; out.code = 0; out.rotation = 0; out.hamming = 0; out.pad = 0;
+            out.valid = 0; out.id = 0; out.code = 0; out.rotation = 0; out.hamming = 0; out.patch = keep_patch ? wi : kNone;
             out.hom_ok = ok; out.decode_ok = have;
             for (int r = 0; r < 4; r++) out.codes[r] = have ? s_codes[r] : 0;
             int found_any = 0;
@@ -593,7 +601,8 @@ __global__ __launch_bounds__(256) void k_compact_markers_par(const DecodeOut* __
                                                              const uint32_t* __restrict__ fin_count, uint32_t n_frames, uint32_t max_cand,
                                                              a3_marker* __restrict__ markers, uint32_t marker_cap,
                                                              const uint32_t* __restrict__ per_frame, unsigned int* __restrict__ marker_total,
-                                                             unsigned int* __restrict__ err_flags) {
+                                                             unsigned int* __restrict__ err_flags, const uint32_t* __restrict__ cand_count,
+                                                             unsigned int* __restrict__ cand_pre_total) {
     const int lane = threadIdx.x & 63;
     const uint32_t f = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (f >= n_frames) return;
@@ -601,6 +610,12 @@ __global__ __launch_bounds__(256) void k_compact_markers_par(const DecodeOut* __
     for (uint32_t g = lane; g < f; g += 64) base += per_frame[g];
     for (int o = 32; o > 0; o >>= 1) base += __shfl_xor(base, o);
     if (f + 1 == n_frames && lane == 0) *marker_total = base + per_frame[f];
+    if (f + 1 == n_frames) {   // a3_stats.candidates_pre: quads after contours_to_candidates, summed over the batch
+        uint32_t pre = 0;
+        for (uint32_t g = lane; g < n_frames; g += 64) pre += min(cand_count[g], max_cand);
+        for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o);
+        if (lane == 0) *cand_pre_total = pre;
+    }
     const uint32_t c = fin_count[f];
     uint32_t pos = base;
     for (uint32_t k0 = 0; k0 < c; k0 += 64) {
@@ -637,11 +652,17 @@ __global__ __launch_bounds__(256) void k_compact_markers(const DecodeOut* __rest
                                                          const uint32_t* __restrict__ fin_count, uint32_t n_frames, uint32_t first_frame,
                                                          uint32_t max_cand, a3_marker* __restrict__ markers, uint32_t marker_cap,
                                                          uint32_t* __restrict__ per_frame, unsigned int* __restrict__ marker_total,
-                                                         unsigned int* __restrict__ err_flags) {
+                                                         unsigned int* __restrict__ err_flags, const uint32_t* __restrict__ cand_count,
+                                                         unsigned int* __restrict__ cand_pre_total) {
     __shared__ uint32_t s_scan[256];
     __shared__ uint32_t s_base;
     const int tid = threadIdx.x;
     if (tid == 0) s_base = *marker_total;
+    {
+        uint32_t pre = 0;
+        for (uint32_t g = tid; g < n_frames; g += 256) pre += min(cand_count[g], max_cand);
+        if (pre) atomicAdd(cand_pre_total, pre);
+    }
     __syncthreads();
     for (uint32_t f0 = 0; f0 < n_frames; f0 += 256) {
         const uint32_t f = f0 + tid;
@@ -691,6 +712,43 @@ __global__ __launch_bounds__(256) void k_compact_markers(const DecodeOut* __rest
         __syncthreads();
     }
     if (tid == 0) *marker_total = s_base;
+}
+
+// Fixed-capacity detection records for the multi-GPU gather: one record per frame,
+//   u32 count | u32 global frame index | maxm x a3_marker (marker.frame rewritten to the global index, unused slots zero),
+// written straight from the device-resident marker list of the last batch: one wave per frame.  A frame with more than maxm
+// markers raises *overflow (the host turns it into A3_ERR_CAPACITY: records are never clipped silently).
+__global__ __launch_bounds__(256) void k_pack_detections(const a3_marker* __restrict__ markers, const uint32_t* __restrict__ per_frame,
+                                                         uint32_t n_frames, uint32_t first_frame_global, uint32_t maxm,
+                                                         uint32_t* __restrict__ dst, unsigned int* __restrict__ overflow) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t f = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (f >= n_frames) return;
+    uint32_t base = 0;
+    for (uint32_t g = lane; g < f; g += 64) base += per_frame[g];
+    for (int o = 32; o > 0; o >>= 1) base += __shfl_xor(base, o);
+    const uint32_t cnt = per_frame[f];
+    constexpr uint32_t kMarkerWords = sizeof(a3_marker) / 4;
+    const uint32_t rec_words = 2u + maxm * kMarkerWords;
+    uint32_t* rec = dst + (size_t)f * rec_words;
+    if (cnt > maxm) { if (lane == 0) atomicOr(overflow, 1u); }
+    const uint32_t kept = min(cnt, maxm);
+    if (lane == 0) { rec[0] = kept; rec[1] = first_frame_global + f; }
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(markers + base);
+    for (uint32_t w = lane; w < maxm * kMarkerWords; w += 64) {
+        uint32_t v = 0u;
+        if (w < kept * kMarkerWords) v = (w % kMarkerWords == 0u) ? first_frame_global + f : src[w];   // word 0 of a marker = .frame
+        rec[2u + w] = v;
+    }
+}
+
+// the bit-matrix rotation of the decode kernel on its own (reference vectors: src/aruco.rs:414-444)
+__global__ void k_debug_rotate_bits(const uint8_t* __restrict__ in, uint32_t n, uint32_t r, uint8_t* __restrict__ out) {
+    const uint32_t i = threadIdx.x;
+    if (i >= n * n) return;
+    uint32_t sy, sx;
+    rotated_source(r, n, i / n, i % n, &sy, &sx);
+    out[i] = in[sy * n + sx];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -908,11 +966,11 @@ size_t proj_rec_bytes() { return sizeof(ProjRec); }
 
 hipError_t launch_decode(hipStream_t st, PixelSrc src, int W, int H, uint32_t first_frame, const uint16_t* fin_xy, const uint32_t* work,
                          const unsigned int* work_count, uint32_t max_cand, uint32_t S, uint32_t n, uint32_t max_taps, const uint64_t* dict,
-                         uint32_t n_codes, uint32_t tau, int filter, void* proj, void* outs, uint8_t* patches, uint32_t* per_frame, int grid_blocks, int dbg) {
+                         uint32_t n_codes, uint32_t tau, int filter, void* proj, void* outs, uint8_t* patches, uint32_t patch_cap, uint32_t* per_frame, int grid_blocks, int dbg) {
     if (dbg >= 0) hipLaunchKernelGGL(k_projection, dim3(256), dim3(64), 0, st, fin_xy, work, work_count, S, reinterpret_cast<ProjRec*>(proj));
     hipLaunchKernelGGL(k_decode, dim3(grid_blocks), dim3(256), decode_lds_bytes(S, n, max_taps), st, src, W, H, first_frame, fin_xy, work,
                        work_count, max_cand, S, n, max_taps, dict, n_codes, tau, filter, reinterpret_cast<const ProjRec*>(proj),
-                       reinterpret_cast<DecodeOut*>(outs), patches, per_frame, dbg < 0 ? -dbg : dbg);
+                       reinterpret_cast<DecodeOut*>(outs), patches, patch_cap, per_frame, dbg < 0 ? -dbg : dbg);
     return hipGetLastError();
 }
 
@@ -920,13 +978,25 @@ size_t decode_out_bytes() { return sizeof(DecodeOut); }
 
 hipError_t launch_compact_markers(hipStream_t st, const void* outs, const uint16_t* fin_xy, const uint32_t* fin_count, uint32_t n_frames,
                                   uint32_t first_frame, uint32_t max_cand, a3_marker* markers, uint32_t marker_cap, uint32_t* per_frame,
-                                  unsigned int* marker_total, unsigned int* err_flags) {
+                                  unsigned int* marker_total, unsigned int* err_flags, const uint32_t* cand_count, unsigned int* cand_pre_total) {
     if (first_frame == 0 && n_frames <= kCompactParMax)
         hipLaunchKernelGGL(k_compact_markers_par, dim3((n_frames + 3) / 4), dim3(256), 0, st, reinterpret_cast<const DecodeOut*>(outs), fin_xy, fin_count,
-                           n_frames, max_cand, markers, marker_cap, per_frame, marker_total, err_flags);
+                           n_frames, max_cand, markers, marker_cap, per_frame, marker_total, err_flags, cand_count, cand_pre_total);
     else
         hipLaunchKernelGGL(k_compact_markers, dim3(1), dim3(256), 0, st, reinterpret_cast<const DecodeOut*>(outs), fin_xy, fin_count, n_frames,
-                           first_frame, max_cand, markers, marker_cap, per_frame, marker_total, err_flags);
+                           first_frame, max_cand, markers, marker_cap, per_frame, marker_total, err_flags, cand_count, cand_pre_total);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_detections(hipStream_t st, const a3_marker* markers, const uint32_t* per_frame, uint32_t n_frames, uint32_t first_frame_global,
+                                  uint32_t maxm, void* dst, unsigned int* overflow) {
+    hipLaunchKernelGGL(k_pack_detections, dim3((n_frames + 3) / 4), dim3(256), 0, st, markers, per_frame, n_frames, first_frame_global, maxm,
+                       reinterpret_cast<uint32_t*>(dst), overflow);
+    return hipGetLastError();
+}
+
+hipError_t launch_debug_rotate_bits(hipStream_t st, const uint8_t* in, uint32_t n, uint32_t r, uint8_t* out) {
+    hipLaunchKernelGGL(k_debug_rotate_bits, dim3(1), dim3(256), 0, st, in, n, r, out);
     return hipGetLastError();
 }
 

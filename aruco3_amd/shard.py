@@ -45,39 +45,97 @@ def broadcast_dictionary(d: ARDictionary = None, device="cpu", src: int = 0) -> 
     return ARDictionary(num_bits, tau, codes.cpu().numpy().view(np.uint64), d.name if rank == src and d is not None else "")
 
 
-def pack_detections(markers: np.ndarray, per_frame: np.ndarray, first_frame: int = 0) -> np.ndarray:
-    """-> uint8 [frames, 8 + MAXM*56]: u32 count, u32 global frame index, then up to MAXM a3_marker records."""
+class RecordOverflow(ValueError):
+    """A frame holds more markers than the gather record: raised, never clipped."""
+
+
+def record_bytes(maxm: int = MAXM) -> int:
+    return 8 + maxm * _REC_BYTES
+
+
+_PAD_FRAME = 0xFFFFFFFF   # global frame index of a padding record (ranks with fewer frames than the largest block)
+
+
+def pack_detections(markers: np.ndarray, per_frame: np.ndarray, first_frame: int = 0, maxm: int = MAXM) -> np.ndarray:
+    """Host statement of the record format a3_pack_detections writes on the device (the tests compare the two):
+    -> uint8 [frames, 8 + maxm*56]: u32 count, u32 global frame index, then maxm a3_marker records whose .frame field holds
+    the GLOBAL frame index; unused slots are zero.  A frame with more than maxm markers raises RecordOverflow."""
     n = per_frame.size
-    rec = np.zeros((n, 8 + MAXM * _REC_BYTES), dtype=np.uint8)
+    if n and int(per_frame.max()) > maxm:
+        raise RecordOverflow(f"a frame holds {int(per_frame.max())} markers, the gather record only {maxm}")
+    rec = np.zeros((n, record_bytes(maxm)), dtype=np.uint8)
     head = rec[:, :8].view(np.uint32)
-    head[:, 0] = np.minimum(per_frame, MAXM)
+    head[:, 0] = per_frame
     head[:, 1] = np.arange(first_frame, first_frame + n, dtype=np.uint32)
-    body = rec[:, 8:].reshape(n, MAXM, _REC_BYTES)
+    body = rec[:, 8:].reshape(n, maxm, _REC_BYTES)
     total = int(per_frame.sum())
     if total:
-        raw = np.ascontiguousarray(markers[:total]).view(np.uint8).reshape(total, _REC_BYTES)
         counts = per_frame.astype(np.int64)
         frame_of = np.repeat(np.arange(n), counts)                      # frame of every marker (markers are frame-major)
         rank_in_frame = np.arange(total) - np.repeat(np.cumsum(counts) - counts, counts)
-        keep = rank_in_frame < MAXM
-        body[frame_of[keep], rank_in_frame[keep]] = raw[keep]
+        raw = np.ascontiguousarray(markers[:total]).view(np.uint8).reshape(total, _REC_BYTES).copy()   # the caller's list keeps its local indices
+        raw[:, :4] = (first_frame + frame_of).astype("<u4").view(np.uint8).reshape(total, 4)           # bytes 0..3 = a3_marker.frame
+        body[frame_of, rank_in_frame] = raw
     return rec
 
 
 def unpack_detections(rec: np.ndarray):
-    """inverse of pack_detections -> list of (global frame index, marker structured array)"""
+    """inverse of pack_detections -> list of (global frame index, marker structured array); padding records are skipped"""
     out = []
-    for row in rec:
+    rec = np.asarray(rec)
+    for row in rec.reshape(-1, rec.shape[-1]):
         cnt, frame = (int(v) for v in row[:8].view(np.uint32))
+        if frame == _PAD_FRAME:
+            continue
         m = row[8: 8 + cnt * _REC_BYTES].copy().view(_lib.MARKER_DTYPE)
         out.append((frame, m))
     return out
 
 
-def gather_detections(markers: np.ndarray, per_frame: np.ndarray, first_frame: int, device="cpu") -> torch.Tensor:
-    """All ranks contribute the same number of frames (weak scaling); returns uint8 [world, frames, record] on every rank."""
-    rec = torch.from_numpy(pack_detections(markers, per_frame, first_frame)).to(device)
+def _pad_rows(rec: torch.Tensor, rows: int) -> torch.Tensor:
+    """all_gather_into_tensor needs equal contributions: ranks whose block is shorter append padding records"""
+    if rec.shape[0] == rows:
+        return rec
+    pad = torch.zeros((rows - rec.shape[0], rec.shape[1]), dtype=torch.uint8, device=rec.device)
+    pad[:, 4:8] = 0xFF   # frame = _PAD_FRAME
+    return torch.cat([rec, pad])
+
+
+def _all_gather(rec: torch.Tensor, rows: int) -> torch.Tensor:
     world = dist.get_world_size()
-    out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=torch.uint8, device=device)
+    rec = _pad_rows(rec, rows)
+    out = torch.empty((world * rows, rec.shape[1]), dtype=torch.uint8, device=rec.device)
     dist.all_gather_into_tensor(out, rec)  # ranks concatenated along dim 0
-    return out.view(world, rec.shape[0], rec.shape[1])
+    return out.view(world, rows, rec.shape[1])
+
+
+def gather_detections(markers: np.ndarray, per_frame: np.ndarray, first_frame: int, device="cpu", rows: int = None,
+                      maxm: int = MAXM) -> torch.Tensor:
+    """Host-side variant (records packed with numpy): the CPU rehearsal of the gather.  `rows` = frames of the largest block
+    (defaults to this rank's count: equal blocks).  Returns uint8 [world, rows, record] on every rank."""
+    rec = torch.from_numpy(pack_detections(markers, per_frame, first_frame, maxm)).to(device)
+    return _all_gather(rec, rows if rows is not None else rec.shape[0])
+
+
+def pack_detections_device(ctx: "_lib.Context", n_frames: int, first_frame: int, device, maxm: int = MAXM) -> torch.Tensor:
+    """The last batch of `ctx` as gather records, written by a kernel straight from the device-resident marker list
+    (a3_pack_detections): no D2H, no numpy, no H2D.  Enqueued on the context's stream -- call under
+    `torch.cuda.stream(<that stream>)` so that torch orders the collective after it."""
+    rec = torch.empty((n_frames, record_bytes(maxm)), dtype=torch.uint8, device=device)
+    try:
+        ctx.pack_detections(first_frame, maxm, rec.data_ptr(), rec.numel())
+    except _lib.A3Error as e:
+        if e.code == _lib.ERR_CAPACITY:
+            raise RecordOverflow(str(e)) from e
+        raise
+    return rec
+
+
+def gather_detections_device(ctx: "_lib.Context", n_frames: int, first_frame: int, device, coll_device=None, rows: int = None,
+                             maxm: int = MAXM) -> torch.Tensor:
+    """Per batch: device-packed records of this rank's frames, all-gathered (RCCL all-gather over xGMI with backend "nccl").
+    coll_device = "cpu" moves the packed tensor to the host first (gloo rehearsal on a box with fewer GPUs than ranks)."""
+    rec = pack_detections_device(ctx, n_frames, first_frame, device, maxm)
+    if coll_device is not None and torch.device(coll_device).type == "cpu":
+        rec = rec.cpu()
+    return _all_gather(rec, rows if rows is not None else n_frames)

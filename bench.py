@@ -25,8 +25,9 @@ sys.path.insert(0, str(ROOT))
 FRAMES_PER_GPU = 256
 WIDTH, HEIGHT = 1920, 1080
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-K1_BYTES_PER_PIXEL = 5             # 3 B RGB read + 1 B grey + 1 B binary written
-K1_BYTES_MOVED_PER_PIXEL = 3.125   # what K1 moves now: 3 B read + 1/8 B packed binary written, no grey plane
+K1_BYTES_PER_PIXEL = 3.125         # what K1 has to move: 3 B RGB read + 1/8 B bit-packed binary written; NO grey plane is written
+K1_SURVEY_BYTES_PER_PIXEL = 5      # SURVEY.md section 8d's figure (3 B read + 1 B grey + 1 B byte-wide binary): reported separately
+PROFILE_TAG = "r02"                # profiles/<tag>_pmc_bench_c2.json holds the PMC passes of this same command
 
 
 def _render(args):
@@ -68,6 +69,10 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
                                                        "multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--synth-workers", type=int, default=0, help="host processes rendering frames (0 = auto)")
+    ap.add_argument("--repeats", type=int, default=25, help="the timed region (exactly --steps steps between barrier + synchronize) is run "
+                                                            "this many times back to back; the median is reported, every value listed "
+                                                            "(20 steps are 20 ms: one region alone measures clocks ramping)")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the other_workloads block (reference bench recipe, configs 4 and 5)")
     ap.add_argument("--frames-cache", default="", help="npz path: reuse rendered frames between runs (profiling runs use it so that "
                                                         "nothing forks under the profiler)")
     args = ap.parse_args()
@@ -144,6 +149,14 @@ def main():
 
     batch_args = (d_frames.data_ptr(), _lib.MEM_DEVICE, _lib.FMT_RGB8, w, h, w * c, h * w * c, n)
 
+    last_gather = [None]
+
+    def gather(cx):
+        # per batch: fixed-capacity records written by a kernel from the device-resident marker list (a3_pack_detections),
+        # all-gathered over RCCL; the pack and the collective are ordered on the contexts' stream, no host copy in between
+        with torch.cuda.stream(stream):
+            last_gather[0] = shard.gather_detections_device(cx, n, first_frame, dev, coll_dev)
+
     def run_steps(k):
         """k steps; a step = one pass of Detector::detect over the rank's batch, results on the host (and all-gathered)."""
         markers, per = None, None
@@ -151,7 +164,7 @@ def main():
             for _ in range(k):
                 markers, per = ctx.detect_batch(*batch_args, out_cap=n * 64)
                 if world > 1:
-                    shard.gather_detections(markers, per, first_frame, coll_dev)   # RCCL all-gather of the compact records
+                    gather(ctx)
             return markers, per
         if k > 0:
             ctxs[0].submit(*batch_args, out_cap=n * 64)
@@ -160,7 +173,7 @@ def main():
                 ctxs[(i + 1) % 2].submit(*batch_args, out_cap=n * 64)
             markers, per = ctxs[i % 2].collect()
             if world > 1:
-                shard.gather_detections(markers, per, first_frame, coll_dev)
+                gather(ctxs[i % 2])
         return markers, per
 
     # set-up, not steps: every context allocates its device buffers on its first batches (hipMalloc is slow and synchronous)
@@ -184,19 +197,24 @@ def main():
         for cx in ctxs:
             cx.set_profiling(_lib.PROFILE_THRESHOLD_ONLY)
 
+    # The timed region: EXACTLY --steps steps between barrier + synchronize on both sides, max over ranks.  It is run
+    # --repeats times back to back and the median region is the one reported (all are listed in ms_per_step_all).
+    regions = []
+    for _ in range(max(1, args.repeats)):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        markers, per = run_steps(args.steps)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        regions.append(time.perf_counter() - t0)
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    markers, per = run_steps(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+        t = torch.tensor(regions, dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        regions = [float(v) for v in t.tolist()]
+    elapsed = sorted(regions)[len(regions) // 2]
 
     # sanity: what was rendered is what was read (ids per frame), on this rank's last step
     pos, id_ok = 0, 0
@@ -214,12 +232,29 @@ def main():
             stage_ms[name] = round(tot / max(k1_n, 1), 3)
     stats = ctx.stats()
 
+    gathered = None
+    if world > 1:
+        # what the last all-gather delivered, checked on rank 0: every rank's frames, global indices in order, ids as rendered
+        torch.cuda.synchronize()
+        g = last_gather[0].cpu().numpy()
+        if rank == 0:
+            from aruco3_amd import synth
+            spec2, _ = synth.config_spec(2)
+            recs = shard.unpack_detections(g.reshape(-1, g.shape[-1]))
+            seeds_all = [synth.frame_seed(2, i) for i in range(world * args.frames)]
+            truth_all = [sorted(t.id for t in tr) for tr in synth.device_layout(spec2, d.code_list, d.num_bits, seeds_all)[2]]
+            gathered = {"frames": len(recs), "global_frame_indices_in_order": [f for f, _ in recs] == list(range(world * args.frames)),
+                        "all_ranks_ids_correct": int(sum(sorted(int(x) for x in m["id"]) == truth_all[f] for f, m in recs)),
+                        "record_bytes": int(g.shape[-1]), "packed_on": "device (a3_pack_detections)",
+                        "collective": f"all_gather_into_tensor over {args.backend}"}
+
     if rank == 0:
         total_frames = args.frames * world * args.steps
         value = total_frames / elapsed
         k1_avg_ms = k1_ms / max(k1_n, 1)
-        k1_bytes = K1_BYTES_PER_PIXEL * WIDTH * HEIGHT * args.frames          # algorithmic bytes per launch
+        k1_bytes = int(K1_BYTES_PER_PIXEL * WIDTH * HEIGHT * args.frames)     # algorithmic bytes per launch = the bytes that move
         achieved = k1_bytes / (k1_avg_ms * 1e-3) / 1e9 if k1_avg_ms > 0 else 0.0
+        survey_gbs = K1_SURVEY_BYTES_PER_PIXEL * WIDTH * HEIGHT * args.frames / (k1_avg_ms * 1e-3) / 1e9 if k1_avg_ms > 0 else 0.0
         out = {
             "metric": "frames/sec at 1920x1080 ARUCO dict",
             "value": round(value, 2),
@@ -227,7 +262,10 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "repeats": len(regions),
+            "ms_per_step_all": [round(r / args.steps * 1e3, 4) for r in regions],
+            "timed_region_s_total": round(sum(regions), 3),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -243,20 +281,22 @@ def main():
                 "sharding": "frames by rank, no data-path collective; dictionary broadcast once, detections all-gathered per batch" if world > 1 else "single GPU",
             },
             "roofline": {
-                "kernel": "k_grey_threshold7 (RGB->grey + 15x15 adaptive threshold)",
+                "kernel": "k_grey_threshold7 (RGB->grey + 15x15 adaptive threshold; output bit-packed, no grey plane)",
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": pmc_traffic_bytes(),
+                # 3.125 B/px: the frame is read once (3 B/px) and only the bit-packed binary image (1/8 B/px) is written; the
+                # grey plane of SURVEY's 5 B/px accounting is never materialised (the decode stage re-derives the grey levels
+                # it samples).  achieved / frac count the bytes that move; the 5 B/px figure is kept under its own name.
+                "bytes_per_pixel": K1_BYTES_PER_PIXEL,
                 "bytes_per_launch": k1_bytes,
                 "avg_launch_ms": round(k1_avg_ms, 4),
-                # what this kernel has to move: it reads the frame (3 B/px) and writes only the bit-packed binary image
-                # (1/8 B/px) -- the grey plane of SURVEY's 5 B/px is never materialised (the decode stage re-derives the
-                # grey levels it samples), so `achieved` counts a write the kernel avoids; this is the rate of real bytes
-                "bytes_moved_per_launch": int(K1_BYTES_MOVED_PER_PIXEL * WIDTH * HEIGHT * args.frames),
-                "moved_gbs": round(K1_BYTES_MOVED_PER_PIXEL * WIDTH * HEIGHT * args.frames / (k1_avg_ms * 1e-3) / 1e9, 1) if k1_avg_ms > 0 else 0.0,
+                "launches_timed": k1_n,
+                "survey_5Bpp_gbs": round(survey_gbs, 1),
+                "survey_5Bpp_frac": round(survey_gbs / HBM_PEAK_GBS, 4),
             },
             # threshold: the timed steps; contour / decode: the warm-up steps (every stage timed there, see above)
             "stage_ms_per_step": {"threshold": round(k1_avg_ms, 3), "contour": stage_ms.get("contour"), "decode": stage_ms.get("decode")},
@@ -265,8 +305,13 @@ def main():
             "frames_with_all_ids_correct": f"{id_ok}/{n}",
             "frame_synthesis_s": round(t_gen, 1),
         }
+        if gathered is not None:
+            out["gathered"] = gathered
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames, d)
+        if not args.no_other_workloads and world == 1:
+            # free the headline batch first: the 4K batch below needs room only in the sense of tidiness (288 GB of HBM)
+            out["other_workloads"] = other_workloads(local_rank, with_cpu=not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -274,10 +319,10 @@ def main():
 
 def pmc_traffic_bytes():
     """HBM bytes per K1 launch from the committed PMC passes of this same command (tools/pmc_k1.sh ->
-    profiles/r01_pmc_bench_c2.json): (2 x FETCH_SIZE + WRITE_SIZE) KiB, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    profiles/<PROFILE_TAG>_pmc_bench_c2.json): (2 x FETCH_SIZE + WRITE_SIZE) KiB, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
     for wide coalesced reads on gfx950.  Counters cannot be read inside this process, so this is the profiled value for the
     default 256-frame batch, or None when the summary is missing."""
-    path = ROOT / "profiles" / "r01_pmc_bench_c2.json"
+    path = ROOT / "profiles" / f"{PROFILE_TAG}_pmc_bench_c2.json"
     try:
         pmc = json.loads(path.read_text())
         k1 = next(v for k, v in pmc.items() if "k_grey_threshold7" in k)
@@ -318,6 +363,87 @@ def cpu_baseline(frames, d):
     out["all_cores"] = {"value": round(done_mt / dt, 2), "unit": "frames/s", "cores": workers,
                         "sample": f"{done_mt} frames, one frame per worker thread"}
     return out
+
+
+def other_workloads(device, with_cpu=True, budget_s=60.0):
+    """The rest of BASELINE.json's configurations as driver-visible numbers, each on frames resident in HBM and with the
+    single-thread oracle ("port") timed on a few of the same frames:
+      C0  the reference's own bench recipe (benches/detect_markers.rs:29-51): uniform-noise RGB at 1920x1080, ARUCO
+      C4  APRILTAG_36H11, 1280x720, +-15 degrees, Gaussian noise sigma 8
+      C5  3840x2160, 16 markers, detect + IPPE pose in one call (a3_detect_batch_pose)
+    One context, synchronous calls (a3_detect_batch), median of `reps` calls after two warm-up calls."""
+    import torch
+
+    from aruco3_amd import _lib, synth
+    from aruco3_amd.aruco import Detector, DetectorConfig
+    from aruco3_amd.dictionaries import ARDictionary
+
+    t_start = time.perf_counter()
+    dev = torch.device("cuda", device)
+    res = {}
+
+    def run(name, frames_dev, dname, pose_mm=None, reps=7, cpu_frames=2, truths=None, note=""):
+        if time.perf_counter() - t_start > budget_s:
+            res[name] = {"skipped": "time budget"}
+            return
+        d = ARDictionary.new_from_named_dict(dname)
+        ctx = Detector(DetectorConfig.default(), d, device=device)._context()
+        n, h, w, c = frames_dev.shape
+        a = (frames_dev.data_ptr(), _lib.MEM_DEVICE, _lib.FMT_RGB8, w, h, w * c, h * w * c, n)
+
+        def call():
+            if pose_mm:
+                return ctx.detect_batch_pose(*a, pose_mm, None, n * 64)
+            return ctx.detect_batch(*a, out_cap=n * 64)
+
+        call(); call()
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            r = call()
+            torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        dt = sorted(ts)[len(ts) // 2]
+        st = ctx.stats()
+        o = {"value": round(n / dt, 1), "unit": "frames/s", "ms_per_batch": round(dt * 1e3, 3), "frames_per_batch": n,
+             "resolution": [w, h], "dictionary": dname, "markers_found": int(len(r[0])), "darts_per_frame": int(st["darts"] // n),
+             "borders_per_frame": int(st["contours_traced"] // n), "chunks": st["chunks"]}
+        if note:
+            o["workload"] = note
+        if truths is not None:
+            pos, ok = 0, 0
+            for f in range(n):
+                got = sorted(int(m["id"]) for m in r[0][pos: pos + int(r[1][f])]); pos += int(r[1][f])
+                ok += got == sorted(t.id for t in truths[f])
+            o["frames_with_all_ids_correct"] = f"{ok}/{n}"
+        if with_cpu:
+            from oracle import a3oracle
+            a3oracle.build()
+            host = frames_dev[:cpu_frames].cpu().numpy()
+            codes = np.ascontiguousarray(d.code_list)
+            t0 = time.perf_counter()
+            for f in range(cpu_frames):
+                a3oracle.detect_markers_only(host[f], codes, d.num_bits, d._tau)
+            o["cpu_baseline"] = {"value": round(cpu_frames / (time.perf_counter() - t0), 2), "unit": "frames/s", "cores": 1, "kind": "port",
+                                 "sample": f"{cpu_frames} of the same frames, single thread, detection only"}
+        res[name] = o
+        ctx.close()
+
+    g = torch.Generator(device=dev); g.manual_seed(20261004)
+    noise = torch.randint(0, 256, (16, 1080, 1920, 3), dtype=torch.uint8, device=dev, generator=g)
+    run("C0_reference_bench_noise_1080p", noise, "ARUCO", cpu_frames=2,
+        note="benches/detect_markers.rs:29-51 recipe: every channel of every pixel uniform random u8; no markers, ~1.6 M darts per frame")
+    del noise
+    spec4, name4 = synth.config_spec(4)
+    d4 = ARDictionary.new_from_named_dict(name4)
+    f4, t4 = synth.render_frames_device(spec4, d4.code_list, d4.num_bits, [synth.frame_seed(4, i) for i in range(32)], device=device)
+    run("C4_apriltag36h11_720p_noise", f4, name4, cpu_frames=4, truths=t4, note="BASELINE config 4")
+    del f4
+    spec5, name5 = synth.config_spec(5)
+    d5 = ARDictionary.new_from_named_dict(name5)
+    f5, t5 = synth.render_frames_device(spec5, d5.code_list, d5.num_bits, [synth.frame_seed(5, i) for i in range(16)], device=device)
+    run("C5_4k_16_markers_detect_plus_pose", f5, name5, pose_mm=40.0, cpu_frames=2, truths=t5,
+        note="BASELINE config 5 on one GPU: detect + solve_with_undistorted_points of every marker in one call")
+    return res
 
 
 if __name__ == "__main__":

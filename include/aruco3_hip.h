@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define A3_ABI_VERSION 1
+#define A3_ABI_VERSION 2
 
 enum {
     A3_OK = 0,
@@ -139,6 +139,24 @@ int  a3_download_candidates(a3_ctx *ctx, uint32_t frame, int before_discard, uin
 int  a3_download_homographies(a3_ctx *ctx, uint32_t frame, uint8_t *dst, uint8_t *ok, uint64_t *codes4, int32_t *decode_ok,
                               size_t cap);
 
+/* The result of find_contours (src/aruco.rs:64) for one frame of the last batch: available when that batch ran with debug
+ * taps on and fitted one chunk.  With taps on, every border the reference follows is materialised (the parity-safe size
+ * pruning is off) except 1-pixel components, which own no border pixel pair.  Contours come in the reference's discovery
+ * order; start_keys[i] = 2 * (y * width + x) of the first point, + 1 for a hole border; points_xy holds x, y pairs. */
+int  a3_contour_count(a3_ctx *ctx, uint32_t frame, uint32_t *n_contours, uint64_t *n_points);
+int  a3_download_contours(a3_ctx *ctx, uint32_t frame, uint32_t *start_keys, uint32_t *lengths, uint32_t *points_xy,
+                          size_t cap_contours, size_t cap_points);
+
+/* Multi-GPU gather (frames are sharded by rank): the markers of the last finished batch as
+ * fixed-capacity records in DEVICE memory, one per frame, ready for one all-gather:
+ *   u32 count | u32 global frame index (first_frame_global + f) | max_markers_per_frame x a3_marker
+ * with a3_marker.frame rewritten to the global index and unused slots zeroed.  Written by a kernel on the context's stream
+ * (no host copy); the caller orders its collective after it.  A frame with more markers than the record holds is an
+ * error (A3_ERR_CAPACITY), never a silent clip. */
+size_t a3_detection_record_bytes(uint32_t max_markers_per_frame);
+int  a3_pack_detections(a3_ctx *ctx, uint32_t first_frame_global, uint32_t max_markers_per_frame, void *dst_device,
+                        size_t dst_bytes);
+
 /* pose::solve_with_undistorted_points (intr == NULL, src/pose.rs:59-62) or
  * pose::solve_with_intrinsics (src/pose.rs:52-55) for n markers; out holds 2*n poses,
  * the lower-error one first (src/pose.rs:76-80). */
@@ -159,11 +177,6 @@ enum { A3_PROFILE_OFF = 0, A3_PROFILE_STAGES = 1, A3_PROFILE_THRESHOLD_ONLY = 2 
 int  a3_set_profiling(a3_ctx *ctx, int mode);
 int  a3_get_profile(a3_ctx *ctx, int stage, double *total_ms, uint64_t *launches, int reset);
 
-/* kernel-level timing for tuning (tools/kernel_probe.py): re-runs one contour-stage kernel (0 dart_count, 1 dart_assign,
- * 2 local_contract) on the buffers of the last single-chunk batch, optionally truncated (dbg), and returns the
- * average device time.  The internal contour buffers hold garbage afterwards; results already returned are unaffected. */
-int  a3_debug_kernel_time(a3_ctx *ctx, int kernel, int dbg, int reps, float *avg_ms);
-
 /* Synthetic frames rendered on the device (the reference's counterparts are its test renderer
  * and ARDictionary::make_binary_image, src/dictionaries.rs:209-232).  The caller lays the frames out -- background
  * gradient, and per marker the inverse homography image -> cell coordinates, a bounding box and the n x n cell bitmap
@@ -183,11 +196,6 @@ typedef struct a3_synth_frame {
 int  a3_synth_render(int device, void *hip_stream, const a3_synth_frame *frames, uint32_t n_frames, const a3_synth_marker *markers,
                      uint32_t n_markers, uint32_t width, uint32_t height, int paper, float black, float white, int supersample,
                      void *out_rgb_device, size_t row_stride, size_t frame_stride);
-
-/* numerics self-check used by the GPU tests: evaluates the IEEE operations the kernels rely on
- * (f64 sqrt/div, f32 sqrt/div) for n inputs so that the host can compare them bit for bit */
-int  a3_selftest_ieee(a3_ctx *ctx, const double *a, const double *b, size_t n, double *sqrt_a, double *a_div_b,
-                      float *sqrtf_a, float *a_divf_b);
 
 #ifdef __cplusplus
 }

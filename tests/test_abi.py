@@ -8,8 +8,8 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _declared():
-    text = (ROOT / "include" / "aruco3_hip.h").read_text()
+def _declared(path=None):
+    text = (path or ROOT / "include" / "aruco3_hip.h").read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(a3_[a-z0-9_]+)\s*\(", text)))
 
@@ -23,7 +23,13 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), n
     assert sorted(_lib.SYMBOLS) == names
-    assert L.a3_abi_version() == 1
+    assert L.a3_abi_version() == 2
+    # tuning probes and single-stage hooks live in an internal header, out of the binding surface
+    internal = _declared(ROOT / "aruco3_amd" / "csrc" / "a3_internal.h")
+    assert sorted(_lib.INTERNAL_SYMBOLS) == internal and not set(internal) & set(names)
+    for n in internal:
+        assert hasattr(L, n), n
+    assert L.a3_detection_record_bytes(32) == 8 + 32 * 56
 
 
 def test_struct_layouts_match_header():

@@ -10,6 +10,7 @@ import torch.multiprocessing as mp
 
 from aruco3_amd import _lib, shard
 from aruco3_amd.dictionaries import ARDictionary
+from tests.util import marker_tuples
 
 
 def test_partition_covers_every_frame_once():
@@ -35,15 +36,33 @@ def _fake_markers(rank, frames):
     return m, per
 
 
+def _expect(m, per, first_frame):
+    """the markers of one rank as the gathered records must return them: .frame holds the GLOBAL frame index"""
+    g = m.copy()
+    g["frame"] = g["frame"] + first_frame
+    out, pos = [], 0
+    for f in range(per.size):
+        out.append((first_frame + f, marker_tuples(g[pos: pos + int(per[f])])))
+        pos += int(per[f])
+    return out
+
+
 def test_pack_unpack_roundtrip():
     m, per = _fake_markers(0, 9)
     rec = shard.pack_detections(m, per, first_frame=40)
-    out = shard.unpack_detections(rec)
-    pos = 0
-    for f, (frame, mm) in enumerate(out):
-        assert frame == 40 + f
-        assert mm.tobytes() == m[pos: pos + int(per[f])].tobytes()
-        pos += int(per[f])
+    assert rec.shape == (9, shard.record_bytes())
+    got = [(frame, marker_tuples(mm)) for frame, mm in shard.unpack_detections(rec)]
+    assert got == _expect(m, per, 40)
+    assert m["frame"].max() < 9   # the caller's list keeps its local indices
+
+
+def test_overflowing_frame_raises_instead_of_clipping():
+    per = np.array([1, shard.MAXM + 1, 0], dtype=np.uint32)
+    m = np.zeros(int(per.sum()), dtype=_lib.MARKER_DTYPE)
+    m["frame"] = np.repeat(np.arange(3), per)
+    with pytest.raises(shard.RecordOverflow):
+        shard.pack_detections(m, per, 0)
+    assert shard.pack_detections(m, per, 0, maxm=shard.MAXM + 1).shape[1] == 8 + (shard.MAXM + 1) * 56
 
 
 def _worker(rank, world, port, q):
@@ -54,17 +73,19 @@ def _worker(rank, world, port, q):
         d = shard.broadcast_dictionary(d0, "cpu", 0)
         ref = ARDictionary.new_from_named_dict("APRILTAG_36H11")
         ok = d.num_bits == 36 and d._tau == 11 and np.array_equal(d.code_list, ref.code_list)
-        frames = 6
-        lo, hi = shard.partition(frames * world, world, rank)
+        total = 13   # not a multiple of the world size: the shorter block is padded for the all-gather
+        lo, hi = shard.partition(total, world, rank)
+        rows = max(b - a for a, b in (shard.partition(total, world, r) for r in range(world)))
         m, per = _fake_markers(rank, hi - lo)
-        g = shard.gather_detections(m, per, lo, "cpu").numpy()
+        g = shard.gather_detections(m, per, lo, "cpu", rows=rows).numpy()
+        seen = []
         for r in range(world):
-            mr, perr = _fake_markers(r, frames)
-            got = shard.unpack_detections(g[r])
-            pos = 0
-            for f, (frame, mm) in enumerate(got):
-                ok = ok and frame == r * frames + f and mm.tobytes() == mr[pos: pos + int(perr[f])].tobytes()
-                pos += int(perr[f])
+            a, b = shard.partition(total, world, r)
+            mr, perr = _fake_markers(r, b - a)
+            got = [(frame, marker_tuples(mm)) for frame, mm in shard.unpack_detections(g[r])]
+            ok = ok and got == _expect(mr, perr, a)
+            seen += [frame for frame, _ in got]
+        ok = ok and seen == list(range(total))
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

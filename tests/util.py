@@ -32,3 +32,9 @@ def assert_frame_parity(ctx, frame_idx, img, res, w, h, check_patches=True):
     assert codes.tolist() == res["codes"].tolist()
     if check_patches:
         assert np.array_equal(patches, res["homographies"]), "warped patches differ"
+
+
+def marker_tuples(m):
+    """a3_marker records as plain tuples (field values only: the 4 padding bytes of the 56-byte record are not data)"""
+    return [(int(r["frame"]), int(r["id"]), int(r["code"]), tuple(int(v) for v in r["corners"]), int(r["hamming_distance"]),
+             int(r["rotation"]), int(r["candidate_index"])) for r in m]
