@@ -7,14 +7,21 @@
 //   white iff L >= floor(sum / area) over the window clipped to the image
 //         <=> sum < (L + 1) * area                        (no division)
 //
-// HBM-bound: 3 B read + 1 B grey + 1/8 B binary per pixel (RGB8): the thresholded image leaves the kernel
-// bit-packed (a3_common.h: words_per_row), which is all the contour stage reads.  One 256-thread workgroup
-// produces a 240 x 64 tile: 78 rows x 256 columns of pixels are loaded once with 12-byte
-// (4-pixel) lane loads, one wave-instruction per image row segment, converted to grey
-// bytes in LDS; a separable box sum follows -- horizontal 15-tap sums as u16 (24 bytes in,
-// 8 sums out per lane), then vertical sliding sums on packed u16 pairs (15*15*255 < 2^16,
-// so two sums share a dword and plain 32-bit adds never carry across).  Out-of-image
-// pixels are stored as 0, which makes the unclipped sum equal the clipped one.
+// What must move per pixel: 3 B read (RGB8) + 1/8 B written -- the thresholded image leaves the kernel bit-packed
+// (a3_common.h: words_per_row), which is all the contour stage reads, and no grey plane is written unless somebody asks
+// for Detection.grey (debug taps).  No LDS, no barriers: one wave walks down a strip of 1024 columns, lane l owns 16
+// consecutive columns, and everything between the 48-byte row slice it loads and the 16 bits it stores stays in
+// registers (k_grey_threshold7 below).  The arithmetic is laid out for instruction count -- the first register-resident
+// version spent 21 VALU lane-instructions per pixel and was issue-bound at 0.56 of the HBM roofline:
+//   grey        two v_dot4_u32_u8 + one v_mul_hi_u32_u24 per pixel, the >> 5 writes the byte into place (SDWA dst_sel)
+//   horizontal  15-wide sums of the NEW grey row first, on bytes: four v_sad_u8 start two chains (pixels 0 and 8), each
+//               slide step advances both chains with two packed-u16 instructions (byte pairs come from v_perm_b32)
+//   vertical    15-row sliding sums of those row sums as packed u16 pairs: v_pk_add_u16 / v_pk_sub_u16 against a ring of
+//               the last 15 rows of row sums (15 * 255 * 15 < 2^16)
+//   compare     sum < (L + 1) * area on pairs: v_pk_mad_u16, saturating v_pk_sub_u16, v_pk_min_u16, bits shifted in by
+//               another v_pk_mad_u16
+// Out-of-image pixels count as 0, which makes the unclipped sum equal the clipped one; the area is the clipped window.
+#include <algorithm>
 #include <cstdlib>
 #include <utility>
 
@@ -34,19 +41,43 @@ constexpr int T_OUT = 62 * T_LPX;    // 992 output columns per wave (lanes 0 and
 constexpr int T_PF = A3_T_PF;        // rows of loads kept in flight per lane
 
 
-// grey of one RGB(A) pixel held in the low 3 bytes of `px` (4th byte ignored): two byte-wise dot products with
-// the split weights 2126 = 8*256+78, 7152 = 27*256+240, 722 = 2*256+210, then the exact /10000.
-template <bool BGR = false>
-__device__ __forceinline__ uint32_t luma_dot(uint32_t px) {
-    // byte 0 of px is R (RGB/RGBA) or B (BGRA): the weight bytes swap ends
-    const uint32_t lo = __builtin_amdgcn_udot4(px, BGR ? 0x004EF0D2u : 0x00D2F04Eu, 0u, false);
-    const uint32_t hi = __builtin_amdgcn_udot4(px, BGR ? 0x00081B02u : 0x00021B08u, 0u, false);
-    // l <= 10000*255 < 2^22; floor(l / 10000) == (l * 13743896) >> 37 for every such l (checked exhaustively;
-    // 429497 >> 32 is NOT exact), i.e. one full-rate v_mul_hi_u32_u24 plus a shift instead of a quarter-rate
-    // 32-bit multiply-high
-    const uint32_t l = lo + (hi << 8);
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_pk(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+// packed u16 pairs in one dword: v_pk_add_u16 / v_pk_sub_u16 / v_pk_mad_u16 / v_pk_sub_u16 clamp / v_pk_min_u16
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return as_u32(as_pk(a) + as_pk(b)); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return as_u32(as_pk(a) - as_pk(b)); }
+// The compare stage is written with these three as inline assembly: given the vector expressions the optimiser rewrites
+// min(sat(T - S), 1) into two scalar compares, two selects and a re-pack per pair (5x the instructions).
+__device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) {   // a * b + c per half
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_shift_in(uint32_t acc, uint32_t bit) {      // acc * 2 + bit per half
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(acc), "v"(bit));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_nonzero_diff(uint32_t t, uint32_t s) {      // min(saturating t - s, 1) per half: 1 iff s < t
+    uint32_t d;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp\n\tv_pk_min_u16 %0, %0, 1 op_sel_hi:[1,0]" : "=v"(d) : "v"(t), "v"(s));
+    return d;
+}
+
+// (l * 13743896) >> 32 for l < 2^22: the upper half of floor(l / 10000) == (l * 13743896) >> 37, exact for every such l
+// (checked exhaustively; 429497 >> 32 is NOT exact): one full-rate v_mul_hi_u32_u24, the remaining >> 5 is done by the
+// instruction that puts the byte into place
+template <bool BGR, int BYTE_OFF>
+__device__ __forceinline__ uint32_t luma_hi(uint32_t px) {
+    // pixel in bytes BYTE_OFF .. BYTE_OFF+2 of px (the other byte has weight 0).  Byte-wise dot products with the split
+    // weights 2126 = 8*256+78, 7152 = 27*256+240, 722 = 2*256+210; the first byte is R (RGB/RGBA) or B (BGRA)
+    constexpr uint32_t wlo = (BGR ? 0x004EF0D2u : 0x00D2F04Eu) << (8 * BYTE_OFF), whi = (BGR ? 0x00081B02u : 0x00021B08u) << (8 * BYTE_OFF);
+    const uint32_t lo = __builtin_amdgcn_udot4(px, wlo, 0u, false);
+    const uint32_t hi = __builtin_amdgcn_udot4(px, whi, 0u, false);
+    const uint32_t l = lo + (hi << 8);   // <= 10000 * 255 < 2^22
     __builtin_assume(l < (1u << 22));
-    return (uint32_t)(((uint64_t)l * 13743896ull) >> 37);
+    return (uint32_t)(((uint64_t)l * 13743896ull) >> 32);   // both factors < 2^24: one v_mul_hi_u32_u24
 }
 
 template <int FMT> struct RawRow { static constexpr int NDW = FMT == A3_FMT_RGB8 ? 12 : (FMT == A3_FMT_L8 ? 4 : 16); uint32_t d[NDW]; };
@@ -78,61 +109,58 @@ __device__ __forceinline__ void load_raw16(const uint8_t* __restrict__ frame, si
     }
 }
 
-// raw row -> 16 grey bytes in 4 dwords
+// raw row -> 16 grey bytes in 4 dwords (byte i & 3 of g[i >> 2] = pixel i)
 template <int FMT>
 __device__ __forceinline__ void grey16(const RawRow<FMT>& r, uint32_t g[4]) {
     if constexpr (FMT == A3_FMT_L8) {
 #pragma unroll
         for (int i = 0; i < 4; i++) g[i] = r.d[i];
     } else {
+        uint32_t m[16];   // (l * 13743896) >> 32; grey = m >> 5
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            uint32_t l[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int i = 4 * q + j;
-                uint32_t px;
-                if constexpr (FMT == A3_FMT_RGBA8 || FMT == A3_FMT_BGRA8) px = r.d[i];
-                else {
-                    const int byte = 3 * i, k = byte >> 2, sh = 8 * (byte & 3);   // compile-time after unrolling
-                    px = sh == 0 ? r.d[k] : __builtin_amdgcn_alignbit(k + 1 < 12 ? r.d[k + 1] : 0u, r.d[k], sh);
-                }
-                l[j] = luma_dot<FMT == A3_FMT_BGRA8>(px);
+        for (int i = 0; i < 16; i++) {
+            if constexpr (FMT == A3_FMT_RGBA8 || FMT == A3_FMT_BGRA8) m[i] = luma_hi<FMT == A3_FMT_BGRA8, 0>(r.d[i]);
+            else {
+                // RGB8: pixel i starts at byte 3 i.  Pixels 0 and 3 of every group of four lie inside one dword (byte offsets
+                // 0 and 1: the dot weights move instead of the data); pixels 1 and 2 straddle two dwords (one v_alignbit)
+                const int byte = 3 * i, k = byte >> 2, off = byte & 3;   // compile-time after unrolling
+                if (off == 0) m[i] = luma_hi<false, 0>(r.d[k]);
+                else if (off == 1) m[i] = luma_hi<false, 1>(r.d[k]);
+                else m[i] = luma_hi<false, 0>(__builtin_amdgcn_alignbit(r.d[k + 1], r.d[k], 8 * off));
             }
-            g[q] = l[0] | (l[1] << 8) | (l[2] << 16) | (l[3] << 24);
         }
+        // g[q].byte[j] = m[4 q + j] >> 5, the shift writing its byte in place (SDWA dst_sel).  One asm block so that the order
+        // is fixed: gfx950 needs one instruction between a dst_sel write of a VGPR and the next read of it (the partial
+        // write is not forwarded); consecutive writes of one g[q] are four instructions apart here, and the s_nop covers
+        // whatever the compiler schedules right behind the block.
+        asm("v_lshrrev_b32_sdwa %0, %4, %5 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_lshrrev_b32_sdwa %1, %4, %9 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_lshrrev_b32_sdwa %2, %4, %13 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_lshrrev_b32_sdwa %3, %4, %17 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_lshrrev_b32_sdwa %0, %4, %6 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_lshrrev_b32_sdwa %1, %4, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_lshrrev_b32_sdwa %2, %4, %14 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_lshrrev_b32_sdwa %3, %4, %18 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_lshrrev_b32_sdwa %0, %4, %7 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_lshrrev_b32_sdwa %1, %4, %11 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_lshrrev_b32_sdwa %2, %4, %15 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_lshrrev_b32_sdwa %3, %4, %19 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_lshrrev_b32_sdwa %0, %4, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_lshrrev_b32_sdwa %1, %4, %12 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_lshrrev_b32_sdwa %2, %4, %16 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+            "v_lshrrev_b32_sdwa %3, %4, %20 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+            "s_nop 0"
+            : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3])
+            : "v"(5u), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "v"(m[9]),
+              "v"(m[10]), "v"(m[11]), "v"(m[12]), "v"(m[13]), "v"(m[14]), "v"(m[15]));
     }
 }
 
 // full-rate 24-bit multiply (the compiler prefers the quarter-rate v_mul_lo_u32 when one operand is scalar)
 __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) {
     uint32_t r;
-    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    asm volatile("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));   // volatile: stays inside its (rarely taken) branch
     return r;
-}
-
-__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t r;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-// s +/- one 16-bit half of a packed pair, operand-selected (SDWA): no separate unpack instruction
-template <int HALF> __device__ __forceinline__ uint32_t add_half(uint32_t s, uint32_t p) {
-    uint32_t r;
-    if constexpr (HALF == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(s), "v"(p));
-    else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(s), "v"(p));
-    return r;
-}
-template <int HALF> __device__ __forceinline__ uint32_t sub_half(uint32_t s, uint32_t p) {
-    uint32_t r;
-    if constexpr (HALF == 0) asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(s), "v"(p));
-    else asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(s), "v"(p));
-    return r;
-}
-// bits = (bits << 1) | (a < b): compare into vcc, then add-with-carry
-__device__ __forceinline__ uint32_t shift_in_lt(uint32_t bits, uint32_t a, uint32_t b) {
-    asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(a), "v"(b) : "vcc");
-    return bits;
 }
 
 __device__ __forceinline__ uint32_t wave_from_left(uint32_t v) {   // lane i <- lane i-1
@@ -142,25 +170,57 @@ __device__ __forceinline__ uint32_t wave_from_right(uint32_t v) {  // lane i <- 
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
 }
 
-// One wave walks down a strip: lane l owns columns xs - 16 + 16 l .. + 15 and keeps, in registers, the last 15 grey rows
-// of those 16 columns plus their running vertical sums (u16 pairs: 15*255 < 2^16).  Per output row it needs 7 column
-// sums from each neighbouring lane (wave shifts, no LDS), slides a 15-wide window over 30 column sums and compares
-// sum < (L+1)*area.  No LDS, no barriers; T_PF rows of loads stay in flight per lane.
+// bytes k & 3 of `lo` and of `hi` as a pair of u16 (lo's in the low half): the grey levels of pixels p and p + 8
+template <int K> __device__ __forceinline__ uint32_t byte_pair(uint32_t hi, uint32_t lo) {
+    return __builtin_amdgcn_perm(hi, lo, 0x0C000C00u | (uint32_t)(K & 3) | ((uint32_t)(4 + (K & 3)) << 16));
+}
+
+// 15-wide horizontal sums of one grey row: Hp[j] = (sum over pixels j-7 .. j+7) | (sum over pixels j+1 .. j+15) << 16,
+// j = 0..7, for the lane's 16 pixels; 7 grey bytes come from each neighbouring lane (wave shifts, no LDS).
+__device__ __forceinline__ void row_sums16(const uint32_t g[4], uint32_t Hp[8]) {
+    // D[0..7] = pixels -8..-5, -4..-1, 0..3, 4..7, 8..11, 12..15, 16..19, 20..23
+    const uint32_t D[8] = {wave_from_left(g[2]), wave_from_left(g[3]), g[0], g[1], g[2], g[3], wave_from_right(g[0]), wave_from_right(g[1])};
+    // the two chains start at pixels 0 and 8: bytes -7..7 and 1..15
+    const uint32_t mid = __builtin_amdgcn_sad_u8(D[3], 0u, 0u);                                   // pixels 4..7, in both
+    uint32_t h0 = __builtin_amdgcn_sad_u8(D[0] & 0xFFFFFF00u, 0u, mid);
+    h0 = __builtin_amdgcn_sad_u8(D[1], 0u, h0);
+    h0 = __builtin_amdgcn_sad_u8(D[2], 0u, h0);
+    uint32_t h8 = __builtin_amdgcn_sad_u8(D[2] & 0xFFFFFF00u, 0u, mid);
+    h8 = __builtin_amdgcn_sad_u8(D[4], 0u, h8);
+    h8 = __builtin_amdgcn_sad_u8(D[5], 0u, h8);
+    Hp[0] = h0 | (h8 << 16);
+    // slide both chains one pixel: + (B[j+8], B[j+16]) - (B[j-7], B[j+1]); B[k] = byte k & 3 of D[(k + 8) >> 2]
+#define A3_STEP(J)                                                                                                \
+    Hp[J + 1] = pk_sub(pk_add(Hp[J], byte_pair<(J + 8) & 3>(D[(J + 24) >> 2], D[(J + 16) >> 2])),                 \
+                       byte_pair<(J + 1) & 3>(D[(J + 9) >> 2], D[(J + 1) >> 2]))
+    A3_STEP(0); A3_STEP(1); A3_STEP(2); A3_STEP(3); A3_STEP(4); A3_STEP(5); A3_STEP(6);
+#undef A3_STEP
+}
+
+// One wave walks down a strip: lane l owns columns xs - 16 + 16 l .. + 15.  Per image row it converts its 16 pixels to
+// grey, forms their 15-wide horizontal sums (row_sums16) and slides a 15-row vertical window over those row sums, all as
+// packed u16 pairs (pixel j with pixel j + 8); the row 7 iterations old is then thresholded: sum < (L+1)*area.
+// No LDS, no barriers; T_PF rows of loads stay in flight per lane.
 // grid: 8 * ceil(frames * strips_x / 8) * strips_y workgroups of one wave.
 template <int FMT, bool FAST>
 __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_t* __restrict__ pixels, size_t row_stride, size_t frame_stride,
                                                         int W, int H, int rows_per_wave, int strips_y, int n_pairs,
                                                         uint8_t* __restrict__ grey,
-                                                        uint8_t* __restrict__ bits, int aligned_in, int aligned_out) {
+                                                        uint8_t* __restrict__ bits, int aligned_in, int aligned_out, int map_by_frame) {
     const int lane = threadIdx.x;
     // XCD-aware block -> strip mapping.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), each
     // with its own L2.  Vertically adjacent strips of one column share 14 rows of input, so all strips of a
     // (frame, column) pair are given to ONE XCD, in top-to-bottom order: the shared rows are then L2 hits instead of a
     // second trip over the fabric.  (Placement only affects speed; any mapping is correct.)
     const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-    const int pair = (k / strips_y) * 8 + xcd, sy = k % strips_y;
-    if (pair >= n_pairs) return;
     const int strips_x = (W + T_OUT - 1) / T_OUT;
+    int pair, sy;
+    if (map_by_frame) {   // every strip of a frame on one XCD: the two column strips share the lines they both touch
+        const int per_frame = strips_x * strips_y, idx = k % per_frame;
+        pair = ((k / per_frame) * 8 + xcd) * strips_x + idx / strips_y;
+        sy = idx % strips_y;
+    } else { pair = (k / strips_y) * 8 + xcd; sy = k % strips_y; }
+    if (pair >= n_pairs) return;
     const int sx = pair % strips_x;
     const uint32_t f = pair / strips_x;
     const uint8_t* frame = pixels + (size_t)f * frame_stride;
@@ -183,14 +243,19 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
         axp[i >> 3] |= (uint32_t)a << (4 * (i & 7));
     }
 
-    uint32_t area[T_LPX];   // clipped window area of each column for the current row's window height
+    uint32_t area[8];       // clipped window areas of columns j | j + 8 << 16 for the current row's window height
     uint32_t ay_cur = 0;
-    uint32_t ring[15][4];   // the last 15 grey rows; row `it` lives in slot it % 15 (static: the row loop is unrolled 15x)
-    uint32_t VE[4] = {0, 0, 0, 0}, VO[4] = {0, 0, 0, 0};   // column sums, VE[i] = v(4i) | v(4i+2)<<16, VO[i] = v(4i+1) | v(4i+3)<<16
+    uint32_t gring[15][4];  // grey rows; row `it` lives in slot it % 15 (static: the row loop is unrolled 15x); a row is read
+                            // again 7 iterations later, so only 8 of the slots are live at any time
+    uint32_t hring[15][8];  // the last 15 rows of horizontal sums (pairs)
+    uint32_t S[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 15x15 window sums of the row 7 iterations old (pairs)
 #pragma unroll
-    for (int k = 0; k < 15; k++)
+    for (int q = 0; q < 15; q++) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) ring[k][i] = 0u;
+        for (int i = 0; i < 4; i++) gring[q][i] = 0u;
+#pragma unroll
+        for (int i = 0; i < 8; i++) hring[q][i] = 0u;
+    }
 
     // Odd strips walk upwards.  Strip k (going down) and strip k+1 (going up) then both reach their common boundary --
     // the 14 rows each must also read from the other's territory -- at the END of their runs, and strips k+1 and k+2
@@ -246,55 +311,37 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
                     for (int i = 0; i < T_LPX; i++) if (x0 + i < W) dst[i] = (uint8_t)(g[i >> 2] >> (8 * (i & 3)));
                 }
             }
-            // vertical sliding sums: + newest row, - the row that leaves the 15-row window
-            // VE = (v0 | v2<<16), VO = (v1 | v3<<16): add the new row's bytes, subtract the leaving row's (the one that
-            // entered 15 iterations ago); each 16-bit half is updated in place by one byte-selecting SDWA instruction, the
-            // eight independent registers advance in lock step so that no dependent pair is back to back
-#define A3_SDWA(OP, DST, SRC, W, B) asm(OP " %0, %0, %1 dst_sel:WORD_" #W " dst_unused:UNUSED_PRESERVE src0_sel:WORD_" #W " src1_sel:BYTE_" #B : "+v"(DST) : "v"(SRC))
+            // horizontal sums of the new row, then the vertical window: + the new row's sums, - those of the row that
+            // entered 15 iterations ago (they never underflow: the add comes first and the true sum is >= 0)
+            uint32_t Hn[8];
+            row_sums16(g, Hn);
 #pragma unroll
-            for (int i = 0; i < 4; i++) { A3_SDWA("v_add_u32_sdwa", VE[i], g[i], 0, 0); A3_SDWA("v_add_u32_sdwa", VO[i], g[i], 0, 1); }
+            for (int j = 0; j < 8; j++) { S[j] = pk_sub(pk_add(S[j], Hn[j]), hring[k15][j]); hring[k15][j] = Hn[j]; }
 #pragma unroll
-            for (int i = 0; i < 4; i++) { A3_SDWA("v_add_u32_sdwa", VE[i], g[i], 1, 2); A3_SDWA("v_add_u32_sdwa", VO[i], g[i], 1, 3); }
-#pragma unroll
-            for (int i = 0; i < 4; i++) { A3_SDWA("v_sub_u32_sdwa", VE[i], ring[k15][i], 0, 0); A3_SDWA("v_sub_u32_sdwa", VO[i], ring[k15][i], 0, 1); }
-#pragma unroll
-            for (int i = 0; i < 4; i++) { A3_SDWA("v_sub_u32_sdwa", VE[i], ring[k15][i], 1, 2); A3_SDWA("v_sub_u32_sdwa", VO[i], ring[k15][i], 1, 3); }
-#undef A3_SDWA
-#pragma unroll
-            for (int i = 0; i < 4; i++) ring[k15][i] = g[i];
-            const uint32_t* centre = ring[(k15 + 8) % 15];   // the row 7 iterations old: the one being thresholded
+            for (int i = 0; i < 4; i++) gring[k15][i] = g[i];
+            const uint32_t* centre = gring[(k15 + 8) % 15];   // the row 7 iterations old: the one being thresholded
 
             const int y = r - dir * T_R;   // the row whose window is now complete
             if (y < y_begin || y >= y_end) continue;   // wave-uniform
-            // 30 column sums: 7 from the left lane, own 16, 7 from the right lane
-            const uint32_t le2 = wave_from_left(VE[2]), lo2 = wave_from_left(VO[2]), le3 = wave_from_left(VE[3]), lo3 = wave_from_left(VO[3]);
-            const uint32_t re0 = wave_from_right(VE[0]), ro0 = wave_from_right(VO[0]), re1 = wave_from_right(VE[1]), ro1 = wave_from_right(VO[1]);
-            uint32_t e[30];   // the 30 column sums: 7 from the left lane, own 16, 7 from the right lane
-            e[0] = lo2 & 0xFFFFu; e[1] = le2 >> 16; e[2] = lo2 >> 16;
-            e[3] = le3 & 0xFFFFu; e[4] = lo3 & 0xFFFFu; e[5] = le3 >> 16; e[6] = lo3 >> 16;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                e[7 + 4 * i] = VE[i] & 0xFFFFu; e[8 + 4 * i] = VO[i] & 0xFFFFu; e[9 + 4 * i] = VE[i] >> 16; e[10 + 4 * i] = VO[i] >> 16;
-            }
-            e[23] = re0 & 0xFFFFu; e[24] = ro0 & 0xFFFFu; e[25] = re0 >> 16; e[26] = ro0 >> 16;
-            e[27] = re1 & 0xFFFFu; e[28] = ro1 & 0xFFFFu; e[29] = re1 >> 16;
             const uint32_t ay = (uint32_t)(min(y + T_R, H - 1) - max(y - T_R, 0) + 1);
             if (ay != ay_cur) {   // wave-uniform; only the first and last 7 image rows differ from 15
                 ay_cur = ay;
 #pragma unroll
-                for (int i = 0; i < T_LPX; i++) area[i] = mul24((axp[i >> 3] >> (4 * (i & 7))) & 15u, ay);
+                for (int j = 0; j < 8; j++)
+                    area[j] = mul24((axp[0] >> (4 * j)) & 15u, ay) | (mul24((axp[1] >> (4 * j)) & 15u, ay) << 16);
             }
-            // window of pixel 15 first, then slide left: the comparison bits are shifted in from the top
-            uint32_t S = 0;
+            // white iff S < (L + 1) * area, two pixels per instruction: T = L * area + area, d = saturating T - S (non-zero
+            // iff S < T), bit = min(d, 1), shifted in from pixel 7 | 15 down to 0 | 8: acc = acc * 2 + bit
+            uint32_t acc = 0u;
 #pragma unroll
-            for (int j = 15; j < 30; j++) S += e[j];
-            uint32_t outb = 0;
-#pragma unroll
-            for (int i = 15; i >= 0; i--) {
-                if (i < 15) S += e[i] - e[i + 15];
-                const uint32_t gv = (centre[i >> 2] >> (8 * (i & 3))) & 255u;
-                outb = shift_in_lt(outb, S, mad24(gv, area[i], area[i]));   // S < (L+1)*area
+            for (int j = 7; j >= 0; j--) {
+                const uint32_t Lp = j < 4 ? __builtin_amdgcn_perm(centre[2], centre[0], 0x0C000C00u | (uint32_t)(j & 3) | ((uint32_t)(4 + (j & 3)) << 16))
+                                          : __builtin_amdgcn_perm(centre[3], centre[1], 0x0C000C00u | (uint32_t)(j & 3) | ((uint32_t)(4 + (j & 3)) << 16));
+                const uint32_t T = pk_mad(Lp, area[j], area[j]);
+                acc = pk_shift_in(acc, pk_nonzero_diff(T, S[j]));
             }
+            // bits of pixels 0..7 sit in byte 0, of pixels 8..15 in byte 2
+            const uint32_t outb = __builtin_amdgcn_perm(0u, acc, 0x0C0C0200u);
             if (owner) *reinterpret_cast<uint16_t*>(bout + (size_t)y * bpr + (x0 >> 3)) = (uint16_t)outb;
         }
     }
@@ -344,18 +391,31 @@ hipError_t launch_grey_threshold(hipStream_t st, const uint8_t* pixels, int fmt,
             hipError_t e = hipMemsetAsync(bits, 0, (size_t)words_per_row((uint32_t)W) * 8 * H * n, st);
             if (e != hipSuccess) return e;
         }
-        // rows per wave: enough waves to fill the chip several times over, few enough that the 14 extra rows each
-        // wave reads above/below its strip stay a small fraction
+        // Rows per wave.  Every wave also reads and converts 14 rows outside its strip, so strips should be tall; but the
+        // chip holds 256 CUs x 4 SIMDs x A3_T_WAVES waves at once and a launch runs in whole rounds of that many, so the
+        // number of strips should fill the last round.  Model: time ~ rounds x (rows per strip + 14); take the best
+        // strip count (at least 16 rows per strip).  256 frames of 1920x1080: 4 strips of 270 rows = exactly one round.
         const int strips_x = (W + T_OUT - 1) / T_OUT;
-        int rows_per_wave = 106;   // 106 + 14 halo rows = 8 blocks of 15
+        const long long slots = 256LL * 4 * A3_T_WAVES, cols = (long long)strips_x * n;
+        int best_sy = 1; double best_cost = 1e300;
+        for (int sy = 1; sy <= std::max(1, H / 16); sy++) {
+            const int rows = (H + sy - 1) / sy;
+            const long long waves = cols * ((H + rows - 1) / rows);
+            const double cost = (double)((waves + slots - 1) / slots) * (rows + 2 * T_R);
+            if (cost < best_cost - 1e-9) { best_cost = cost; best_sy = sy; }
+        }
+        int rows_per_wave = (H + best_sy - 1) / best_sy;
         if (const char* ev = getenv("A3_ROWS_PER_WAVE")) rows_per_wave = atoi(ev) > 0 ? atoi(ev) : rows_per_wave;  // tuning knob
-        while (rows_per_wave > 31 && (long long)strips_x * ((H + rows_per_wave - 1) / rows_per_wave) * n < 3 * 256 * 8) rows_per_wave -= 15;
         const int strips_y = (H + rows_per_wave - 1) / rows_per_wave;
         const int n_pairs = (int)n * strips_x;
-        dim3 grid(8 * ((n_pairs + 7) / 8) * strips_y), block(64);
+        const char* mv = getenv("A3_K1_MAP");
+        // every strip of a frame on one XCD (1) or every (frame, column strip) pair on its own XCD (0).  By frame is ~3 % faster:
+        // the two column strips of a frame overlap by 32 columns and write the same lines of the packed image
+        const int map_by_frame = mv ? atoi(mv) : 1;   // tuning knob
+        dim3 grid(map_by_frame ? 8 * (((int)n + 7) / 8) * strips_x * strips_y : 8 * ((n_pairs + 7) / 8) * strips_y), block(64);
         const bool fast = aligned_in && aligned_out;   // W % 16 == 0: a lane's 16 pixels are all inside or all outside
 #define A3_LAUNCH_K1(F, B) hipLaunchKernelGGL((k_grey_threshold7<F, B>), grid, block, 0, st, pixels, row_stride, frame_stride, W, H, \
-                                              rows_per_wave, strips_y, n_pairs, grey, bin, aligned_in, aligned_out)
+                                              rows_per_wave, strips_y, n_pairs, grey, bin, aligned_in, aligned_out, map_by_frame)
         if (fmt == A3_FMT_RGB8) { if (fast) A3_LAUNCH_K1(A3_FMT_RGB8, true); else A3_LAUNCH_K1(A3_FMT_RGB8, false); }
         else if (fmt == A3_FMT_RGBA8) { if (fast) A3_LAUNCH_K1(A3_FMT_RGBA8, true); else A3_LAUNCH_K1(A3_FMT_RGBA8, false); }
         else if (fmt == A3_FMT_BGRA8) { if (fast) A3_LAUNCH_K1(A3_FMT_BGRA8, true); else A3_LAUNCH_K1(A3_FMT_BGRA8, false); }

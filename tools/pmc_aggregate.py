@@ -10,7 +10,7 @@ from collections import defaultdict
 
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 src = pathlib.Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "gpurun_out" / "pmc"
-dst = pathlib.Path(sys.argv[2]) if len(sys.argv) > 2 else ROOT / "profiles" / "r01_pmc_bench_c2.json"
+dst = pathlib.Path(sys.argv[2]) if len(sys.argv) > 2 else ROOT / "profiles" / "r02_pmc_bench_c2.json"
 
 acc = defaultdict(lambda: defaultdict(list))
 for path in sorted(src.glob("*_counter_collection.csv")):

@@ -1,15 +1,13 @@
 #!/bin/bash
-# Rebuild K1 with different compile-time knobs and time it inside bench.py (run on the GPU box).
-set -u
-cd "$(dirname "$0")/../aruco3_amd/csrc"
-OUT=${1:-/tmp/tune_k1.log}
-: > "$OUT"
-for cfg in "3 3" "2 5" "4 3"; do
-  set -- $cfg; w=$1; pf=$2
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DA3_T_PF=$pf -DA3_T_WAVES=$w -c k_threshold.hip -o k_threshold.o || exit 1
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libaruco3_hip.so a3_api.o k_threshold.o k_contours.o k_decode.o || exit 1
-  for rows in 106 256; do
-    r=$(cd ../.. && A3_ROWS_PER_WAVE=$rows python bench.py --steps 8 --warmup 2 --frames-cache /tmp/c2frames --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['stage_ms_per_step']['threshold'], d['roofline']['frac'], d['value'])")
-    echo "waves=$w pf=$pf rows=$rows -> threshold_ms frac fps: $r" | tee -a "$OUT"
-  done
-done
+# On the GPU box: rebuild k_threshold with other prefetch depths / launch bounds and time K1 (tuning aid).
+ROOT=$(cd "$(dirname "$0")/.." && pwd); export TMPDIR=/tmp
+cd $ROOT/aruco3_amd/csrc
+B="python3 $ROOT/bench.py --device-synth --no-cpu-baseline --no-other-workloads --repeats 5 --steps 20 --warmup 3"
+show() { python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', 'k1_ms', d['stage_ms_per_step']['threshold'], 'fps', d['value'], 'ids', d['frames_with_all_ids_correct'])"; }
+for rep in 1 2; do
+for cfg in "3 2" "5 2" "1 2"; do
+  set -- $cfg
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -DA3_T_PF=$1 -DA3_T_WAVES=$2 -c k_threshold.hip -o k_threshold.o || exit 1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libaruco3_hip.so a3_api.o k_threshold.o k_contours.o k_decode.o k_synth.o || exit 1
+  for map in 0 1; do (cd $ROOT && A3_K1_MAP=$map $B 2>/dev/null | tail -1 | show "PF=$1 waves=$2 map=$map"); done
+done; done
