@@ -165,9 +165,9 @@ def load():
     L.a3_download_contours.restype = C.c_int
     L.a3_download_contours.argtypes = [vp, C.c_uint32, u32p, u32p, u32p, C.c_size_t, C.c_size_t]
     L.a3_detection_record_bytes.restype = C.c_size_t
-    L.a3_detection_record_bytes.argtypes = [C.c_uint32]
+    L.a3_detection_record_bytes.argtypes = [C.c_uint32, C.c_int]
     L.a3_pack_detections.restype = C.c_int
-    L.a3_pack_detections.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_size_t]
+    L.a3_pack_detections.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, vp, C.c_size_t]
     L.a3_debug_clockwise.restype = C.c_int
     L.a3_debug_clockwise.argtypes = [vp, C.POINTER(C.c_int32), C.c_size_t, C.POINTER(C.c_int32)]
     L.a3_debug_rotate_bits.restype = C.c_int
@@ -345,10 +345,10 @@ class Context:
         offs = np.concatenate([[0], np.cumsum(lens, dtype=np.int64)])
         return keys, [pts[offs[i]: offs[i + 1]].astype(np.int64) for i in range(nc.value)]
 
-    def pack_detections(self, first_frame_global: int, max_markers: int, dst_ptr: int, dst_bytes: int):
-        """a3_pack_detections: the last batch's markers as fixed-capacity per-frame records in device memory at dst_ptr
-        (enqueued on the context's stream)."""
-        check(load().a3_pack_detections(self.handle, first_frame_global, max_markers, C.c_void_p(dst_ptr), dst_bytes), self.handle)
+    def pack_detections(self, first_frame_global: int, max_markers: int, dst_ptr: int, dst_bytes: int, with_poses: bool = False):
+        """a3_pack_detections: the last batch's markers (and, after detect_batch_pose, their poses) as fixed-capacity per-frame
+        records in device memory at dst_ptr (enqueued on the context's stream)."""
+        check(load().a3_pack_detections(self.handle, first_frame_global, max_markers, int(with_poses), C.c_void_p(dst_ptr), dst_bytes), self.handle)
 
     # ---- a3_internal.h: the reference's small helpers on the device, for its own vectors ----
     def debug_clockwise(self, quads: np.ndarray) -> np.ndarray:

@@ -48,7 +48,7 @@ hipError_t launch_decode(hipStream_t, PixelSrc, int, int, uint32_t, const uint16
                          uint32_t, uint32_t, uint32_t, const uint64_t*, uint32_t, uint32_t, int, void*, void*, uint8_t*, uint32_t, uint32_t*, int, int);
 hipError_t launch_compact_markers(hipStream_t, const void*, const uint16_t*, const uint32_t*, uint32_t, uint32_t, uint32_t, a3_marker*,
                                   uint32_t, uint32_t*, unsigned int*, unsigned int*, const uint32_t*, unsigned int*);
-hipError_t launch_pack_detections(hipStream_t, const a3_marker*, const uint32_t*, uint32_t, uint32_t, uint32_t, void*, unsigned int*);
+hipError_t launch_pack_detections(hipStream_t, const a3_marker*, const a3_pose*, const uint32_t*, uint32_t, uint32_t, uint32_t, void*, unsigned int*);
 hipError_t launch_debug_rotate_bits(hipStream_t, const uint8_t*, uint32_t, uint32_t, uint8_t*);
 hipError_t launch_pose(hipStream_t, const uint32_t*, uint32_t, const float*, uint32_t, const unsigned int*, int, float, float, float, float,
                        float, float, float, a3_pose*);
@@ -162,6 +162,8 @@ struct a3_ctx {
     unsigned int* scratch_u32 = nullptr; DeviceCounters* counters = nullptr; uint32_t* per_frame = nullptr; uint32_t* frame_cursor = nullptr; uint32_t* cand_count = nullptr;
     uint32_t last_marker_total = 0;   // sizes the speculative marker read-back of the next batch
     DevBuf tmp_a, tmp_b, tmp_c, tmp_d;
+    DevBuf pose_buf;            // a3_detect_batch_pose: both poses of every marker of the last batch (kept for a3_pack_detections)
+    bool poses_valid = false;
     void* pinned = nullptr;
     size_t pinned_cap = 0;
 };
@@ -268,7 +270,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     if (ctx->debug_taps) A3_HIP(ctx->patches.ensure((size_t)kPatchCap * S * S));
     ctx->W = W; ctx->H = H; ctx->frames = n;
     ctx->stats = a3_stats{};
-    ctx->contours_valid = false; ctx->markers_valid = false;
+    ctx->contours_valid = false; ctx->markers_valid = false; ctx->poses_valid = false;
 
     // ---- K1 ----
     if (ctx->profiling) A3_HIP(hipEventRecord(ctx->ev[0], st));
@@ -431,11 +433,11 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     A3_HIP(launch_compact_markers(st, ctx->outs.p, ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(), n, 0, kMaxCand,
                                   ctx->markers_ptr, marker_cap, ctx->per_frame, d_marker_total, d_err, ctx->cand_count, ctx->scratch_u32 + 2));
     if (ctx->want_pose) {   // IPPE on the device-resident marker list (src/pose.rs:52-81), no extra round trip
-        A3_HIP(ctx->tmp_b.ensure((size_t)marker_cap * 2 * sizeof(a3_pose)));
+        A3_HIP(ctx->pose_buf.ensure((size_t)marker_cap * 2 * sizeof(a3_pose)));
         const a3_intrinsics& in = ctx->pose_intr;
         A3_HIP(launch_pose(st, reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(ctx->markers_ptr) + offsetof(a3_marker, corners)),
                            (uint32_t)(sizeof(a3_marker) / 4), nullptr, marker_cap, d_marker_total, ctx->pose_has_intr ? 1 : 0, ctx->pose_size_mm,
-                           (float)W, (float)H, in.focal_x, in.focal_y, in.principal_x, in.principal_y, ctx->tmp_b.as<a3_pose>()));
+                           (float)W, (float)H, in.focal_x, in.focal_y, in.principal_x, in.principal_y, ctx->pose_buf.as<a3_pose>()));
     }
     if (ctx->profiling >= 2) A3_HIP(hipEventRecord(ctx->ev[3], st));
 
@@ -448,7 +450,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     uint8_t* hp = (uint8_t*)ctx->pinned;
     a3_pose* h_poses = reinterpret_cast<a3_pose*>(hp + head_pad + (size_t)guess * sizeof(a3_marker));
     A3_HIP(hipMemcpyAsync(hp, ctx->scratch_u32, head_bytes + (size_t)guess * sizeof(a3_marker), hipMemcpyDeviceToHost, st));
-    if (pose_bytes) A3_HIP(hipMemcpyAsync(h_poses, ctx->tmp_b.p, (size_t)guess * pose_bytes, hipMemcpyDeviceToHost, st));
+    if (pose_bytes) A3_HIP(hipMemcpyAsync(h_poses, ctx->pose_buf.p, (size_t)guess * pose_bytes, hipMemcpyDeviceToHost, st));
     A3_HIP(hipEventRecord(ctx->ev[4], st));
     Pending& pd = ctx->pending;
     pd.active = true; pd.n_chunks = chunks.size(); pd.chunk0_darts = chunks.empty() ? 0 : chunks[0].darts; pd.ctr_bytes = ctr_bytes;
@@ -532,7 +534,7 @@ int finish_batch(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_fram
         h_markers = reinterpret_cast<a3_marker*>(ctx->pinned);
         h_poses = reinterpret_cast<a3_pose*>((uint8_t*)ctx->pinned + (size_t)total * sizeof(a3_marker));
         A3_HIP(hipMemcpyAsync(h_markers, ctx->markers_ptr, (size_t)total * sizeof(a3_marker), hipMemcpyDeviceToHost, st));
-        if (pose_bytes) A3_HIP(hipMemcpyAsync(h_poses, ctx->tmp_b.p, (size_t)total * pose_bytes, hipMemcpyDeviceToHost, st));
+        if (pose_bytes) A3_HIP(hipMemcpyAsync(h_poses, ctx->pose_buf.p, (size_t)total * pose_bytes, hipMemcpyDeviceToHost, st));
         A3_HIP(hipStreamSynchronize(st));
     }
     if (total) {
@@ -545,6 +547,7 @@ int finish_batch(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_fram
     ctx->stats.candidates = n_work;      // work items = quads that survived discard_too_near
     ctx->stats.candidates_pre = n_pre;   // quads after contours_to_candidates (k_compact_markers sums the per-frame counts)
     ctx->markers_valid = true; ctx->last_n = n; ctx->last_max_per_frame = max_per_frame;
+    ctx->poses_valid = pose_bytes != 0;
     ctx->contours_valid = ctx->debug_taps && n_chunks == 1;
     if (ctx->contours_valid) { ctx->tap_contours = tap_contours; ctx->tap_points = tap_points; }
     if (pd.profiling >= 1) {   // the level in force when the batch was enqueued
@@ -656,7 +659,7 @@ void a3_destroy(a3_ctx* ctx) {
                       &ctx->leader_list, &ctx->leader_keep, &ctx->entry_list, &ctx->entry_pos, &ctx->es_a, &ctx->es_b,
                       &ctx->contours, &ctx->cyc_start_off, &ctx->points, &ctx->zero_blk, &ctx->cands,
                       &ctx->pre_xy, &ctx->fin_xy, &ctx->fin_count, &ctx->work, &ctx->outs, &ctx->proj, &ctx->patches,
-                      &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_d};
+                      &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_d, &ctx->pose_buf};
     for (DevBuf* b : bufs) b->release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
@@ -948,13 +951,16 @@ int a3_download_homographies(a3_ctx* ctx, uint32_t frame, uint8_t* dst, uint8_t*
 }
 
 // ---- Detection gather records on the device (multi-GPU) ----
-size_t a3_detection_record_bytes(uint32_t max_markers_per_frame) { return 8 + (size_t)max_markers_per_frame * sizeof(a3_marker); }
+size_t a3_detection_record_bytes(uint32_t max_markers_per_frame, int with_poses) {
+    return 8 + (size_t)max_markers_per_frame * (sizeof(a3_marker) + (with_poses ? 2 * sizeof(a3_pose) : 0));
+}
 
-int a3_pack_detections(a3_ctx* ctx, uint32_t first_frame_global, uint32_t max_markers_per_frame, void* dst_device, size_t dst_bytes) {
+int a3_pack_detections(a3_ctx* ctx, uint32_t first_frame_global, uint32_t max_markers_per_frame, int with_poses, void* dst_device, size_t dst_bytes) {
     if (!ctx || !dst_device) return A3_ERR_INVALID;
     if (!ctx->markers_valid) return fail(ctx, A3_ERR_INVALID, "a3_pack_detections: no finished batch on this context");
+    if (with_poses && !ctx->poses_valid) return fail(ctx, A3_ERR_INVALID, "a3_pack_detections: the last batch was not an a3_detect_batch_pose call");
     if (max_markers_per_frame == 0) return fail(ctx, A3_ERR_INVALID, "a3_pack_detections: max_markers_per_frame must be > 0");
-    const size_t need = a3_detection_record_bytes(max_markers_per_frame) * ctx->last_n;
+    const size_t need = a3_detection_record_bytes(max_markers_per_frame, with_poses) * ctx->last_n;
     if (dst_bytes < need) return fail(ctx, A3_ERR_CAPACITY, "a3_pack_detections: dst_bytes smaller than frames x record size");
     if (reinterpret_cast<uintptr_t>(dst_device) % 4 != 0) return fail(ctx, A3_ERR_INVALID, "a3_pack_detections: dst must be 4-byte aligned");
     // the host already knows the per-frame counts of that batch: refuse before anything is clipped
@@ -965,8 +971,8 @@ int a3_pack_detections(a3_ctx* ctx, uint32_t first_frame_global, uint32_t max_ma
     }
     A3_HIP(hipSetDevice(ctx->device));
     // scratch word 3 is the kernel's overflow flag (cannot fire after the host check; kept as the device-side guard)
-    A3_HIP(launch_pack_detections(ctx->stream, ctx->markers_ptr, ctx->per_frame, ctx->last_n, first_frame_global, max_markers_per_frame, dst_device,
-                                  ctx->scratch_u32 + 3));
+    A3_HIP(launch_pack_detections(ctx->stream, ctx->markers_ptr, with_poses ? ctx->pose_buf.as<a3_pose>() : nullptr, ctx->per_frame, ctx->last_n,
+                                  first_frame_global, max_markers_per_frame, dst_device, ctx->scratch_u32 + 3));
     return A3_OK;
 }
 

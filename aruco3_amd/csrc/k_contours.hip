@@ -127,60 +127,87 @@ __device__ __forceinline__ Nb8 tile_nb8(const uint64_t* __restrict__ img, int W,
     return r;
 }
 
-// grid: (ceil(tiles_x / 4) * tiles_y, frames).  A workgroup counts four tiles lying side by side: 66 rows of 18 words are
-// staged with all loads in flight at once, in row segments of 144 bytes (the 48-byte segments of a single tile used a third
-// of every cache line they touched; a tile per workgroup took 86 us, four stacked tiles 61 us).
-constexpr int kCountTiles = 4, kCountWords = kCountTiles * kTileWords;
-__global__ __launch_bounds__(256) void k_dart_count(const uint64_t* __restrict__ bits, int W, int H, uint32_t first_frame,
-                                                    unsigned long long* __restrict__ frame_darts, uint32_t* __restrict__ tile_darts) {
-    __shared__ uint64_t s_t[kTileRows + 2][kCountWords + 2];
-    __shared__ uint32_t s_tot[kCountTiles];
+// Dart counts per 256 x 64-pixel tile, without LDS staging: one wave walks down one tile row (64 image rows plus the row
+// above and below), lane l holding packed word l - 1 of the row (lanes 0 and 61 only feed their neighbours; images wider
+// than 60 words take several waves side by side).  Of the horizontal neighbours only one bit is needed (bit 63 of the word
+// to the left, bit 0 of the word to the right): two wave shifts per row; the rows above and below stay in registers.
+// grid: (chunks_x * tiles_y, frames) workgroups of one wave.  (The LDS-tiled version took 44 us for 256 frames of
+// 1920x1080: it staged every tile with its apron before looking at it; most words of a frame are all white and are now
+// dismissed after three compares.)
+constexpr int kCountLanes = 60;   // words per wave and row: 15 whole tiles (lanes 1..60; lanes 0 and 61 feed their neighbours)
+// Images of at most 30 words per row (1920 pixels) put TWO tile rows into one wave: lanes 0..31 walk one, lanes 32..63 the
+// next (words 0..29 in lanes 1..30 of each half; lanes 0 and 31 hold zeros, which is what lies outside the image, so the wave
+// shifts across the middle deliver the right bits).
+template <int G>
+__global__ __launch_bounds__(64) void k_dart_count(const uint64_t* __restrict__ bits, int W, int H, uint32_t first_frame,
+                                                   unsigned long long* __restrict__ frame_darts, uint32_t* __restrict__ tile_darts) {
+    static_assert(kCountLanes % kTileWords == 0, "a wave counts whole tiles");
+    constexpr int kGroups = 64 / G, kOwners = G == 64 ? kCountLanes : 30, kTilesPerGroup = (kOwners + kTileWords - 1) / kTileWords;
+    __shared__ uint32_t s_tile[kGroups][kTilesPerGroup];
     const int wpr = (int)words_per_row((uint32_t)W);
     const uint32_t f = blockIdx.y;
     const uint32_t tiles_x = dart_tiles_x((uint32_t)W), tiles_y = ((uint32_t)H + kTileRows - 1) / kTileRows;
-    const uint32_t groups_x = (tiles_x + kCountTiles - 1) / kCountTiles;
-    const int gx = blockIdx.x % groups_x, ty = blockIdx.x / groups_x;
+    const int chunks_x = G == 64 ? (wpr + kCountLanes - 1) / kCountLanes : 1;
+    const int lane = threadIdx.x, gl = lane & (G - 1), grp = lane / G;
+    const int cx = blockIdx.x % chunks_x, ty = (blockIdx.x / chunks_x) * kGroups + grp;
+    const int j = cx * kOwners + gl - 1;                       // this lane's word column (may lie outside the image: zeros)
+    const bool owner = gl >= 1 && gl <= kOwners && j < wpr && ty < (int)tiles_y;
     const uint64_t* img = bits + (size_t)(first_frame + f) * wpr * H;
-    const int j0 = gx * kCountWords - 1, y0 = ty * kTileRows - 1;
-    if (threadIdx.x < kCountTiles) s_tot[threadIdx.x] = 0;
-    for (int i = threadIdx.x; i < (kTileRows + 2) * (kCountWords + 2); i += 256) {
-        const int r = i / (kCountWords + 2), c = i - r * (kCountWords + 2);
-        s_t[r][c] = ldw(img, wpr, H, j0 + c, y0 + r);
-    }
-    __syncthreads();
-    const int jl = threadIdx.x & (kCountWords - 1), rg = threadIdx.x >> 4;   // word of the row, row group (rows rg, rg + 16, ...)
+    if (lane < kGroups * kTilesPerGroup) (&s_tile[0][0])[lane] = 0;
+    const int y0 = ty * kTileRows;
+    auto word = [&](int y) -> uint64_t { return (y >= 0 && y < H && j >= 0 && j < wpr) ? img[(size_t)y * wpr + j] : 0ull; };
+    auto edge_bits = [](uint64_t c, uint32_t* lbit, uint32_t* rbit) {   // bit 63 of the word to the left, bit 0 of the word to the right
+        *lbit = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(c >> 32), 0x138 /* wave_shr:1 */, 0xF, 0xF, true) >> 31;
+        *rbit = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)c, 0x130 /* wave_shl:1 */, 0xF, 0xF, true) & 1u;
+    };
+    struct Row3 { uint64_t c; uint32_t lbit, rbit; };
+    Row3 up, cur;
+    up.c = word(y0 - 1); edge_bits(up.c, &up.lbit, &up.rbit);
+    cur.c = word(y0); edge_bits(cur.c, &cur.lbit, &cur.rbit);
+    // rows are fetched kAhead at a time so that a tile row is a few round trips to memory, not 66
+    constexpr int kAhead = 8;
     uint32_t nd = 0;
+    for (int r0 = 0; r0 < kTileRows; r0 += kAhead) {
+        uint64_t nxt[kAhead];
 #pragma unroll
-    for (int k = 0; k < kTileRows / 16; k++) {
-        const int rl = rg + 16 * k;
-        const uint64_t c = s_t[rl + 1][jl + 1];
-        if (c == 0) continue;   // rows / words outside the image were staged as zeros
-        const uint64_t al = s_t[rl][jl], a = s_t[rl][jl + 1], ar = s_t[rl][jl + 2];
-        const uint64_t cl = s_t[rl + 1][jl], cr = s_t[rl + 1][jl + 2];
-        const uint64_t bl = s_t[rl + 2][jl], b = s_t[rl + 2][jl + 1], br = s_t[rl + 2][jl + 2];
-        // a word in the middle of a white area (all nine words all ones: most words of a frame on white paper) owns no dart
-        if ((c & a & b & al & ar & cl & cr & bl & br) == ~0ull) continue;
-        Nb8 nb;
-        nb.c = c;
-        nb.n[0] = (c << 1) | (cl >> 63); nb.n[1] = (a << 1) | (al >> 63); nb.n[2] = a; nb.n[3] = (a >> 1) | (ar << 63);
-        nb.n[4] = (c >> 1) | (cr << 63); nb.n[5] = (b >> 1) | (br << 63); nb.n[6] = b; nb.n[7] = (b << 1) | (bl >> 63);
-        uint64_t p[8];
-        pdart_words(nb, p);
+        for (int u = 0; u < kAhead; u++) nxt[u] = word(y0 + r0 + u + 1);
 #pragma unroll
-        for (int q = 0; q < 8; q++) nd += __popcll(p[q]);
+        for (int u = 0; u < kAhead; u++) {
+            Row3 dn;
+            dn.c = nxt[u]; edge_bits(dn.c, &dn.lbit, &dn.rbit);
+            const uint64_t c = cur.c;
+            // no foreground pixel, or a word in the middle of a white area (the word, the words above and below and the
+            // six neighbour bits all ones: most words of a frame on white paper): no dart
+            const bool white = (c & up.c & dn.c) == ~0ull && (cur.lbit & cur.rbit & up.lbit & up.rbit & dn.lbit & dn.rbit) != 0u;
+            if (c != 0ull && !white) {
+                Nb8 nb;
+                nb.c = c;
+                nb.n[0] = (c << 1) | cur.lbit;          nb.n[4] = (c >> 1) | ((uint64_t)cur.rbit << 63);
+                nb.n[1] = (up.c << 1) | up.lbit;        nb.n[3] = (up.c >> 1) | ((uint64_t)up.rbit << 63);
+                nb.n[2] = up.c;                         nb.n[6] = dn.c;
+                nb.n[7] = (dn.c << 1) | dn.lbit;        nb.n[5] = (dn.c >> 1) | ((uint64_t)dn.rbit << 63);
+                uint64_t p[8];
+                pdart_words(nb, p);
+#pragma unroll
+                for (int q = 0; q < 8; q++) nd += __popcll(p[q]);
+            }
+            up = cur; cur = dn;
+        }
     }
-    // lanes of one tile inside a wave: same (lane & 15) >> 2; reduce over the word in the tile (xor 1, 2) and the row groups (xor 16, 32)
-    nd += __shfl_xor(nd, 1); nd += __shfl_xor(nd, 2); nd += __shfl_xor(nd, 16); nd += __shfl_xor(nd, 32);
-    if ((threadIdx.x & 0x33) == 0 && nd) atomicAdd(&s_tot[(threadIdx.x & 15) >> 2], nd);
-    __syncthreads();
-    if (threadIdx.x < kCountTiles) {
-        const uint32_t tx = gx * kCountTiles + threadIdx.x;
-        if (tx < tiles_x) tile_darts[(size_t)(first_frame + f) * (tiles_x * tiles_y) + ty * tiles_x + tx] = s_tot[threadIdx.x];   // lets k_dart_assign skip empty tiles
+    // a tile is four word columns: sum over its lanes through LDS (one wave per workgroup: no barrier needed)
+    if (owner && nd) atomicAdd(&s_tile[grp][(gl - 1) / kTileWords], nd);
+    __builtin_amdgcn_s_waitcnt(0);   // LDS atomics of this wave have landed before it reads the totals back
+    __builtin_amdgcn_wave_barrier();
+    uint32_t total = 0;
+    if (gl < kTilesPerGroup && ty < (int)tiles_y) {
+        const uint32_t tx = (uint32_t)(cx * kTilesPerGroup + gl);
+        if (tx < tiles_x) {
+            total = s_tile[grp][gl];
+            tile_darts[(size_t)(first_frame + f) * (tiles_x * tiles_y) + ty * tiles_x + tx] = total;   // lets k_dart_assign skip empty tiles
+        }
     }
-    if (threadIdx.x == 0) {
-        const uint32_t total = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
-        if (total) atomicAdd(&frame_darts[f], (unsigned long long)total);
-    }
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+    if (lane == 0 && total) atomicAdd(&frame_darts[f], (unsigned long long)total);
 }
 
 // Per frame: exclusive prefix sums of its tiles' dart counts, so that every tile knows its dart range without an atomic
@@ -1096,12 +1123,21 @@ __device__ __forceinline__ void contour_quads_body(uint32_t block, uint32_t n_bl
             const int la = ay - by, lb = bx - ax;
             const long long lc = (long long)ax * by - (long long)bx * ay;
             unsigned long long best = 0;  // (|num| << 30) | ~index (30 bits): max picks largest num, then smallest index
-            for (uint32_t i = a + 1 + lane; i <= b; i += G) {
-                const uint32_t p = P[i];
-                long long num = (long long)la * (int)(p & 0xFFFF) + (long long)lb * (int)(p >> 16) + lc;   // 32 x 32 -> 64 multiplies
-                if (num < 0) num = -num;
-                const unsigned long long cand = ((unsigned long long)num << 30) | (unsigned long long)(~i & 0x3FFFFFFFu);
-                if (cand > best) best = cand;
+            // four strided points per trip, their loads issued together: a long border is a chain of dependent round trips to
+            // the point pool otherwise (the arg-max keeps the smallest index among equal distances whatever the visiting order)
+            for (uint32_t i0 = a + 1 + lane; i0 <= b; i0 += 4 * G) {
+                uint32_t p[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) p[u] = P[min(i0 + (uint32_t)u * G, b)];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * G;
+                    if (i > b) break;
+                    long long num = (long long)la * (int)(p[u] & 0xFFFF) + (long long)lb * (int)(p[u] >> 16) + lc;   // 32 x 32 -> 64 multiplies
+                    if (num < 0) num = -num;
+                    const unsigned long long cand = ((unsigned long long)num << 30) | (unsigned long long)(~i & 0x3FFFFFFFu);
+                    if (cand > best) best = cand;
+                }
             }
 #pragma unroll
             for (int o = G / 2; o > 0; o >>= 1) {
@@ -1244,8 +1280,12 @@ size_t tile_darts_bytes(uint32_t W, uint32_t H, uint32_t n_frames) { return (siz
 hipError_t launch_dart_count(hipStream_t st, const uint64_t* bits, int W, int H, uint32_t first_frame, uint32_t n_frames,
                              unsigned long long* frame_darts, uint32_t* tile_darts) {
     const uint32_t tiles_x = dart_tiles_x((uint32_t)W), tiles_y = ((uint32_t)H + kTileRows - 1) / kTileRows;
-    hipLaunchKernelGGL(k_dart_count, dim3(((tiles_x + kCountTiles - 1) / kCountTiles) * tiles_y, n_frames), dim3(256), 0, st, bits, W, H, first_frame,
-                       frame_darts, tile_darts);
+    const uint32_t wpr = words_per_row((uint32_t)W);
+    if (wpr <= 30)   // two tile rows per wave
+        hipLaunchKernelGGL(k_dart_count<32>, dim3((tiles_y + 1) / 2, n_frames), dim3(64), 0, st, bits, W, H, first_frame, frame_darts, tile_darts);
+    else
+        hipLaunchKernelGGL(k_dart_count<64>, dim3(((wpr + kCountLanes - 1) / kCountLanes) * tiles_y, n_frames), dim3(64), 0, st, bits, W, H, first_frame,
+                           frame_darts, tile_darts);
     hipLaunchKernelGGL(k_tile_scan, dim3(n_frames), dim3(256), 0, st, tile_darts, tiles_x * tiles_y, first_frame, tile_darts + (size_t)tiles_x * tiles_y * n_frames);
     return hipGetLastError();
 }
@@ -1330,7 +1370,8 @@ hipError_t launch_select_scatter(hipStream_t st, const JumpState* fin, uint32_t 
 hipError_t launch_contour_quads(hipStream_t st, const ContourRec* contours, const DeviceCounters* ctr, uint32_t max_contours,
                                 const uint32_t* points, double eps_factor, uint32_t min_edge_length, uint32_t first_frame, uint32_t max_cand,
                                 CandRec* cands, uint32_t* cand_count, unsigned int* err_flags) {
-    hipLaunchKernelGGL(k_contour_quads, dim3(1024 + 512), dim3(256), 0, st, 1024u, contours, ctr, max_contours, points, eps_factor, min_edge_length,
+    const uint32_t b64 = (uint32_t)env_cap("A3_QUAD_BLOCKS64", 2560), b16 = (uint32_t)env_cap("A3_QUAD_BLOCKS16", 768);
+    hipLaunchKernelGGL(k_contour_quads, dim3(b64 + b16), dim3(256), 0, st, b64, contours, ctr, max_contours, points, eps_factor, min_edge_length,
                        first_frame, max_cand, cands, cand_count, err_flags);
     return hipGetLastError();
 }

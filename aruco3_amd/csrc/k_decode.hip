@@ -715,10 +715,12 @@ __global__ __launch_bounds__(256) void k_compact_markers(const DecodeOut* __rest
 }
 
 // Fixed-capacity detection records for the multi-GPU gather: one record per frame,
-//   u32 count | u32 global frame index | maxm x a3_marker (marker.frame rewritten to the global index, unused slots zero),
-// written straight from the device-resident marker list of the last batch: one wave per frame.  A frame with more than maxm
-// markers raises *overflow (the host turns it into A3_ERR_CAPACITY: records are never clipped silently).
-__global__ __launch_bounds__(256) void k_pack_detections(const a3_marker* __restrict__ markers, const uint32_t* __restrict__ per_frame,
+//   u32 count | u32 global frame index | maxm x a3_marker | (with poses: maxm x 2 x a3_pose, the pair of marker k at 2k, 2k+1)
+// (marker.frame rewritten to the global index, unused slots zero), written straight from the device-resident marker (and pose)
+// list of the last batch: one wave per frame.  A frame with more than maxm markers raises *overflow (the host turns it into
+// A3_ERR_CAPACITY: records are never clipped silently).
+__global__ __launch_bounds__(256) void k_pack_detections(const a3_marker* __restrict__ markers, const a3_pose* __restrict__ poses /*nullable*/,
+                                                         const uint32_t* __restrict__ per_frame,
                                                          uint32_t n_frames, uint32_t first_frame_global, uint32_t maxm,
                                                          uint32_t* __restrict__ dst, unsigned int* __restrict__ overflow) {
     const int lane = threadIdx.x & 63;
@@ -728,8 +730,8 @@ __global__ __launch_bounds__(256) void k_pack_detections(const a3_marker* __rest
     for (uint32_t g = lane; g < f; g += 64) base += per_frame[g];
     for (int o = 32; o > 0; o >>= 1) base += __shfl_xor(base, o);
     const uint32_t cnt = per_frame[f];
-    constexpr uint32_t kMarkerWords = sizeof(a3_marker) / 4;
-    const uint32_t rec_words = 2u + maxm * kMarkerWords;
+    constexpr uint32_t kMarkerWords = sizeof(a3_marker) / 4, kPoseWords = 2 * sizeof(a3_pose) / 4;
+    const uint32_t rec_words = 2u + maxm * (kMarkerWords + (poses ? kPoseWords : 0u));
     uint32_t* rec = dst + (size_t)f * rec_words;
     if (cnt > maxm) { if (lane == 0) atomicOr(overflow, 1u); }
     const uint32_t kept = min(cnt, maxm);
@@ -739,6 +741,11 @@ __global__ __launch_bounds__(256) void k_pack_detections(const a3_marker* __rest
         uint32_t v = 0u;
         if (w < kept * kMarkerWords) v = (w % kMarkerWords == 0u) ? first_frame_global + f : src[w];   // word 0 of a marker = .frame
         rec[2u + w] = v;
+    }
+    if (poses) {
+        const uint32_t* ps = reinterpret_cast<const uint32_t*>(poses + 2 * (size_t)base);
+        uint32_t* pd = rec + 2u + maxm * kMarkerWords;
+        for (uint32_t w = lane; w < maxm * kPoseWords; w += 64) pd[w] = w < kept * kPoseWords ? ps[w] : 0u;
     }
 }
 
@@ -988,9 +995,9 @@ hipError_t launch_compact_markers(hipStream_t st, const void* outs, const uint16
     return hipGetLastError();
 }
 
-hipError_t launch_pack_detections(hipStream_t st, const a3_marker* markers, const uint32_t* per_frame, uint32_t n_frames, uint32_t first_frame_global,
-                                  uint32_t maxm, void* dst, unsigned int* overflow) {
-    hipLaunchKernelGGL(k_pack_detections, dim3((n_frames + 3) / 4), dim3(256), 0, st, markers, per_frame, n_frames, first_frame_global, maxm,
+hipError_t launch_pack_detections(hipStream_t st, const a3_marker* markers, const a3_pose* poses, const uint32_t* per_frame, uint32_t n_frames,
+                                  uint32_t first_frame_global, uint32_t maxm, void* dst, unsigned int* overflow) {
+    hipLaunchKernelGGL(k_pack_detections, dim3((n_frames + 3) / 4), dim3(256), 0, st, markers, poses, per_frame, n_frames, first_frame_global, maxm,
                        reinterpret_cast<uint32_t*>(dst), overflow);
     return hipGetLastError();
 }

@@ -49,25 +49,29 @@ class RecordOverflow(ValueError):
     """A frame holds more markers than the gather record: raised, never clipped."""
 
 
-def record_bytes(maxm: int = MAXM) -> int:
-    return 8 + maxm * _REC_BYTES
+_POSE_PAIR_BYTES = 2 * 52        # two a3_pose records (error, 9 rotation floats row-major, 3 translation floats) per marker
+
+
+def record_bytes(maxm: int = MAXM, with_poses: bool = False) -> int:
+    return 8 + maxm * (_REC_BYTES + (_POSE_PAIR_BYTES if with_poses else 0))
 
 
 _PAD_FRAME = 0xFFFFFFFF   # global frame index of a padding record (ranks with fewer frames than the largest block)
 
 
-def pack_detections(markers: np.ndarray, per_frame: np.ndarray, first_frame: int = 0, maxm: int = MAXM) -> np.ndarray:
+def pack_detections(markers: np.ndarray, per_frame: np.ndarray, first_frame: int = 0, maxm: int = MAXM, poses: np.ndarray = None) -> np.ndarray:
     """Host statement of the record format a3_pack_detections writes on the device (the tests compare the two):
-    -> uint8 [frames, 8 + maxm*56]: u32 count, u32 global frame index, then maxm a3_marker records whose .frame field holds
-    the GLOBAL frame index; unused slots are zero.  A frame with more than maxm markers raises RecordOverflow."""
+    -> uint8 [frames, record]: u32 count, u32 global frame index, then maxm a3_marker records whose .frame field holds the
+    GLOBAL frame index and, when `poses` (float32 [markers, 2, 13]) is given, maxm pose pairs; unused slots are zero.
+    A frame with more than maxm markers raises RecordOverflow."""
     n = per_frame.size
     if n and int(per_frame.max()) > maxm:
         raise RecordOverflow(f"a frame holds {int(per_frame.max())} markers, the gather record only {maxm}")
-    rec = np.zeros((n, record_bytes(maxm)), dtype=np.uint8)
+    rec = np.zeros((n, record_bytes(maxm, poses is not None)), dtype=np.uint8)
     head = rec[:, :8].view(np.uint32)
     head[:, 0] = per_frame
     head[:, 1] = np.arange(first_frame, first_frame + n, dtype=np.uint32)
-    body = rec[:, 8:].reshape(n, maxm, _REC_BYTES)
+    body = rec[:, 8: 8 + maxm * _REC_BYTES].reshape(n, maxm, _REC_BYTES)
     total = int(per_frame.sum())
     if total:
         counts = per_frame.astype(np.int64)
@@ -76,19 +80,28 @@ def pack_detections(markers: np.ndarray, per_frame: np.ndarray, first_frame: int
         raw = np.ascontiguousarray(markers[:total]).view(np.uint8).reshape(total, _REC_BYTES).copy()   # the caller's list keeps its local indices
         raw[:, :4] = (first_frame + frame_of).astype("<u4").view(np.uint8).reshape(total, 4)           # bytes 0..3 = a3_marker.frame
         body[frame_of, rank_in_frame] = raw
+        if poses is not None:
+            pbody = rec[:, 8 + maxm * _REC_BYTES:].reshape(n, maxm, _POSE_PAIR_BYTES)
+            pbody[frame_of, rank_in_frame] = np.ascontiguousarray(poses[:total], dtype=np.float32).view(np.uint8).reshape(total, _POSE_PAIR_BYTES)
     return rec
 
 
-def unpack_detections(rec: np.ndarray):
-    """inverse of pack_detections -> list of (global frame index, marker structured array); padding records are skipped"""
+def unpack_detections(rec: np.ndarray, with_poses: bool = False):
+    """inverse of pack_detections -> list of (global frame index, marker structured array[, poses float32 [count, 2, 13]]);
+    padding records are skipped"""
     out = []
     rec = np.asarray(rec)
+    maxm = (rec.shape[-1] - 8) // (_REC_BYTES + (_POSE_PAIR_BYTES if with_poses else 0))
     for row in rec.reshape(-1, rec.shape[-1]):
         cnt, frame = (int(v) for v in row[:8].view(np.uint32))
         if frame == _PAD_FRAME:
             continue
         m = row[8: 8 + cnt * _REC_BYTES].copy().view(_lib.MARKER_DTYPE)
-        out.append((frame, m))
+        if with_poses:
+            p0 = 8 + maxm * _REC_BYTES
+            out.append((frame, m, row[p0: p0 + cnt * _POSE_PAIR_BYTES].copy().view(np.float32).reshape(cnt, 2, 13)))
+        else:
+            out.append((frame, m))
     return out
 
 
@@ -117,13 +130,14 @@ def gather_detections(markers: np.ndarray, per_frame: np.ndarray, first_frame: i
     return _all_gather(rec, rows if rows is not None else rec.shape[0])
 
 
-def pack_detections_device(ctx: "_lib.Context", n_frames: int, first_frame: int, device, maxm: int = MAXM) -> torch.Tensor:
+def pack_detections_device(ctx: "_lib.Context", n_frames: int, first_frame: int, device, maxm: int = MAXM, with_poses: bool = False) -> torch.Tensor:
     """The last batch of `ctx` as gather records, written by a kernel straight from the device-resident marker list
-    (a3_pack_detections): no D2H, no numpy, no H2D.  Enqueued on the context's stream -- call under
+    (a3_pack_detections): no D2H, no numpy, no H2D.  with_poses: the batch was a detect_batch_pose call and every marker's
+    pose pair travels with it (BASELINE config 5).  Enqueued on the context's stream -- call under
     `torch.cuda.stream(<that stream>)` so that torch orders the collective after it."""
-    rec = torch.empty((n_frames, record_bytes(maxm)), dtype=torch.uint8, device=device)
+    rec = torch.empty((n_frames, record_bytes(maxm, with_poses)), dtype=torch.uint8, device=device)
     try:
-        ctx.pack_detections(first_frame, maxm, rec.data_ptr(), rec.numel())
+        ctx.pack_detections(first_frame, maxm, rec.data_ptr(), rec.numel(), with_poses)
     except _lib.A3Error as e:
         if e.code == _lib.ERR_CAPACITY:
             raise RecordOverflow(str(e)) from e
@@ -132,10 +146,10 @@ def pack_detections_device(ctx: "_lib.Context", n_frames: int, first_frame: int,
 
 
 def gather_detections_device(ctx: "_lib.Context", n_frames: int, first_frame: int, device, coll_device=None, rows: int = None,
-                             maxm: int = MAXM) -> torch.Tensor:
+                             maxm: int = MAXM, with_poses: bool = False) -> torch.Tensor:
     """Per batch: device-packed records of this rank's frames, all-gathered (RCCL all-gather over xGMI with backend "nccl").
     coll_device = "cpu" moves the packed tensor to the host first (gloo rehearsal on a box with fewer GPUs than ranks)."""
-    rec = pack_detections_device(ctx, n_frames, first_frame, device, maxm)
+    rec = pack_detections_device(ctx, n_frames, first_frame, device, maxm, with_poses)
     if coll_device is not None and torch.device(coll_device).type == "cpu":
         rec = rec.cpu()
     return _all_gather(rec, rows if rows is not None else n_frames)

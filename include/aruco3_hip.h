@@ -150,12 +150,14 @@ int  a3_download_contours(a3_ctx *ctx, uint32_t frame, uint32_t *start_keys, uin
 /* Multi-GPU gather (frames are sharded by rank): the markers of the last finished batch as
  * fixed-capacity records in DEVICE memory, one per frame, ready for one all-gather:
  *   u32 count | u32 global frame index (first_frame_global + f) | max_markers_per_frame x a3_marker
+ *   | with_poses: max_markers_per_frame x 2 x a3_pose (the poses of marker k at 2k, 2k+1; the last batch must then have
+ *     been an a3_detect_batch_pose call -- BASELINE config 5 gathers poses with the detections)
  * with a3_marker.frame rewritten to the global index and unused slots zeroed.  Written by a kernel on the context's stream
  * (no host copy); the caller orders its collective after it.  A frame with more markers than the record holds is an
  * error (A3_ERR_CAPACITY), never a silent clip. */
-size_t a3_detection_record_bytes(uint32_t max_markers_per_frame);
-int  a3_pack_detections(a3_ctx *ctx, uint32_t first_frame_global, uint32_t max_markers_per_frame, void *dst_device,
-                        size_t dst_bytes);
+size_t a3_detection_record_bytes(uint32_t max_markers_per_frame, int with_poses);
+int  a3_pack_detections(a3_ctx *ctx, uint32_t first_frame_global, uint32_t max_markers_per_frame, int with_poses,
+                        void *dst_device, size_t dst_bytes);
 
 /* pose::solve_with_undistorted_points (intr == NULL, src/pose.rs:59-62) or
  * pose::solve_with_intrinsics (src/pose.rs:52-55) for n markers; out holds 2*n poses,

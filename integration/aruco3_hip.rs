@@ -191,9 +191,9 @@ extern "C" {
     pub fn a3_contour_count(ctx: *mut A3Ctx, frame: u32, n_contours: *mut u32, n_points: *mut u64) -> c_int;
     pub fn a3_download_contours(ctx: *mut A3Ctx, frame: u32, start_keys: *mut u32, lengths: *mut u32, points_xy: *mut u32,
                                 cap_contours: usize, cap_points: usize) -> c_int;
-    pub fn a3_detection_record_bytes(max_markers_per_frame: u32) -> usize;
-    pub fn a3_pack_detections(ctx: *mut A3Ctx, first_frame_global: u32, max_markers_per_frame: u32, dst_device: *mut c_void,
-                              dst_bytes: usize) -> c_int;
+    pub fn a3_detection_record_bytes(max_markers_per_frame: u32, with_poses: c_int) -> usize;
+    pub fn a3_pack_detections(ctx: *mut A3Ctx, first_frame_global: u32, max_markers_per_frame: u32, with_poses: c_int,
+                              dst_device: *mut c_void, dst_bytes: usize) -> c_int;
     pub fn a3_estimate_pose(ctx: *mut A3Ctx, corners_xy: *const u32, n: usize, marker_size_mm: f32, intr: *const A3Intrinsics,
                             image_width: u32, image_height: u32, out: *mut A3Pose) -> c_int;
     pub fn a3_estimate_pose_normalized(ctx: *mut A3Ctx, points_xy: *const f32, n: usize, marker_size_mm: f32,

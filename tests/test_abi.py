@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.INTERNAL_SYMBOLS) == internal and not set(internal) & set(names)
     for n in internal:
         assert hasattr(L, n), n
-    assert L.a3_detection_record_bytes(32) == 8 + 32 * 56
+    assert L.a3_detection_record_bytes(32, 0) == 8 + 32 * 56 and L.a3_detection_record_bytes(16, 1) == 8 + 16 * (56 + 104)
 
 
 def test_struct_layouts_match_header():

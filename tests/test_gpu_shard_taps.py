@@ -153,6 +153,57 @@ def test_config3_2048_frames_in_8_rank_slices(dicts, oracle):
     assert all_ids >= int(0.9 * total)     # the rest lose a marker to the reference's quirks Q2/Q3, in the oracle too
 
 
+def test_config5_4k_pose_in_4_rank_slices(dicts, oracle):
+    """BASELINE config 5 (3840x2160, 16 markers, detect + IPPE pose, 4 GPUs) on one GPU: 8 frames walked through the 4 rank
+    slices of shard.partition -> a3_detect_batch_pose -> device-packed records that carry both poses of every marker ->
+    concatenation -> unpack.  Markers against the oracle bit for bit, poses within 1e-4 (BASELINE.json's tolerance), and the
+    device records equal the host statement of the format."""
+    import torch
+
+    from aruco3_amd import _lib, shard, synth
+
+    spec, name = synth.config_spec(5)
+    d = dicts.new_from_named_dict(name)
+    det = _detector(dicts, name)
+    ctx = det._context()
+    ctx.set_debug_taps(False)
+    dev = torch.device("cuda", 0)
+    total, world = 8, 4
+    gathered, host_frames = [], {}
+    for rank in range(world):
+        lo, hi = shard.partition(total, world, rank)
+        frames, _ = synth.render_frames_device(spec, d.code_list, d.num_bits, [synth.frame_seed(5, i) for i in range(lo, hi)])
+        n, h, w, c = frames.shape
+        markers, per, poses = ctx.detect_batch_pose(frames.data_ptr(), _lib.MEM_DEVICE, _lib.FMT_RGB8, w, h, w * c, h * w * c, n, 40.0)
+        rec = shard.pack_detections_device(ctx, n, lo, dev, with_poses=True)
+        torch.cuda.synchronize()
+        got = rec.cpu().numpy()
+        want = shard.pack_detections(markers, per, lo, poses=poses)
+        assert got.shape == want.shape == (n, shard.record_bytes(with_poses=True))
+        a, b = shard.unpack_detections(got, with_poses=True), shard.unpack_detections(want, with_poses=True)
+        assert [(f, marker_tuples(m)) for f, m, _ in a] == [(f, marker_tuples(m)) for f, m, _ in b]
+        assert all(np.array_equal(pa.view(np.uint32), pb.view(np.uint32)) for (_, _, pa), (_, _, pb) in zip(a, b))
+        gathered.append(got)
+        for i in range(lo, hi):
+            host_frames[i] = frames[i - lo].cpu().numpy()
+        with pytest.raises(_lib.A3Error):      # poses are only there after a detect_batch_pose call
+            ctx.detect_batch(frames.data_ptr(), _lib.MEM_DEVICE, _lib.FMT_RGB8, w, h, w * c, h * w * c, n)
+            shard.pack_detections_device(ctx, n, lo, dev, with_poses=True)
+    out = shard.unpack_detections(np.concatenate(gathered), with_poses=True)
+    assert [f for f, _, _ in out] == list(range(total))
+    n_markers = 0
+    for f, m, poses in out:
+        res = oracle.detect(host_frames[f], d.code_list, d.num_bits, d._tau)
+        assert markers_of_hip(m) == markers_of_oracle(res), f
+        for k, mk in enumerate(res["markers"]):
+            ref = oracle.solve_with_undistorted_points(mk["corners"], 40.0, (3840, 2160))      # ((error, rotation, translation), (..))
+            for (e, r, t), q in zip(ref, poses[k]):
+                assert abs(float(q[0]) - e) <= 1e-4 and np.abs(q[1:10].reshape(3, 3) - np.asarray(r).reshape(3, 3)).max() <= 1e-4
+                assert np.abs(q[10:13] - np.asarray(t).reshape(3)).max() <= 1e-4 * max(1.0, float(np.abs(t).max()))
+        n_markers += len(m)
+    assert n_markers >= 100
+
+
 def test_two_rank_rehearsal_as_child_processes():
     """bench.py --gpus 2 --backend gloo: two ranks started as FRESH child processes (this process has touched the GPU and is
     never re-executed), both on the one leased GPU: partition, dictionary broadcast, detect, device-packed records,

@@ -13,13 +13,10 @@ from aruco3_amd.aruco import Detector, DetectorConfig
 from aruco3_amd.dictionaries import ARDictionary
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-cache = pathlib.Path("/tmp/c2frames.n256.r0.npz")   # written by bench.py --frames-cache /tmp/c2frames
-if cache.exists() and n == 256:
-    frames = np.load(cache, allow_pickle=True)["frames"]
-else:
-    frames, _ = synth.config_frames(2, n)
-dev = torch.from_numpy(frames).cuda()
-det = Detector(DetectorConfig(), ARDictionary.new_from_named_dict("ARUCO"))
+d = ARDictionary.new_from_named_dict("ARUCO")
+spec, _ = synth.config_spec(2)
+dev, _ = synth.render_frames_device(spec, d.code_list, d.num_bits, [synth.frame_seed(2, i) for i in range(n)])
+det = Detector(DetectorConfig(), d)
 for _ in range(2):
     det.detect_batch_raw(dev)
 ctx = det._context()

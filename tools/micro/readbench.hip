@@ -42,6 +42,15 @@ __global__ __launch_bounds__(64) void k_read(const uint8_t* __restrict__ base, s
             if (STORE == 5 && ((r + i) & 7) == 7) reinterpret_cast<uint4*>(bits + ((size_t)blockIdx.x * rows + r + i - 7) * 64)[lane] = make_uint4(acc, t, u, v);
             if (STORE == 7 && ((r + i) & 63) == 63) reinterpret_cast<uint4*>(bits + ((size_t)blockIdx.x * rows + r + i - 63) * 64)[lane] = make_uint4(acc, t, u, v);
             if (STORE == 8 && ((r + i) & 7) == 7) __builtin_nontemporal_store(make_uint4(acc, t, u, v).x, reinterpret_cast<uint32_t*>(bits + ((size_t)blockIdx.x * rows + r + i - 7) * 64) + lane);
+            if (STORE == 9 && ((r + i) & 7) == 7) {
+                uint4* dst = reinterpret_cast<uint4*>(bits + ((size_t)blockIdx.x * rows + r + i - 7) * 64) + lane;
+                __builtin_nontemporal_store(acc, &dst->x); __builtin_nontemporal_store(t, &dst->y); __builtin_nontemporal_store(u, &dst->z); __builtin_nontemporal_store(v, &dst->w);
+            }
+            if (STORE == 10 && ((r + i) & 7) == 7) {
+                uint32_t* dst = reinterpret_cast<uint32_t*>(bits + ((size_t)blockIdx.x * rows + r + i - 7) * 64) + lane * 4;
+                __hip_atomic_store(dst, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(dst + 1, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 2, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(dst + 3, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (STORE == 6 && ((r + i) & 3) == 3) reinterpret_cast<uint2*>(bits + ((size_t)blockIdx.x * rows + r + i - 3) * 64)[lane] = make_uint2(acc, t);
             if (STORE >= 2 && STORE <= 4) {   // gather 2 / 4 / 8 lanes' 16 bits into one dword / dwordx2 / dwordx4 store
                 uint16_t* rowp = bits + ((size_t)blockIdx.x * rows + r + i) * 64;
@@ -99,12 +108,13 @@ int main() {
     for (int occ : {2, 4}) {
         const size_t lds = occ == 8 ? 0 : (occ == 4 ? 9000 : 19000);
         for (int sy : {4, 8}) {
-            printf("occ %d strips_y %d: read-only %.3f | short x64 %.3f | dword x32 %.3f | dwordx2 x16 %.3f | dwordx4 x8 %.3f | 1 KB every 8 rows %.3f | 512 B every 4 rows %.3f | 1 KB every 64 rows %.3f | nt dword every 8 rows %.3f\n", occ, sy,
+            printf("occ %d strips_y %d: read-only %.3f | short x64 %.3f | dword x32 %.3f | dwordx2 x16 %.3f | dwordx4 x8 %.3f | 1 KB every 8 rows %.3f | 512 B every 4 rows %.3f | 1 KB every 64 rows %.3f | nt dword every 8 rows %.3f | nt 1 KB / 8 rows %.3f | sc1 1 KB / 8 rows %.3f\n", occ, sy,
                    run<0, 3, 0, 0>(d, row_stride, frames, H, sy, lds, out, 10), run<0, 3, 0, 1>(d, row_stride, frames, H, sy, lds, out, 10),
                    run<0, 3, 0, 2>(d, row_stride, frames, H, sy, lds, out, 10), run<0, 3, 0, 3>(d, row_stride, frames, H, sy, lds, out, 10),
                    run<0, 3, 0, 4>(d, row_stride, frames, H, sy, lds, out, 10), run<0, 3, 0, 5>(d, row_stride, frames, H, sy, lds, out, 10),
                    run<0, 3, 0, 6>(d, row_stride, frames, H, sy, lds, out, 10), run<0, 3, 0, 7>(d, row_stride, frames, H, sy, lds, out, 10),
-                   run<0, 3, 0, 8>(d, row_stride, frames, H, sy, lds, out, 10));
+                   run<0, 3, 0, 8>(d, row_stride, frames, H, sy, lds, out, 10), run<0, 3, 0, 9>(d, row_stride, frames, H, sy, lds, out, 10),
+                   run<0, 3, 0, 10>(d, row_stride, frames, H, sy, lds, out, 10));
             fflush(stdout);
         }
     }
