@@ -44,8 +44,10 @@ size_t decode_out_bytes();
 hipError_t launch_frame_candidates(hipStream_t, const CandRec*, const uint32_t*, uint32_t, uint32_t, float, uint16_t*, uint16_t*, uint32_t*,
                                    uint32_t*, unsigned int*);
 size_t proj_rec_bytes();
+size_t weight_table_bytes();
+hipError_t launch_weight_table(hipStream_t, uint32_t, uint32_t, uint32_t, float*);
 hipError_t launch_decode(hipStream_t, PixelSrc, int, int, uint32_t, const uint16_t*, const uint32_t*, const unsigned int*, uint32_t,
-                         uint32_t, uint32_t, uint32_t, const uint64_t*, uint32_t, uint32_t, int, void*, void*, uint8_t*, uint32_t, uint32_t*, int, int);
+                         uint32_t, uint32_t, uint32_t, const uint64_t*, uint32_t, uint32_t, int, void*, const float*, void*, uint8_t*, uint32_t, uint32_t*, int, int);
 hipError_t launch_compact_markers(hipStream_t, const void*, const uint16_t*, const uint32_t*, uint32_t, uint32_t, uint32_t, a3_marker*,
                                   uint32_t, uint32_t*, unsigned int*, unsigned int*, const uint32_t*, unsigned int*);
 hipError_t launch_pack_detections(hipStream_t, const a3_marker*, const a3_pose*, const uint32_t*, uint32_t, uint32_t, uint32_t, void*, unsigned int*);
@@ -162,6 +164,7 @@ struct a3_ctx {
     unsigned int* scratch_u32 = nullptr; DeviceCounters* counters = nullptr; uint32_t* per_frame = nullptr; uint32_t* frame_cursor = nullptr; uint32_t* cand_count = nullptr;
     uint32_t last_marker_total = 0;   // sizes the speculative marker read-back of the next batch
     DevBuf tmp_a, tmp_b, tmp_c, tmp_d;
+    DevBuf wtab;                // triangle-resize weights of a full patch (sample -> mark_size), written once at a3_create
     DevBuf pose_buf;            // a3_detect_batch_pose: both poses of every marker of the last batch (kept for a3_pack_detections)
     bool poses_valid = false;
     void* pinned = nullptr;
@@ -428,7 +431,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
                                    : PixelSrc{pixels, row_stride, frame_stride, fmt};
     A3_HIP(launch_decode(st, src, (int)W, (int)H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), d_work_count,
                          kMaxCand, S, ctx->mark_size, S, ctx->dict.as<uint64_t>(), ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors,
-                         ctx->proj.p, ctx->outs.p, ctx->debug_taps ? ctx->patches.as<uint8_t>() : nullptr, kPatchCap, ctx->per_frame, 4096, 0));
+                         ctx->proj.p, ctx->wtab.as<float>(), ctx->outs.p, ctx->debug_taps ? ctx->patches.as<uint8_t>() : nullptr, kPatchCap, ctx->per_frame, 4096, 0));
     ctx->dbg_src = src;
     A3_HIP(launch_compact_markers(st, ctx->outs.p, ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(), n, 0, kMaxCand,
                                   ctx->markers_ptr, marker_cap, ctx->per_frame, d_marker_total, d_err, ctx->cand_count, ctx->scratch_u32 + 2));
@@ -639,6 +642,10 @@ int a3_create(int device, const a3_config* cfg, const uint64_t* codes, size_t n_
     e = c->dict.ensure(std::max<size_t>(n_codes, 1) * 8);
     if (e == hipSuccess && n_codes) e = hipMemcpy(c->dict.p, codes, n_codes * 8, hipMemcpyHostToDevice);
     if (e != hipSuccess) { a3_destroy(c); ctx = nullptr; return fail(ctx, A3_ERR_HIP, "dictionary upload", e); }
+    e = c->wtab.ensure(weight_table_bytes());
+    if (e == hipSuccess) e = launch_weight_table(c->stream, cfg->homography_sample_size, c->mark_size, cfg->homography_sample_size, c->wtab.as<float>());
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { a3_destroy(c); ctx = nullptr; return fail(ctx, A3_ERR_HIP, "resize weight table", e); }
     if (tau == 0) {  // src/dictionaries.rs:124
         uint8_t t = 255;
         int rc = a3_calculate_tau(device, codes, n_codes, &t);
@@ -659,7 +666,7 @@ void a3_destroy(a3_ctx* ctx) {
                       &ctx->leader_list, &ctx->leader_keep, &ctx->entry_list, &ctx->entry_pos, &ctx->es_a, &ctx->es_b,
                       &ctx->contours, &ctx->cyc_start_off, &ctx->points, &ctx->zero_blk, &ctx->cands,
                       &ctx->pre_xy, &ctx->fin_xy, &ctx->fin_count, &ctx->work, &ctx->outs, &ctx->proj, &ctx->patches,
-                      &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_d, &ctx->pose_buf};
+                      &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_d, &ctx->pose_buf, &ctx->wtab};
     for (DevBuf* b : bufs) b->release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
@@ -826,7 +833,7 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
         } else if (kernel == 3) {   // dbg < 0: k_decode alone (variant -dbg), dbg >= 0: k_projection + k_decode
             A3_HIP(launch_decode(st, ctx->dbg_src, (int)ctx->W, (int)ctx->H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), ctx->scratch_u32,
                                  kMaxCand, ctx->cfg.homography_sample_size, ctx->mark_size, ctx->cfg.homography_sample_size, ctx->dict.as<uint64_t>(),
-                                 ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors, ctx->proj.p, ctx->outs.p, nullptr, 0u, nullptr, 4096, dbg));
+                                 ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors, ctx->proj.p, ctx->wtab.as<float>(), ctx->outs.p, nullptr, 0u, nullptr, 4096, dbg));
         } else return fail(ctx, A3_ERR_INVALID, "kernel: 0 dart_count, 1 dart_assign, 2 local_contract, 3 decode");
         A3_HIP(hipEventRecord(e1, st));
         A3_HIP(hipStreamSynchronize(st));

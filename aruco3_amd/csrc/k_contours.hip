@@ -494,17 +494,19 @@ __global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W,
     // every lane owns 8 darts (i = lane + 256 u) and keeps their window state in registers across the rounds; LDS holds the
     // copy the other lanes read (per dart and round: one 16-byte read of the next window, one 16-byte write)
     constexpr int PER = kLT / 256;
-    uint64_t nk[PER]; uint32_t np[PER], no[PER], nd[PER];
+    uint64_t nk[PER]; uint32_t np[PER], no[PER], nd[PER], succ0[PER], frm[PER];
 #pragma unroll
     for (int u = 0; u < PER; u++) {
         const uint32_t i = threadIdx.x + u * 256;
+        succ0[u] = 0; frm[u] = 0;
         if (i < cnt) {
             const uint32_t d = lo + i;
             const uint64_t rec = d_rec[d];
             const uint32_t xy = rec_xy(rec), info = rec_info(rec);
             const uint32_t q = (xy >> 16) * (uint32_t)W + (xy & 0xFFFF);
             const uint32_t ek = (info & kInfoW) ? 2u * q : ((info & kInfoE) ? 2u * q + 1u : kNoKey);
-            nk[u] = ((uint64_t)ek << 32) | d; np[u] = d_succ[d]; no[u] = 0; nd[u] = 1;
+            succ0[u] = d_succ[d]; frm[u] = rec_frame(rec);   // kept for the entry registration below (no second read)
+            nk[u] = ((uint64_t)ek << 32) | d; np[u] = succ0[u]; no[u] = 0; nd[u] = 1;
             s_win[i] = Win{nk[u], np[u], 1u << 16};
         }
     }
@@ -556,11 +558,11 @@ __global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W,
         JumpState r;
         r.key = nk[u]; r.ptr = e; r.off = loc_pack(no[u], nd[u], frozen);
         loc[d] = r;
-        const uint32_t s0 = d_succ[d];
+        const uint32_t s0 = succ0[u];
         if ((s0 - lo) >= cnt) {
             my_e[u] = s0;
             if (frame_entries) {   // a border never leaves its frame: the successor's frame is this dart's
-                const uint32_t f = rec_frame(d_rec[d]);
+                const uint32_t f = frm[u];
                 my_f[u] = f;
                 if (f - f0 < kFrameWin) my_slot[u] = atomicAdd(&s_fcnt[f - f0], 1u);          // rank inside (tile, frame)
                 else {                                                                           // a tile over > 64 tiny frames

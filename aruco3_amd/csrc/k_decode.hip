@@ -40,12 +40,18 @@ __global__ __launch_bounds__(64) void k_frame_candidates(const CandRec* __restri
     const int lane = threadIdx.x;
     const uint32_t c = min(cand_count[f], max_cand);
     const CandRec* src = cands + (size_t)f * max_cand;
-    // rank sort by start key (keys are unique: one border starts per pixel visit)
+    // rank sort by start key (keys are unique: one border starts per pixel visit).  The keys go to LDS first: ranking
+    // straight from global memory was a chain of c dependent loads per lane (s_per doubles as the key buffer until the
+    // perimeters are written).
+    uint32_t* s_key = reinterpret_cast<uint32_t*>(s_per);
+    for (uint32_t i = lane; i < c; i += 64) s_key[i] = src[i].start_key;
+    __syncthreads();
     for (uint32_t i = lane; i < c; i += 64) {
-        const uint32_t key = src[i].start_key;
+        const uint32_t key = s_key[i];
+        const CandRec r = src[i];   // in flight while the rank is counted
         uint32_t rank = 0;
-        for (uint32_t j = 0; j < c; j++) rank += src[j].start_key < key;
-        for (int k = 0; k < 8; k++) s_xy[rank * 8 + k] = src[i].xy[k];
+        for (uint32_t j = 0; j < c; j++) rank += s_key[j] < key;
+        for (int k = 0; k < 8; k++) s_xy[rank * 8 + k] = r.xy[k];
     }
     __syncthreads();
     for (uint32_t i = lane; i < c; i += 64) {
@@ -317,6 +323,17 @@ __device__ uint32_t resize_weights(uint32_t in_len, uint32_t out_len, uint32_t o
 // CU, so it runs first, one lane per candidate, and leaves 9 floats + a flag per candidate.
 struct __attribute__((aligned(8))) ProjRec { float inv[9]; int ok; };
 
+// The triangle-resize weights of a full patch (S -> n) are the same for every candidate of a context: a table computed once
+// (k_weight_table, at a3_create) replaces seven lanes of every decode workgroup computing them while the other 249 waited
+// (~30 f32 divisions in a row: ~4 us on the critical path of each candidate).  Row o of the table: left, count, weights.
+constexpr size_t kWeightTableBytes = 16384;   // n <= 10 rows of (2 + max_taps <= 202) floats
+__global__ void k_weight_table(uint32_t S, uint32_t n, uint32_t max_taps, float* __restrict__ wtab) {
+    if (threadIdx.x >= n) return;
+    float* row = wtab + (size_t)threadIdx.x * (max_taps + 2);
+    uint32_t cnt;
+    const uint32_t left = resize_weights(S, n, threadIdx.x, row + 2, &cnt);
+    row[0] = __uint_as_float(left); row[1] = __uint_as_float(cnt);
+}
 __global__ __launch_bounds__(64) void k_projection(const uint16_t* __restrict__ fin_xy, const uint32_t* __restrict__ work,
                                                    const unsigned int* __restrict__ work_count, uint32_t S, ProjRec* __restrict__ proj) {
     const uint32_t n_work = *work_count;
@@ -341,13 +358,29 @@ __device__ __forceinline__ void rotated_source(uint32_t r, uint32_t n, uint32_t 
     else { *sy = n - 1 - x; *sx = y; }
 }
 
-// grid-stride over the work list; block = 256 threads; dynamic LDS:
+// grid-stride over the work list; block = NT threads; dynamic LDS:
 //   patch S*S | tmp n*S f32 | wtab n*max_taps f32 | wleft n u32 | wcnt n u32 | bits n*n
-__global__ __launch_bounds__(256) void k_decode(PixelSrc src, int W, int H, uint32_t first_frame,
+#ifndef A3_D_KU
+#define A3_D_KU 2
+#endif
+#ifndef A3_D_WAVES
+#define A3_D_WAVES 5
+#endif
+#ifndef A3_D_THREADS
+#define A3_D_THREADS 64
+#endif
+// NT threads work on one candidate.  NT = 64 (one wave per candidate, the default): the "barriers" below are free, and --
+// what matters -- hundreds of candidates per CU are in flight at different stages, so the sampling of some (bound by the
+// rate at which the texture-address path takes 64 scattered requests per instruction) overlaps the LDS / VALU stages of
+// others; 96 VGPRs give five waves per SIMD.  Measured on the 2.5 k candidates of BASELINE config 2 (tools/tune_decode.sh):
+// 256 threads, 4 samples in flight per lane, row-major sample order (round 1): 116 us; 64 threads, 2 in flight, 8 x 8
+// blocked order: 98 us, of which the scattered tap loads alone are ~70.
+template <int NT>
+__global__ __launch_bounds__(NT, NT == 64 ? A3_D_WAVES : 3) void k_decode(PixelSrc src, int W, int H, uint32_t first_frame,
                                                 const uint16_t* __restrict__ fin_xy, const uint32_t* __restrict__ work,
                                                 const unsigned int* __restrict__ work_count, uint32_t max_cand, uint32_t S, uint32_t n,
                                                 uint32_t max_taps, const uint64_t* __restrict__ dict, uint32_t n_codes, uint32_t tau,
-                                                int filter, const ProjRec* __restrict__ proj, DecodeOut* __restrict__ outs,
+                                                int filter, const ProjRec* __restrict__ proj, const float* __restrict__ wtab, DecodeOut* __restrict__ outs,
                                                 uint8_t* __restrict__ patches /*nullable*/, uint32_t patch_cap, uint32_t* __restrict__ per_frame /*nullable*/, int dbg) {
     // dbg (a3_debug_kernel_time only, 0 in the product path): 1 = no sampling, 2 / 3 / 4 = stop after sampling / Otsu / bits
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -363,10 +396,11 @@ __global__ __launch_bounds__(256) void k_decode(PixelSrc src, int W, int H, uint
     __shared__ int s_ok, s_have;
     __shared__ uint32_t s_otsu;
     __shared__ uint64_t s_codes[4];
-    __shared__ unsigned long long s_best[4][4];
-    __shared__ uint32_t s_scan_w[4], s_scan_s[4];
-    __shared__ double s_var[4];
-    __shared__ int s_vt[4];
+    __shared__ unsigned long long s_best[NT / 64][4];
+    constexpr int NW = NT / 64;   // waves per candidate
+    __shared__ uint32_t s_scan_w[NW], s_scan_s[NW];
+    __shared__ double s_var[NW];
+    __shared__ int s_vt[NW];
 
     const int tid = threadIdx.x;
     const uint32_t n_work = *work_count;
@@ -377,41 +411,58 @@ __global__ __launch_bounds__(256) void k_decode(PixelSrc src, int W, int H, uint
         __syncthreads();
         if (tid < 9) s_inv[tid] = proj[wi].inv[tid];
         if (tid == 9) s_ok = proj[wi].ok;
-        s_hist[tid] = 0;
+        for (int i = tid; i < 256; i += NT) s_hist[i] = 0;
         __syncthreads();
         const bool ok = s_ok != 0;
         const uint32_t pw = ok ? S : 1u, ph = pw;
         // warp_into: integer output coordinates, no centre offset, mapping = the projection's inverse
         if (ok && dbg == 1) {
-            for (uint32_t i = tid; i < S * S; i += 256) { s_patch[i] = (uint8_t)(i * 7u); atomicAdd(&s_hist[(i * 7u) & 255u], 1u); }
+            for (uint32_t i = tid; i < S * S; i += NT) { s_patch[i] = (uint8_t)(i * 7u); atomicAdd(&s_hist[(i * 7u) & 255u], 1u); }
         } else if (ok) {
             const float t0 = s_inv[0], t1 = s_inv[1], t2 = s_inv[2], t3 = s_inv[3], t4 = s_inv[4], t5 = s_inv[5], t6 = s_inv[6],
                         t7 = s_inv[7], t8 = s_inv[8];
             // kU samples per lane per trip: all their row reads (one 12-byte load per row and sample: the two taps of a row
             // are adjacent) are in flight before the first is converted
-            constexpr int kU = 4;
-            // i / S and i % S for i < S * S by a multiply-high (S is uniform but not a compile-time constant: the division
-            // would be a ~35-instruction sequence per sample); exact because i * (M * S - 2^32) < 2^32
-            const uint32_t M = S > 1 ? 0xFFFFFFFFu / S + 1u : 0u;
+            constexpr int kU = A3_D_KU;
+            // Sample order: blocks of 8 x 8 output pixels, one block per wave instruction (lane = 8 * (y & 7) + (x & 7)).  Taps
+            // of a block lie in a compact patch of the frame whatever the marker's rotation, so the 64 lanes of a load touch
+            // a few dozen cache lines; a row-major order puts the 64 samples of an instruction on a slanted line that crosses
+            // a new image row -- a new cache line -- at almost every sample of a rotated marker (A3_D_BLOCKED=0: row-major).
+#ifndef A3_D_BLOCKED
+#define A3_D_BLOCKED 1
+#endif
             const uint32_t bpp = (src.fmt == A3_FMT_RGB8) ? 3u : ((src.fmt == A3_FMT_RGBA8 || src.fmt == A3_FMT_BGRA8) ? 4u : 1u);
-            for (uint32_t i0 = tid; i0 < S * S; i0 += 256 * kU) {
+            const uint32_t nbx = (S + 7u) / 8u, n_slots = A3_D_BLOCKED ? nbx * nbx * 64u : S * S;
+            // slot -> (x, y); i / S by a multiply-high in the row-major order (S is uniform but not a compile-time constant)
+            const uint32_t M = S > 1 ? 0xFFFFFFFFu / S + 1u : 0u, Mb = 0xFFFFFFFFu / nbx + 1u;
+            auto slot_xy = [&](uint32_t slot, uint32_t* x, uint32_t* y) -> bool {
+                if (A3_D_BLOCKED) {
+                    const uint32_t blk = slot >> 6, l = slot & 63u, by = __umulhi(blk, Mb), bx = blk - by * nbx;   // blk < nbx^2 <= 625
+                    *x = bx * 8u + (l & 7u); *y = by * 8u + (l >> 3);
+                    return slot < n_slots && *x < S && *y < S;
+                }
+                const uint32_t row = S > 1 ? __umulhi(slot, M) : slot;
+                *x = slot - row * S; *y = row;
+                return slot < n_slots;
+            };
+            for (uint32_t i0 = tid; i0 < n_slots; i0 += NT * kU) {
                 TapLoad tl[kU];
 #pragma unroll
                 for (int u = 0; u < kU; u++) {
-                    const uint32_t i = i0 + 256u * u;
-                    const uint32_t row = S > 1 ? __umulhi(i, M) : i;
-                    const float fx = (float)(i - row * S), fy = (float)row;
+                    uint32_t x, y;
+                    const bool valid = slot_xy(i0 + (uint32_t)NT * u, &x, &y);
+                    const float fx = (float)x, fy = (float)y;
                     const float d = t6 * fx + t7 * fy + t8;
                     const float px = (t0 * fx + t1 * fy + t2) / d;
                     const float py = (t3 * fx + t4 * fy + t5) / d;
-                    sample_issue(tl[u], img, (size_t)src.row_stride, bpp, (uint32_t)W, (uint32_t)H, px, py, i < S * S);
+                    sample_issue(tl[u], img, (size_t)src.row_stride, bpp, (uint32_t)W, (uint32_t)H, px, py, valid);
                 }
 #pragma unroll
                 for (int u = 0; u < kU; u++) {
-                    const uint32_t i = i0 + 256u * u;
-                    if (i < S * S) {
+                    uint32_t x, y;
+                    if (slot_xy(i0 + (uint32_t)NT * u, &x, &y)) {
                         const uint8_t v = sample_finish(tl[u], img, (size_t)src.row_stride, src.fmt, bpp);
-                        s_patch[i] = v;
+                        s_patch[y * S + x] = v;
                         atomicAdd(&s_hist[v], 1u);
                     }
                 }
@@ -427,15 +478,23 @@ __global__ __launch_bounds__(256) void k_decode(PixelSrc src, int W, int H, uint
         const bool keep_patch = patches != nullptr && wi < patch_cap;
         if (keep_patch) {
             uint8_t* dst = patches + (size_t)wi * S * S;
-            for (uint32_t i = tid; i < S * S; i += 256) dst[i] = ok ? s_patch[i] : 0;
+            for (uint32_t i = tid; i < S * S; i += NT) dst[i] = ok ? s_patch[i] : 0;
         }
         // otsu_level (imageproc): the reference scans thresholds 0..255 keeping running integer sums and the first strict
         // maximum of w_b * w_f * (mean_b - mean_f)^2 in f64.  The running sums are exact integers, so every threshold can
         // be evaluated independently from prefix sums with the very same f64 operations; the first strict maximum is the
         // largest variance, lowest threshold among equals, and it must exceed the initial 0.0.
         {
-            const uint32_t hcnt = s_hist[tid];
-            uint32_t bw = hcnt, bs = (uint32_t)tid * hcnt;   // inclusive prefix sums over thresholds
+            constexpr int B = 256 / NT;                 // thresholds per lane: t = tid * B + k
+            uint32_t cw[B], cs[B];                      // inclusive prefix sums inside the lane's run of thresholds
+            uint32_t rw = 0, rs = 0;
+#pragma unroll
+            for (int k = 0; k < B; k++) {
+                const uint32_t t = (uint32_t)tid * B + k, hcnt = s_hist[t];
+                rw += hcnt; rs += t * hcnt;
+                cw[k] = rw; cs[k] = rs;
+            }
+            uint32_t bw = rw, bs = rs;                  // inclusive prefix sums over lanes
 #pragma unroll
             for (int o2 = 1; o2 < 64; o2 <<= 1) {
                 const uint32_t a = __shfl_up(bw, o2), b = __shfl_up(bs, o2);
@@ -444,24 +503,30 @@ __global__ __launch_bounds__(256) void k_decode(PixelSrc src, int W, int H, uint
             if ((tid & 63) == 63) { s_scan_w[tid >> 6] = bw; s_scan_s[tid >> 6] = bs; }
             __syncthreads();
             uint32_t total_sum_u = 0;
-            for (int w = 0; w < 4; w++) {
+            for (int w = 0; w < NW; w++) {
                 if (w < (tid >> 6)) { bw += s_scan_w[w]; bs += s_scan_s[w]; }
                 total_sum_u += s_scan_s[w];
             }
+            const uint32_t before_w = bw - rw, before_s = bs - rs;   // everything below this lane's first threshold
             const uint32_t total_weight = pw * ph;
             const double total_pixel_sum = (double)total_sum_u;
             double var = -1.0;   // "not a candidate"
-            const uint32_t fw = total_weight - bw;
-            if (bw != 0 && fw != 0) {
-                const double background_pixel_sum = (double)bs;
-                const double foreground_pixel_sum = total_pixel_sum - background_pixel_sum;
-                const double background_mean = background_pixel_sum / (double)bw;
-                const double foreground_mean = foreground_pixel_sum / (double)fw;
-                const double diff = background_mean - foreground_mean;
-                const double mean_diff_squared = diff * diff;
-                var = (double)bw * (double)fw * mean_diff_squared;
+            int best_t = tid * B;
+#pragma unroll
+            for (int k = 0; k < B; k++) {
+                const uint32_t bwk = before_w + cw[k], bsk = before_s + cs[k];
+                const uint32_t fw = total_weight - bwk;
+                if (bwk != 0 && fw != 0) {
+                    const double background_pixel_sum = (double)bsk;
+                    const double foreground_pixel_sum = total_pixel_sum - background_pixel_sum;
+                    const double background_mean = background_pixel_sum / (double)bwk;
+                    const double foreground_mean = foreground_pixel_sum / (double)fw;
+                    const double diff = background_mean - foreground_mean;
+                    const double mean_diff_squared = diff * diff;
+                    const double v = (double)bwk * (double)fw * mean_diff_squared;
+                    if (v > var) { var = v; best_t = tid * B + k; }   // ascending k: the first strict maximum of the run
+                }
             }
-            int best_t = tid;
             for (int o2 = 32; o2 > 0; o2 >>= 1) {
                 const double ov = __shfl_xor(var, o2);
                 const int ot = __shfl_xor(best_t, o2);
@@ -471,26 +536,35 @@ __global__ __launch_bounds__(256) void k_decode(PixelSrc src, int W, int H, uint
             __syncthreads();
             if (tid == 0) {
                 double bv = s_var[0]; int bt = s_vt[0];
-                for (int w = 1; w < 4; w++) if (s_var[w] > bv || (s_var[w] == bv && s_vt[w] < bt)) { bv = s_var[w]; bt = s_vt[w]; }
+                for (int w = 1; w < NW; w++) if (s_var[w] > bv || (s_var[w] == bv && s_vt[w] < bt)) { bv = s_var[w]; bt = s_vt[w]; }
                 s_otsu = bv > 0.0 ? (uint32_t)bt : 0u;
             }
         }
         if (dbg == 3) continue;
-        // resize weights (same table for both passes: the patch and the grid are square)
-        if (tid >= 64 && tid < 64 + (int)n) {
-            const uint32_t oi = tid - 64;
+        // resize weights (same table for both passes: the patch and the grid are square): the launch-wide table for a full
+        // patch, computed in place for the 1x1 stand-in of a failed projection (quirk Q4)
+        if (ok) {
+            for (uint32_t i = tid; i < n * (max_taps + 2); i += NT) {
+                const uint32_t oi = i / (max_taps + 2), k = i - oi * (max_taps + 2);
+                const float v = wtab[i];
+                if (k == 0) s_left[oi] = __float_as_uint(v);
+                else if (k == 1) s_cnt[oi] = __float_as_uint(v);
+                else if (k - 2 < __float_as_uint(wtab[(size_t)oi * (max_taps + 2) + 1])) s_w[(size_t)oi * max_taps + (k - 2)] = v;
+            }
+        } else if (tid < (int)n) {
+            const uint32_t oi = tid;
             uint32_t cnt;
             s_left[oi] = resize_weights(pw, n, oi, s_w + (size_t)oi * max_taps, &cnt);
             s_cnt[oi] = cnt;
         }
         __syncthreads();
         const uint32_t otsu = s_otsu;
-        for (uint32_t i = tid; i < pw * ph; i += 256) s_patch[i] = s_patch[i] > otsu ? 255 : 0;  // threshold(.., Binary)
+        for (uint32_t i = tid; i < pw * ph; i += NT) s_patch[i] = s_patch[i] > otsu ? 255 : 0;  // threshold(.., Binary)
         __syncthreads();
         if (pw == n) {  // resize() copies when the size already matches
-            for (uint32_t i = tid; i < n * n; i += 256) s_bits[i] = s_patch[i] > 127;
+            for (uint32_t i = tid; i < n * n; i += NT) s_bits[i] = s_patch[i] > 127;
         } else {
-            for (uint32_t i = tid; i < n * pw; i += 256) {  // vertical pass into f32
+            for (uint32_t i = tid; i < n * pw; i += NT) {  // vertical pass into f32
                 const uint32_t oy = i / pw, x = i - oy * pw;
                 const float* ws = s_w + (size_t)oy * max_taps;
                 const uint32_t left = s_left[oy], cnt = s_cnt[oy];
@@ -499,7 +573,7 @@ __global__ __launch_bounds__(256) void k_decode(PixelSrc src, int W, int H, uint
                 s_tmp[oy * pw + x] = t;
             }
             __syncthreads();
-            for (uint32_t i = tid; i < n * n; i += 256) {  // horizontal pass, clamp, round to nearest
+            for (uint32_t i = tid; i < n * n; i += NT) {  // horizontal pass, clamp, round to nearest
                 const uint32_t y = i / n, ox = i - y * n;
                 const float* ws = s_w + (size_t)ox * max_taps;
                 const uint32_t left = s_left[ox], cnt = s_cnt[ox];
@@ -525,14 +599,16 @@ __global__ __launch_bounds__(256) void k_decode(PixelSrc src, int W, int H, uint
         }
         __syncthreads();
         {
-            const uint32_t inner = n >= 2 ? n - 2 : 0, cells = inner * inner;   // <= 36 cells, 4 rotations <= 144 lanes
-            if (s_have && (uint32_t)tid < 4u * cells) {
-                const uint32_t r = (uint32_t)tid / cells, idx = (uint32_t)tid - r * cells;
-                const uint32_t y = 1 + idx / inner, x = 1 + idx % inner;
-                // rotation r of the bit matrix, read row-major
-                uint32_t sy, sx;
-                rotated_source(r, n, y, x, &sy, &sx);
-                if (s_bits[sy * n + sx]) atomicOr(reinterpret_cast<unsigned long long*>(&s_codes[r]), 1ull << (cells - 1 - idx));
+            const uint32_t inner = n >= 2 ? n - 2 : 0, cells = inner * inner;   // <= 64 cells, 4 rotations
+            if (s_have) {
+                for (uint32_t t = (uint32_t)tid; t < 4u * cells; t += NT) {
+                    const uint32_t r = t / cells, idx = t - r * cells;
+                    const uint32_t y = 1 + idx / inner, x = 1 + idx % inner;
+                    // rotation r of the bit matrix, read row-major
+                    uint32_t sy, sx;
+                    rotated_source(r, n, y, x, &sy, &sx);
+                    if (s_bits[sy * n + sx]) atomicOr(reinterpret_cast<unsigned long long*>(&s_codes[r]), 1ull << (cells - 1 - idx));
+                }
             }
         }
         __syncthreads();
@@ -541,7 +617,7 @@ __global__ __launch_bounds__(256) void k_decode(PixelSrc src, int W, int H, uint
         unsigned long long best[4] = {~0ull, ~0ull, ~0ull, ~0ull};
         if (have) {
             const uint64_t c0 = s_codes[0], c1 = s_codes[1], c2 = s_codes[2], c3 = s_codes[3];
-            for (uint32_t i = tid; i < n_codes; i += 256) {
+            for (uint32_t i = tid; i < n_codes; i += NT) {
                 const uint64_t c = dict[i];
                 const unsigned long long k0 = ((unsigned long long)__popcll(c ^ c0) << 32) | i;
                 const unsigned long long k1 = ((unsigned long long)__popcll(c ^ c1) << 32) | i;
@@ -573,7 +649,7 @@ __global__ __launch_bounds__(256) void k_decode(PixelSrc src, int W, int H, uint
             if (have) {
                 for (uint32_t r = 0; r < 4; r++) {
                     unsigned long long b = s_best[0][r];
-                    for (int w = 1; w < 4; w++) b = s_best[w][r] < b ? s_best[w][r] : b;
+                    for (int w = 1; w < NW; w++) b = s_best[w][r] < b ? s_best[w][r] : b;
                     // empty dictionary: find_nearest returns (0, 0xFF)
                     const uint32_t nearest_dist = n_codes ? (uint32_t)(b >> 32) : 0xFFu;
                     const uint32_t nearest_id = n_codes ? (uint32_t)b : 0u;
@@ -970,13 +1046,20 @@ hipError_t launch_frame_candidates(hipStream_t st, const CandRec* cands, const u
 }
 
 size_t proj_rec_bytes() { return sizeof(ProjRec); }
+size_t weight_table_bytes() { return kWeightTableBytes; }
+hipError_t launch_weight_table(hipStream_t st, uint32_t S, uint32_t n, uint32_t max_taps, float* wtab) {
+    if ((size_t)n * (max_taps + 2) * 4 > kWeightTableBytes || n > 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_weight_table, dim3(1), dim3(64), 0, st, S, n, max_taps, wtab);
+    return hipGetLastError();
+}
 
 hipError_t launch_decode(hipStream_t st, PixelSrc src, int W, int H, uint32_t first_frame, const uint16_t* fin_xy, const uint32_t* work,
                          const unsigned int* work_count, uint32_t max_cand, uint32_t S, uint32_t n, uint32_t max_taps, const uint64_t* dict,
-                         uint32_t n_codes, uint32_t tau, int filter, void* proj, void* outs, uint8_t* patches, uint32_t patch_cap, uint32_t* per_frame, int grid_blocks, int dbg) {
-    if (dbg >= 0) hipLaunchKernelGGL(k_projection, dim3(256), dim3(64), 0, st, fin_xy, work, work_count, S, reinterpret_cast<ProjRec*>(proj));
-    hipLaunchKernelGGL(k_decode, dim3(grid_blocks), dim3(256), decode_lds_bytes(S, n, max_taps), st, src, W, H, first_frame, fin_xy, work,
-                       work_count, max_cand, S, n, max_taps, dict, n_codes, tau, filter, reinterpret_cast<const ProjRec*>(proj),
+                         uint32_t n_codes, uint32_t tau, int filter, void* proj, const float* wtab, void* outs, uint8_t* patches, uint32_t patch_cap, uint32_t* per_frame, int grid_blocks, int dbg) {
+    ProjRec* recs = reinterpret_cast<ProjRec*>(proj);
+    if (dbg >= 0) hipLaunchKernelGGL(k_projection, dim3(256), dim3(64), 0, st, fin_xy, work, work_count, S, recs);
+    hipLaunchKernelGGL(k_decode<A3_D_THREADS>, dim3(grid_blocks), dim3(A3_D_THREADS), decode_lds_bytes(S, n, max_taps), st, src, W, H, first_frame, fin_xy, work,
+                       work_count, max_cand, S, n, max_taps, dict, n_codes, tau, filter, recs, wtab,
                        reinterpret_cast<DecodeOut*>(outs), patches, patch_cap, per_frame, dbg < 0 ? -dbg : dbg);
     return hipGetLastError();
 }
