@@ -272,7 +272,7 @@ def main():
             "dtype": "u8",
             "data": "synthetic" + (" (rendered on the device)" if args.device_synth else ""),
             "config": {
-                "workload": "BASELINE config 2: batch of 256 x 1920x1080 synthetic RGB frames per GPU, ARUCO dict, 4-8 markers per frame, "
+                "workload": f"BASELINE config 2: batch of {args.frames} x 1920x1080 synthetic RGB frames per GPU, ARUCO dict, 4-8 markers per frame, "
                             "frames resident in HBM; Detector::detect end to end (grey, threshold, contours, quads, warp+decode, lookup) "
                             "incl. D2H of the marker list",
                 "frames_per_gpu": args.frames,
@@ -318,7 +318,7 @@ def main():
 
 
 def pmc_traffic_bytes():
-    """HBM bytes per K1 launch from the committed PMC passes of this same command (tools/pmc_k1.sh ->
+    """HBM bytes per K1 launch from the committed PMC passes of this same workload (tools/pmc_k1.sh ->
     profiles/<PROFILE_TAG>_pmc_bench_c2.json): (2 x FETCH_SIZE + WRITE_SIZE) KiB, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
     for wide coalesced reads on gfx950.  Counters cannot be read inside this process, so this is the profiled value for the
     default 256-frame batch, or None when the summary is missing."""
@@ -414,7 +414,8 @@ def other_workloads(device, with_cpu=True, budget_s=60.0):
             for f in range(n):
                 got = sorted(int(m["id"]) for m in r[0][pos: pos + int(r[1][f])]); pos += int(r[1][f])
                 ok += got == sorted(t.id for t in truths[f])
-            o["frames_with_all_ids_correct"] = f"{ok}/{n}"
+            # recall of the reference ALGORITHM on this workload (the oracle finds the same: parity is what tests/ check)
+            o["frames_with_all_drawn_ids_found"] = f"{ok}/{n}"
         if with_cpu:
             from oracle import a3oracle
             a3oracle.build()

@@ -1,15 +1,21 @@
 #!/bin/bash
-# Run on the GPU box (gpurun -- 'bash tools/refresh_profiles.sh'): bench line, rocprofv3 kernel stats and the PMC passes of the
-# same command; everything lands in gpurun_out/refresh/.  Copy into profiles/ afterwards (tools/pmc_aggregate.py for the PMC).
+# Run on the GPU box (gpurun -- 'bash tools/refresh_profiles.sh'): the driver's bench command, the same command under
+# rocprofv3 --kernel-trace --stats, the PMC passes (tools/pmc_k1.sh), the streaming-read microbenchmark and the 2-rank gloo
+# rehearsal; everything lands in gpurun_out/refresh/.  tools/install_profiles.py then copies the summaries into profiles/.
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/refresh
-mkdir -p "$OUT" "$ROOT/gpurun_out/pmc"; export TMPDIR=/tmp
+rm -rf "$OUT" "$ROOT/gpurun_out/pmc"; mkdir -p "$OUT" "$ROOT/gpurun_out/pmc"; export TMPDIR=/tmp
 cd "$ROOT"
-timeout -k 10 600 python3 bench.py --frames-cache /tmp/c2frames > "$OUT/bench.json.log" 2> "$OUT/bench.err" || exit 1
-cat "$OUT/bench.json.log"
+timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench.json.log" 2> "$OUT/bench.err" || exit 1
+cut -c1-600 "$OUT/bench.json.log"
 cd /tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o stats -- python3 "$ROOT/bench.py" --frames-cache /tmp/c2frames --no-cpu-baseline > "$OUT/stats.log" 2>&1 || exit 2
-tail -1 "$OUT/stats.log"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o stats -- python3 "$ROOT/bench.py" --gpus 1 --steps 20 --warmup 5 --device-synth --no-cpu-baseline --no-other-workloads > "$OUT/stats.log" 2>&1 || exit 2
+tail -c 400 "$OUT/stats.log"; echo
 bash "$ROOT/tools/pmc_k1.sh" > "$OUT/pmc.log" 2>&1 || exit 3
+cd "$ROOT"
+[ -x tools/micro/readbench ] && timeout -k 5 120 ./tools/micro/readbench > "$OUT/readbench.txt" 2>&1
+HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29555 \
+    bench.py --gpus 2 --steps 20 --warmup 5 --backend gloo --device-synth --no-cpu-baseline > "$OUT/rehearsal_n2_gloo.log" 2> "$OUT/rehearsal_n2_gloo.err" || echo "rehearsal failed"
+grep '^{' "$OUT/rehearsal_n2_gloo.log" | cut -c1-300
 ls "$OUT" "$ROOT/gpurun_out/pmc"
