@@ -206,7 +206,13 @@ template <int FMT, bool FAST>
 __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_t* __restrict__ pixels, size_t row_stride, size_t frame_stride,
                                                         int W, int H, int rows_per_wave, int strips_y, int n_pairs,
                                                         uint8_t* __restrict__ grey,
-                                                        uint8_t* __restrict__ bits, int aligned_in, int aligned_out, int map_by_frame) {
+                                                        uint8_t* __restrict__ bits, int aligned_in, int aligned_out, int map_by_frame,
+                                                        int flush_rows) {
+    // flush_rows > 0: the 16 result bits per lane and row are parked in LDS (flush_rows x 64 u16) and leave in bursts of
+    // flush_rows rows.  66 MB of 124-byte stores dribbling into a saturating read stream cost K1 ~0.07 ms (HBM bus turnarounds:
+    // tools/micro/readbench.hip); the same bytes in a few large bursts per wave cost about half of that.
+    extern __shared__ uint16_t s_out[];
+    int n_buf = 0, y_buf0 = 0;
     const int lane = threadIdx.x;
     // XCD-aware block -> strip mapping.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), each
     // with its own L2.  Vertically adjacent strips of one column share 14 rows of input, so all strips of a
@@ -342,9 +348,25 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
             }
             // bits of pixels 0..7 sit in byte 0, of pixels 8..15 in byte 2
             const uint32_t outb = __builtin_amdgcn_perm(0u, acc, 0x0C0C0200u);
-            if (owner) *reinterpret_cast<uint16_t*>(bout + (size_t)y * bpr + (x0 >> 3)) = (uint16_t)outb;
+            if (flush_rows <= 0) {
+                if (owner) *reinterpret_cast<uint16_t*>(bout + (size_t)y * bpr + (x0 >> 3)) = (uint16_t)outb;
+            } else {
+                if (n_buf == 0) y_buf0 = y;
+                s_out[n_buf * 64 + lane] = (uint16_t)outb;
+                n_buf++;
+            }
+        }
+        // (checked once per block of 15 rows, outside the unrolled body: the buffer holds flush_rows + 15 rows)
+        if (flush_rows > 0 && n_buf >= flush_rows) {   // wave-uniform
+            if (owner)
+                for (int q = 0; q < n_buf; q++)
+                    *reinterpret_cast<uint16_t*>(bout + (size_t)(y_buf0 + dir * q) * bpr + (x0 >> 3)) = s_out[q * 64 + lane];
+            n_buf = 0;
         }
     }
+    if (flush_rows > 0 && owner)
+        for (int q = 0; q < n_buf; q++)
+            *reinterpret_cast<uint16_t*>(bout + (size_t)(y_buf0 + dir * q) * bpr + (x0 >> 3)) = s_out[q * 64 + lane];
 }
 
 // ---- generic radius: plain two-kernel path (correct for any threshold_window, not tuned) ----
@@ -412,10 +434,15 @@ hipError_t launch_grey_threshold(hipStream_t st, const uint8_t* pixels, int fmt,
         // every strip of a frame on one XCD (1) or every (frame, column strip) pair on its own XCD (0).  By frame is ~3 % faster:
         // the two column strips of a frame overlap by 32 columns and write the same lines of the packed image
         const int map_by_frame = mv ? atoi(mv) : 1;   // tuning knob
+        // rows of results a wave parks in LDS before it writes them out (0: store row by row); 128 (+15) rows = 18 KB per wave, eight
+        // waves per CU fit the 160 KB
+        const char* fv = getenv("A3_K1_FLUSH");
+        const int flush_rows = std::min(fv ? atoi(fv) : 128, rows_per_wave);   // tuning knob
+        const size_t lds_bytes = flush_rows > 0 ? (size_t)(flush_rows + 15) * 128 : 0;
         dim3 grid(map_by_frame ? 8 * (((int)n + 7) / 8) * strips_x * strips_y : 8 * ((n_pairs + 7) / 8) * strips_y), block(64);
         const bool fast = aligned_in && aligned_out;   // W % 16 == 0: a lane's 16 pixels are all inside or all outside
-#define A3_LAUNCH_K1(F, B) hipLaunchKernelGGL((k_grey_threshold7<F, B>), grid, block, 0, st, pixels, row_stride, frame_stride, W, H, \
-                                              rows_per_wave, strips_y, n_pairs, grey, bin, aligned_in, aligned_out, map_by_frame)
+#define A3_LAUNCH_K1(F, B) hipLaunchKernelGGL((k_grey_threshold7<F, B>), grid, block, lds_bytes, st, pixels, row_stride, frame_stride, W, H, \
+                                              rows_per_wave, strips_y, n_pairs, grey, bin, aligned_in, aligned_out, map_by_frame, flush_rows)
         if (fmt == A3_FMT_RGB8) { if (fast) A3_LAUNCH_K1(A3_FMT_RGB8, true); else A3_LAUNCH_K1(A3_FMT_RGB8, false); }
         else if (fmt == A3_FMT_RGBA8) { if (fast) A3_LAUNCH_K1(A3_FMT_RGBA8, true); else A3_LAUNCH_K1(A3_FMT_RGBA8, false); }
         else if (fmt == A3_FMT_BGRA8) { if (fast) A3_LAUNCH_K1(A3_FMT_BGRA8, true); else A3_LAUNCH_K1(A3_FMT_BGRA8, false); }

@@ -51,6 +51,27 @@ __global__ __launch_bounds__(64) void k_read(const uint8_t* __restrict__ base, s
                 __hip_atomic_store(dst, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(dst + 1, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(dst + 2, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(dst + 3, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if (STORE == 12) {   // sparse output: an 8-byte flag word per row from one lane, the 128 data bytes for one row in ten
+                unsigned long long* fl = reinterpret_cast<unsigned long long*>(bits + (size_t)gridDim.x * rows * 64) + (size_t)blockIdx.x * rows + r + i;
+                if (lane == 0) *fl = acc;
+                if (((r + i) % 10) == 0) bits[((size_t)blockIdx.x * rows + r + i) * 64 + lane] = (uint16_t)acc;
+            }
+            if (STORE == 13) {   // the same with the flag words of 8 rows in one 64-byte store
+                if (((r + i) & 7) == 7 && lane < 8) reinterpret_cast<unsigned long long*>(bits + (size_t)gridDim.x * rows * 64)[(size_t)blockIdx.x * rows + r + i - 7 + lane] = acc;
+                if (((r + i) % 10) == 0) bits[((size_t)blockIdx.x * rows + r + i) * 64 + lane] = (uint16_t)acc;
+            }
+            if (STORE >= 100) {
+                constexpr int PER = STORE - 100;
+                const int rr = r + i;
+                reinterpret_cast<uint16_t*>(lds)[(rr % PER) * 64 + lane] = (uint16_t)acc;
+                if (rr % PER == PER - 1 || rr == rows - 1) {
+                    const int first = rr - rr % PER, cnt = rr - first + 1;
+                    for (int q = 0; q < cnt; q += 8) {
+                        uint4 v = reinterpret_cast<const uint4*>(lds + (size_t)q * 128)[lane];
+                        reinterpret_cast<uint4*>(bits + ((size_t)blockIdx.x * rows + first + q) * 64)[lane] = v;
+                    }
+                }
+            }
             if (STORE == 11) reinterpret_cast<uint16_t*>(lds)[(r + i) * 64 + lane] = (uint16_t)acc;
             if (STORE == 6 && ((r + i) & 3) == 3) reinterpret_cast<uint2*>(bits + ((size_t)blockIdx.x * rows + r + i - 3) * 64)[lane] = make_uint2(acc, t);
             if (STORE >= 2 && STORE <= 4) {   // gather 2 / 4 / 8 lanes' 16 bits into one dword / dwordx2 / dwordx4 store
@@ -112,17 +133,20 @@ int main() {
     CK(hipDeviceSynchronize());
     const double gb = (double)frames * H * 2 * 3072 / 1e9;
     printf("random data, %.2f GB requested per launch; ms per launch\n", gb);
-    for (int occ : {2, 4}) {
+    for (int occ : {2}) {
         const size_t lds = occ == 8 ? 0 : (occ == 4 ? 9000 : 19000);
-        for (int sy : {8, 12}) {
-            printf("occ %d strips_y %d: read-only %.3f | short x64 %.3f | dword x32 %.3f | dwordx2 x16 %.3f | dwordx4 x8 %.3f | 1 KB every 8 rows %.3f | 512 B every 4 rows %.3f | 1 KB every 64 rows %.3f | nt dword every 8 rows %.3f | nt 1 KB / 8 rows %.3f | sc1 1 KB / 8 rows %.3f | LDS-buffered, burst at wave end %.3f\n", occ, sy,
+        for (int sy : {4, 8}) {
+            printf("occ %d strips_y %d: read-only %.3f | short x64 %.3f | dword x32 %.3f | dwordx2 x16 %.3f | dwordx4 x8 %.3f | 1 KB every 8 rows %.3f | 512 B every 4 rows %.3f | 1 KB every 64 rows %.3f | nt dword every 8 rows %.3f | nt 1 KB / 8 rows %.3f | sc1 1 KB / 8 rows %.3f | LDS-buffered, burst at wave end %.3f | sparse: flags/row + 10%% rows %.3f | sparse, flags per 8 rows %.3f | LDS flush every 32 rows %.3f | 64 rows %.3f | 96 rows %.3f | 136 rows %.3f\n", occ, sy,
                    run<0, 3, 0, 0>(d, row_stride, frames, H, sy, lds, out, 10), run<0, 3, 0, 1>(d, row_stride, frames, H, sy, lds, out, 10),
                    run<0, 3, 0, 2>(d, row_stride, frames, H, sy, lds, out, 10), run<0, 3, 0, 3>(d, row_stride, frames, H, sy, lds, out, 10),
                    run<0, 3, 0, 4>(d, row_stride, frames, H, sy, lds, out, 10), run<0, 3, 0, 5>(d, row_stride, frames, H, sy, lds, out, 10),
                    run<0, 3, 0, 6>(d, row_stride, frames, H, sy, lds, out, 10), run<0, 3, 0, 7>(d, row_stride, frames, H, sy, lds, out, 10),
                    run<0, 3, 0, 8>(d, row_stride, frames, H, sy, lds, out, 10), run<0, 3, 0, 9>(d, row_stride, frames, H, sy, lds, out, 10),
                    run<0, 3, 0, 10>(d, row_stride, frames, H, sy, lds, out, 10),
-                   run<0, 3, 0, 11>(d, row_stride, frames, H, sy, (size_t)(H / sy + 8) * 128 > lds ? (size_t)(H / sy + 8) * 128 : lds, out, 10));
+                   run<0, 3, 0, 11>(d, row_stride, frames, H, sy, (size_t)(H / sy + 8) * 128 > lds ? (size_t)(H / sy + 8) * 128 : lds, out, 10),
+                   run<0, 3, 0, 12>(d, row_stride, frames, H, sy, lds, out, 10), run<0, 3, 0, 13>(d, row_stride, frames, H, sy, lds, out, 10),
+                   run<0, 3, 0, 132>(d, row_stride, frames, H, sy, 19000, out, 10), run<0, 3, 0, 164>(d, row_stride, frames, H, sy, 19000, out, 10),
+                   run<0, 3, 0, 196>(d, row_stride, frames, H, sy, 19000, out, 10), run<0, 3, 0, 236>(d, row_stride, frames, H, sy, 19000, out, 10));
             fflush(stdout);
         }
     }
