@@ -349,7 +349,7 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
             // bits of pixels 0..7 sit in byte 0, of pixels 8..15 in byte 2
             const uint32_t outb = __builtin_amdgcn_perm(0u, acc, 0x0C0C0200u);
             if (flush_rows <= 0) {
-                if (owner) *reinterpret_cast<uint16_t*>(bout + (size_t)y * bpr + (x0 >> 3)) = (uint16_t)outb;
+                if (owner && (flush_rows == 0 || outb == 0x12345u)) *reinterpret_cast<uint16_t*>(bout + (size_t)y * bpr + (x0 >> 3)) = (uint16_t)outb;   // (-1: tuning probe, no stores)
             } else {
                 if (n_buf == 0) y_buf0 = y;
                 s_out[n_buf * 64 + lane] = (uint16_t)outb;
@@ -437,7 +437,7 @@ hipError_t launch_grey_threshold(hipStream_t st, const uint8_t* pixels, int fmt,
         // rows of results a wave parks in LDS before it writes them out (0: store row by row); 128 (+15) rows = 18 KB per wave, eight
         // waves per CU fit the 160 KB
         const char* fv = getenv("A3_K1_FLUSH");
-        const int flush_rows = std::min(fv ? atoi(fv) : 128, rows_per_wave);   // tuning knob
+        const int flush_rows = fv && atoi(fv) < 0 ? -1 : std::min(fv ? atoi(fv) : 128, rows_per_wave);   // tuning knob
         const size_t lds_bytes = flush_rows > 0 ? (size_t)(flush_rows + 15) * 128 : 0;
         dim3 grid(map_by_frame ? 8 * (((int)n + 7) / 8) * strips_x * strips_y : 8 * ((n_pairs + 7) / 8) * strips_y), block(64);
         const bool fast = aligned_in && aligned_out;   // W % 16 == 0: a lane's 16 pixels are all inside or all outside
