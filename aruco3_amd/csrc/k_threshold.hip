@@ -23,6 +23,7 @@
 // Out-of-image pixels count as 0, which makes the unclipped sum equal the clipped one; the area is the clipped window.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include <utility>
 
 #include "a3_common.h"
@@ -30,15 +31,26 @@
 namespace a3 {
 
 constexpr int T_R = 7;               // fast path radius (threshold_window = 7)
-constexpr int T_LPX = 16;            // pixels per lane and row
-constexpr int T_OUT = 62 * T_LPX;    // 992 output columns per wave (lanes 0 and 63 only feed their neighbours)
+#ifndef A3_T_LPX
+#define A3_T_LPX 16
+#endif
 #ifndef A3_T_PF
 #define A3_T_PF 3
 #endif
 #ifndef A3_T_WAVES
-#define A3_T_WAVES 2
+#define A3_T_WAVES (A3_T_LPX == 8 ? 3 : 2)
 #endif
+// Pixels per lane and row.  16 (the default): 256 VGPRs (the ring of row sums alone is 120), two waves per SIMD.  8: every
+// per-lane array halves, 144 VGPRs, three waves per SIMD -- built to see whether occupancy was what kept the kernel (stores off)
+// 0.025 ms above the bare reads of tools/micro/readbench.hip.  It was not: 0.293 ms against 0.286 with stores off, 0.343 against
+// 0.324 with them (tools/tune_k1.sh); the difference to the microbenchmark is the 5 % of halo rows and the feeder lanes.
+constexpr int T_LPX = A3_T_LPX;
+static_assert(T_LPX == 8 || T_LPX == 16, "a lane owns 8 or 16 consecutive pixels");
+constexpr int T_NG = T_LPX / 4;      // grey dwords per lane and row
+constexpr int T_NP = T_LPX / 2;      // packed pairs per lane and row: pixel j with pixel j + T_NP
+constexpr int T_OUT = 62 * T_LPX;    // output columns per wave (lanes 0 and 63 only feed their neighbours)
 constexpr int T_PF = A3_T_PF;        // rows of loads kept in flight per lane
+typedef typename std::conditional<T_LPX == 16, uint16_t, uint8_t>::type out_bits_t;   // a lane's result bits of one row
 
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -80,25 +92,37 @@ __device__ __forceinline__ uint32_t luma_hi(uint32_t px) {
     return (uint32_t)(((uint64_t)l * 13743896ull) >> 32);   // both factors < 2^24: one v_mul_hi_u32_u24
 }
 
-template <int FMT> struct RawRow { static constexpr int NDW = FMT == A3_FMT_RGB8 ? 12 : (FMT == A3_FMT_L8 ? 4 : 16); uint32_t d[NDW]; };
-
-// 16 consecutive pixels of row y starting at x0 (a multiple of 16, may be negative or past the image): raw bytes,
-// zero where the image is not.  Fully-inside lanes use 16-byte vector loads.
-template <int FMT, bool FAST>
-__device__ __forceinline__ void load_raw16(const uint8_t* __restrict__ frame, size_t row_stride, int x0, int y, int W, int H, bool aligned,
-                                           RawRow<FMT>& r) {
+template <int FMT> struct RawRow {
+    static constexpr int BPP = FMT == A3_FMT_RGB8 ? 3 : (FMT == A3_FMT_L8 ? 1 : 4);
+    static constexpr int NDW = T_LPX * BPP / 4;
+    uint32_t d[NDW];
+};
+// the lane's NDW dwords of one row with the widest vector loads its alignment allows (8 bytes always; 16 when NDW % 4 == 0)
+template <int FMT>
+__device__ __forceinline__ void load_vec(const uint8_t* __restrict__ p, RawRow<FMT>& r) {
     constexpr int NDW = RawRow<FMT>::NDW;
-    constexpr int BPP = FMT == A3_FMT_RGB8 ? 3 : (FMT == A3_FMT_L8 ? 1 : 4);
+    if constexpr (NDW % 4 == 0) {
+        const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+        for (int i = 0; i < NDW / 4; i++) { const uint4 v = q[i]; r.d[4 * i] = v.x; r.d[4 * i + 1] = v.y; r.d[4 * i + 2] = v.z; r.d[4 * i + 3] = v.w; }
+    } else {
+        const uint2* q = reinterpret_cast<const uint2*>(p);
+#pragma unroll
+        for (int i = 0; i < NDW / 2; i++) { const uint2 v = q[i]; r.d[2 * i] = v.x; r.d[2 * i + 1] = v.y; }
+    }
+}
+
+// T_LPX consecutive pixels of row y starting at x0 (a multiple of T_LPX, may be negative or past the image): raw bytes,
+// zero where the image is not.  Fully-inside lanes use vector loads.
+template <int FMT>
+__device__ __forceinline__ void load_raw(const uint8_t* __restrict__ frame, size_t row_stride, int x0, int y, int W, int H, bool aligned,
+                                         RawRow<FMT>& r) {
+    constexpr int NDW = RawRow<FMT>::NDW, BPP = RawRow<FMT>::BPP;
 #pragma unroll
     for (int i = 0; i < NDW; i++) r.d[i] = 0u;
     if (y < 0 || y >= H || x0 + T_LPX <= 0 || x0 >= W) return;
     const uint8_t* row = frame + (size_t)y * row_stride;
-    if (FAST || (aligned && x0 >= 0 && x0 + T_LPX <= W)) {
-        const uint4* p = reinterpret_cast<const uint4*>(row + (size_t)x0 * BPP);
-#pragma unroll
-        for (int i = 0; i < NDW / 4; i++) { const uint4 v = p[i]; r.d[4 * i] = v.x; r.d[4 * i + 1] = v.y; r.d[4 * i + 2] = v.z; r.d[4 * i + 3] = v.w; }
-        return;
-    }
+    if (aligned && x0 >= 0 && x0 + T_LPX <= W) { load_vec<FMT>(row + (size_t)x0 * BPP, r); return; }
     for (int i = 0; i < T_LPX; i++) {
         const int x = x0 + i;
         if (x < 0 || x >= W) continue;
@@ -109,16 +133,16 @@ __device__ __forceinline__ void load_raw16(const uint8_t* __restrict__ frame, si
     }
 }
 
-// raw row -> 16 grey bytes in 4 dwords (byte i & 3 of g[i >> 2] = pixel i)
+// raw row -> T_LPX grey bytes in T_NG dwords (byte i & 3 of g[i >> 2] = pixel i)
 template <int FMT>
-__device__ __forceinline__ void grey16(const RawRow<FMT>& r, uint32_t g[4]) {
+__device__ __forceinline__ void grey_row(const RawRow<FMT>& r, uint32_t g[T_NG]) {
     if constexpr (FMT == A3_FMT_L8) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) g[i] = r.d[i];
+        for (int i = 0; i < T_NG; i++) g[i] = r.d[i];
     } else {
-        uint32_t m[16];   // (l * 13743896) >> 32; grey = m >> 5
+        uint32_t m[T_LPX];   // (l * 13743896) >> 32; grey = m >> 5
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
+        for (int i = 0; i < T_LPX; i++) {
             if constexpr (FMT == A3_FMT_RGBA8 || FMT == A3_FMT_BGRA8) m[i] = luma_hi<FMT == A3_FMT_BGRA8, 0>(r.d[i]);
             else {
                 // RGB8: pixel i starts at byte 3 i.  Pixels 0 and 3 of every group of four lie inside one dword (byte offsets
@@ -131,28 +155,34 @@ __device__ __forceinline__ void grey16(const RawRow<FMT>& r, uint32_t g[4]) {
         }
         // g[q].byte[j] = m[4 q + j] >> 5, the shift writing its byte in place (SDWA dst_sel).  One asm block so that the order
         // is fixed: gfx950 needs one instruction between a dst_sel write of a VGPR and the next read of it (the partial
-        // write is not forwarded); consecutive writes of one g[q] are four instructions apart here, and the s_nop covers
+        // write is not forwarded); consecutive writes of one g[q] are T_NG instructions apart here, and the s_nop covers
         // whatever the compiler schedules right behind the block.
-        asm("v_lshrrev_b32_sdwa %0, %4, %5 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
-            "v_lshrrev_b32_sdwa %1, %4, %9 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
-            "v_lshrrev_b32_sdwa %2, %4, %13 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
-            "v_lshrrev_b32_sdwa %3, %4, %17 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
-            "v_lshrrev_b32_sdwa %0, %4, %6 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-            "v_lshrrev_b32_sdwa %1, %4, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-            "v_lshrrev_b32_sdwa %2, %4, %14 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-            "v_lshrrev_b32_sdwa %3, %4, %18 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-            "v_lshrrev_b32_sdwa %0, %4, %7 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-            "v_lshrrev_b32_sdwa %1, %4, %11 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-            "v_lshrrev_b32_sdwa %2, %4, %15 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-            "v_lshrrev_b32_sdwa %3, %4, %19 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-            "v_lshrrev_b32_sdwa %0, %4, %8 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-            "v_lshrrev_b32_sdwa %1, %4, %12 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-            "v_lshrrev_b32_sdwa %2, %4, %16 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-            "v_lshrrev_b32_sdwa %3, %4, %20 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
-            "s_nop 0"
-            : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3])
-            : "v"(5u), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "v"(m[9]),
-              "v"(m[10]), "v"(m[11]), "v"(m[12]), "v"(m[13]), "v"(m[14]), "v"(m[15]));
+#define A3_SH(DST, SRC, B, U) "v_lshrrev_b32_sdwa " DST ", %" A3_STR(A3_SHAMT) ", " SRC " dst_sel:BYTE_" #B " dst_unused:UNUSED_" U " src0_sel:DWORD src1_sel:DWORD\n\t"
+        if constexpr (T_LPX == 16) {
+#define A3_SHAMT 4
+#define A3_STR_(x) #x
+#define A3_STR(x) A3_STR_(x)
+            asm(A3_SH("%0", "%5", 0, "PAD") A3_SH("%1", "%9", 0, "PAD") A3_SH("%2", "%13", 0, "PAD") A3_SH("%3", "%17", 0, "PAD")
+                A3_SH("%0", "%6", 1, "PRESERVE") A3_SH("%1", "%10", 1, "PRESERVE") A3_SH("%2", "%14", 1, "PRESERVE") A3_SH("%3", "%18", 1, "PRESERVE")
+                A3_SH("%0", "%7", 2, "PRESERVE") A3_SH("%1", "%11", 2, "PRESERVE") A3_SH("%2", "%15", 2, "PRESERVE") A3_SH("%3", "%19", 2, "PRESERVE")
+                A3_SH("%0", "%8", 3, "PRESERVE") A3_SH("%1", "%12", 3, "PRESERVE") A3_SH("%2", "%16", 3, "PRESERVE") A3_SH("%3", "%20", 3, "PRESERVE")
+                "s_nop 0"
+                : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[T_NG - 2]), "=&v"(g[T_NG - 1])
+                : "v"(5u), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[T_LPX - 8]), "v"(m[T_LPX - 7]),
+                  "v"(m[T_LPX - 6]), "v"(m[T_LPX - 5]), "v"(m[T_LPX - 4]), "v"(m[T_LPX - 3]), "v"(m[T_LPX - 2]), "v"(m[T_LPX - 1]));
+#undef A3_SHAMT
+        } else {
+#define A3_SHAMT 2
+            asm(A3_SH("%0", "%3", 0, "PAD") A3_SH("%1", "%7", 0, "PAD")
+                A3_SH("%0", "%4", 1, "PRESERVE") A3_SH("%1", "%8", 1, "PRESERVE")
+                A3_SH("%0", "%5", 2, "PRESERVE") A3_SH("%1", "%9", 2, "PRESERVE")
+                A3_SH("%0", "%6", 3, "PRESERVE") A3_SH("%1", "%10", 3, "PRESERVE")
+                "s_nop 0"
+                : "=&v"(g[0]), "=&v"(g[1])
+                : "v"(5u), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]));
+#undef A3_SHAMT
+        }
+#undef A3_SH
     }
 }
 
@@ -170,48 +200,55 @@ __device__ __forceinline__ uint32_t wave_from_right(uint32_t v) {  // lane i <- 
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
 }
 
-// bytes k & 3 of `lo` and of `hi` as a pair of u16 (lo's in the low half): the grey levels of pixels p and p + 8
-template <int K> __device__ __forceinline__ uint32_t byte_pair(uint32_t hi, uint32_t lo) {
-    return __builtin_amdgcn_perm(hi, lo, 0x0C000C00u | (uint32_t)(K & 3) | ((uint32_t)(4 + (K & 3)) << 16));
+// bytes k & 3 of `lo` and of `hi` as a pair of u16 (lo's in the low half): the grey levels of pixels p and p + T_NP
+__device__ __forceinline__ uint32_t byte_pair(int k, uint32_t hi, uint32_t lo) {
+    return __builtin_amdgcn_perm(hi, lo, 0x0C000C00u | (uint32_t)(k & 3) | ((uint32_t)(4 + (k & 3)) << 16));
 }
 
-// 15-wide horizontal sums of one grey row: Hp[j] = (sum over pixels j-7 .. j+7) | (sum over pixels j+1 .. j+15) << 16,
-// j = 0..7, for the lane's 16 pixels; 7 grey bytes come from each neighbouring lane (wave shifts, no LDS).
-__device__ __forceinline__ void row_sums16(const uint32_t g[4], uint32_t Hp[8]) {
-    // D[0..7] = pixels -8..-5, -4..-1, 0..3, 4..7, 8..11, 12..15, 16..19, 20..23
-    const uint32_t D[8] = {wave_from_left(g[2]), wave_from_left(g[3]), g[0], g[1], g[2], g[3], wave_from_right(g[0]), wave_from_right(g[1])};
-    // the two chains start at pixels 0 and 8: bytes -7..7 and 1..15
-    const uint32_t mid = __builtin_amdgcn_sad_u8(D[3], 0u, 0u);                                   // pixels 4..7, in both
-    uint32_t h0 = __builtin_amdgcn_sad_u8(D[0] & 0xFFFFFF00u, 0u, mid);
-    h0 = __builtin_amdgcn_sad_u8(D[1], 0u, h0);
-    h0 = __builtin_amdgcn_sad_u8(D[2], 0u, h0);
-    uint32_t h8 = __builtin_amdgcn_sad_u8(D[2] & 0xFFFFFF00u, 0u, mid);
-    h8 = __builtin_amdgcn_sad_u8(D[4], 0u, h8);
-    h8 = __builtin_amdgcn_sad_u8(D[5], 0u, h8);
-    Hp[0] = h0 | (h8 << 16);
-    // slide both chains one pixel: + (B[j+8], B[j+16]) - (B[j-7], B[j+1]); B[k] = byte k & 3 of D[(k + 8) >> 2]
-#define A3_STEP(J)                                                                                                \
-    Hp[J + 1] = pk_sub(pk_add(Hp[J], byte_pair<(J + 8) & 3>(D[(J + 24) >> 2], D[(J + 16) >> 2])),                 \
-                       byte_pair<(J + 1) & 3>(D[(J + 9) >> 2], D[(J + 1) >> 2]))
-    A3_STEP(0); A3_STEP(1); A3_STEP(2); A3_STEP(3); A3_STEP(4); A3_STEP(5); A3_STEP(6);
-#undef A3_STEP
+// 15-wide horizontal sums of one grey row: Hp[j] = (sum over pixels j-7 .. j+7) | (sum over pixels j+T_NP-7 .. j+T_NP+7) << 16,
+// j = 0 .. T_NP-1, for the lane's T_LPX pixels; 7 grey bytes come from each neighbouring lane (wave shifts, no LDS).
+__device__ __forceinline__ void row_sums(const uint32_t g[T_NG], uint32_t Hp[T_NP]) {
+    // D[] = the dwords of pixels -8 .. T_LPX+7; B[k] = byte k & 3 of D[(k + 8) >> 2]
+    uint32_t D[T_NG + 4];
+    D[0] = wave_from_left(g[T_NG - 2]); D[1] = wave_from_left(g[T_NG - 1]);
+#pragma unroll
+    for (int i = 0; i < T_NG; i++) D[2 + i] = g[i];
+    D[T_NG + 2] = wave_from_right(g[0]); D[T_NG + 3] = wave_from_right(g[1]);
+    // the two chains start at pixels 0 and T_NP: bytes p-7 .. p+7 = bytes 1..3 of D[(p + 1) >> 2] and the three dwords behind it
+    uint32_t ha, hb;
+    if constexpr (T_LPX == 16) {
+        const uint32_t mid = __builtin_amdgcn_sad_u8(D[3], 0u, 0u);                               // pixels 4..7, in both
+        ha = __builtin_amdgcn_sad_u8(D[2], 0u, __builtin_amdgcn_sad_u8(D[1], 0u, __builtin_amdgcn_sad_u8(D[0] & 0xFFFFFF00u, 0u, mid)));
+        hb = __builtin_amdgcn_sad_u8(D[5], 0u, __builtin_amdgcn_sad_u8(D[4], 0u, __builtin_amdgcn_sad_u8(D[2] & 0xFFFFFF00u, 0u, mid)));
+    } else {
+        const uint32_t mid = __builtin_amdgcn_sad_u8(D[3], 0u, __builtin_amdgcn_sad_u8(D[2], 0u, 0u));   // pixels 0..7, in both
+        ha = __builtin_amdgcn_sad_u8(D[1], 0u, __builtin_amdgcn_sad_u8(D[0] & 0xFFFFFF00u, 0u, mid));
+        hb = __builtin_amdgcn_sad_u8(D[4], 0u, __builtin_amdgcn_sad_u8(D[1] & 0xFFFFFF00u, 0u, mid));
+    }
+    Hp[0] = ha | (hb << 16);
+    // slide both chains one pixel: + (B[J+8], B[J+8+T_NP]) - (B[J-7], B[J-7+T_NP])
+#pragma unroll
+    for (int J = 0; J + 1 < T_NP; J++)
+        Hp[J + 1] = pk_sub(pk_add(Hp[J], byte_pair(J, D[(J + 16 + T_NP) >> 2], D[(J + 16) >> 2])),
+                           byte_pair(J + 1, D[(J + 1 + T_NP) >> 2], D[(J + 1) >> 2]));
 }
 
-// One wave walks down a strip: lane l owns columns xs - 16 + 16 l .. + 15.  Per image row it converts its 16 pixels to
-// grey, forms their 15-wide horizontal sums (row_sums16) and slides a 15-row vertical window over those row sums, all as
-// packed u16 pairs (pixel j with pixel j + 8); the row 7 iterations old is then thresholded: sum < (L+1)*area.
-// No LDS, no barriers; T_PF rows of loads stay in flight per lane.
-// grid: 8 * ceil(frames * strips_x / 8) * strips_y workgroups of one wave.
+// One wave walks down a strip: lane l owns columns xs - T_LPX + T_LPX l .. + T_LPX - 1.  Per image row it converts its pixels
+// to grey, forms their 15-wide horizontal sums (row_sums) and slides a 15-row vertical window over those row sums, all as
+// packed u16 pairs (pixel j with pixel j + T_NP); the row 7 iterations old is then thresholded: sum < (L+1)*area.
+// No barriers; T_PF rows of loads stay in flight per lane; LDS only parks the result bits between bursts of stores.
+// grid: 8 * ceil(frames / 8) * strips_x * strips_y workgroups of one wave.
 template <int FMT, bool FAST>
 __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_t* __restrict__ pixels, size_t row_stride, size_t frame_stride,
                                                         int W, int H, int rows_per_wave, int strips_y, int n_pairs,
                                                         uint8_t* __restrict__ grey,
                                                         uint8_t* __restrict__ bits, int aligned_in, int aligned_out, int map_by_frame,
                                                         int flush_rows) {
-    // flush_rows > 0: the 16 result bits per lane and row are parked in LDS (flush_rows x 64 u16) and leave in bursts of
-    // flush_rows rows.  66 MB of 124-byte stores dribbling into a saturating read stream cost K1 ~0.07 ms (HBM bus turnarounds:
+    // flush_rows > 0: the result bits per lane and row are parked in LDS (flush_rows + 15 rows of 64 lanes) and leave in bursts
+    // of flush_rows rows.  66 MB of small stores dribbling into a saturating read stream cost K1 ~0.07 ms (HBM bus turnarounds:
     // tools/micro/readbench.hip); the same bytes in a few large bursts per wave cost about half of that.
-    extern __shared__ uint16_t s_out[];
+    extern __shared__ uint8_t s_out_raw[];
+    out_bits_t* s_out = reinterpret_cast<out_bits_t*>(s_out_raw);
     int n_buf = 0, y_buf0 = 0;
     const int lane = threadIdx.x;
     // XCD-aware block -> strip mapping.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), each
@@ -221,7 +258,7 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
     const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
     const int strips_x = (W + T_OUT - 1) / T_OUT;
     int pair, sy;
-    if (map_by_frame) {   // every strip of a frame on one XCD: the two column strips share the lines they both touch
+    if (map_by_frame) {   // every strip of a frame on one XCD: the column strips share the lines they both touch
         const int per_frame = strips_x * strips_y, idx = k % per_frame;
         pair = ((k / per_frame) * 8 + xcd) * strips_x + idx / strips_y;
         sy = idx % strips_y;
@@ -239,7 +276,7 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
     const int y_begin = sy * rows_per_wave, y_end = min(H, y_begin + rows_per_wave);
     const bool owner = lane >= 1 && lane <= 62 && x0 < W;   // lanes that write results
 
-    // clipped window widths of the lane's 16 columns, 4 bits each (0 past the right edge: the comparison then fails)
+    // clipped window widths of the lane's columns, 4 bits each (0 past the right edge: the comparison then fails)
     uint32_t axp[2] = {0u, 0u};
 #pragma unroll
     for (int i = 0; i < T_LPX; i++) {
@@ -249,18 +286,20 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
         axp[i >> 3] |= (uint32_t)a << (4 * (i & 7));
     }
 
-    uint32_t area[8];       // clipped window areas of columns j | j + 8 << 16 for the current row's window height
+    uint32_t area[T_NP];       // clipped window areas of columns j | j + T_NP << 16 for the current row's window height
     uint32_t ay_cur = 0;
-    uint32_t gring[15][4];  // grey rows; row `it` lives in slot it % 15 (static: the row loop is unrolled 15x); a row is read
-                            // again 7 iterations later, so only 8 of the slots are live at any time
-    uint32_t hring[15][8];  // the last 15 rows of horizontal sums (pairs)
-    uint32_t S[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 15x15 window sums of the row 7 iterations old (pairs)
+    uint32_t gring[15][T_NG];  // grey rows; row `it` lives in slot it % 15 (static: the row loop is unrolled 15x); a row is read
+                               // again 7 iterations later, so only 8 of the slots are live at any time
+    uint32_t hring[15][T_NP];  // the last 15 rows of horizontal sums (pairs)
+    uint32_t S[T_NP];          // 15x15 window sums of the row 7 iterations old (pairs)
+#pragma unroll
+    for (int i = 0; i < T_NP; i++) S[i] = 0u;
 #pragma unroll
     for (int q = 0; q < 15; q++) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) gring[q][i] = 0u;
+        for (int i = 0; i < T_NG; i++) gring[q][i] = 0u;
 #pragma unroll
-        for (int i = 0; i < 8; i++) hring[q][i] = 0u;
+        for (int i = 0; i < T_NP; i++) hring[q][i] = 0u;
     }
 
     // Odd strips walk upwards.  Strip k (going down) and strip k+1 (going up) then both reach their common boundary --
@@ -274,18 +313,11 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
     // FAST: every load is unconditional (row and column clamped into the image) so that the loop body has no branch
     // around a load and the compiler can keep T_PF rows in flight with counted waits; what the clamped address
     // fetched for an outside lane/row is discarded by zeroing the grey below.
-    constexpr int BPPK = FMT == A3_FMT_RGB8 ? 3 : (FMT == A3_FMT_L8 ? 1 : 4);
     const bool lane_in = x0 >= 0 && x0 + T_LPX <= W;
-    const uint8_t* lane_ptr = frame + (size_t)(lane_in ? x0 : 0) * BPPK;
+    const uint8_t* lane_ptr = frame + (size_t)(lane_in ? x0 : 0) * RawRow<FMT>::BPP;
     auto issue = [&](int r, RawRow<FMT>& dst) {
-        if constexpr (FAST) {
-            const int rc = min(max(r, 0), H - 1);
-            const uint4* p = reinterpret_cast<const uint4*>(lane_ptr + (size_t)(uint32_t)rc * row_stride);
-#pragma unroll
-            for (int i = 0; i < RawRow<FMT>::NDW / 4; i++) { const uint4 v = p[i]; dst.d[4 * i] = v.x; dst.d[4 * i + 1] = v.y; dst.d[4 * i + 2] = v.z; dst.d[4 * i + 3] = v.w; }
-        } else {
-            load_raw16<FMT, false>(frame, row_stride, x0, r, W, H, aligned_in != 0, dst);
-        }
+        if constexpr (FAST) load_vec<FMT>(lane_ptr + (size_t)(uint32_t)min(max(r, 0), H - 1) * row_stride, dst);
+        else load_raw<FMT>(frame, row_stride, x0, r, W, H, aligned_in != 0, dst);
     };
 #pragma unroll
     for (int k = 0; k < T_PF; k++) issue(r_first + dir * k, q[k]);
@@ -301,30 +333,35 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
             const int it = base + k15;
             if (!FAST && it >= n_iter) break;
             const int r = r_first + dir * it;
-            uint32_t g[4];
-            grey16<FMT>(q[k], g);                                   // consumes the row loaded T_PF iterations ago ...
+            uint32_t g[T_NG];
+            grey_row<FMT>(q[k], g);                                 // consumes the row loaded T_PF iterations ago ...
             if (FAST || it + T_PF < n_rows) issue(r + dir * T_PF, q[k]);  // ... and its registers take the next load at once
             if constexpr (FAST) {
-                if (!(lane_in && r >= 0 && r < H)) { g[0] = 0u; g[1] = 0u; g[2] = 0u; g[3] = 0u; }
+                if (!(lane_in && r >= 0 && r < H)) {
+#pragma unroll
+                    for (int i = 0; i < T_NG; i++) g[i] = 0u;
+                }
             }
             // Detection.grey of the rows this wave owns -- only when somebody reads the plane (debug taps); the decode stage
             // otherwise recomputes the few grey levels it samples from the frame itself
             if (write_grey && owner && r >= y_begin && r < y_end) {
                 uint8_t* dst = gout + (size_t)r * W + x0;
-                if (FAST || (aligned_out && x0 + T_LPX <= W)) *reinterpret_cast<uint4*>(dst) = make_uint4(g[0], g[1], g[2], g[3]);
-                else {
+                if (FAST || (aligned_out && x0 + T_LPX <= W)) {
+                    if constexpr (T_LPX == 16) *reinterpret_cast<uint4*>(dst) = make_uint4(g[0], g[1], g[T_NG - 2], g[T_NG - 1]);
+                    else *reinterpret_cast<uint2*>(dst) = make_uint2(g[0], g[1]);
+                } else {
 #pragma unroll
                     for (int i = 0; i < T_LPX; i++) if (x0 + i < W) dst[i] = (uint8_t)(g[i >> 2] >> (8 * (i & 3)));
                 }
             }
             // horizontal sums of the new row, then the vertical window: + the new row's sums, - those of the row that
             // entered 15 iterations ago (they never underflow: the add comes first and the true sum is >= 0)
-            uint32_t Hn[8];
-            row_sums16(g, Hn);
+            uint32_t Hn[T_NP];
+            row_sums(g, Hn);
 #pragma unroll
-            for (int j = 0; j < 8; j++) { S[j] = pk_sub(pk_add(S[j], Hn[j]), hring[k15][j]); hring[k15][j] = Hn[j]; }
+            for (int j = 0; j < T_NP; j++) { S[j] = pk_sub(pk_add(S[j], Hn[j]), hring[k15][j]); hring[k15][j] = Hn[j]; }
 #pragma unroll
-            for (int i = 0; i < 4; i++) gring[k15][i] = g[i];
+            for (int i = 0; i < T_NG; i++) gring[k15][i] = g[i];
             const uint32_t* centre = gring[(k15 + 8) % 15];   // the row 7 iterations old: the one being thresholded
 
             const int y = r - dir * T_R;   // the row whose window is now complete
@@ -333,26 +370,26 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
             if (ay != ay_cur) {   // wave-uniform; only the first and last 7 image rows differ from 15
                 ay_cur = ay;
 #pragma unroll
-                for (int j = 0; j < 8; j++)
-                    area[j] = mul24((axp[0] >> (4 * j)) & 15u, ay) | (mul24((axp[1] >> (4 * j)) & 15u, ay) << 16);
+                for (int j = 0; j < T_NP; j++)
+                    area[j] = mul24((axp[j >> 3] >> (4 * (j & 7))) & 15u, ay) | (mul24((axp[(j + T_NP) >> 3] >> (4 * ((j + T_NP) & 7))) & 15u, ay) << 16);
             }
             // white iff S < (L + 1) * area, two pixels per instruction: T = L * area + area, d = saturating T - S (non-zero
-            // iff S < T), bit = min(d, 1), shifted in from pixel 7 | 15 down to 0 | 8: acc = acc * 2 + bit
+            // iff S < T), bit = min(d, 1), shifted in from the last pair down to the first: acc = acc * 2 + bit
             uint32_t acc = 0u;
 #pragma unroll
-            for (int j = 7; j >= 0; j--) {
-                const uint32_t Lp = j < 4 ? __builtin_amdgcn_perm(centre[2], centre[0], 0x0C000C00u | (uint32_t)(j & 3) | ((uint32_t)(4 + (j & 3)) << 16))
-                                          : __builtin_amdgcn_perm(centre[3], centre[1], 0x0C000C00u | (uint32_t)(j & 3) | ((uint32_t)(4 + (j & 3)) << 16));
+            for (int j = T_NP - 1; j >= 0; j--) {
+                const uint32_t Lp = byte_pair(j, centre[(j + T_NP) >> 2], centre[j >> 2]);
                 const uint32_t T = pk_mad(Lp, area[j], area[j]);
                 acc = pk_shift_in(acc, pk_nonzero_diff(T, S[j]));
             }
-            // bits of pixels 0..7 sit in byte 0, of pixels 8..15 in byte 2
-            const uint32_t outb = __builtin_amdgcn_perm(0u, acc, 0x0C0C0200u);
+            // the bits of pixels 0 .. T_NP-1 sit in the low half of acc, those of pixels T_NP .. in the high half
+            const uint32_t outb = T_LPX == 16 ? __builtin_amdgcn_perm(0u, acc, 0x0C0C0200u) : ((acc | (acc >> 12)) & 0xFFu);
             if (flush_rows <= 0) {
-                if (owner && (flush_rows == 0 || outb == 0x12345u)) *reinterpret_cast<uint16_t*>(bout + (size_t)y * bpr + (x0 >> 3)) = (uint16_t)outb;   // (-1: tuning probe, no stores)
+                if (owner && (flush_rows == 0 || outb == 0x12345u))   // (-1: tuning probe, no stores)
+                    *reinterpret_cast<out_bits_t*>(bout + (size_t)y * bpr + (x0 >> 3)) = (out_bits_t)outb;
             } else {
                 if (n_buf == 0) y_buf0 = y;
-                s_out[n_buf * 64 + lane] = (uint16_t)outb;
+                s_out[n_buf * 64 + lane] = (out_bits_t)outb;
                 n_buf++;
             }
         }
@@ -360,13 +397,13 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
         if (flush_rows > 0 && n_buf >= flush_rows) {   // wave-uniform
             if (owner)
                 for (int q = 0; q < n_buf; q++)
-                    *reinterpret_cast<uint16_t*>(bout + (size_t)(y_buf0 + dir * q) * bpr + (x0 >> 3)) = s_out[q * 64 + lane];
+                    *reinterpret_cast<out_bits_t*>(bout + (size_t)(y_buf0 + dir * q) * bpr + (x0 >> 3)) = s_out[q * 64 + lane];
             n_buf = 0;
         }
     }
     if (flush_rows > 0 && owner)
         for (int q = 0; q < n_buf; q++)
-            *reinterpret_cast<uint16_t*>(bout + (size_t)(y_buf0 + dir * q) * bpr + (x0 >> 3)) = s_out[q * 64 + lane];
+            *reinterpret_cast<out_bits_t*>(bout + (size_t)(y_buf0 + dir * q) * bpr + (x0 >> 3)) = s_out[q * 64 + lane];
 }
 
 // ---- generic radius: plain two-kernel path (correct for any threshold_window, not tuned) ----
@@ -416,7 +453,8 @@ hipError_t launch_grey_threshold(hipStream_t st, const uint8_t* pixels, int fmt,
         // Rows per wave.  Every wave also reads and converts 14 rows outside its strip, so strips should be tall; but the
         // chip holds 256 CUs x 4 SIMDs x A3_T_WAVES waves at once and a launch runs in whole rounds of that many, so the
         // number of strips should fill the last round.  Model: time ~ rounds x (rows per strip + 14); take the best
-        // strip count (at least 16 rows per strip).  256 frames of 1920x1080: 4 strips of 270 rows = exactly one round.
+        // strip count (at least 16 rows per strip).  256 frames of 1920x1080 with 8 pixels per lane: 4 column strips x 3 strips of
+        // 360 rows = 3072 waves = exactly one round of three waves per SIMD.
         const int strips_x = (W + T_OUT - 1) / T_OUT;
         const long long slots = 256LL * 4 * A3_T_WAVES, cols = (long long)strips_x * n;
         int best_sy = 1; double best_cost = 1e300;
@@ -434,11 +472,11 @@ hipError_t launch_grey_threshold(hipStream_t st, const uint8_t* pixels, int fmt,
         // every strip of a frame on one XCD (1) or every (frame, column strip) pair on its own XCD (0).  By frame is ~3 % faster:
         // the two column strips of a frame overlap by 32 columns and write the same lines of the packed image
         const int map_by_frame = mv ? atoi(mv) : 1;   // tuning knob
-        // rows of results a wave parks in LDS before it writes them out (0: store row by row); 128 (+15) rows = 18 KB per wave, eight
-        // waves per CU fit the 160 KB
+        // rows of results a wave parks in LDS before it writes them out (0: store row by row): 128 (+15) rows x 64 lanes x 1 or 2
+        // bytes = 9 or 18 KB per wave; twelve resp. eight waves per CU fit the 160 KB
         const char* fv = getenv("A3_K1_FLUSH");
         const int flush_rows = fv && atoi(fv) < 0 ? -1 : std::min(fv ? atoi(fv) : 128, rows_per_wave);   // tuning knob
-        const size_t lds_bytes = flush_rows > 0 ? (size_t)(flush_rows + 15) * 128 : 0;
+        const size_t lds_bytes = flush_rows > 0 ? (size_t)(flush_rows + 15) * 64 * sizeof(out_bits_t) : 0;
         dim3 grid(map_by_frame ? 8 * (((int)n + 7) / 8) * strips_x * strips_y : 8 * ((n_pairs + 7) / 8) * strips_y), block(64);
         const bool fast = aligned_in && aligned_out;   // W % 16 == 0: a lane's 16 pixels are all inside or all outside
 #define A3_LAUNCH_K1(F, B) hipLaunchKernelGGL((k_grey_threshold7<F, B>), grid, block, lds_bytes, st, pixels, row_stride, frame_stride, W, H, \
