@@ -1361,7 +1361,7 @@ hipError_t launch_select_scatter(hipStream_t st, const JumpState* fin, uint32_t 
                                  uint32_t max_contours, uint64_t max_points, DeviceCounters* ctr, const uint64_t* d_rec, uint32_t* points,
                                  const uint32_t* n_live, int inline_resolve_W, uint32_t* keep_tmp, int keep_all) {
     const dim3 grid(blocks_for(n_darts, 256, env_cap("A3_SCATTER_BLOCKS", 4096))), block(256);
-    hipLaunchKernelGGL(k_cycle_select, dim3(blocks_for(n_darts / 64 + 1, 256, 1024)), block, 0, st, fin, leader_list, leader_count, d_succ, t_cur,
+    hipLaunchKernelGGL(k_cycle_select, dim3(blocks_for(n_darts / 64 + 1, 256, env_cap("A3_SELECT_BLOCKS", 1024))), block, 0, st, fin, leader_list, leader_count, d_succ, t_cur,
                        frame_base, n_frames, first_frame, min_edge_length,
                        eps_factor, image_diag, cyc_slot, contours, cyc_start_off, max_contours, max_points, ctr, leader_shard_cap(n_darts), d_rec,
                        inline_resolve_W, keep_tmp, keep_all);
@@ -1372,7 +1372,7 @@ hipError_t launch_select_scatter(hipStream_t st, const JumpState* fin, uint32_t 
 hipError_t launch_contour_quads(hipStream_t st, const ContourRec* contours, const DeviceCounters* ctr, uint32_t max_contours,
                                 const uint32_t* points, double eps_factor, uint32_t min_edge_length, uint32_t first_frame, uint32_t max_cand,
                                 CandRec* cands, uint32_t* cand_count, unsigned int* err_flags) {
-    const uint32_t b64 = (uint32_t)env_cap("A3_QUAD_BLOCKS64", 2560), b16 = (uint32_t)env_cap("A3_QUAD_BLOCKS16", 768);
+    const uint32_t b64 = (uint32_t)env_cap("A3_QUAD_BLOCKS64", 2560), b16 = (uint32_t)env_cap("A3_QUAD_BLOCKS16", 4096);
     hipLaunchKernelGGL(k_contour_quads, dim3(b64 + b16), dim3(256), 0, st, b64, contours, ctr, max_contours, points, eps_factor, min_edge_length,
                        first_frame, max_cand, cands, cand_count, err_flags);
     return hipGetLastError();
