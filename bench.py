@@ -430,7 +430,7 @@ def other_workloads(device, with_cpu=True, budget_s=60.0):
         ctx.close()
 
     g = torch.Generator(device=dev); g.manual_seed(20261004)
-    noise = torch.randint(0, 256, (16, 1080, 1920, 3), dtype=torch.uint8, device=dev, generator=g)
+    noise = torch.randint(0, 256, (32, 1080, 1920, 3), dtype=torch.uint8, device=dev, generator=g)
     run("C0_reference_bench_noise_1080p", noise, "ARUCO", cpu_frames=2,
         note="benches/detect_markers.rs:29-51 recipe: every channel of every pixel uniform random u8; no markers, ~1.6 M darts per frame")
     del noise

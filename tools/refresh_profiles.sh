@@ -1,5 +1,6 @@
 #!/bin/bash
-# Run on the GPU box (gpurun -- 'bash tools/refresh_profiles.sh'): the driver's bench command, the same command under
+# Run on the GPU box (gpurun -- 'bash tools/refresh_profiles.sh'): the driver's bench command (its host-rendered frames kept in a
+# cache file so that the profiled runs read the very same frames and nothing forks under the profiler), the same command under
 # rocprofv3 --kernel-trace --stats, the PMC passes (tools/pmc_k1.sh), the streaming-read microbenchmark and the 2-rank gloo
 # rehearsal; everything lands in gpurun_out/refresh/.  tools/install_profiles.py then copies the summaries into profiles/.
 set -u
@@ -7,10 +8,10 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/refresh
 rm -rf "$OUT" "$ROOT/gpurun_out/pmc"; mkdir -p "$OUT" "$ROOT/gpurun_out/pmc"; export TMPDIR=/tmp
 cd "$ROOT"
-timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench.json.log" 2> "$OUT/bench.err" || exit 1
+timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 --frames-cache /tmp/c2frames > "$OUT/bench.json.log" 2> "$OUT/bench.err" || exit 1
 cut -c1-600 "$OUT/bench.json.log"
 cd /tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o stats -- python3 "$ROOT/bench.py" --gpus 1 --steps 20 --warmup 5 --device-synth --no-cpu-baseline --no-other-workloads > "$OUT/stats.log" 2>&1 || exit 2
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o stats -- python3 "$ROOT/bench.py" --gpus 1 --steps 20 --warmup 5 --frames-cache /tmp/c2frames --no-cpu-baseline --no-other-workloads > "$OUT/stats.log" 2>&1 || exit 2
 tail -c 400 "$OUT/stats.log"; echo
 bash "$ROOT/tools/pmc_k1.sh" > "$OUT/pmc.log" 2>&1 || exit 3
 cd "$ROOT"
