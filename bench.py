@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--repeats", type=int, default=25, help="the timed region (exactly --steps steps between barrier + synchronize) is run "
                                                             "this many times back to back; the median is reported, every value listed "
                                                             "(20 steps are 20 ms: one region alone measures clocks ramping)")
+    ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path (process group, dictionary broadcast, device-packed "
+                                                                "records, all-gather) even with one rank: lets a 1-GPU box exercise the RCCL branch")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the other_workloads block (reference bench recipe, configs 4 and 5)")
     ap.add_argument("--frames-cache", default="", help="npz path: reuse rendered frames between runs (profiling runs use it so that "
                                                         "nothing forks under the profiler)")
@@ -112,15 +114,17 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     coll_dev = dev if args.backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     d = ARDictionary.new_from_named_dict("ARUCO") if rank == 0 or world == 1 else None
-    if world > 1:
+    if use_dist:
         d = shard.broadcast_dictionary(d, coll_dev, 0)   # RCCL broadcast, once
     # two contexts on ONE stream: kernels of consecutive steps never overlap (K1 is timed alone), but the host enqueues step
     # i+1 while step i runs, so the GPU does not idle between steps
@@ -150,12 +154,23 @@ def main():
     batch_args = (d_frames.data_ptr(), _lib.MEM_DEVICE, _lib.FMT_RGB8, w, h, w * c, h * w * c, n)
 
     last_gather = [None]
+    side = torch.cuda.Stream(device=dev)   # the collective runs beside the detection stream, not in it
 
     def gather(cx):
-        # per batch: fixed-capacity records written by a kernel from the device-resident marker list (a3_pack_detections),
-        # all-gathered over RCCL; the pack and the collective are ordered on the contexts' stream, no host copy in between
+        # Per batch: fixed-capacity records written by a kernel from the device-resident marker list (a3_pack_detections, on the
+        # contexts' stream), then all-gathered over RCCL on a side stream that waits for the pack: the detection stream goes on
+        # with the next batch instead of waiting for the collective; no host copy in between.
         with torch.cuda.stream(stream):
-            last_gather[0] = shard.gather_detections_device(cx, n, first_frame, dev, coll_dev)
+            rec = shard.pack_detections_device(cx, n, first_frame, dev)
+            if coll_dev.type == "cpu":                  # gloo rehearsal: host tensors (the copy is ordered on the same stream)
+                rec = rec.cpu()
+        if coll_dev.type == "cpu":
+            last_gather[0] = shard._all_gather(rec, n)
+            return
+        side.wait_stream(stream)
+        with torch.cuda.stream(side):
+            last_gather[0] = shard._all_gather(rec, n)
+        rec.record_stream(side)
 
     def run_steps(k):
         """k steps; a step = one pass of Detector::detect over the rank's batch, results on the host (and all-gathered)."""
@@ -163,7 +178,7 @@ def main():
         if args.no_pipeline:
             for _ in range(k):
                 markers, per = ctx.detect_batch(*batch_args, out_cap=n * 64)
-                if world > 1:
+                if use_dist:
                     gather(ctx)
             return markers, per
         if k > 0:
@@ -172,7 +187,7 @@ def main():
             if i + 1 < k:
                 ctxs[(i + 1) % 2].submit(*batch_args, out_cap=n * 64)
             markers, per = ctxs[i % 2].collect()
-            if world > 1:
+            if use_dist:
                 gather(ctxs[i % 2])
         return markers, per
 
@@ -201,16 +216,16 @@ def main():
     # --repeats times back to back and the median region is the one reported (all are listed in ms_per_step_all).
     regions = []
     for _ in range(max(1, args.repeats)):
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         markers, per = run_steps(args.steps)
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         regions.append(time.perf_counter() - t0)
-    if world > 1:
+    if use_dist:
         t = torch.tensor(regions, dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         regions = [float(v) for v in t.tolist()]
@@ -233,7 +248,7 @@ def main():
     stats = ctx.stats()
 
     gathered = None
-    if world > 1:
+    if use_dist:
         # what the last all-gather delivered, checked on rank 0: every rank's frames, global indices in order, ids as rendered
         torch.cuda.synchronize()
         g = last_gather[0].cpu().numpy()
@@ -313,7 +328,7 @@ def main():
             # free the headline batch first: the 4K batch below needs room only in the sense of tidiness (288 GB of HBM)
             out["other_workloads"] = other_workloads(local_rank, with_cpu=not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
