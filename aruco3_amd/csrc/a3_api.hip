@@ -42,7 +42,7 @@ hipError_t launch_contour_quads(hipStream_t, const ContourRec*, const DeviceCoun
 // k_decode.hip
 size_t decode_out_bytes();
 hipError_t launch_frame_candidates(hipStream_t, const CandRec*, const uint32_t*, uint32_t, uint32_t, float, uint16_t*, uint16_t*, uint32_t*,
-                                   uint32_t*, unsigned int*);
+                                   uint32_t*, unsigned int*, uint32_t, void*);
 size_t proj_rec_bytes();
 size_t weight_table_bytes();
 hipError_t launch_weight_table(hipStream_t, uint32_t, uint32_t, uint32_t, float*);
@@ -426,7 +426,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     // ---- candidates -> markers, all frames at once ----
     A3_HIP(launch_frame_candidates(st, ctx->cands.as<CandRec>(), ctx->cand_count, n, kMaxCand, min_corner_separation,
                                    ctx->pre_xy.as<uint16_t>(), ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(),
-                                   ctx->work.as<uint32_t>(), d_work_count));
+                                   ctx->work.as<uint32_t>(), d_work_count, S, ctx->proj.p));
     const PixelSrc src = need_grey ? PixelSrc{ctx->grey.as<uint8_t>(), W, (unsigned long long)npx, kFmtGreyPlane}
                                    : PixelSrc{pixels, row_stride, frame_stride, fmt};
     A3_HIP(launch_decode(st, src, (int)W, (int)H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), d_work_count,
@@ -833,7 +833,8 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
         } else if (kernel == 3) {   // dbg < 0: k_decode alone (variant -dbg), dbg >= 0: k_projection + k_decode
             A3_HIP(launch_decode(st, ctx->dbg_src, (int)ctx->W, (int)ctx->H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), ctx->scratch_u32,
                                  kMaxCand, ctx->cfg.homography_sample_size, ctx->mark_size, ctx->cfg.homography_sample_size, ctx->dict.as<uint64_t>(),
-                                 ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors, ctx->proj.p, ctx->wtab.as<float>(), ctx->outs.p, nullptr, 0u, nullptr, 4096, dbg));
+                                 ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors, ctx->proj.p, ctx->wtab.as<float>(), ctx->outs.p, nullptr, 0u, nullptr, 4096,
+                                 dbg == 0 ? -1000 : dbg));   // 0: k_projection + k_decode, < 0: k_decode alone (variant -dbg)
         } else return fail(ctx, A3_ERR_INVALID, "kernel: 0 dart_count, 1 dart_assign, 2 local_contract, 3 decode");
         A3_HIP(hipEventRecord(e1, st));
         A3_HIP(hipStreamSynchronize(st));
@@ -1081,7 +1082,7 @@ int a3_debug_discard_too_near(a3_ctx* ctx, const uint32_t* quads_xy, size_t n, f
     A3_HIP(hipMemcpyAsync(small, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
     uint16_t* pre = ctx->tmp_b.as<uint16_t>(); uint16_t* fin = pre + kMaxCand * 8;
     A3_HIP(launch_frame_candidates(ctx->stream, ctx->tmp_a.as<CandRec>(), small, 1, kMaxCand, min_distance, pre, fin, small + 1,
-                                   ctx->tmp_c.as<uint32_t>(), small + 2));
+                                   ctx->tmp_c.as<uint32_t>(), small + 2, 0u, nullptr));
     uint32_t cnt = 0;
     A3_HIP(hipMemcpyAsync(&cnt, small + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
     A3_HIP(hipStreamSynchronize(ctx->stream));

@@ -27,11 +27,17 @@ __device__ __forceinline__ float perimeter4(const uint16_t* q) {  // src/aruco.r
     return p;
 }
 
+struct __attribute__((aligned(8))) ProjRec { float inv[9]; int ok; };
+__device__ bool solve_projection(const float* from, float S, float* inv_out);
+
 // one wave per frame.  cands: unordered CandRec[max_cand] per frame (as k_contour_quads appended them).
+// proj != nullptr: the wave also solves the projection of every surviving candidate (one lane each: the 8x8 system needs
+// ~200 VGPRs, affordable in a one-wave workgroup) into proj[work index], which saves the separate k_projection launch.
 __global__ __launch_bounds__(64) void k_frame_candidates(const CandRec* __restrict__ cands, const uint32_t* __restrict__ cand_count,
                                                          uint32_t max_cand, float min_distance, uint16_t* __restrict__ pre_xy,
                                                          uint16_t* __restrict__ fin_xy, uint32_t* __restrict__ fin_count,
-                                                         uint32_t* __restrict__ work, unsigned int* __restrict__ work_count) {
+                                                         uint32_t* __restrict__ work, unsigned int* __restrict__ work_count,
+                                                         uint32_t S, ProjRec* __restrict__ proj) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint16_t* s_xy = reinterpret_cast<uint16_t*>(smem);                       // max_cand * 8
     float* s_per = reinterpret_cast<float*>(smem + (size_t)max_cand * 16);    // max_cand
@@ -93,7 +99,18 @@ __global__ __launch_bounds__(64) void k_frame_candidates(const CandRec* __restri
         __syncthreads();
     }
     __syncthreads();
-    // survivors, order preserved
+    // survivors, order preserved: count them, take a range of the work list, then write quads, work items and projections
+    uint32_t total = 0;
+    for (uint32_t i0 = 0; i0 < c; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        total += (uint32_t)__popcll(__ballot(i < c && !s_dead[i]));
+    }
+    uint32_t w0 = 0;
+    if (lane == 0) {
+        fin_count[f] = total;
+        if (total) w0 = atomicAdd(work_count, total);
+    }
+    w0 = __shfl(w0, 0);
     uint32_t base = 0;
     for (uint32_t i0 = 0; i0 < c; i0 += 64) {
         const uint32_t i = i0 + lane;
@@ -101,16 +118,16 @@ __global__ __launch_bounds__(64) void k_frame_candidates(const CandRec* __restri
         const unsigned long long m = __ballot(alive);
         if (alive) {
             const uint32_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
-            for (int k = 0; k < 8; k++) fin_xy[((size_t)f * max_cand + pos) * 8 + k] = s_xy[i * 8 + k];
+            float from[8];
+            for (int k = 0; k < 8; k++) { const uint16_t v = s_xy[i * 8 + k]; fin_xy[((size_t)f * max_cand + pos) * 8 + k] = v; from[k] = (float)v; }
+            work[w0 + pos] = f * max_cand + pos;
+            if (proj) {
+                ProjRec r;
+                r.ok = solve_projection(from, (float)S, r.inv) ? 1 : 0;
+                proj[w0 + pos] = r;
+            }
         }
         base += __popcll(m);
-    }
-    if (lane == 0) {
-        fin_count[f] = base;
-        if (base) {
-            const uint32_t w0 = atomicAdd(work_count, base);
-            for (uint32_t k = 0; k < base; k++) work[w0 + k] = f * max_cand + k;
-        }
     }
 }
 
@@ -319,9 +336,9 @@ __device__ uint32_t resize_weights(uint32_t in_len, uint32_t out_len, uint32_t o
     return (uint32_t)left;
 }
 
-// The 8x8 solve needs ~200 VGPRs for one lane's work; inside k_decode it would cap that kernel at two workgroups per
-// CU, so it runs first, one lane per candidate, and leaves 9 floats + a flag per candidate.
-struct __attribute__((aligned(8))) ProjRec { float inv[9]; int ok; };
+// The 8x8 solve needs ~200 VGPRs for one lane's work; inside k_decode it would cap that kernel's occupancy, so it runs
+// first, one lane per candidate (inside k_frame_candidates; k_projection is the stand-alone form the tuning probe uses), and
+// leaves 9 floats + a flag per candidate.
 
 // The triangle-resize weights of a full patch (S -> n) are the same for every candidate of a context: a table computed once
 // (k_weight_table, at a3_create) replaces seven lanes of every decode workgroup computing them while the other 249 waited
@@ -1038,10 +1055,10 @@ size_t decode_lds_bytes(uint32_t S, uint32_t n, uint32_t max_taps) {
 
 hipError_t launch_frame_candidates(hipStream_t st, const CandRec* cands, const uint32_t* cand_count, uint32_t n_frames, uint32_t max_cand,
                                    float min_distance, uint16_t* pre_xy, uint16_t* fin_xy, uint32_t* fin_count, uint32_t* work,
-                                   unsigned int* work_count) {
+                                   unsigned int* work_count, uint32_t S, void* proj) {
     const size_t lds = (size_t)max_cand * 21 + 16;
     hipLaunchKernelGGL(k_frame_candidates, dim3(n_frames), dim3(64), lds, st, cands, cand_count, max_cand, min_distance, pre_xy, fin_xy,
-                       fin_count, work, work_count);
+                       fin_count, work, work_count, S, reinterpret_cast<ProjRec*>(proj));
     return hipGetLastError();
 }
 
@@ -1057,10 +1074,10 @@ hipError_t launch_decode(hipStream_t st, PixelSrc src, int W, int H, uint32_t fi
                          const unsigned int* work_count, uint32_t max_cand, uint32_t S, uint32_t n, uint32_t max_taps, const uint64_t* dict,
                          uint32_t n_codes, uint32_t tau, int filter, void* proj, const float* wtab, void* outs, uint8_t* patches, uint32_t patch_cap, uint32_t* per_frame, int grid_blocks, int dbg) {
     ProjRec* recs = reinterpret_cast<ProjRec*>(proj);
-    if (dbg >= 0) hipLaunchKernelGGL(k_projection, dim3(256), dim3(64), 0, st, fin_xy, work, work_count, S, recs);
+    if (dbg > 0 || dbg == -1000) hipLaunchKernelGGL(k_projection, dim3(256), dim3(64), 0, st, fin_xy, work, work_count, S, recs);
     hipLaunchKernelGGL(k_decode<A3_D_THREADS>, dim3(grid_blocks), dim3(A3_D_THREADS), decode_lds_bytes(S, n, max_taps), st, src, W, H, first_frame, fin_xy, work,
                        work_count, max_cand, S, n, max_taps, dict, n_codes, tau, filter, recs, wtab,
-                       reinterpret_cast<DecodeOut*>(outs), patches, patch_cap, per_frame, dbg < 0 ? -dbg : dbg);
+                       reinterpret_cast<DecodeOut*>(outs), patches, patch_cap, per_frame, dbg == -1000 ? 0 : (dbg < 0 ? -dbg : dbg));
     return hipGetLastError();
 }
 
