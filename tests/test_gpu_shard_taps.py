@@ -208,11 +208,14 @@ def test_two_rank_rehearsal_as_child_processes():
     """bench.py --gpus 2 --backend gloo: two ranks started as FRESH child processes (this process has touched the GPU and is
     never re-executed), both on the one leased GPU: partition, dictionary broadcast, detect, device-packed records,
     all-gather, barrier + max-over-ranks timing.  The JSON line must carry both ranks' frames and correct ids."""
+    import socket
+
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()   # a free rendezvous port
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "16",
+           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "16",
            "--backend", "gloo", "--device-synth", "--repeats", "1", "--no-other-workloads"]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-4000:]
