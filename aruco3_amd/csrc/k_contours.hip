@@ -472,9 +472,18 @@ __device__ __forceinline__ uint32_t loc_pack(uint32_t off, uint32_t dist, bool f
 __device__ __forceinline__ uint32_t loc_off(uint32_t w) { return w & 0xFFFu; }
 __device__ __forceinline__ uint32_t loc_dist(uint32_t w) { return (w >> 12) & 0x1FFFu; }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global load, store and returning
+// atomic the wave has in flight (s_waitcnt vmcnt(0)); where the barrier only hands LDS data between waves that wait would
+// put the round trip of an unrelated global access on the critical path.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // Phase 1: 11 doubling rounds inside one tile, entirely in LDS.  A window stops growing ("freezes") when its end leaves
 // the tile; cycles that close inside the tile finish here.  Darts that some frozen window ends on become "entries".
-__global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W, const uint64_t* __restrict__ d_rec,
+__global__ __launch_bounds__(256, 4) void k_local_contract(uint32_t n_darts, int W, const uint64_t* __restrict__ d_rec,
                                                         const uint32_t* __restrict__ d_succ,
                                                         JumpState* __restrict__ loc,
                                                         uint32_t* __restrict__ entry_list,
@@ -487,6 +496,9 @@ __global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W,
     // one 16-byte record per dart (a single ds_read_b128 fetches the next window): off <= 2047 and dist <= 2048 share a word
     struct __attribute__((aligned(16))) Win { uint64_t key; uint32_t ptr; uint32_t offdist; };
     __shared__ Win s_win[kLT];
+    constexpr uint32_t kFrameWin = 64;               // frames a tile may span with block-aggregated counting (beyond: direct atomics)
+    __shared__ uint32_t s_fcnt[kFrameWin], s_fbase[kFrameWin];
+    __shared__ uint32_t s_new_count, s_new_base, s_f0;
     if (n_live) n_darts = min(n_darts, *n_live);
     const uint32_t lo = blockIdx.x * kLT;
     if (lo >= n_darts) return;   // the grid covers the pool's capacity, the graph may be smaller
@@ -495,22 +507,68 @@ __global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W,
     // copy the other lanes read (per dart and round: one 16-byte read of the next window, one 16-byte write)
     constexpr int PER = kLT / 256;
     uint64_t nk[PER]; uint32_t np[PER], no[PER], nd[PER], succ0[PER], frm[PER];
+    if (threadIdx.x == 0) s_new_count = 0;
+    if (threadIdx.x < kFrameWin) s_fcnt[threadIdx.x] = 0;
+    // all 16 loads of a lane are issued before the first is used: unconditional, from a clamped index (behind an `if (i < cnt)`
+    // the compiler issues them one at a time, each with its own wait: 16 round trips to memory instead of one)
+    uint64_t recs[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const uint32_t d = lo + min(threadIdx.x + u * 256u, cnt - 1u);
+        recs[u] = d_rec[d];
+        succ0[u] = d_succ[d];
+    }
 #pragma unroll
     for (int u = 0; u < PER; u++) {
         const uint32_t i = threadIdx.x + u * 256;
-        succ0[u] = 0; frm[u] = 0;
-        if (i < cnt) {
-            const uint32_t d = lo + i;
-            const uint64_t rec = d_rec[d];
-            const uint32_t xy = rec_xy(rec), info = rec_info(rec);
-            const uint32_t q = (xy >> 16) * (uint32_t)W + (xy & 0xFFFF);
-            const uint32_t ek = (info & kInfoW) ? 2u * q : ((info & kInfoE) ? 2u * q + 1u : kNoKey);
-            succ0[u] = d_succ[d]; frm[u] = rec_frame(rec);   // kept for the entry registration below (no second read)
-            nk[u] = ((uint64_t)ek << 32) | d; np[u] = succ0[u]; no[u] = 0; nd[u] = 1;
-            s_win[i] = Win{nk[u], np[u], 1u << 16};
+        const uint64_t rec = recs[u];
+        const uint32_t xy = rec_xy(rec), info = rec_info(rec);
+        const uint32_t q = (xy >> 16) * (uint32_t)W + (xy & 0xFFFF);
+        const uint32_t ek = (info & kInfoW) ? 2u * q : ((info & kInfoE) ? 2u * q + 1u : kNoKey);
+        frm[u] = rec_frame(rec);   // kept, like succ0, for the entry registration (no second read)
+        nk[u] = ((uint64_t)ek << 32) | (lo + i); np[u] = succ0[u]; no[u] = 0; nd[u] = 1;
+        if (i < cnt) s_win[i] = Win{nk[u], np[u], 1u << 16};
+    }
+    if (threadIdx.x == 0) s_f0 = frm[0];   // darts are frame-major: the tile's frames are f0, f0+1, ...
+    lds_barrier();
+    // Entries.  The entries of the reduced list are exactly the successors that lie outside their predecessor's tile; succ is
+    // injective, so each is registered once, by that predecessor, with no global dedupe.  Slots are counted per workgroup
+    // (one global atomic per tile and frame) -- and counted HERE, before the doubling rounds, which need nothing of it: the
+    // returning atomics are then in flight while the rounds run, instead of being two more round trips to memory at the end
+    // of every workgroup's life.
+    const uint32_t f0 = frame_entries ? s_f0 : 0u;
+    uint32_t my_slot[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const uint32_t i = threadIdx.x + u * 256;
+        my_slot[u] = kNone;
+        if (i >= cnt) continue;
+        const uint32_t s0 = succ0[u];
+        if ((s0 - lo) >= cnt) {
+            if (frame_entries) {   // a border never leaves its frame: the successor's frame is this dart's
+                const uint32_t f = frm[u];
+                if (f - f0 < kFrameWin) my_slot[u] = atomicAdd(&s_fcnt[f - f0], 1u);          // rank inside (tile, frame)
+                else {                                                                           // a tile over > 64 tiny frames
+                    const uint32_t slot = frame_base[f] + atomicAdd(&frame_entries[f], 1u);
+                    entry_list[slot] = s0;
+                    entry_pos[s0] = slot;
+                }
+            } else my_slot[u] = atomicAdd(&s_new_count, 1u);
         }
     }
-    __syncthreads();
+    lds_barrier();
+    // (threads < kFrameWin, resp. thread 0): first slot of the tile's entries in that frame / shard = slot_a + slot_b, added
+    // only after the rounds so that nothing waits for the atomic's return before
+    uint32_t slot_a = 0, slot_b = 0;
+    if (frame_entries) {
+        if (threadIdx.x < kFrameWin && s_fcnt[threadIdx.x]) {
+            slot_a = frame_base[f0 + threadIdx.x];
+            slot_b = atomicAdd(&frame_entries[f0 + threadIdx.x], s_fcnt[threadIdx.x]);
+        }
+    } else if (threadIdx.x == 0) {
+        slot_a = (blockIdx.x & (kEntryShards - 1)) * ecap;
+        if (s_new_count) slot_b = atomicAdd(&entry_count[blockIdx.x & (kEntryShards - 1)], s_new_count);
+    }
     // (Skipping windows that are already final -- frozen, or wrapped, visible as "the next window has the same minimum" --
     // was tried: most windows of a clean frame only become final in the last rounds, and the extra flags made it 20 % slower.)
     const int n_rounds = dbg == 0 ? 11 : (dbg < 0 ? 0 : dbg);
@@ -528,76 +586,34 @@ __global__ __launch_bounds__(256) void k_local_contract(uint32_t n_darts, int W,
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             const uint32_t i = threadIdx.x + u * 256;
             if (i < cnt) s_win[i] = Win{nk[u], np[u], no[u] | (nd[u] << 16)};
         }
-        __syncthreads();
+        lds_barrier();
     }
-    // results + entries.  The entries of the reduced list are exactly the successors that lie outside their
-    // predecessor's tile; succ is injective, so each is registered once, by that predecessor, with no global dedupe.
-    // Slots are counted per workgroup: one global atomic per tile.
-    __shared__ uint32_t s_new_count, s_new_base;
-    constexpr uint32_t kFrameWin = 64;               // frames a tile may span with block-aggregated counting (beyond: direct atomics)
-    __shared__ uint32_t s_fcnt[kFrameWin], s_fbase[kFrameWin];
-    if (threadIdx.x == 0) s_new_count = 0;
-    if (threadIdx.x < kFrameWin) s_fcnt[threadIdx.x] = 0;
-    const uint32_t f0 = frame_entries ? rec_frame(d_rec[lo]) : 0u;   // darts are frame-major: the tile's frames are f0, f0+1, ...
-    __syncthreads();
-    uint32_t my_e[kLT / 256], my_slot[kLT / 256], my_f[kLT / 256];
+    // results
+    if (frame_entries) { if (threadIdx.x < kFrameWin) s_fbase[threadIdx.x] = slot_a + slot_b; }
+    else if (threadIdx.x == 0) s_new_base = slot_a + slot_b;
 #pragma unroll
-    for (int u = 0; u < kLT / 256; u++) {
+    for (int u = 0; u < PER; u++) {
         const uint32_t i = threadIdx.x + u * 256;
-        my_slot[u] = kNone;
         if (i >= cnt) continue;
-        const uint32_t d = lo + i;
         const uint32_t e = np[u];
         const bool frozen = (e - lo) >= cnt;
         JumpState r;
         r.key = nk[u]; r.ptr = e; r.off = loc_pack(no[u], nd[u], frozen);
-        loc[d] = r;
-        const uint32_t s0 = succ0[u];
-        if ((s0 - lo) >= cnt) {
-            my_e[u] = s0;
-            if (frame_entries) {   // a border never leaves its frame: the successor's frame is this dart's
-                const uint32_t f = frm[u];
-                my_f[u] = f;
-                if (f - f0 < kFrameWin) my_slot[u] = atomicAdd(&s_fcnt[f - f0], 1u);          // rank inside (tile, frame)
-                else {                                                                           // a tile over > 64 tiny frames
-                    const uint32_t slot = frame_base[f] + atomicAdd(&frame_entries[f], 1u);
-                    entry_list[slot] = s0;
-                    entry_pos[s0] = slot;
-                }
-            } else my_slot[u] = atomicAdd(&s_new_count, 1u);
-        }
+        loc[lo + i] = r;
     }
-    __syncthreads();
-    if (frame_entries) {
-        // one global bump per frame the tile touches (slot = frame_base[f] + running count of the frame)
-        if (threadIdx.x < kFrameWin && s_fcnt[threadIdx.x]) s_fbase[threadIdx.x] = atomicAdd(&frame_entries[f0 + threadIdx.x], s_fcnt[threadIdx.x]);
-        __syncthreads();
+    lds_barrier();
 #pragma unroll
-        for (int u = 0; u < kLT / 256; u++)
-            if (my_slot[u] != kNone) {
-                const uint32_t slot = frame_base[my_f[u]] + s_fbase[my_f[u] - f0] + my_slot[u];
-                entry_list[slot] = my_e[u];
-                entry_pos[my_e[u]] = slot;
-            }
-        return;
-    }
-    if (threadIdx.x == 0) {
-        const uint32_t shard = blockIdx.x & (kEntryShards - 1);
-        s_new_base = shard * ecap + (s_new_count ? atomicAdd(&entry_count[shard], s_new_count) : 0u);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < kLT / 256; u++)
+    for (int u = 0; u < PER; u++)
         if (my_slot[u] != kNone) {
-            const uint32_t slot = s_new_base + my_slot[u];
-            entry_list[slot] = my_e[u];
-            entry_pos[my_e[u]] = slot;
+            const uint32_t slot = (frame_entries ? s_fbase[frm[u] - f0] : s_new_base) + my_slot[u];
+            entry_list[slot] = succ0[u];
+            entry_pos[succ0[u]] = slot;
         }
 }
 

@@ -1,0 +1,12 @@
+#!/bin/bash
+# On the GPU box: the bench under each of a list of environment settings (tuning knobs are read per launch), interleaved REPS
+# times so that drift of the box shows.  ENVS="A=1;A=2 B=3;..."  (an empty entry = defaults)
+ROOT=$(cd "$(dirname "$0")/.." && pwd); export TMPDIR=/tmp
+cd "$ROOT"
+B="python3 bench.py --device-synth --no-cpu-baseline --no-other-workloads --repeats ${REPEATS:-7} --steps 20 --warmup 3"
+IFS=';' read -ra LIST <<< "${ENVS:-;}"
+for rep in $(seq 1 ${REPS:-2}); do
+  for e in "${LIST[@]}"; do
+    env $e $B 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('[$e]', 'stages', d['stage_ms_per_step'], 'fps', d['value'], d['frames_with_all_ids_correct'])"
+  done
+done
