@@ -103,9 +103,23 @@ __device__ __forceinline__ Nb8 tile_nb8(const uint64_t* __restrict__ img, int W,
     const int wpr = (int)words_per_row((uint32_t)W);
     const int tx = blockIdx.x % dart_tiles_x((uint32_t)W), ty = blockIdx.x / dart_tiles_x((uint32_t)W);
     const int j0 = tx * kTileWords - 1, y0 = ty * kTileRows - 1;
-    for (int i = threadIdx.x; i < (kTileRows + 2) * (kTileWords + 2); i += 256) {
+    // both words of a lane are requested before either is stored (unconditional loads from clamped addresses, masked
+    // afterwards: a load behind a bounds test is issued and waited for on its own)
+    constexpr int kStage = (kTileRows + 2) * (kTileWords + 2);
+    static_assert(kStage <= 512, "two words per lane");
+    uint64_t v[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int i = min((int)threadIdx.x + 256 * k, kStage - 1);
         const int r = i / (kTileWords + 2), c = i - r * (kTileWords + 2);
-        s_t[r][c] = ldw(img, wpr, H, j0 + c, y0 + r);
+        const int jj = j0 + c, yy = y0 + r;
+        const uint64_t w = img[(size_t)min(max(yy, 0), H - 1) * wpr + min(max(jj, 0), wpr - 1)];
+        v[k] = w & (0ull - (uint64_t)(yy >= 0 && yy < H && jj >= 0 && jj < wpr));
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int i = (int)threadIdx.x + 256 * k;
+        if (i < kStage) (&s_t[0][0])[i] = v[k];
     }
     __syncthreads();
     const int jl = threadIdx.x & (kTileWords - 1), rl = threadIdx.x >> 2;
@@ -155,22 +169,37 @@ __global__ __launch_bounds__(64) void k_dart_count(const uint64_t* __restrict__ 
     const uint64_t* img = bits + (size_t)(first_frame + f) * wpr * H;
     if (lane < kGroups * kTilesPerGroup) (&s_tile[0][0])[lane] = 0;
     const int y0 = ty * kTileRows;
-    auto word = [&](int y) -> uint64_t { return (y >= 0 && y < H && j >= 0 && j < wpr) ? img[(size_t)y * wpr + j] : 0ull; };
+    // (unconditional load from a clamped address, then a select: a load behind a branch cannot be batched with its neighbours)
+    const int jc = min(max(j, 0), wpr - 1);
+    auto word = [&](int y) -> uint64_t {
+        const uint64_t v = img[(size_t)min(max(y, 0), H - 1) * wpr + jc];
+        return v & (0ull - (uint64_t)(y >= 0 && y < H && j >= 0 && j < wpr));   // (an AND, not a select: a select lets the compiler sink the load into a branch again)
+    };
     auto edge_bits = [](uint64_t c, uint32_t* lbit, uint32_t* rbit) {   // bit 63 of the word to the left, bit 0 of the word to the right
         *lbit = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(c >> 32), 0x138 /* wave_shr:1 */, 0xF, 0xF, true) >> 31;
         *rbit = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)c, 0x130 /* wave_shl:1 */, 0xF, 0xF, true) & 1u;
     };
     struct Row3 { uint64_t c; uint32_t lbit, rbit; };
+    // rows are fetched kAhead at a time, and the next kAhead rows are requested before the current ones are looked at: the
+    // launch is only a couple of waves per SIMD, so a tile row's time is its chain of round trips to memory -- five of them
+    // now, overlapped with the bit work, instead of ten
+    constexpr int kAhead = 16;
+    static_assert(kTileRows % kAhead == 0, "whole batches of rows");
     Row3 up, cur;
-    up.c = word(y0 - 1); edge_bits(up.c, &up.lbit, &up.rbit);
-    cur.c = word(y0); edge_bits(cur.c, &cur.lbit, &cur.rbit);
-    // rows are fetched kAhead at a time so that a tile row is a few round trips to memory, not 66
-    constexpr int kAhead = 8;
-    uint32_t nd = 0;
-    for (int r0 = 0; r0 < kTileRows; r0 += kAhead) {
-        uint64_t nxt[kAhead];
+    uint64_t nxt[kAhead], ahead[kAhead];
+    up.c = word(y0 - 1);
+    cur.c = word(y0);
 #pragma unroll
-        for (int u = 0; u < kAhead; u++) nxt[u] = word(y0 + r0 + u + 1);
+    for (int u = 0; u < kAhead; u++) nxt[u] = word(y0 + u + 1);
+    edge_bits(up.c, &up.lbit, &up.rbit);
+    edge_bits(cur.c, &cur.lbit, &cur.rbit);
+    uint32_t nd = 0;
+#pragma unroll
+    for (int r0 = 0; r0 < kTileRows; r0 += kAhead) {
+        if (r0 + kAhead < kTileRows) {
+#pragma unroll
+            for (int u = 0; u < kAhead; u++) ahead[u] = word(y0 + r0 + kAhead + u + 1);
+        }
 #pragma unroll
         for (int u = 0; u < kAhead; u++) {
             Row3 dn;
@@ -193,6 +222,8 @@ __global__ __launch_bounds__(64) void k_dart_count(const uint64_t* __restrict__ 
             }
             up = cur; cur = dn;
         }
+#pragma unroll
+        for (int u = 0; u < kAhead; u++) nxt[u] = ahead[u];
     }
     // a tile is four word columns: sum over its lanes through LDS (one wave per workgroup: no barrier needed)
     if (owner && nd) atomicAdd(&s_tile[grp][(gl - 1) / kTileWords], nd);
@@ -427,8 +458,37 @@ __global__ __launch_bounds__(256) void k_dart_link(int W, int H, uint32_t first_
                                                    uint32_t* __restrict__ d_succ, uint32_t n_darts, const uint32_t* __restrict__ n_live) {
     if (n_live) n_darts = min(n_darts, *n_live);
     const int wpr = (int)words_per_row((uint32_t)W);
-    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x)
-        if (d_succ[d] == kNone) d_succ[d] = cross_tile_succ(d, d_rec[d], W, H, wpr, first_frame, pix_base, bits);
+    // A wave sweeps 8 x 64 successors per step (eight loads in flight per lane); the few that are open (~4 %) are then dealt
+    // out over the lanes -- lane j takes the j-th open dart of the step, found from the eight ballot masks -- so that the
+    // chain of dependent loads behind an open successor (record -> image words -> pix_base) is walked once per step by ~20
+    // busy lanes, not once per load by one or two.
+    constexpr int B = 8;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t w0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); w0 < n_darts; w0 += B * stride) {   // wave-uniform
+        uint32_t sv[B];
+#pragma unroll
+        for (int u = 0; u < B; u++) sv[u] = d_succ[min(w0 + lane + (uint32_t)u * stride, n_darts - 1u)];
+        uint64_t m[B];
+        uint32_t total = 0;
+#pragma unroll
+        for (int u = 0; u < B; u++) {
+            m[u] = __ballot(w0 + lane + (uint32_t)u * stride < n_darts && sv[u] == kNone);
+            total += (uint32_t)__popcll(m[u]);
+        }
+        for (uint32_t j = lane; j < total; j += 64u) {
+            uint32_t acc = 0, r = 0, su = 0;
+            uint64_t mm = 0;
+#pragma unroll
+            for (int u = 0; u < B; u++) {
+                const uint32_t c = (uint32_t)__popcll(m[u]);
+                if (j >= acc && j < acc + c) { mm = m[u]; r = j - acc; su = (uint32_t)u; }
+                acc += c;
+            }
+            const uint32_t d = w0 + (uint32_t)select_bit(mm, r) + su * stride;
+            d_succ[d] = cross_tile_succ(d, d_rec[d], W, H, wpr, first_frame, pix_base, bits);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -735,17 +795,31 @@ __global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const J
     const uint32_t shard = blockIdx.x & (kLeaderShards - 1);   // spread the slot counter over 16 addresses
     const uint32_t stride = gridDim.x * blockDim.x;            // the launcher keeps ceil(n_darts / stride) <= 32
     uint32_t mask = 0;                                          // bit i: my i-th dart leads a cycle that has a start event
+    // Four darts per lane at a time, each of the three dependent loads (local state -> slot of the entry the window froze at ->
+    // that entry's state) issued for all four before the first is used: the kernel is a chain of round trips to memory, and
+    // one dart at a time it is three of them per dart.  Loads are unconditional from clamped indices (slot 0 for windows that
+    // did not freeze: a cached line); behind an `if` the compiler would issue them one at a time again.
+    constexpr int B = 4;
     int it = 0;
-    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += stride, it++) {
-        JumpState s = loc[d];
-        const uint32_t od = s.off;
-        s.off = loc_off(od);
-        if (od & kFrozen) {
-            const EntryState g = es[entry_pos[s.ptr]];
-            if (g.key < s.key) { s.key = g.key; s.off = loc_dist(od) + g.off; }
+    for (uint32_t d0 = blockIdx.x * blockDim.x + threadIdx.x; d0 < n_darts; d0 += B * stride, it += B) {
+        JumpState s[B];
+        uint32_t od[B], pos[B];
+        EntryState g[B];
+#pragma unroll
+        for (int u = 0; u < B; u++) s[u] = loc[min(d0 + (uint32_t)u * stride, n_darts - 1u)];
+#pragma unroll
+        for (int u = 0; u < B; u++) { od[u] = s[u].off; pos[u] = entry_pos[(od[u] & kFrozen) ? s[u].ptr : 0u]; }
+#pragma unroll
+        for (int u = 0; u < B; u++) g[u] = es[(od[u] & kFrozen) ? pos[u] : 0u];
+#pragma unroll
+        for (int u = 0; u < B; u++) {
+            const uint32_t d = d0 + (uint32_t)u * stride;
+            if (d >= n_darts) break;
+            s[u].off = loc_off(od[u]);
+            if ((od[u] & kFrozen) && g[u].key < s[u].key) { s[u].key = g[u].key; s[u].off = loc_dist(od[u]) + g[u].off; }
+            fin[d] = s[u];
+            if ((uint32_t)s[u].key == d && (uint32_t)(s[u].key >> 32) != kNoKey) mask |= 1u << (it + u);
         }
-        fin[d] = s;
-        if ((uint32_t)s.key == d && (uint32_t)(s.key >> 32) != kNoKey) mask |= 1u << it;
     }
     // one global atomic per workgroup: leaders are counted in a block scan first
     uint32_t total;
@@ -1025,18 +1099,44 @@ __global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restr
                                                         const uint32_t* __restrict__ n_live, const DeviceCounters* __restrict__ ctr) {
     if (ctr->entry_overflow) return;
     if (n_live) n_darts = min(n_darts, *n_live);
-    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
-        const JumpState s = st[d];
-        if ((uint32_t)(s.key >> 32) == kNoKey) continue;   // no start event anywhere on this cycle: never traced
-        const uint32_t leader = (uint32_t)s.key;
-        if ((uint32_t)st[leader].key != leader) continue;  // open chain: its "leader" slot was never written
-        const uint32_t c = cyc_slot[leader];
-        if (c == kNone) continue;
-        const ContourRec r = contours[c];
-        const uint32_t so = cyc_start_off[c];
-        // off = hops forward to the leader; position along the border counted from the start dart
-        const uint32_t rank = so >= s.off ? so - s.off : so + r.n - s.off;
-        points[r.point_base + rank] = rec_xy(d_rec[d]);
+    // Four darts per lane at a time, three rounds of loads instead of five per dart: {state, record} -> {leader's key, border
+    // slot of the leader} -> {border record, start offset}.  Unconditional loads from clamped indices, see k_jump_finalize.
+    constexpr int B = 4;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t d0 = blockIdx.x * blockDim.x + threadIdx.x; d0 < n_darts; d0 += B * stride) {
+        JumpState s[B];
+        uint64_t rec[B];
+        uint32_t c[B], so[B];
+        uint64_t lk[B];
+        ContourRec r[B];
+        bool live[B];
+#pragma unroll
+        for (int u = 0; u < B; u++) {
+            const uint32_t d = min(d0 + (uint32_t)u * stride, n_darts - 1u);
+            s[u] = st[d]; rec[u] = d_rec[d];
+        }
+#pragma unroll
+        for (int u = 0; u < B; u++) {
+            live[u] = d0 + (uint32_t)u * stride < n_darts && (uint32_t)(s[u].key >> 32) != kNoKey;   // else: no start event on this cycle
+            const uint32_t leader = live[u] ? (uint32_t)s[u].key : 0u;
+            c[u] = cyc_slot[leader];
+            lk[u] = st[leader].key;
+        }
+#pragma unroll
+        for (int u = 0; u < B; u++) {
+            // a leader that does not hold its own key: an open chain, or states of a run that has not converged (the batch is
+            // then re-run) -- its slot was never written this batch
+            live[u] = live[u] && (uint32_t)lk[u] == (uint32_t)s[u].key && c[u] != kNone;
+            r[u] = contours[live[u] ? c[u] : 0u];
+            so[u] = cyc_start_off[live[u] ? c[u] : 0u];
+        }
+#pragma unroll
+        for (int u = 0; u < B; u++) {
+            if (!live[u]) continue;
+            // off = hops forward to the leader; position along the border counted from the start dart
+            const uint32_t rank = so[u] >= s[u].off ? so[u] - s[u].off : so[u] + r[u].n - s[u].off;
+            points[r[u].point_base + rank] = rec_xy(rec[u]);
+        }
     }
 }
 
