@@ -1207,6 +1207,30 @@ __global__ void k_debug_clockwise(const int32_t* __restrict__ in, uint32_t n, in
     for (int k = 0; k < 8; k++) out[8 * i + k] = q[k];
 }
 
+// Largest value over a group of G = 64 or 16 lanes, returned in every lane of the group.  DPP row shifts (and, for the wave,
+// row broadcasts) run in the VALU; a butterfly of __shfl_xor is two ds_bpermute round trips through the LDS crossbar per
+// step for a 64-bit value, and Douglas-Peucker waits for one such reduction per chord.
+#define A3_DPP_MAX64(V, CTRL, ROWMASK)                                                                                   \
+    {                                                                                                                    \
+        const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(V), CTRL, ROWMASK, 0xF, false);        \
+        const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)((V) >> 32), CTRL, ROWMASK, 0xF, false); \
+        const unsigned long long o_ = ((unsigned long long)hi_ << 32) | lo_;                                             \
+        (V) = o_ > (V) ? o_ : (V);                                                                                       \
+    }
+template <int G>
+__device__ __forceinline__ unsigned long long group_max_u64(unsigned long long v) {
+    A3_DPP_MAX64(v, 0x111, 0xF)   // row_shr:1 .. 8: lane 15 of every row of 16 holds the row's maximum (lanes without a source keep 0)
+    A3_DPP_MAX64(v, 0x112, 0xF)
+    A3_DPP_MAX64(v, 0x114, 0xF)
+    A3_DPP_MAX64(v, 0x118, 0xF)
+    if constexpr (G == 16) return __shfl(v, 15, 16);
+    A3_DPP_MAX64(v, 0x142, 0xA)   // row_bcast:15 into rows 1 and 3
+    A3_DPP_MAX64(v, 0x143, 0xC)   // row_bcast:31 into rows 2 and 3: lane 63 holds the maximum
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+#undef A3_DPP_MAX64
+
 // G lanes work on one border: 64 for long ones, 16 (four borders per wave) for the short ones that noisy frames produce by
 // the hundred thousand -- a full wave per 20-point border is latency with 60 idle lanes.  Control flow is uniform inside a
 // group and the shuffles stay inside it.
@@ -1257,11 +1281,7 @@ __device__ __forceinline__ void contour_quads_body(uint32_t block, uint32_t n_bl
                     if (cand > best) best = cand;
                 }
             }
-#pragma unroll
-            for (int o = G / 2; o > 0; o >>= 1) {
-                const unsigned long long other = __shfl_xor(best, o);
-                if (other > best) best = other;
-            }
+            best = group_max_u64<G>(best);
             const unsigned long long num = best >> 30;
             if (num == 0) continue;
             const uint32_t index = ~(uint32_t)best & 0x3FFFFFFFu;

@@ -255,35 +255,37 @@ __device__ __forceinline__ uint32_t luma_px(uint32_t px, bool bgr) {
 // imageproc interpolate_bilinear: default (0) outside, the two horizontal lerps truncated to u8 first.
 // Split in two so that a lane can have the loads of several samples in flight before it converts any of them:
 // issue() decides the case and starts the two 12-byte row reads, finish() turns them into the sample.
+// The reads are UNCONDITIONAL -- a sample that falls outside the frame, or so close to its end that a 12-byte read would run
+// past it, reads the frame's first bytes instead and ignores them -- and the case is data (`mode`), not control flow: with the
+// loads behind an `if`, the compiler threads the case through to finish() and ends up with issue + wait + finish per sample,
+// i.e. one round trip to memory per sample instead of one per kU samples.
 struct TapLoad {
     uint32_t top[3], bot[3];
     float rw, bw;
-    uint32_t sh;         // byte misalignment of the first tap, in bits
-    int mode;            // 0 outside (sample = 0), 1 wide loads issued, 2 near the end of the frame: byte loads in finish()
+    uint32_t sh;         // byte misalignment of the first tap, in bits (top row | bottom row << 8)
+    int mode;            // 0 outside (sample = 0), 1 wide loads hold the taps, 2 near the end of the frame: byte loads in finish()
     uint32_t l, t;       // first tap (mode 2 only)
 };
 
-__device__ __forceinline__ void sample_issue(TapLoad& tl, const uint8_t* __restrict__ img, size_t row_stride, uint32_t bpp, uint32_t w, uint32_t h,
-                                             float x, float y, bool valid) {
+__device__ __forceinline__ void sample_issue(TapLoad& tl, const uint8_t* __restrict__ img, const uint8_t* __restrict__ safe, size_t row_stride,
+                                             uint32_t bpp, uint32_t w, uint32_t h, float x, float y, bool valid) {
+    // safe: where a sample without wide taps reads instead -- the frame itself, unless it is smaller than one wide read
     const float left = floorf(x), right = left + 1.0f, top = floorf(y), bottom = top + 1.0f;
     tl.rw = x - left; tl.bw = y - top;
-    tl.mode = 0;
-    if (!valid || left < 0.0f || right >= (float)w || top < 0.0f || bottom >= (float)h) return;
-    const uint32_t l = sat_u32(left), t = sat_u32(top), b = sat_u32(bottom);
-    const uint8_t* rt = img + (size_t)t * row_stride;
-    const uint8_t* rb = img + (size_t)b * row_stride;
+    const bool inside = valid && !(left < 0.0f || right >= (float)w || top < 0.0f || bottom >= (float)h);
+    const uint32_t l = inside ? sat_u32(left) : 0u, t = inside ? sat_u32(top) : 0u, b = inside ? sat_u32(bottom) : 0u;
     tl.l = l; tl.t = t;
     // the wide read of the bottom row must end inside this frame (running on into the next row is fine)
-    if ((size_t)b * row_stride + (size_t)bpp * l + 12u <= (size_t)(h - 1u) * row_stride + (size_t)w * bpp) {
-        const uintptr_t pt = reinterpret_cast<uintptr_t>(rt) + (size_t)bpp * l, pb = reinterpret_cast<uintptr_t>(rb) + (size_t)bpp * l;
-        const uint32_t* qt = reinterpret_cast<const uint32_t*>(pt & ~(uintptr_t)3);
-        const uint32_t* qb = reinterpret_cast<const uint32_t*>(pb & ~(uintptr_t)3);
-        tl.top[0] = qt[0]; tl.top[1] = qt[1]; tl.top[2] = qt[2];
-        tl.bot[0] = qb[0]; tl.bot[1] = qb[1]; tl.bot[2] = qb[2];
-        // both rows start at the same misalignment only if row_stride % 4 == 0; keep one shift per row in sh's halves
-        tl.sh = ((uint32_t)(pt & 3u) * 8u) | (((uint32_t)(pb & 3u) * 8u) << 8);
-        tl.mode = 1;
-    } else tl.mode = 2;
+    const bool wide = inside && (size_t)b * row_stride + (size_t)bpp * l + 12u <= (size_t)(h - 1u) * row_stride + (size_t)w * bpp;
+    tl.mode = inside ? (wide ? 1 : 2) : 0;
+    const uintptr_t pt = reinterpret_cast<uintptr_t>(wide ? img + (size_t)t * row_stride + (size_t)bpp * l : safe);
+    const uintptr_t pb = reinterpret_cast<uintptr_t>(wide ? img + (size_t)b * row_stride + (size_t)bpp * l : safe);
+    const uint32_t* qt = reinterpret_cast<const uint32_t*>(pt & ~(uintptr_t)3);
+    const uint32_t* qb = reinterpret_cast<const uint32_t*>(pb & ~(uintptr_t)3);
+    tl.top[0] = qt[0]; tl.top[1] = qt[1]; tl.top[2] = qt[2];
+    tl.bot[0] = qb[0]; tl.bot[1] = qb[1]; tl.bot[2] = qb[2];
+    // both rows start at the same misalignment only if row_stride % 4 == 0; keep one shift per row in sh's halves
+    tl.sh = ((uint32_t)(pt & 3u) * 8u) | (((uint32_t)(pb & 3u) * 8u) << 8);
 }
 
 __device__ __forceinline__ void pair_from(const uint32_t d[3], uint32_t sh, int fmt, uint32_t bpp, float* g0, float* g1) {
@@ -296,19 +298,18 @@ __device__ __forceinline__ void pair_from(const uint32_t d[3], uint32_t sh, int 
 }
 
 __device__ __forceinline__ uint8_t sample_finish(const TapLoad& tl, const uint8_t* __restrict__ img, size_t row_stride, int fmt, uint32_t bpp) {
-    if (tl.mode == 0) return 0;
     float a, b, c, d;
-    if (tl.mode == 1) {
-        pair_from(tl.top, tl.sh & 0xFFu, fmt, bpp, &a, &b);
-        pair_from(tl.bot, tl.sh >> 8, fmt, bpp, &c, &d);
-    } else {
+    pair_from(tl.top, tl.sh & 0xFFu, fmt, bpp, &a, &b);
+    pair_from(tl.bot, tl.sh >> 8, fmt, bpp, &c, &d);
+    if (tl.mode == 2) {   // the last few pixels of a frame: byte loads
         const uint8_t* rt = img + (size_t)tl.t * row_stride;
         const uint8_t* rb = rt + row_stride;
         a = grey_tap(rt, tl.l, fmt); b = grey_tap(rt, tl.l + 1u, fmt); c = grey_tap(rb, tl.l, fmt); d = grey_tap(rb, tl.l + 1u, fmt);
     }
     const uint8_t tv = clamp_u8((1.0f - tl.rw) * a + tl.rw * b);
     const uint8_t bv = clamp_u8((1.0f - tl.rw) * c + tl.rw * d);
-    return clamp_u8((1.0f - tl.bw) * (float)tv + tl.bw * (float)bv);
+    const uint8_t v = clamp_u8((1.0f - tl.bw) * (float)tv + tl.bw * (float)bv);
+    return tl.mode == 0 ? (uint8_t)0 : v;
 }
 
 __device__ __forceinline__ float triangle_kernel(float x) { return fabsf(x) < 1.0f ? 1.0f - fabsf(x) : 0.0f; }
@@ -449,6 +450,8 @@ __global__ __launch_bounds__(NT, NT == 64 ? A3_D_WAVES : 3) void k_decode(PixelS
 #define A3_D_BLOCKED 1
 #endif
             const uint32_t bpp = (src.fmt == A3_FMT_RGB8) ? 3u : ((src.fmt == A3_FMT_RGBA8 || src.fmt == A3_FMT_BGRA8) ? 4u : 1u);
+            // (a frame smaller than one wide read cannot hold a candidate; the weight table is merely something of 16 KB to read)
+            const uint8_t* safe = (size_t)(H - 1) * src.row_stride + (size_t)W * bpp >= 16u ? img : reinterpret_cast<const uint8_t*>(wtab);
             const uint32_t nbx = (S + 7u) / 8u, n_slots = A3_D_BLOCKED ? nbx * nbx * 64u : S * S;
             // slot -> (x, y); i / S by a multiply-high in the row-major order (S is uniform but not a compile-time constant)
             const uint32_t M = S > 1 ? 0xFFFFFFFFu / S + 1u : 0u, Mb = 0xFFFFFFFFu / nbx + 1u;
@@ -472,7 +475,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? A3_D_WAVES : 3) void k_decode(PixelS
                     const float d = t6 * fx + t7 * fy + t8;
                     const float px = (t0 * fx + t1 * fy + t2) / d;
                     const float py = (t3 * fx + t4 * fy + t5) / d;
-                    sample_issue(tl[u], img, (size_t)src.row_stride, bpp, (uint32_t)W, (uint32_t)H, px, py, valid);
+                    sample_issue(tl[u], img, safe, (size_t)src.row_stride, bpp, (uint32_t)W, (uint32_t)H, px, py, valid);
                 }
 #pragma unroll
                 for (int u = 0; u < kU; u++) {
