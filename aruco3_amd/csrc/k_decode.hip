@@ -387,6 +387,9 @@ __device__ __forceinline__ void rotated_source(uint32_t r, uint32_t n, uint32_t 
 #ifndef A3_D_THREADS
 #define A3_D_THREADS 64
 #endif
+#ifndef A3_D_DB
+#define A3_D_DB 8     // dictionary codes per lane and trip in the nearest-code scan
+#endif
 // NT threads work on one candidate.  NT = 64 (one wave per candidate, the default): the "barriers" below are free, and --
 // what matters -- hundreds of candidates per CU are in flight at different stages, so the sampling of some (bound by the
 // rate at which the texture-address path takes 64 scattered requests per instruction) overlaps the LDS / VALU stages of
@@ -433,6 +436,23 @@ __global__ __launch_bounds__(NT, NT == 64 ? A3_D_WAVES : 3) void k_decode(PixelS
         __syncthreads();
         const bool ok = s_ok != 0;
         const uint32_t pw = ok ? S : 1u, ph = pw;
+        // resize weights (same table for both passes: the patch and the grid are square): the launch-wide table for a full
+        // patch, computed in place for the 1x1 stand-in of a failed projection (quirk Q4).  Fetched here, ahead of the
+        // sampling, so that the trip to the table is not on the path between the Otsu level and the resize.
+        if (ok) {
+            for (uint32_t i = tid; i < n * (max_taps + 2); i += NT) {
+                const uint32_t oi = i / (max_taps + 2), k = i - oi * (max_taps + 2);
+                const float v = wtab[i];
+                if (k == 0) s_left[oi] = __float_as_uint(v);
+                else if (k == 1) s_cnt[oi] = __float_as_uint(v);
+                else if (k - 2 < __float_as_uint(wtab[(size_t)oi * (max_taps + 2) + 1])) s_w[(size_t)oi * max_taps + (k - 2)] = v;
+            }
+        } else if (tid < (int)n) {
+            const uint32_t oi = tid;
+            uint32_t cnt;
+            s_left[oi] = resize_weights(pw, n, oi, s_w + (size_t)oi * max_taps, &cnt);
+            s_cnt[oi] = cnt;
+        }
         // warp_into: integer output coordinates, no centre offset, mapping = the projection's inverse
         if (ok && dbg == 1) {
             for (uint32_t i = tid; i < S * S; i += NT) { s_patch[i] = (uint8_t)(i * 7u); atomicAdd(&s_hist[(i * 7u) & 255u], 1u); }
@@ -561,35 +581,17 @@ __global__ __launch_bounds__(NT, NT == 64 ? A3_D_WAVES : 3) void k_decode(PixelS
             }
         }
         if (dbg == 3) continue;
-        // resize weights (same table for both passes: the patch and the grid are square): the launch-wide table for a full
-        // patch, computed in place for the 1x1 stand-in of a failed projection (quirk Q4)
-        if (ok) {
-            for (uint32_t i = tid; i < n * (max_taps + 2); i += NT) {
-                const uint32_t oi = i / (max_taps + 2), k = i - oi * (max_taps + 2);
-                const float v = wtab[i];
-                if (k == 0) s_left[oi] = __float_as_uint(v);
-                else if (k == 1) s_cnt[oi] = __float_as_uint(v);
-                else if (k - 2 < __float_as_uint(wtab[(size_t)oi * (max_taps + 2) + 1])) s_w[(size_t)oi * max_taps + (k - 2)] = v;
-            }
-        } else if (tid < (int)n) {
-            const uint32_t oi = tid;
-            uint32_t cnt;
-            s_left[oi] = resize_weights(pw, n, oi, s_w + (size_t)oi * max_taps, &cnt);
-            s_cnt[oi] = cnt;
-        }
-        __syncthreads();
+        // threshold(.., Binary) is applied where the patch is read: a pixel counts as 255 iff it is above the Otsu level
         const uint32_t otsu = s_otsu;
-        for (uint32_t i = tid; i < pw * ph; i += NT) s_patch[i] = s_patch[i] > otsu ? 255 : 0;  // threshold(.., Binary)
-        __syncthreads();
         if (pw == n) {  // resize() copies when the size already matches
-            for (uint32_t i = tid; i < n * n; i += NT) s_bits[i] = s_patch[i] > 127;
+            for (uint32_t i = tid; i < n * n; i += NT) s_bits[i] = s_patch[i] > otsu;   // (255 or 0) > 127
         } else {
             for (uint32_t i = tid; i < n * pw; i += NT) {  // vertical pass into f32
                 const uint32_t oy = i / pw, x = i - oy * pw;
                 const float* ws = s_w + (size_t)oy * max_taps;
                 const uint32_t left = s_left[oy], cnt = s_cnt[oy];
                 float t = 0.0f;
-                for (uint32_t k = 0; k < cnt; k++) t += (float)s_patch[(left + k) * pw + x] * ws[k];
+                for (uint32_t k = 0; k < cnt; k++) t += (s_patch[(left + k) * pw + x] > otsu ? 255.0f : 0.0f) * ws[k];
                 s_tmp[oy * pw + x] = t;
             }
             __syncthreads();
@@ -608,14 +610,15 @@ __global__ __launch_bounds__(NT, NT == 64 ? A3_D_WAVES : 3) void k_decode(PixelS
         // border test + 4 rotated codes, src/aruco.rs:287-310.  One lane per (rotation, cell): the bit goes to its place in
         // the code with an LDS atomic (row-major, first cell = most significant bit).
         if (tid < 4) s_codes[tid] = 0;
-        if (tid == 4) {
-            int have = 1;
+        {   // the marker's border must be black all round: one lane per border cell (left, right, top, bottom x n)
             const uint32_t end = n ? n - 1 : 0;
-            for (uint32_t i = 0; i < n && have; i++) {
-                if (s_bits[i * n] || s_bits[i * n + end]) have = 0;
-                else if (s_bits[i] || s_bits[end * n + i]) have = 0;
+            int lit = 0;
+            for (uint32_t t = (uint32_t)tid; t < 4u * n; t += NT) {
+                const uint32_t side = t / n, i = t - side * n;
+                lit |= s_bits[side == 0 ? i * n : (side == 1 ? i * n + end : (side == 2 ? i : end * n + i))];
             }
-            s_have = have;
+            const int any_lit = __syncthreads_or(lit);
+            if (tid == 0) s_have = !any_lit;
         }
         __syncthreads();
         {
@@ -637,16 +640,27 @@ __global__ __launch_bounds__(NT, NT == 64 ? A3_D_WAVES : 3) void k_decode(PixelS
         unsigned long long best[4] = {~0ull, ~0ull, ~0ull, ~0ull};
         if (have) {
             const uint64_t c0 = s_codes[0], c1 = s_codes[1], c2 = s_codes[2], c3 = s_codes[3];
-            for (uint32_t i = tid; i < n_codes; i += NT) {
-                const uint64_t c = dict[i];
-                const unsigned long long k0 = ((unsigned long long)__popcll(c ^ c0) << 32) | i;
-                const unsigned long long k1 = ((unsigned long long)__popcll(c ^ c1) << 32) | i;
-                const unsigned long long k2 = ((unsigned long long)__popcll(c ^ c2) << 32) | i;
-                const unsigned long long k3 = ((unsigned long long)__popcll(c ^ c3) << 32) | i;
-                best[0] = k0 < best[0] ? k0 : best[0];
-                best[1] = k1 < best[1] ? k1 : best[1];
-                best[2] = k2 < best[2] ? k2 : best[2];
-                best[3] = k3 < best[3] ? k3 : best[3];
+            // eight codes per lane and trip, their loads issued together (unconditional, clamped index): one code per trip is a
+            // chain of n_codes / 64 round trips to the table -- 16 for a 1024-code dictionary
+            constexpr int DB = A3_D_DB;
+            for (uint32_t i0 = tid; i0 < n_codes; i0 += NT * DB) {
+                uint64_t cw[DB];
+#pragma unroll
+                for (int u = 0; u < DB; u++) cw[u] = dict[min(i0 + (uint32_t)(u * NT), n_codes - 1u)];
+#pragma unroll
+                for (int u = 0; u < DB; u++) {
+                    const uint32_t i = i0 + (uint32_t)(u * NT);
+                    const unsigned long long past = 0ull - (unsigned long long)(i >= n_codes);   // all ones: never the minimum
+                    const uint64_t c = cw[u];
+                    const unsigned long long k0 = (((unsigned long long)__popcll(c ^ c0) << 32) | i) | past;
+                    const unsigned long long k1 = (((unsigned long long)__popcll(c ^ c1) << 32) | i) | past;
+                    const unsigned long long k2 = (((unsigned long long)__popcll(c ^ c2) << 32) | i) | past;
+                    const unsigned long long k3 = (((unsigned long long)__popcll(c ^ c3) << 32) | i) | past;
+                    best[0] = k0 < best[0] ? k0 : best[0];
+                    best[1] = k1 < best[1] ? k1 : best[1];
+                    best[2] = k2 < best[2] ? k2 : best[2];
+                    best[3] = k3 < best[3] ? k3 : best[3];
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; r++)
