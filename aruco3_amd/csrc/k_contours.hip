@@ -633,6 +633,8 @@ __global__ __launch_bounds__(256, 4) void k_local_contract(uint32_t n_darts, int
     // was tried: most windows of a clean frame only become final in the last rounds, and the extra flags made it 20 % slower.)
     const int n_rounds = dbg == 0 ? 11 : (dbg < 0 ? 0 : dbg);
     for (int round = 0; round < n_rounds; round++) {
+        uint32_t upd = 0;   // bit u: window u was joined with its successor window in this round (a frozen one is not: its
+                            // LDS copy stays as it is and need not be written again)
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             const uint32_t i = threadIdx.x + u * 256;
@@ -643,6 +645,7 @@ __global__ __launch_bounds__(256, 4) void k_local_contract(uint32_t n_darts, int
                     if (w.key < nk[u]) { nk[u] = w.key; no[u] = nd[u] + (w.offdist & 0xFFFFu); }
                     nd[u] += w.offdist >> 16;
                     np[u] = w.ptr;
+                    upd |= 1u << u;
                 }
             }
         }
@@ -650,10 +653,12 @@ __global__ __launch_bounds__(256, 4) void k_local_contract(uint32_t n_darts, int
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             const uint32_t i = threadIdx.x + u * 256;
-            if (i < cnt) s_win[i] = Win{nk[u], np[u], no[u] | (nd[u] << 16)};
+            if (upd & (1u << u)) s_win[i] = Win{nk[u], np[u], no[u] | (nd[u] << 16)};
         }
         lds_barrier();
     }
+    // (Leaving the loop as soon as no window of the tile grew any more -- all frozen, wrapped round their cycle, or run into a
+    // dead end -- was tried as well: most tiles of a clean frame hold a chain that needs all eleven rounds.)
     // results
     if (frame_entries) { if (threadIdx.x < kFrameWin) s_fbase[threadIdx.x] = slot_a + slot_b; }
     else if (threadIdx.x == 0) s_new_base = slot_a + slot_b;
