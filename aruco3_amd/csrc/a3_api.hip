@@ -405,10 +405,10 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
         A3_HIP(launch_rank_cycles(st, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(),
                                   ctx->stA.as<JumpState>(),
                                   ctx->entry_list.as<uint32_t>(), ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
-                                  ctx->stB.as<JumpState>(), ctx->leader_list.as<uint32_t>(), d_leader_count, rounds, ctr, n_live, 0, fb,
+                                  ctx->stA.as<JumpState>() /* final states in place */, ctx->leader_list.as<uint32_t>(), d_leader_count, rounds, ctr, n_live, 0, fb,
                                   ctx->entry_global_ttl > 0 ? nullptr : ctx->frame_cursor /* per-frame entry counts */, c.count));
         ctx->dbg_nd = nd; ctx->dbg_frames = c.count; ctx->dbg_chunks = (uint32_t)chunks.size();
-        const JumpState* fin = ctx->stB.as<JumpState>();
+        const JumpState* fin = ctx->stA.as<JumpState>();
         A3_HIP(launch_resolve(st, fin, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->leader_list.as<uint32_t>(), d_leader_count,
                               ctx->t_cur.as<uint64_t>(), ctx->t_next.as<uint64_t>(), ctr, ctx->resolve_full_ttl > 0 ? ctx->resolve_iters_hint : 0, n_live));
         A3_HIP(launch_select_scatter(st, fin, nd, ctx->leader_list.as<uint32_t>(), d_leader_count, ctx->d_succ.as<uint32_t>(), ctx->t_cur.as<uint64_t>(), fb, c.count, c.first, min_edge_length,

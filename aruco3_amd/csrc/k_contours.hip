@@ -530,6 +530,10 @@ constexpr uint32_t kFrozen = 0x80000000u;     // the window reached a dart outsi
 // (bits 0-11, <= 2047), window length in hops (bits 12-24, <= 2048) and kFrozen
 __device__ __forceinline__ uint32_t loc_pack(uint32_t off, uint32_t dist, bool frozen) { return off | (dist << 12) | (frozen ? kFrozen : 0u); }
 __device__ __forceinline__ uint32_t loc_off(uint32_t w) { return w & 0xFFFu; }
+// After k_jump_finalize the `off` word of a dart is either still the packed local one (the local window was final: its low 12
+// bits are the hop count) or kFinal | hops to the leader (< 2^30)
+constexpr uint32_t kFinal = 0x40000000u;
+__device__ __forceinline__ uint32_t fin_off(uint32_t w) { return (w & kFinal) ? (w & 0x3FFFFFFFu) : (w & 0xFFFu); }
 __device__ __forceinline__ uint32_t loc_dist(uint32_t w) { return (w >> 12) & 0x1FFFu; }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global load, store and returning
@@ -786,9 +790,10 @@ __host__ __device__ inline uint32_t leader_shard_cap(uint32_t n_darts) { return 
 
 // ... and the leaders of cycles that carry at least one start event are collected (one atomic per wave) for the
 // per-border kernels that follow.
-__global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const JumpState* __restrict__ loc,
+__global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const JumpState* loc,
                                                        const uint32_t* __restrict__ entry_pos, const EntryState* __restrict__ es,
-                                                       JumpState* __restrict__ fin, uint32_t* __restrict__ leader_list,
+                                                       JumpState* fin /* may be loc: only the states that change are then written */,
+                                                       uint32_t* __restrict__ leader_list,
                                                        unsigned int* __restrict__ leader_count /*[kLeaderShards]*/, uint32_t shard_cap,
                                                        const uint32_t* __restrict__ n_live, const DeviceCounters* __restrict__ ctr) {
     // a frame's entries did not fit k_entry_frame's LDS: their states were never written and the batch is re-run; with no
@@ -820,9 +825,11 @@ __global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const J
         for (int u = 0; u < B; u++) {
             const uint32_t d = d0 + (uint32_t)u * stride;
             if (d >= n_darts) break;
-            s[u].off = loc_off(od[u]);
-            if ((od[u] & kFrozen) && g[u].key < s[u].key) { s[u].key = g[u].key; s[u].off = loc_dist(od[u]) + g[u].off; }
-            fin[d] = s[u];
+            // a window that was final inside its tile -- wrapped, or frozen at an entry whose own cycle minimum is not smaller --
+            // keeps its state as it is (fin_off reads the packed word); two thirds of the states are not written again
+            const bool better = (od[u] & kFrozen) && g[u].key < s[u].key;
+            if (better) { s[u].key = g[u].key; s[u].off = (loc_dist(od[u]) + g[u].off) | kFinal; }
+            if (better || fin != loc) fin[d] = s[u];
             if ((uint32_t)s[u].key == d && (uint32_t)(s[u].key >> 32) != kNoKey) mask |= 1u << (it + u);
         }
     }
@@ -1010,7 +1017,7 @@ __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restric
         // the successor's window must have wrapped around to this leader, else this is a chain, not a cycle
         const uint32_t sl = d_succ[e.d];
         if (sl == e.d || (uint32_t)st[sl].key != e.d) { e.broken = true; return e; }
-        e.n = st[sl].off + 1u;
+        e.n = fin_off(st[sl].off) + 1u;
         // Parity-safe pruning (src/aruco.rs:133-158):
         //  (1) a candidate keeps 4 points whose hull-adjacent pairs are >= sqrt(min_edge_length) apart; two
         //      border points i < j are at most min(j-i, n-(j-i)) 8-connected steps apart, i.e.
@@ -1089,7 +1096,7 @@ __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restric
                 r.point_base = (uint32_t)pb;
                 r.n = e.n;
                 contours[c] = r;
-                cyc_start_off[c] = st[(uint32_t)e.t].off;
+                cyc_start_off[c] = fin_off(st[(uint32_t)e.t].off);
                 slot = c;
             }
             c++; pb += e.n;
@@ -1139,7 +1146,8 @@ __global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restr
         for (int u = 0; u < B; u++) {
             if (!live[u]) continue;
             // off = hops forward to the leader; position along the border counted from the start dart
-            const uint32_t rank = so[u] >= s[u].off ? so[u] - s[u].off : so[u] + r[u].n - s[u].off;
+            const uint32_t off = fin_off(s[u].off);
+            const uint32_t rank = so[u] >= off ? so[u] - off : so[u] + r[u].n - off;
             points[r[u].point_base + rank] = rec_xy(rec[u]);
         }
     }
