@@ -703,12 +703,28 @@ __global__ __launch_bounds__(256) void k_entry_frame(const uint32_t* __restrict_
     const uint32_t cnt = frame_entries[f], base = frame_base[f];
     if (cnt == 0) return;
     if (cnt > kEntryLdsCap) { if (threadIdx.x == 0) ctr->entry_overflow = 1u; return; }
-    for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
-        const uint32_t e = entry_list[base + i];
-        const JumpState l = loc[e];
-        s_key[i] = l.key; s_off[i] = loc_off(l.off); s_dist[i] = loc_dist(l.off);
-        // an entry's local window always freezes (its predecessor lies in another tile) unless its chain dead-ends in the tile
-        s_ptr[i] = (l.off & kFrozen) ? entry_pos[l.ptr] - base : i;
+    // the three dependent loads (entry -> its local state -> slot of the entry it froze at) for two entries per lane at a time:
+    // a clean frame has a few hundred entries, i.e. one trip of this loop
+    for (uint32_t i0 = threadIdx.x; i0 < cnt + threadIdx.x; i0 += 512) {   // (uniform trip count)
+        uint32_t e[2], pos[2];
+        JumpState l[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) e[u] = entry_list[base + min(i0 + 256u * u, cnt - 1u)];
+#pragma unroll
+        for (int u = 0; u < 2; u++) l[u] = loc[e[u]];
+#pragma unroll
+        for (int u = 0; u < 2; u++) pos[u] = entry_pos[l[u].ptr];   // (some dart, and ignored, when the window did not freeze)
+        // (the values are "used" here so that the compiler cannot sink entry 1's loads into the `i < cnt` test below, which
+        // would turn two overlapped chains of three round trips into six in a row)
+        asm volatile("" : "+v"(pos[0]), "+v"(pos[1]), "+v"(l[0].key), "+v"(l[1].key), "+v"(l[0].off), "+v"(l[1].off));
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint32_t i = i0 + 256u * u;
+            if (i >= cnt) break;
+            s_key[i] = l[u].key; s_off[i] = loc_off(l[u].off); s_dist[i] = loc_dist(l[u].off);
+            // an entry's local window always freezes (its predecessor lies in another tile) unless its chain dead-ends in the tile
+            s_ptr[i] = (l[u].off & kFrozen) ? pos[u] - base : i;
+        }
     }
     __syncthreads();
     constexpr int PER = kEntryLdsCap / 256;
@@ -869,13 +885,20 @@ __device__ __forceinline__ bool natural_start_fires(uint32_t d, uint64_t key0, c
     const uint32_t base = d - __popc(P & ((1u << k) - 1u));
     const int cnt = __popc(P);
     bool wfires = true;
-    for (int j = 0; j < cnt; j++) {
-        const uint64_t kj = st[base + j].key;
-        const uint32_t leader = (uint32_t)kj;
+    // a pixel owns at most four darts: their keys, then their leaders' keys, each as one batch of loads (clamped indices) rather
+    // than a chain of up to eight round trips with an early exit
+    uint64_t kj[4], lk[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) kj[j] = st[base + (uint32_t)min(j, cnt - 1)].key;
+#pragma unroll
+    for (int j = 0; j < 4; j++) lk[j] = st[(uint32_t)kj[j]].key;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t leader = (uint32_t)kj[j];
         // T0 of the border through this dart: its key, provided the dart sits on an intact cycle with an event
-        uint32_t t = (uint32_t)(kj >> 32);
-        if (leader != d && (uint32_t)st[leader].key != leader) t = kNoKey;
-        if (t < 2u * q) { wfires = false; break; }
+        uint32_t t = (uint32_t)(kj[j] >> 32);
+        if (leader != d && (uint32_t)lk[j] != leader) t = kNoKey;
+        if (j < cnt && t < 2u * q) wfires = false;
     }
     const bool has_w = x > 0 && !(F & 1u);
     uint32_t key = kNoKey;
