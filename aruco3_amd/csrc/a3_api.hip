@@ -38,7 +38,7 @@ hipError_t launch_select_scatter(hipStream_t, const JumpState*, uint32_t, const 
 hipError_t launch_debug_clockwise(hipStream_t, const int32_t*, uint32_t, int32_t*);
 hipError_t launch_unpack_bits(hipStream_t, const uint64_t*, int, int, uint8_t*);
 hipError_t launch_contour_quads(hipStream_t, const ContourRec*, const DeviceCounters*, uint32_t, const uint32_t*, double, uint32_t, uint32_t,
-                                uint32_t, CandRec*, uint32_t*, unsigned int*);
+                                uint32_t, CandRec*, uint32_t*, unsigned int*, int);
 // k_decode.hip
 size_t decode_out_bytes();
 hipError_t launch_frame_candidates(hipStream_t, const CandRec*, const uint32_t*, uint32_t, uint32_t, float, uint16_t*, uint16_t*, uint32_t*,
@@ -419,7 +419,8 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
                                      ctx->debug_taps ? 1 : 0));
         A3_HIP(launch_contour_quads(st, ctx->contours.as<ContourRec>(), ctr, ctx->max_contours, ctx->points.as<uint32_t>(),
                                     ctx->cfg.contour_simplification_epsilon, min_edge_length, c.first, kMaxCand,
-                                    ctx->cands.as<CandRec>() + (size_t)c.first * kMaxCand, ctx->cand_count + c.first, d_err));
+                                    ctx->cands.as<CandRec>() + (size_t)c.first * kMaxCand, ctx->cand_count + c.first, d_err,
+                                    W <= 16384u && H <= 16384u ? 1 : 0));
     }
     if (ctx->profiling >= 2) A3_HIP(hipEventRecord(ctx->ev[2], st));
 

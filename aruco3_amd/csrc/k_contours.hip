@@ -1276,7 +1276,8 @@ __device__ __forceinline__ void contour_quads_body(uint32_t block, uint32_t n_bl
                                                        uint32_t max_contours, const uint32_t* __restrict__ points, double eps_factor,
                                                        uint32_t min_edge_length, uint32_t first_frame, uint32_t max_cand,
                                                        CandRec* __restrict__ cands, uint32_t* __restrict__ cand_count,
-                                                       unsigned int* __restrict__ err_flags) {
+                                                       unsigned int* __restrict__ err_flags, bool coords14) {
+    // coords14: every coordinate is below 2^14 (the image is at most 16384 x 16384): the distance numerators fit 32 bits
     const uint32_t n_contours = min(ctr->contours, max_contours);
     const int lane = threadIdx.x & (G - 1);
     const uint32_t wave_global = (block * blockDim.x + threadIdx.x) / G, n_waves = (n_blocks * blockDim.x) / G;
@@ -1311,9 +1312,15 @@ __device__ __forceinline__ void contour_quads_body(uint32_t block, uint32_t n_bl
                 for (int u = 0; u < 4; u++) {
                     const uint32_t i = i0 + (uint32_t)u * G;
                     if (i > b) break;
-                    long long num = (long long)la * (int)(p[u] & 0xFFFF) + (long long)lb * (int)(p[u] >> 16) + lc;   // 32 x 32 -> 64 multiplies
-                    if (num < 0) num = -num;
-                    const unsigned long long cand = ((unsigned long long)num << 30) | (unsigned long long)(~i & 0x3FFFFFFFu);
+                    unsigned long long anum;
+                    if (coords14) {   // |la x|, |lb y|, |lc| < 2^28: two 24-bit multiply-adds instead of two 32 x 32 -> 64 ones
+                        const int v = __mul24(la, (int)(p[u] & 0xFFFF)) + __mul24(lb, (int)(p[u] >> 16)) + (int)lc;
+                        anum = (unsigned long long)(uint32_t)(v < 0 ? -v : v);
+                    } else {
+                        long long num = (long long)la * (int)(p[u] & 0xFFFF) + (long long)lb * (int)(p[u] >> 16) + lc;
+                        anum = (unsigned long long)(num < 0 ? -num : num);
+                    }
+                    const unsigned long long cand = (anum << 30) | (unsigned long long)(~i & 0x3FFFFFFFu);
                     if (cand > best) best = cand;
                 }
             }
@@ -1321,9 +1328,17 @@ __device__ __forceinline__ void contour_quads_body(uint32_t block, uint32_t n_bl
             const unsigned long long num = best >> 30;
             if (num == 0) continue;
             const uint32_t index = ~(uint32_t)best & 0x3FFFFFFFu;
-            // d = |a x + b y + c| / sqrt(a^2 + b^2) in f64, compared with `>` (imageproc approximate_polygon_dp)
-            const double dmax = (double)num / sqrt((double)((long long)la * la + (long long)lb * lb));
-            if (dmax > eps) {
+            // d = |a x + b y + c| / sqrt(a^2 + b^2) in f64, compared with `>` (imageproc approximate_polygon_dp).  The quotient
+            // carries a relative error of a few 2^-53, so unless num^2 and eps^2 (a^2 + b^2) agree to nine digits the squared
+            // comparison -- no square root, no division: those two are ~60 instructions for every chord, in every lane --
+            // gives the same answer; in the band in between the reference's expression is evaluated as it stands.
+            const double dn = (double)num, den = (double)((long long)la * la + (long long)lb * lb);
+            const double lhs = dn * dn, rhs = eps * eps * den;
+            bool far;
+            if (lhs > rhs * (1.0 + 1e-9)) far = true;
+            else if (lhs < rhs * (1.0 - 1e-9)) far = false;
+            else far = dn / sqrt(den) > eps;
+            if (far) {
                 if (splits == 3) { reject = true; break; }
                 kept[splits++] = index;
                 seg_a[nseg] = a; seg_b[nseg] = index; nseg++;
@@ -1365,13 +1380,13 @@ __global__ __launch_bounds__(256) void k_contour_quads(uint32_t blocks64, const 
                                                        uint32_t max_contours, const uint32_t* __restrict__ points, double eps_factor,
                                                        uint32_t min_edge_length, uint32_t first_frame, uint32_t max_cand,
                                                        CandRec* __restrict__ cands, uint32_t* __restrict__ cand_count,
-                                                       unsigned int* __restrict__ err_flags) {
+                                                       unsigned int* __restrict__ err_flags, int coords14) {
     if (blockIdx.x < blocks64)
         contour_quads_body<64>(blockIdx.x, blocks64, contours, ctr, max_contours, points, eps_factor, min_edge_length, first_frame, max_cand, cands,
-                               cand_count, err_flags);
+                               cand_count, err_flags, coords14 != 0);
     else
         contour_quads_body<16>(blockIdx.x - blocks64, gridDim.x - blocks64, contours, ctr, max_contours, points, eps_factor, min_edge_length,
-                               first_frame, max_cand, cands, cand_count, err_flags);
+                               first_frame, max_cand, cands, cand_count, err_flags, coords14 != 0);
 }
 
 // expand the packed thresholded image to 0/255 bytes (debug tap a3_download_thresholded)
@@ -1543,10 +1558,10 @@ hipError_t launch_select_scatter(hipStream_t st, const JumpState* fin, uint32_t 
 
 hipError_t launch_contour_quads(hipStream_t st, const ContourRec* contours, const DeviceCounters* ctr, uint32_t max_contours,
                                 const uint32_t* points, double eps_factor, uint32_t min_edge_length, uint32_t first_frame, uint32_t max_cand,
-                                CandRec* cands, uint32_t* cand_count, unsigned int* err_flags) {
+                                CandRec* cands, uint32_t* cand_count, unsigned int* err_flags, int coords14) {
     const uint32_t b64 = (uint32_t)env_cap("A3_QUAD_BLOCKS64", 2560), b16 = (uint32_t)env_cap("A3_QUAD_BLOCKS16", 4096);
     hipLaunchKernelGGL(k_contour_quads, dim3(b64 + b16), dim3(256), 0, st, b64, contours, ctr, max_contours, points, eps_factor, min_edge_length,
-                       first_frame, max_cand, cands, cand_count, err_flags);
+                       first_frame, max_cand, cands, cand_count, err_flags, coords14);
     return hipGetLastError();
 }
 
