@@ -17,11 +17,10 @@ namespace a3 {
 // k_threshold.hip
 hipError_t launch_grey_threshold(hipStream_t, const uint8_t*, int, size_t, size_t, int, int, uint32_t, uint32_t, uint8_t*, uint64_t*);
 // k_contours.hip
-hipError_t launch_dart_count(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, unsigned long long*, uint32_t*);
+hipError_t launch_dart_count(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, unsigned long long*, uint32_t*, uint64_t, uint32_t*, uint32_t*);
 size_t tile_darts_bytes(uint32_t W, uint32_t H, uint32_t n_frames);
 hipError_t launch_dart_build(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*, const uint32_t*,
                              uint64_t*, uint32_t*, uint32_t, const uint32_t*, int);
-hipError_t launch_plan(hipStream_t, const unsigned long long*, uint32_t, uint64_t, uint32_t*, uint32_t*);
 hipError_t launch_zero(hipStream_t, void*, size_t);
 size_t entry_state_bytes();
 size_t entry_slots(uint32_t);
@@ -321,7 +320,10 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
         ctx->frame_darts_ptr = ctx->frame_darts.as<unsigned long long>();
         A3_HIP(hipMemsetAsync(ctx->frame_darts.p, 0, (size_t)n * 8, st));
     }
-    A3_HIP(launch_dart_count(st, ctx->bin.as<uint64_t>(), (int)W, (int)H, 0, n, ctx->frame_darts_ptr, ctx->tile_darts.as<uint32_t>()));
+    // device plan: frame bases and the dart total come out of the same launch sequence (scratch words 8..11, read back with the results)
+    if (device_plan) A3_HIP(ctx->frame_base.ensure((size_t)(n + 1) * 4));
+    A3_HIP(launch_dart_count(st, ctx->bin.as<uint64_t>(), (int)W, (int)H, 0, n, ctx->frame_darts_ptr, ctx->tile_darts.as<uint32_t>(), cap_d,
+                             device_plan ? ctx->frame_base.as<uint32_t>() : nullptr, device_plan ? ctx->scratch_u32 + 8 : nullptr));
     if (!device_plan) {
         if (int rc = ensure_pinned(ctx, std::max<size_t>((size_t)n * 8, 1 << 16))) return rc;
         A3_HIP(hipMemcpyAsync(ctx->pinned, ctx->frame_darts.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
@@ -360,9 +362,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
 
     const uint32_t* n_live = nullptr;
     if (device_plan) {
-        // frame bases and the dart total come from k_plan (scratch words 8..11, read back with the results)
-        A3_HIP(launch_plan(st, ctx->frame_darts_ptr, n, cap_d, ctx->frame_base.as<uint32_t>(), ctx->scratch_u32 + 8));
-        n_live = ctx->scratch_u32 + 8;
+        n_live = ctx->scratch_u32 + 8;   // written by the plan workgroup of launch_dart_count
     } else {
         // frame bases of every chunk, uploaded once
         std::vector<uint32_t> bases;
@@ -820,7 +820,7 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
         if (kernel == 0) {
             A3_HIP(hipMemsetAsync(ctx->frame_darts.p, 0, (size_t)ctx->frames * 8, st));
             A3_HIP(launch_dart_count(st, ctx->bin.as<uint64_t>(), (int)ctx->W, (int)ctx->H, 0, ctx->frames, ctx->frame_darts.as<unsigned long long>(),
-                                     ctx->tile_darts.as<uint32_t>()));
+                                     ctx->tile_darts.as<uint32_t>(), 0, nullptr, nullptr));
         } else if (kernel == 1) {
             A3_HIP(launch_dart_build(st, ctx->bin.as<uint64_t>(), (int)ctx->W, (int)ctx->H, 0, ctx->dbg_frames, ctx->frame_base.as<uint32_t>(),
                                      ctx->tile_darts.as<uint32_t>() + tile_darts_bytes(ctx->W, ctx->H, ctx->frames) / 8, ctx->pix_base.as<uint32_t>(),

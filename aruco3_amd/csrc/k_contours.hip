@@ -241,10 +241,54 @@ __global__ __launch_bounds__(64) void k_dart_count(const uint64_t* __restrict__ 
     if (lane == 0 && total) atomicAdd(&frame_darts[f], (unsigned long long)total);
 }
 
+// Device-side plan for a batch whose contour graph is expected to fit one chunk (the host learnt its size from the previous
+// batch): exclusive prefix sums of the per-frame dart counts -> frame_base[0..n], total -> plan[0] (0 and plan[1] = 1 when
+// the total exceeds `cap`, which makes every later kernel a no-op; the host then re-plans with a read-back), largest
+// frame -> plan[2].  One workgroup of 256 threads (the last one of k_tile_scan's launch); n_frames is small.
+__device__ void plan_frames(const unsigned long long* __restrict__ frame_darts, uint32_t n_frames, unsigned long long cap,
+                            uint32_t* __restrict__ frame_base, uint32_t* __restrict__ plan) {
+    __shared__ unsigned long long s_pw[4];
+    __shared__ unsigned long long s_run;
+    __shared__ unsigned int s_max;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { s_run = 0; s_max = 0; }
+    __syncthreads();
+    for (uint32_t base = 0; base < n_frames; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        const unsigned long long v = i < n_frames ? frame_darts[i] : 0ull;
+        unsigned long long inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned long long t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        if (lane == 63) s_pw[wave] = inc;
+        atomicMax(&s_max, (unsigned int)min(v, 0xFFFFFFFFull));
+        __syncthreads();
+        unsigned long long before = s_run, tot = 0;
+        for (int w = 0; w < 4; w++) { const unsigned long long t = s_pw[w]; if (w < wave) before += t; tot += t; }
+        if (i < n_frames) frame_base[i] = (uint32_t)min(before + inc - v, 0xFFFFFFFFull);
+        __syncthreads();
+        if (threadIdx.x == 0) s_run += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const unsigned long long total = s_run;
+        const bool fits = total <= cap;
+        frame_base[n_frames] = fits ? (uint32_t)total : 0u;
+        plan[0] = fits ? (uint32_t)total : 0u;
+        plan[1] = fits ? 0u : 1u;
+        plan[2] = s_max;
+        plan[3] = (uint32_t)min(total, 0xFFFFFFFFull);
+    }
+}
+
 // Per frame: exclusive prefix sums of its tiles' dart counts, so that every tile knows its dart range without an atomic
 // (and dart numbering no longer depends on scheduling).  grid: frames; tiles per frame is a few hundred.
+// (Workgroup n_frames of the launch, when there is one, does the device-side plan: it needs the per-frame totals k_dart_count
+// has just added up and nothing of this kernel, and a launch of its own costs 6 us for 2 us of work.)
 __global__ __launch_bounds__(256) void k_tile_scan(const uint32_t* __restrict__ tile_darts, uint32_t tiles, uint32_t first_frame,
-                                                   uint32_t* __restrict__ tile_off) {
+                                                   uint32_t* __restrict__ tile_off, uint32_t n_frames,
+                                                   const unsigned long long* __restrict__ frame_darts, unsigned long long cap,
+                                                   uint32_t* __restrict__ frame_base, uint32_t* __restrict__ plan) {
+    if (blockIdx.x == n_frames) { plan_frames(frame_darts, n_frames, cap, frame_base, plan); return; }
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_run;
     const size_t base = (size_t)(first_frame + blockIdx.x) * tiles;
@@ -1409,45 +1453,6 @@ static inline int blocks_for(uint64_t n, int per_block, int cap) {
     return (int)b;
 }
 
-// Device-side plan for a batch whose contour graph is expected to fit one chunk (the host learnt its size from the previous
-// batch): exclusive prefix sums of the per-frame dart counts -> frame_base[0..n], total -> plan[0] (0 and plan[1] = 1 when
-// the total exceeds `cap`, which makes every later kernel a no-op; the host then re-plans with a read-back), largest
-// frame -> plan[2].  One workgroup; n_frames is small.
-__global__ __launch_bounds__(1024) void k_plan(const unsigned long long* __restrict__ frame_darts, uint32_t n_frames, unsigned long long cap,
-                                               uint32_t* __restrict__ frame_base, uint32_t* __restrict__ plan) {
-    __shared__ unsigned long long s_wave[16];
-    __shared__ unsigned long long s_run;
-    __shared__ unsigned int s_max;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) { s_run = 0; s_max = 0; }
-    __syncthreads();
-    for (uint32_t base = 0; base < n_frames; base += 1024) {
-        const uint32_t i = base + threadIdx.x;
-        const unsigned long long v = i < n_frames ? frame_darts[i] : 0ull;
-        unsigned long long inc = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const unsigned long long t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-        if (lane == 63) s_wave[wave] = inc;
-        atomicMax(&s_max, (unsigned int)min(v, 0xFFFFFFFFull));
-        __syncthreads();
-        unsigned long long before = s_run, tot = 0;
-        for (int w = 0; w < 16; w++) { const unsigned long long t = s_wave[w]; if (w < wave) before += t; tot += t; }
-        if (i < n_frames) frame_base[i] = (uint32_t)min(before + inc - v, 0xFFFFFFFFull);
-        __syncthreads();
-        if (threadIdx.x == 0) s_run += tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const unsigned long long total = s_run;
-        const bool fits = total <= cap;
-        frame_base[n_frames] = fits ? (uint32_t)total : 0u;
-        plan[0] = fits ? (uint32_t)total : 0u;
-        plan[1] = fits ? 0u : 1u;
-        plan[2] = s_max;
-        plan[3] = (uint32_t)min(total, 0xFFFFFFFFull);
-    }
-}
-
 // zeroing as a kernel: a hipMemsetAsync between two kernels costs its own ~4 us plus a ~6 us switch of packet type
 __global__ __launch_bounds__(256) void k_zero(uint4* __restrict__ p, uint32_t n16) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -1458,16 +1463,12 @@ hipError_t launch_zero(hipStream_t st, void* p, size_t bytes /* multiple of 16, 
     return hipGetLastError();
 }
 
-hipError_t launch_plan(hipStream_t st, const unsigned long long* frame_darts, uint32_t n_frames, uint64_t cap, uint32_t* frame_base, uint32_t* plan) {
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, st, frame_darts, n_frames, (unsigned long long)cap, frame_base, plan);
-    return hipGetLastError();
-}
-
 // tile_darts[frames * tiles] followed by tile_off[frames * tiles]
 size_t tile_darts_bytes(uint32_t W, uint32_t H, uint32_t n_frames) { return (size_t)dart_tiles(W, H) * n_frames * 4 * 2; }
 
+// plan != nullptr: the launch of k_tile_scan also plans the batch on the device (frame_base[0..n_frames], plan[0..3])
 hipError_t launch_dart_count(hipStream_t st, const uint64_t* bits, int W, int H, uint32_t first_frame, uint32_t n_frames,
-                             unsigned long long* frame_darts, uint32_t* tile_darts) {
+                             unsigned long long* frame_darts, uint32_t* tile_darts, uint64_t plan_cap, uint32_t* frame_base, uint32_t* plan) {
     const uint32_t tiles_x = dart_tiles_x((uint32_t)W), tiles_y = ((uint32_t)H + kTileRows - 1) / kTileRows;
     const uint32_t wpr = words_per_row((uint32_t)W);
     if (wpr <= 30)   // two tile rows per wave
@@ -1475,7 +1476,8 @@ hipError_t launch_dart_count(hipStream_t st, const uint64_t* bits, int W, int H,
     else
         hipLaunchKernelGGL(k_dart_count<64>, dim3(((wpr + kCountLanes - 1) / kCountLanes) * tiles_y, n_frames), dim3(64), 0, st, bits, W, H, first_frame,
                            frame_darts, tile_darts);
-    hipLaunchKernelGGL(k_tile_scan, dim3(n_frames), dim3(256), 0, st, tile_darts, tiles_x * tiles_y, first_frame, tile_darts + (size_t)tiles_x * tiles_y * n_frames);
+    hipLaunchKernelGGL(k_tile_scan, dim3(n_frames + (plan ? 1u : 0u)), dim3(256), 0, st, tile_darts, tiles_x * tiles_y, first_frame,
+                       tile_darts + (size_t)tiles_x * tiles_y * n_frames, n_frames, frame_darts, (unsigned long long)plan_cap, frame_base, plan);
     return hipGetLastError();
 }
 
