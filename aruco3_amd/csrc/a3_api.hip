@@ -46,7 +46,7 @@ size_t proj_rec_bytes();
 size_t weight_table_bytes();
 hipError_t launch_weight_table(hipStream_t, uint32_t, uint32_t, uint32_t, float*);
 hipError_t launch_decode(hipStream_t, PixelSrc, int, int, uint32_t, const uint16_t*, const uint32_t*, const unsigned int*, uint32_t,
-                         uint32_t, uint32_t, uint32_t, const uint64_t*, uint32_t, uint32_t, int, void*, const float*, void*, uint8_t*, uint32_t, uint32_t*, int, int);
+                         uint32_t, uint32_t, uint32_t, const uint64_t*, uint32_t, uint32_t, int, void*, const float*, void*, uint8_t*, uint32_t, uint32_t*, int, int, int);
 hipError_t launch_compact_markers(hipStream_t, const void*, const uint16_t*, const uint32_t*, uint32_t, uint32_t, uint32_t, a3_marker*,
                                   uint32_t, uint32_t*, unsigned int*, unsigned int*, const uint32_t*, unsigned int*);
 hipError_t launch_pack_detections(hipStream_t, const a3_marker*, const a3_pose*, const uint32_t*, uint32_t, uint32_t, uint32_t, void*, unsigned int*);
@@ -432,7 +432,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
                                    : PixelSrc{pixels, row_stride, frame_stride, fmt};
     A3_HIP(launch_decode(st, src, (int)W, (int)H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), d_work_count,
                          kMaxCand, S, ctx->mark_size, S, ctx->dict.as<uint64_t>(), ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors,
-                         ctx->proj.p, ctx->wtab.as<float>(), ctx->outs.p, ctx->debug_taps ? ctx->patches.as<uint8_t>() : nullptr, kPatchCap, ctx->per_frame, 4096, 0));
+                         ctx->proj.p, ctx->wtab.as<float>(), ctx->outs.p, ctx->debug_taps ? ctx->patches.as<uint8_t>() : nullptr, kPatchCap, ctx->per_frame, 4096, 0, n <= 64u ? 1 : 0));
     ctx->dbg_src = src;
     A3_HIP(launch_compact_markers(st, ctx->outs.p, ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(), n, 0, kMaxCand,
                                   ctx->markers_ptr, marker_cap, ctx->per_frame, d_marker_total, d_err, ctx->cand_count, ctx->scratch_u32 + 2));
@@ -835,7 +835,7 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
             A3_HIP(launch_decode(st, ctx->dbg_src, (int)ctx->W, (int)ctx->H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), ctx->scratch_u32,
                                  kMaxCand, ctx->cfg.homography_sample_size, ctx->mark_size, ctx->cfg.homography_sample_size, ctx->dict.as<uint64_t>(),
                                  ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors, ctx->proj.p, ctx->wtab.as<float>(), ctx->outs.p, nullptr, 0u, nullptr, 4096,
-                                 dbg == 0 ? -1000 : dbg));   // 0: k_projection + k_decode, < 0: k_decode alone (variant -dbg)
+                                 dbg == 0 ? -1000 : dbg, ctx->frames <= 64u ? 1 : 0));   // 0: k_projection + k_decode, < 0: k_decode alone (variant -dbg)
         } else return fail(ctx, A3_ERR_INVALID, "kernel: 0 dart_count, 1 dart_assign, 2 local_contract, 3 decode");
         A3_HIP(hipEventRecord(e1, st));
         A3_HIP(hipStreamSynchronize(st));

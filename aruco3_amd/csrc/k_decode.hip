@@ -582,6 +582,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? A3_D_WAVES : 3) void k_decode(PixelS
         }
         if (dbg == 3) continue;
         // threshold(.., Binary) is applied where the patch is read: a pixel counts as 255 iff it is above the Otsu level
+        __syncthreads();   // s_otsu (and, long ago, the weights)
         const uint32_t otsu = s_otsu;
         if (pw == n) {  // resize() copies when the size already matches
             for (uint32_t i = tid; i < n * n; i += NT) s_bits[i] = s_patch[i] > otsu;   // (255 or 0) > 127
@@ -1089,12 +1090,21 @@ hipError_t launch_weight_table(hipStream_t st, uint32_t S, uint32_t n, uint32_t 
 
 hipError_t launch_decode(hipStream_t st, PixelSrc src, int W, int H, uint32_t first_frame, const uint16_t* fin_xy, const uint32_t* work,
                          const unsigned int* work_count, uint32_t max_cand, uint32_t S, uint32_t n, uint32_t max_taps, const uint64_t* dict,
-                         uint32_t n_codes, uint32_t tau, int filter, void* proj, const float* wtab, void* outs, uint8_t* patches, uint32_t patch_cap, uint32_t* per_frame, int grid_blocks, int dbg) {
+                         uint32_t n_codes, uint32_t tau, int filter, void* proj, const float* wtab, void* outs, uint8_t* patches, uint32_t patch_cap, uint32_t* per_frame, int grid_blocks, int dbg, int few) {
     ProjRec* recs = reinterpret_cast<ProjRec*>(proj);
     if (dbg > 0 || dbg == -1000) hipLaunchKernelGGL(k_projection, dim3(256), dim3(64), 0, st, fin_xy, work, work_count, S, recs);
-    hipLaunchKernelGGL(k_decode<A3_D_THREADS>, dim3(grid_blocks), dim3(A3_D_THREADS), decode_lds_bytes(S, n, max_taps), st, src, W, H, first_frame, fin_xy, work,
-                       work_count, max_cand, S, n, max_taps, dict, n_codes, tau, filter, recs, wtab,
-                       reinterpret_cast<DecodeOut*>(outs), patches, patch_cap, per_frame, dbg == -1000 ? 0 : (dbg < 0 ? -dbg : dbg));
+    // One wave per candidate is the better shape when thousands of candidates share the memory system (BASELINE config 2: 97 us
+    // against 99 us with four waves per candidate).  A single candidate, though, is then a chain of 19 round trips to the frame
+    // plus the stages after it -- 65 us however idle the chip is; four waves share that chain out (36 us for the 337 candidates
+    // of a 32-frame batch against 69 us).  `few`: the batch is small (a3_api: at most 64 frames).
+    const int d = dbg == -1000 ? 0 : (dbg < 0 ? -dbg : dbg);
+    if (few)
+        hipLaunchKernelGGL(k_decode<256>, dim3(grid_blocks), dim3(256), decode_lds_bytes(S, n, max_taps), st, src, W, H, first_frame, fin_xy, work, work_count,
+                           max_cand, S, n, max_taps, dict, n_codes, tau, filter, recs, wtab, reinterpret_cast<DecodeOut*>(outs), patches, patch_cap, per_frame, d);
+    else
+        hipLaunchKernelGGL(k_decode<A3_D_THREADS>, dim3(grid_blocks), dim3(A3_D_THREADS), decode_lds_bytes(S, n, max_taps), st, src, W, H, first_frame, fin_xy, work,
+                           work_count, max_cand, S, n, max_taps, dict, n_codes, tau, filter, recs, wtab, reinterpret_cast<DecodeOut*>(outs), patches, patch_cap,
+                           per_frame, d);
     return hipGetLastError();
 }
 
