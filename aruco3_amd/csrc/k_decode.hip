@@ -8,6 +8,8 @@
 // Floating point follows the reference operation by operation (f64 for the 8x8 solve and
 // Otsu, f32 elsewhere); the library is built with -ffp-contract=off so that no a*b+c is
 // fused, exactly like the Rust reference and the CPU oracle.
+#include <cstdlib>
+
 #include "a3_common.h"
 
 namespace a3 {
@@ -385,18 +387,16 @@ __device__ __forceinline__ void rotated_source(uint32_t r, uint32_t n, uint32_t 
 #define A3_D_WAVES 5
 #endif
 #ifndef A3_D_THREADS
-#define A3_D_THREADS 64
+#define A3_D_THREADS 256   // threads that sample one candidate (large batches; small ones: 256 throughout)
 #endif
 #ifndef A3_D_DB
 #define A3_D_DB 8     // dictionary codes per lane and trip in the nearest-code scan
 #endif
-// NT threads work on one candidate.  NT = 64 (one wave per candidate, the default): the "barriers" below are free, and --
-// what matters -- hundreds of candidates per CU are in flight at different stages, so the sampling of some (bound by the
-// rate at which the texture-address path takes 64 scattered requests per instruction) overlaps the LDS / VALU stages of
-// others; 96 VGPRs give five waves per SIMD.  Measured on the 2.5 k candidates of BASELINE config 2 (tools/tune_decode.sh):
-// 256 threads, 4 samples in flight per lane, row-major sample order (round 1): 116 us; 64 threads, 2 in flight, 8 x 8
-// blocked order: 98 us, of which the scattered tap loads alone are ~70.
-template <int NT>
+// NT threads sample one candidate, PT of them (64, or all) run the stages after the sampling.  History of the shape, on the
+// 2.5 k candidates of BASELINE config 2 (tools/tune_decode.sh): 256 threads throughout, 4 samples "in flight" per lane, row-major
+// sample order (round 1): 116 us; 64 threads, 8 x 8 blocked order: 98 us; 256 threads sampling, the first wave doing the rest:
+// 94 us -- and 7 us less than the 64-thread version inside the pipeline, where the frames are not in any cache.
+template <int NT, int PT>
 __global__ __launch_bounds__(NT, NT == 64 ? A3_D_WAVES : 3) void k_decode(PixelSrc src, int W, int H, uint32_t first_frame,
                                                 const uint16_t* __restrict__ fin_xy, const uint32_t* __restrict__ work,
                                                 const unsigned int* __restrict__ work_count, uint32_t max_cand, uint32_t S, uint32_t n,
@@ -513,193 +513,204 @@ __global__ __launch_bounds__(NT, NT == 64 ? A3_D_WAVES : 3) void k_decode(PixelS
         }
         __syncthreads();
         if (dbg == 2) continue;
-        // debug taps: the patch buffer holds patch_cap patches, one per work item (NOT per candidate slot: slots are
-        // frame * max_cand + k and would run past the buffer for frames beyond patch_cap / max_cand)
-        const bool keep_patch = patches != nullptr && wi < patch_cap;
-        if (keep_patch) {
-            uint8_t* dst = patches + (size_t)wi * S * S;
-            for (uint32_t i = tid; i < S * S; i += NT) dst[i] = ok ? s_patch[i] : 0;
-        }
-        // otsu_level (imageproc): the reference scans thresholds 0..255 keeping running integer sums and the first strict
-        // maximum of w_b * w_f * (mean_b - mean_f)^2 in f64.  The running sums are exact integers, so every threshold can
-        // be evaluated independently from prefix sums with the very same f64 operations; the first strict maximum is the
-        // largest variance, lowest threshold among equals, and it must exceed the initial 0.0.
-        {
-            constexpr int B = 256 / NT;                 // thresholds per lane: t = tid * B + k
-            uint32_t cw[B], cs[B];                      // inclusive prefix sums inside the lane's run of thresholds
-            uint32_t rw = 0, rs = 0;
-#pragma unroll
-            for (int k = 0; k < B; k++) {
-                const uint32_t t = (uint32_t)tid * B + k, hcnt = s_hist[t];
-                rw += hcnt; rs += t * hcnt;
-                cw[k] = rw; cs[k] = rs;
+        // PT = 64: everything after the sampling is the work of ONE wave, whatever the number of waves that sampled: its stages are short
+        // loops over 64 .. 400 items separated by synchronisation points, which for a single wave cost nothing (LDS operations
+        // of a wave complete in order; POST_SYNC only keeps the compiler from moving accesses across it), while four waves pay
+        // a barrier -- and the wait for every outstanding memory access that comes with it -- at each of them.  The other waves
+        // go on to the top of the loop.
+        static_assert(PT == 64 || PT == NT, "the stages after the sampling run on one wave or on all");
+        constexpr int NWP = PT / 64;
+#define POST_SYNC() { if constexpr (PT == NT) __syncthreads(); else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } }
+        if (PT == NT || tid < PT) {
+            // debug taps: the patch buffer holds patch_cap patches, one per work item (NOT per candidate slot: slots are
+            // frame * max_cand + k and would run past the buffer for frames beyond patch_cap / max_cand)
+            const bool keep_patch = patches != nullptr && wi < patch_cap;
+            if (keep_patch) {
+                uint8_t* dst = patches + (size_t)wi * S * S;
+                for (uint32_t i = tid; i < S * S; i += PT) dst[i] = ok ? s_patch[i] : 0;
             }
-            uint32_t bw = rw, bs = rs;                  // inclusive prefix sums over lanes
-#pragma unroll
-            for (int o2 = 1; o2 < 64; o2 <<= 1) {
-                const uint32_t a = __shfl_up(bw, o2), b = __shfl_up(bs, o2);
-                if ((tid & 63) >= o2) { bw += a; bs += b; }
-            }
-            if ((tid & 63) == 63) { s_scan_w[tid >> 6] = bw; s_scan_s[tid >> 6] = bs; }
-            __syncthreads();
-            uint32_t total_sum_u = 0;
-            for (int w = 0; w < NW; w++) {
-                if (w < (tid >> 6)) { bw += s_scan_w[w]; bs += s_scan_s[w]; }
-                total_sum_u += s_scan_s[w];
-            }
-            const uint32_t before_w = bw - rw, before_s = bs - rs;   // everything below this lane's first threshold
-            const uint32_t total_weight = pw * ph;
-            const double total_pixel_sum = (double)total_sum_u;
-            double var = -1.0;   // "not a candidate"
-            int best_t = tid * B;
-#pragma unroll
-            for (int k = 0; k < B; k++) {
-                const uint32_t bwk = before_w + cw[k], bsk = before_s + cs[k];
-                const uint32_t fw = total_weight - bwk;
-                if (bwk != 0 && fw != 0) {
-                    const double background_pixel_sum = (double)bsk;
-                    const double foreground_pixel_sum = total_pixel_sum - background_pixel_sum;
-                    const double background_mean = background_pixel_sum / (double)bwk;
-                    const double foreground_mean = foreground_pixel_sum / (double)fw;
-                    const double diff = background_mean - foreground_mean;
-                    const double mean_diff_squared = diff * diff;
-                    const double v = (double)bwk * (double)fw * mean_diff_squared;
-                    if (v > var) { var = v; best_t = tid * B + k; }   // ascending k: the first strict maximum of the run
+            // otsu_level (imageproc): the reference scans thresholds 0..255 keeping running integer sums and the first strict
+            // maximum of w_b * w_f * (mean_b - mean_f)^2 in f64.  The running sums are exact integers, so every threshold can
+            // be evaluated independently from prefix sums with the very same f64 operations; the first strict maximum is the
+            // largest variance, lowest threshold among equals, and it must exceed the initial 0.0.
+            {
+                constexpr int B = 256 / PT;                 // thresholds per lane: t = tid * B + k
+                uint32_t cw[B], cs[B];                      // inclusive prefix sums inside the lane's run of thresholds
+                uint32_t rw = 0, rs = 0;
+    #pragma unroll
+                for (int k = 0; k < B; k++) {
+                    const uint32_t t = (uint32_t)tid * B + k, hcnt = s_hist[t];
+                    rw += hcnt; rs += t * hcnt;
+                    cw[k] = rw; cs[k] = rs;
                 }
-            }
-            for (int o2 = 32; o2 > 0; o2 >>= 1) {
-                const double ov = __shfl_xor(var, o2);
-                const int ot = __shfl_xor(best_t, o2);
-                if (ov > var || (ov == var && ot < best_t)) { var = ov; best_t = ot; }
-            }
-            if ((tid & 63) == 0) { s_var[tid >> 6] = var; s_vt[tid >> 6] = best_t; }
-            __syncthreads();
-            if (tid == 0) {
-                double bv = s_var[0]; int bt = s_vt[0];
-                for (int w = 1; w < NW; w++) if (s_var[w] > bv || (s_var[w] == bv && s_vt[w] < bt)) { bv = s_var[w]; bt = s_vt[w]; }
-                s_otsu = bv > 0.0 ? (uint32_t)bt : 0u;
-            }
-        }
-        if (dbg == 3) continue;
-        // threshold(.., Binary) is applied where the patch is read: a pixel counts as 255 iff it is above the Otsu level
-        __syncthreads();   // s_otsu (and, long ago, the weights)
-        const uint32_t otsu = s_otsu;
-        if (pw == n) {  // resize() copies when the size already matches
-            for (uint32_t i = tid; i < n * n; i += NT) s_bits[i] = s_patch[i] > otsu;   // (255 or 0) > 127
-        } else {
-            for (uint32_t i = tid; i < n * pw; i += NT) {  // vertical pass into f32
-                const uint32_t oy = i / pw, x = i - oy * pw;
-                const float* ws = s_w + (size_t)oy * max_taps;
-                const uint32_t left = s_left[oy], cnt = s_cnt[oy];
-                float t = 0.0f;
-                for (uint32_t k = 0; k < cnt; k++) t += (s_patch[(left + k) * pw + x] > otsu ? 255.0f : 0.0f) * ws[k];
-                s_tmp[oy * pw + x] = t;
-            }
-            __syncthreads();
-            for (uint32_t i = tid; i < n * n; i += NT) {  // horizontal pass, clamp, round to nearest
-                const uint32_t y = i / n, ox = i - y * n;
-                const float* ws = s_w + (size_t)ox * max_taps;
-                const uint32_t left = s_left[ox], cnt = s_cnt[ox];
-                float t = 0.0f;
-                for (uint32_t k = 0; k < cnt; k++) t += s_tmp[y * pw + left + k] * ws[k];
-                const float c = t < 0.0f ? 0.0f : (t > 255.0f ? 255.0f : t);
-                s_bits[y * n + ox] = (uint8_t)roundf(c) > 127;
-            }
-        }
-        __syncthreads();
-        if (dbg == 4) continue;
-        // border test + 4 rotated codes, src/aruco.rs:287-310.  One lane per (rotation, cell): the bit goes to its place in
-        // the code with an LDS atomic (row-major, first cell = most significant bit).
-        if (tid < 4) s_codes[tid] = 0;
-        {   // the marker's border must be black all round: one lane per border cell (left, right, top, bottom x n)
-            const uint32_t end = n ? n - 1 : 0;
-            int lit = 0;
-            for (uint32_t t = (uint32_t)tid; t < 4u * n; t += NT) {
-                const uint32_t side = t / n, i = t - side * n;
-                lit |= s_bits[side == 0 ? i * n : (side == 1 ? i * n + end : (side == 2 ? i : end * n + i))];
-            }
-            const int any_lit = __syncthreads_or(lit);
-            if (tid == 0) s_have = !any_lit;
-        }
-        __syncthreads();
-        {
-            const uint32_t inner = n >= 2 ? n - 2 : 0, cells = inner * inner;   // <= 64 cells, 4 rotations
-            if (s_have) {
-                for (uint32_t t = (uint32_t)tid; t < 4u * cells; t += NT) {
-                    const uint32_t r = t / cells, idx = t - r * cells;
-                    const uint32_t y = 1 + idx / inner, x = 1 + idx % inner;
-                    // rotation r of the bit matrix, read row-major
-                    uint32_t sy, sx;
-                    rotated_source(r, n, y, x, &sy, &sx);
-                    if (s_bits[sy * n + sx]) atomicOr(reinterpret_cast<unsigned long long*>(&s_codes[r]), 1ull << (cells - 1 - idx));
+                uint32_t bw = rw, bs = rs;                  // inclusive prefix sums over lanes
+    #pragma unroll
+                for (int o2 = 1; o2 < 64; o2 <<= 1) {
+                    const uint32_t a = __shfl_up(bw, o2), b = __shfl_up(bs, o2);
+                    if ((tid & 63) >= o2) { bw += a; bs += b; }
                 }
-            }
-        }
-        __syncthreads();
-        const int have = s_have;
-        // find_nearest for the 4 codes: strict '<' => lowest index among equal distances
-        unsigned long long best[4] = {~0ull, ~0ull, ~0ull, ~0ull};
-        if (have) {
-            const uint64_t c0 = s_codes[0], c1 = s_codes[1], c2 = s_codes[2], c3 = s_codes[3];
-            // eight codes per lane and trip, their loads issued together (unconditional, clamped index): one code per trip is a
-            // chain of n_codes / 64 round trips to the table -- 16 for a 1024-code dictionary
-            constexpr int DB = A3_D_DB;
-            for (uint32_t i0 = tid; i0 < n_codes; i0 += NT * DB) {
-                uint64_t cw[DB];
-#pragma unroll
-                for (int u = 0; u < DB; u++) cw[u] = dict[min(i0 + (uint32_t)(u * NT), n_codes - 1u)];
-#pragma unroll
-                for (int u = 0; u < DB; u++) {
-                    const uint32_t i = i0 + (uint32_t)(u * NT);
-                    const unsigned long long past = 0ull - (unsigned long long)(i >= n_codes);   // all ones: never the minimum
-                    const uint64_t c = cw[u];
-                    const unsigned long long k0 = (((unsigned long long)__popcll(c ^ c0) << 32) | i) | past;
-                    const unsigned long long k1 = (((unsigned long long)__popcll(c ^ c1) << 32) | i) | past;
-                    const unsigned long long k2 = (((unsigned long long)__popcll(c ^ c2) << 32) | i) | past;
-                    const unsigned long long k3 = (((unsigned long long)__popcll(c ^ c3) << 32) | i) | past;
-                    best[0] = k0 < best[0] ? k0 : best[0];
-                    best[1] = k1 < best[1] ? k1 : best[1];
-                    best[2] = k2 < best[2] ? k2 : best[2];
-                    best[3] = k3 < best[3] ? k3 : best[3];
+                if ((tid & 63) == 63) { s_scan_w[tid >> 6] = bw; s_scan_s[tid >> 6] = bs; }
+                POST_SYNC();
+                uint32_t total_sum_u = 0;
+                for (int w = 0; w < NWP; w++) {
+                    if (w < (tid >> 6)) { bw += s_scan_w[w]; bs += s_scan_s[w]; }
+                    total_sum_u += s_scan_s[w];
                 }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; r++)
+                const uint32_t before_w = bw - rw, before_s = bs - rs;   // everything below this lane's first threshold
+                const uint32_t total_weight = pw * ph;
+                const double total_pixel_sum = (double)total_sum_u;
+                double var = -1.0;   // "not a candidate"
+                int best_t = tid * B;
+    #pragma unroll
+                for (int k = 0; k < B; k++) {
+                    const uint32_t bwk = before_w + cw[k], bsk = before_s + cs[k];
+                    const uint32_t fw = total_weight - bwk;
+                    if (bwk != 0 && fw != 0) {
+                        const double background_pixel_sum = (double)bsk;
+                        const double foreground_pixel_sum = total_pixel_sum - background_pixel_sum;
+                        const double background_mean = background_pixel_sum / (double)bwk;
+                        const double foreground_mean = foreground_pixel_sum / (double)fw;
+                        const double diff = background_mean - foreground_mean;
+                        const double mean_diff_squared = diff * diff;
+                        const double v = (double)bwk * (double)fw * mean_diff_squared;
+                        if (v > var) { var = v; best_t = tid * B + k; }   // ascending k: the first strict maximum of the run
+                    }
+                }
                 for (int o2 = 32; o2 > 0; o2 >>= 1) {
-                    const unsigned long long other = __shfl_xor(best[r], o2);
-                    best[r] = other < best[r] ? other : best[r];
+                    const double ov = __shfl_xor(var, o2);
+                    const int ot = __shfl_xor(best_t, o2);
+                    if (ov > var || (ov == var && ot < best_t)) { var = ov; best_t = ot; }
                 }
-            if ((tid & 63) == 0)
-                for (int r = 0; r < 4; r++) s_best[tid >> 6][r] = best[r];
-        }
-        __syncthreads();
-        if (tid == 0) {
-            DecodeOut out;
-            out.valid = 0; out.id = 0; out.code = 0; out.rotation = 0; out.hamming = 0; out.patch = keep_patch ? wi : kNone;
-            out.hom_ok = ok; out.decode_ok = have;
-            for (int r = 0; r < 4; r++) out.codes[r] = have ? s_codes[r] : 0;
-            int found_any = 0;
-            uint32_t min_code_distance = 0x7FFFFFFFu, min_rotation = 0, min_code_id = 0x7FFFFFFFu;
-            uint64_t min_code = 0x7FFFFFFFull;
-            if (have) {
-                for (uint32_t r = 0; r < 4; r++) {
-                    unsigned long long b = s_best[0][r];
-                    for (int w = 1; w < NW; w++) b = s_best[w][r] < b ? s_best[w][r] : b;
-                    // empty dictionary: find_nearest returns (0, 0xFF)
-                    const uint32_t nearest_dist = n_codes ? (uint32_t)(b >> 32) : 0xFFu;
-                    const uint32_t nearest_id = n_codes ? (uint32_t)b : 0u;
-                    if (nearest_dist < min_code_distance) {
-                        min_code = s_codes[r]; min_code_distance = nearest_dist; min_code_id = nearest_id; min_rotation = r; found_any = 1;
+                if ((tid & 63) == 0) { s_var[tid >> 6] = var; s_vt[tid >> 6] = best_t; }
+                POST_SYNC();
+                if (tid == 0) {
+                    double bv = s_var[0]; int bt = s_vt[0];
+                    for (int w = 1; w < NWP; w++) if (s_var[w] > bv || (s_var[w] == bv && s_vt[w] < bt)) { bv = s_var[w]; bt = s_vt[w]; }
+                    s_otsu = bv > 0.0 ? (uint32_t)bt : 0u;
+                }
+            }
+            if (dbg == 3) continue;
+            // threshold(.., Binary) is applied where the patch is read: a pixel counts as 255 iff it is above the Otsu level
+            POST_SYNC();   // s_otsu (and, long ago, the weights)
+            const uint32_t otsu = s_otsu;
+            if (pw == n) {  // resize() copies when the size already matches
+                for (uint32_t i = tid; i < n * n; i += PT) s_bits[i] = s_patch[i] > otsu;   // (255 or 0) > 127
+            } else {
+                for (uint32_t i = tid; i < n * pw; i += PT) {  // vertical pass into f32
+                    const uint32_t oy = i / pw, x = i - oy * pw;
+                    const float* ws = s_w + (size_t)oy * max_taps;
+                    const uint32_t left = s_left[oy], cnt = s_cnt[oy];
+                    float t = 0.0f;
+                    for (uint32_t k = 0; k < cnt; k++) t += (s_patch[(left + k) * pw + x] > otsu ? 255.0f : 0.0f) * ws[k];
+                    s_tmp[oy * pw + x] = t;
+                }
+                POST_SYNC();
+                for (uint32_t i = tid; i < n * n; i += PT) {  // horizontal pass, clamp, round to nearest
+                    const uint32_t y = i / n, ox = i - y * n;
+                    const float* ws = s_w + (size_t)ox * max_taps;
+                    const uint32_t left = s_left[ox], cnt = s_cnt[ox];
+                    float t = 0.0f;
+                    for (uint32_t k = 0; k < cnt; k++) t += s_tmp[y * pw + left + k] * ws[k];
+                    const float c = t < 0.0f ? 0.0f : (t > 255.0f ? 255.0f : t);
+                    s_bits[y * n + ox] = (uint8_t)roundf(c) > 127;
+                }
+            }
+            POST_SYNC();
+            if (dbg == 4) continue;
+            // border test + 4 rotated codes, src/aruco.rs:287-310.  One lane per (rotation, cell): the bit goes to its place in
+            // the code with an LDS atomic (row-major, first cell = most significant bit).
+            if (tid < 4) s_codes[tid] = 0;
+            {   // the marker's border must be black all round: one lane per border cell (left, right, top, bottom x n)
+                const uint32_t end = n ? n - 1 : 0;
+                int lit = 0;
+                for (uint32_t t = (uint32_t)tid; t < 4u * n; t += PT) {
+                    const uint32_t side = t / n, i = t - side * n;
+                    lit |= s_bits[side == 0 ? i * n : (side == 1 ? i * n + end : (side == 2 ? i : end * n + i))];
+                }
+                const int any_lit = (PT == NT ? __syncthreads_or(lit) : (int)(__ballot(lit) != 0ull));
+                if (tid == 0) s_have = !any_lit;
+            }
+            POST_SYNC();
+            {
+                const uint32_t inner = n >= 2 ? n - 2 : 0, cells = inner * inner;   // <= 64 cells, 4 rotations
+                if (s_have) {
+                    for (uint32_t t = (uint32_t)tid; t < 4u * cells; t += PT) {
+                        const uint32_t r = t / cells, idx = t - r * cells;
+                        const uint32_t y = 1 + idx / inner, x = 1 + idx % inner;
+                        // rotation r of the bit matrix, read row-major
+                        uint32_t sy, sx;
+                        rotated_source(r, n, y, x, &sy, &sx);
+                        if (s_bits[sy * n + sx]) atomicOr(reinterpret_cast<unsigned long long*>(&s_codes[r]), 1ull << (cells - 1 - idx));
                     }
                 }
             }
-            if (found_any && (!filter || min_code_distance < tau)) {
-                out.valid = 1; out.id = min_code_id; out.code = min_code; out.rotation = (uint8_t)min_rotation;
-                out.hamming = (uint8_t)min_code_distance;
+            POST_SYNC();
+            const int have = s_have;
+            // find_nearest for the 4 codes: strict '<' => lowest index among equal distances
+            unsigned long long best[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+            if (have) {
+                const uint64_t c0 = s_codes[0], c1 = s_codes[1], c2 = s_codes[2], c3 = s_codes[3];
+                // eight codes per lane and trip, their loads issued together (unconditional, clamped index): one code per trip is a
+                // chain of n_codes / 64 round trips to the table -- 16 for a 1024-code dictionary
+                constexpr int DB = A3_D_DB;
+                for (uint32_t i0 = tid; i0 < n_codes; i0 += PT * DB) {
+                    uint64_t cw[DB];
+    #pragma unroll
+                    for (int u = 0; u < DB; u++) cw[u] = dict[min(i0 + (uint32_t)(u * PT), n_codes - 1u)];
+    #pragma unroll
+                    for (int u = 0; u < DB; u++) {
+                        const uint32_t i = i0 + (uint32_t)(u * PT);
+                        const unsigned long long past = 0ull - (unsigned long long)(i >= n_codes);   // all ones: never the minimum
+                        const uint64_t c = cw[u];
+                        const unsigned long long k0 = (((unsigned long long)__popcll(c ^ c0) << 32) | i) | past;
+                        const unsigned long long k1 = (((unsigned long long)__popcll(c ^ c1) << 32) | i) | past;
+                        const unsigned long long k2 = (((unsigned long long)__popcll(c ^ c2) << 32) | i) | past;
+                        const unsigned long long k3 = (((unsigned long long)__popcll(c ^ c3) << 32) | i) | past;
+                        best[0] = k0 < best[0] ? k0 : best[0];
+                        best[1] = k1 < best[1] ? k1 : best[1];
+                        best[2] = k2 < best[2] ? k2 : best[2];
+                        best[3] = k3 < best[3] ? k3 : best[3];
+                    }
+                }
+    #pragma unroll
+                for (int r = 0; r < 4; r++)
+                    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+                        const unsigned long long other = __shfl_xor(best[r], o2);
+                        best[r] = other < best[r] ? other : best[r];
+                    }
+                if ((tid & 63) == 0)
+                    for (int r = 0; r < 4; r++) s_best[tid >> 6][r] = best[r];
             }
-            outs[slot] = out;
-            if (out.valid && per_frame) atomicAdd(&per_frame[first_frame + fl], 1u);   // one address per frame: no contention to speak of
+            POST_SYNC();
+            if (tid == 0) {
+                DecodeOut out;
+                out.valid = 0; out.id = 0; out.code = 0; out.rotation = 0; out.hamming = 0; out.patch = keep_patch ? wi : kNone;
+                out.hom_ok = ok; out.decode_ok = have;
+                for (int r = 0; r < 4; r++) out.codes[r] = have ? s_codes[r] : 0;
+                int found_any = 0;
+                uint32_t min_code_distance = 0x7FFFFFFFu, min_rotation = 0, min_code_id = 0x7FFFFFFFu;
+                uint64_t min_code = 0x7FFFFFFFull;
+                if (have) {
+                    for (uint32_t r = 0; r < 4; r++) {
+                        unsigned long long b = s_best[0][r];
+                        for (int w = 1; w < NWP; w++) b = s_best[w][r] < b ? s_best[w][r] : b;
+                        // empty dictionary: find_nearest returns (0, 0xFF)
+                        const uint32_t nearest_dist = n_codes ? (uint32_t)(b >> 32) : 0xFFu;
+                        const uint32_t nearest_id = n_codes ? (uint32_t)b : 0u;
+                        if (nearest_dist < min_code_distance) {
+                            min_code = s_codes[r]; min_code_distance = nearest_dist; min_code_id = nearest_id; min_rotation = r; found_any = 1;
+                        }
+                    }
+                }
+                if (found_any && (!filter || min_code_distance < tau)) {
+                    out.valid = 1; out.id = min_code_id; out.code = min_code; out.rotation = (uint8_t)min_rotation;
+                    out.hamming = (uint8_t)min_code_distance;
+                }
+                outs[slot] = out;
+                if (out.valid && per_frame) atomicAdd(&per_frame[first_frame + fl], 1u);   // one address per frame: no contention to speak of
+            }
         }
+#undef POST_SYNC
     }
 }
 
@@ -1093,16 +1104,18 @@ hipError_t launch_decode(hipStream_t st, PixelSrc src, int W, int H, uint32_t fi
                          uint32_t n_codes, uint32_t tau, int filter, void* proj, const float* wtab, void* outs, uint8_t* patches, uint32_t patch_cap, uint32_t* per_frame, int grid_blocks, int dbg, int few) {
     ProjRec* recs = reinterpret_cast<ProjRec*>(proj);
     if (dbg > 0 || dbg == -1000) hipLaunchKernelGGL(k_projection, dim3(256), dim3(64), 0, st, fin_xy, work, work_count, S, recs);
-    // One wave per candidate is the better shape when thousands of candidates share the memory system (BASELINE config 2: 97 us
-    // against 99 us with four waves per candidate).  A single candidate, though, is then a chain of 19 round trips to the frame
-    // plus the stages after it -- 65 us however idle the chip is; four waves share that chain out (36 us for the 337 candidates
-    // of a 32-frame batch against 69 us).  `few`: the batch is small (a3_api: at most 64 frames).
+    // Four waves sample a candidate: a candidate is a chain of round trips to the frame (19 of them for one wave: 65 us for a lone
+    // candidate however idle the chip is, 33 us with four waves).  What follows the sampling runs on all four waves when the
+    // batch is small and every microsecond of that chain shows (`few`: at most 64 frames; 36 us for the 337 candidates of 32
+    // frames against 39), and on one wave -- no workgroup barriers -- when thousands of candidates are in flight and only the
+    // throughput counts (BASELINE config 2: decode stage 0.123 ms against 0.130 with one wave per candidate throughout).
     const int d = dbg == -1000 ? 0 : (dbg < 0 ? -dbg : dbg);
+    if (const char* ev = getenv("A3_DECODE_WIDE")) few = atoi(ev);   // tuning knob
     if (few)
-        hipLaunchKernelGGL(k_decode<256>, dim3(grid_blocks), dim3(256), decode_lds_bytes(S, n, max_taps), st, src, W, H, first_frame, fin_xy, work, work_count,
+        hipLaunchKernelGGL((k_decode<256, 256>), dim3(grid_blocks), dim3(256), decode_lds_bytes(S, n, max_taps), st, src, W, H, first_frame, fin_xy, work, work_count,
                            max_cand, S, n, max_taps, dict, n_codes, tau, filter, recs, wtab, reinterpret_cast<DecodeOut*>(outs), patches, patch_cap, per_frame, d);
     else
-        hipLaunchKernelGGL(k_decode<A3_D_THREADS>, dim3(grid_blocks), dim3(A3_D_THREADS), decode_lds_bytes(S, n, max_taps), st, src, W, H, first_frame, fin_xy, work,
+        hipLaunchKernelGGL((k_decode<A3_D_THREADS, 64>), dim3(grid_blocks), dim3(A3_D_THREADS), decode_lds_bytes(S, n, max_taps), st, src, W, H, first_frame, fin_xy, work,
                            work_count, max_cand, S, n, max_taps, dict, n_codes, tau, filter, recs, wtab, reinterpret_cast<DecodeOut*>(outs), patches, patch_cap,
                            per_frame, d);
     return hipGetLastError();
