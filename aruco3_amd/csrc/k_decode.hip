@@ -389,6 +389,9 @@ __device__ __forceinline__ void rotated_source(uint32_t r, uint32_t n, uint32_t 
 #ifndef A3_D_THREADS
 #define A3_D_THREADS 256   // threads that sample one candidate (large batches; small ones: 256 throughout)
 #endif
+#ifndef A3_D_WAVES256
+#define A3_D_WAVES256 3   // workgroups of 256 threads per CU-quarter (= waves per SIMD)
+#endif
 #ifndef A3_D_DB
 #define A3_D_DB 8     // dictionary codes per lane and trip in the nearest-code scan
 #endif
@@ -397,7 +400,7 @@ __device__ __forceinline__ void rotated_source(uint32_t r, uint32_t n, uint32_t 
 // sample order (round 1): 116 us; 64 threads, 8 x 8 blocked order: 98 us; 256 threads sampling, the first wave doing the rest:
 // 94 us -- and 7 us less than the 64-thread version inside the pipeline, where the frames are not in any cache.
 template <int NT, int PT>
-__global__ __launch_bounds__(NT, NT == 64 ? A3_D_WAVES : 3) void k_decode(PixelSrc src, int W, int H, uint32_t first_frame,
+__global__ __launch_bounds__(NT, NT == 64 ? A3_D_WAVES : A3_D_WAVES256) void k_decode(PixelSrc src, int W, int H, uint32_t first_frame,
                                                 const uint16_t* __restrict__ fin_xy, const uint32_t* __restrict__ work,
                                                 const unsigned int* __restrict__ work_count, uint32_t max_cand, uint32_t S, uint32_t n,
                                                 uint32_t max_taps, const uint64_t* __restrict__ dict, uint32_t n_codes, uint32_t tau,
