@@ -187,13 +187,22 @@ int fail(a3_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
     } while (0)
 
 // Waiting for a batch that takes about a millisecond: a blocking hipStreamSynchronize wakes the host tens of microseconds
-// late, so poll first and only block when the work is long.
+// late, so poll first (with the CPU's spin-wait hint between polls, which leaves the core's other hardware thread its share)
+// and block once the work has proved long: after 2 ms the wake-up delay no longer matters.
+inline void spin_pause() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+}
+constexpr auto kSpinBudget = std::chrono::milliseconds(2);
+
 hipError_t wait_stream(hipStream_t st) {
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         const hipError_t e = hipStreamQuery(st);
         if (e != hipErrorNotReady) return e;
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) return hipStreamSynchronize(st);
+        if (std::chrono::steady_clock::now() - t0 > kSpinBudget) return hipStreamSynchronize(st);
+        spin_pause();
     }
 }
 
@@ -203,7 +212,8 @@ hipError_t wait_event(hipEvent_t ev, hipStream_t st) {
     for (;;) {
         const hipError_t e = hipEventQuery(ev);
         if (e != hipErrorNotReady) return e;
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) return hipEventSynchronize(ev);
+        if (std::chrono::steady_clock::now() - t0 > kSpinBudget) return hipEventSynchronize(ev);
+        spin_pause();
     }
 }
 
