@@ -226,15 +226,19 @@ __device__ bool solve_projection(const float* from, float S, float* inv_out) {
     return true;
 }
 
-__device__ __forceinline__ uint8_t clamp_u8(float x) {
-    if (x < 255.0f) { if (x > 0.0f) return (uint8_t)x; return 0; }
-    return 255;  // also NaN
+// v_cvt_u32_f32 truncates, saturates (negative -> 0, >= 2^32 -> 0xFFFFFFFF) and turns NaN into 0: Rust's `as u32` in one
+// instruction (written as asm because a C++ cast is undefined outside the range, i.e. free to be anything after optimisation).
+__device__ __forceinline__ uint32_t sat_u32(float x) {
+    uint32_t r;
+    asm("v_cvt_u32_f32_e32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
 }
 
-__device__ __forceinline__ uint32_t sat_u32(float x) {  // Rust `as u32`
-    if (!(x > 0.0f)) return 0u;
-    if (x >= 4294967296.0f) return 0xFFFFFFFFu;
-    return (uint32_t)x;
+// imageproc's Clamp for u8: x < 255 ? (x > 0 ? x as u8 : 0) : 255 -- so NaN gives 255.  Branch-free: the sampling loop runs
+// this three times per sample, and the nested ifs became three exec-mask regions each.
+__device__ __forceinline__ uint8_t clamp_u8(float x) {
+    const uint32_t r = min(sat_u32(x), 255u);
+    return (uint8_t)(x != x ? 255u : r);
 }
 
 // grey level of pixel x in a frame row: the plane K1 wrote, or into_luma8 of the caller's pixel (same integers)
@@ -274,11 +278,12 @@ __device__ __forceinline__ void sample_issue(TapLoad& tl, const uint8_t* __restr
     // safe: where a sample without wide taps reads instead -- the frame itself, unless it is smaller than one wide read
     const float left = floorf(x), right = left + 1.0f, top = floorf(y), bottom = top + 1.0f;
     tl.rw = x - left; tl.bw = y - top;
-    const bool inside = valid && !(left < 0.0f || right >= (float)w || top < 0.0f || bottom >= (float)h);
+    // (bitwise, not short-circuit: no branches)
+    const bool inside = valid & !((left < 0.0f) | (right >= (float)w) | (top < 0.0f) | (bottom >= (float)h));
     const uint32_t l = inside ? sat_u32(left) : 0u, t = inside ? sat_u32(top) : 0u, b = inside ? sat_u32(bottom) : 0u;
     tl.l = l; tl.t = t;
     // the wide read of the bottom row must end inside this frame (running on into the next row is fine)
-    const bool wide = inside && (size_t)b * row_stride + (size_t)bpp * l + 12u <= (size_t)(h - 1u) * row_stride + (size_t)w * bpp;
+    const bool wide = inside & ((size_t)b * row_stride + (size_t)bpp * l + 12u <= (size_t)(h - 1u) * row_stride + (size_t)w * bpp);
     tl.mode = inside ? (wide ? 1 : 2) : 0;
     const uintptr_t pt = reinterpret_cast<uintptr_t>(wide ? img + (size_t)t * row_stride + (size_t)bpp * l : safe);
     const uintptr_t pb = reinterpret_cast<uintptr_t>(wide ? img + (size_t)b * row_stride + (size_t)bpp * l : safe);
