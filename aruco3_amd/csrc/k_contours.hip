@@ -40,6 +40,16 @@
 
 #include "a3_common.h"
 
+// Darts per lane and trip in the per-dart sweeps (build knobs, swept on BASELINE config 2).  k_jump_finalize: 2 / 4 / 6 / 8 darts
+// -> 53 / 48 / 44.5 / 45 us: its three dependent loads want company.  k_scatter_points: 1 / 2 / 3 / 4 -> 34.5 / 37 / 37.5 / 41 us
+// (on 8192 workgroups): its loads of one dart already come two and three at a time, and more threads beat more darts per thread.
+#ifndef A3_FIN_B
+#define A3_FIN_B 6
+#endif
+#ifndef A3_SCAT_B
+#define A3_SCAT_B 1
+#endif
+
 namespace a3 {
 
 // ---------------------------------------------------------------------------------------
@@ -865,11 +875,11 @@ __global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const J
     const uint32_t shard = blockIdx.x & (kLeaderShards - 1);   // spread the slot counter over 16 addresses
     const uint32_t stride = gridDim.x * blockDim.x;            // the launcher keeps ceil(n_darts / stride) <= 32
     uint32_t mask = 0;                                          // bit i: my i-th dart leads a cycle that has a start event
-    // Four darts per lane at a time, each of the three dependent loads (local state -> slot of the entry the window froze at ->
-    // that entry's state) issued for all four before the first is used: the kernel is a chain of round trips to memory, and
+    // B darts per lane at a time, each of the three dependent loads (local state -> slot of the entry the window froze at ->
+    // that entry's state) issued for all of them before the first is used: the kernel is a chain of round trips to memory, and
     // one dart at a time it is three of them per dart.  Loads are unconditional from clamped indices (slot 0 for windows that
     // did not freeze: a cached line); behind an `if` the compiler would issue them one at a time again.
-    constexpr int B = 4;
+    constexpr int B = A3_FIN_B;
     int it = 0;
     for (uint32_t d0 = blockIdx.x * blockDim.x + threadIdx.x; d0 < n_darts; d0 += B * stride, it += B) {
         JumpState s[B];
@@ -1178,9 +1188,9 @@ __global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restr
                                                         const uint32_t* __restrict__ n_live, const DeviceCounters* __restrict__ ctr) {
     if (ctr->entry_overflow) return;
     if (n_live) n_darts = min(n_darts, *n_live);
-    // Four darts per lane at a time, three rounds of loads instead of five per dart: {state, record} -> {leader's key, border
+    // B darts per lane at a time, three rounds of loads instead of five per dart: {state, record} -> {leader's key, border
     // slot of the leader} -> {border record, start offset}.  Unconditional loads from clamped indices, see k_jump_finalize.
-    constexpr int B = 4;
+    constexpr int B = A3_SCAT_B;
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t d0 = blockIdx.x * blockDim.x + threadIdx.x; d0 < n_darts; d0 += B * stride) {
         JumpState s[B];
@@ -1549,7 +1559,7 @@ hipError_t launch_select_scatter(hipStream_t st, const JumpState* fin, uint32_t 
                                  double eps_factor, double image_diag, uint32_t* cyc_slot, ContourRec* contours, uint32_t* cyc_start_off,
                                  uint32_t max_contours, uint64_t max_points, DeviceCounters* ctr, const uint64_t* d_rec, uint32_t* points,
                                  const uint32_t* n_live, int inline_resolve_W, uint32_t* keep_tmp, int keep_all) {
-    const dim3 grid(blocks_for(n_darts, 256, env_cap("A3_SCATTER_BLOCKS", 4096))), block(256);
+    const dim3 grid(blocks_for(n_darts, 256, env_cap("A3_SCATTER_BLOCKS", 8192))), block(256);
     hipLaunchKernelGGL(k_cycle_select, dim3(blocks_for(n_darts / 64 + 1, 256, env_cap("A3_SELECT_BLOCKS", 1024))), block, 0, st, fin, leader_list, leader_count, d_succ, t_cur,
                        frame_base, n_frames, first_frame, min_edge_length,
                        eps_factor, image_diag, cyc_slot, contours, cyc_start_off, max_contours, max_points, ctr, leader_shard_cap(n_darts), d_rec,
