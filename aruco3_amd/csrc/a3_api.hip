@@ -19,6 +19,7 @@ hipError_t launch_grey_threshold(hipStream_t, const uint8_t*, int, size_t, size_
 // k_contours.hip
 hipError_t launch_dart_count(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, unsigned long long*, uint32_t*, uint64_t, uint32_t*, uint32_t*);
 size_t tile_darts_bytes(uint32_t W, uint32_t H, uint32_t n_frames);
+size_t tile_off_offset(uint32_t W, uint32_t H, uint32_t n_frames);
 hipError_t launch_dart_build(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*, const uint32_t*,
                              uint64_t*, uint32_t*, uint32_t, const uint32_t*, int);
 hipError_t launch_zero(hipStream_t, void*, size_t);
@@ -404,7 +405,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
             A3_HIP(hipMemsetAsync(d_leader_count, 0, 4 * 32, st));   // leader + entry counters, adjacent
             A3_HIP(hipMemsetAsync(ctx->frame_cursor, 0, (size_t)c.count * 4, st));   // per-frame entry counts
         }
-        const uint32_t* tile_off = ctx->tile_darts.as<uint32_t>() + tile_darts_bytes(W, H, n) / 8;
+        const uint32_t* tile_off = ctx->tile_darts.as<uint32_t>() + tile_off_offset(W, H, n);
         A3_HIP(launch_dart_build(st, d_bin, (int)W, (int)H, c.first, c.count, fb, tile_off, ctx->pix_base.as<uint32_t>(),
                                  ctx->tile_darts.as<uint32_t>(), ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), nd, n_live, 0));
         int rounds = 1;
@@ -833,7 +834,7 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
                                      ctx->tile_darts.as<uint32_t>(), 0, nullptr, nullptr));
         } else if (kernel == 1) {
             A3_HIP(launch_dart_build(st, ctx->bin.as<uint64_t>(), (int)ctx->W, (int)ctx->H, 0, ctx->dbg_frames, ctx->frame_base.as<uint32_t>(),
-                                     ctx->tile_darts.as<uint32_t>() + tile_darts_bytes(ctx->W, ctx->H, ctx->frames) / 8, ctx->pix_base.as<uint32_t>(),
+                                     ctx->tile_darts.as<uint32_t>() + tile_off_offset(ctx->W, ctx->H, ctx->frames), ctx->pix_base.as<uint32_t>(),
                                      ctx->tile_darts.as<uint32_t>(), ctx->d_xy.as<uint64_t>(),
                                      ctx->d_succ.as<uint32_t>(), ctx->dbg_nd, nullptr, dbg ? dbg : 5));
         } else if (kernel == 2) {

@@ -162,9 +162,18 @@ constexpr int kCountLanes = 60;   // words per wave and row: 15 whole tiles (lan
 // Images of at most 30 words per row (1920 pixels) put TWO tile rows into one wave: lanes 0..31 walk one, lanes 32..63 the
 // next (words 0..29 in lanes 1..30 of each half; lanes 0 and 31 hold zeros, which is what lies outside the image, so the wave
 // shifts across the middle deliver the right bits).
+// A tile row is walked by kCountHalves waves, 64 / kCountHalves image rows each (blockIdx.z; each writes its own count array,
+// k_tile_scan adds them): with one wave per tile row pair the launch was 2304 waves on 1024 SIMDs, i.e. three on some SIMDs
+// and two on the others, and the kernel is bound by its bit arithmetic (VALU busy 70 %), so it took as long as three waves on
+// one SIMD.  1 / 2 / 4 parts: 36 / 31 / 27.6 us (each part re-reads two rows of its neighbours).
+#ifndef A3_COUNT_PARTS
+#define A3_COUNT_PARTS 4
+#endif
+constexpr int kCountHalves = A3_COUNT_PARTS;
 template <int G>
 __global__ __launch_bounds__(64) void k_dart_count(const uint64_t* __restrict__ bits, int W, int H, uint32_t first_frame,
-                                                   unsigned long long* __restrict__ frame_darts, uint32_t* __restrict__ tile_darts) {
+                                                   unsigned long long* __restrict__ frame_darts, uint32_t* __restrict__ tile_darts,
+                                                   uint32_t* __restrict__ tile_darts_h1) {
     static_assert(kCountLanes % kTileWords == 0, "a wave counts whole tiles");
     constexpr int kGroups = 64 / G, kOwners = G == 64 ? kCountLanes : 30, kTilesPerGroup = (kOwners + kTileWords - 1) / kTileWords;
     __shared__ uint32_t s_tile[kGroups][kTilesPerGroup];
@@ -178,7 +187,8 @@ __global__ __launch_bounds__(64) void k_dart_count(const uint64_t* __restrict__ 
     const bool owner = gl >= 1 && gl <= kOwners && j < wpr && ty < (int)tiles_y;
     const uint64_t* img = bits + (size_t)(first_frame + f) * wpr * H;
     if (lane < kGroups * kTilesPerGroup) (&s_tile[0][0])[lane] = 0;
-    const int y0 = ty * kTileRows;
+    constexpr int kRows = kTileRows / kCountHalves;
+    const int y0 = ty * kTileRows + (int)blockIdx.z * kRows;
     // (unconditional load from a clamped address, then a select: a load behind a branch cannot be batched with its neighbours)
     const int jc = min(max(j, 0), wpr - 1);
     auto word = [&](int y) -> uint64_t {
@@ -194,7 +204,7 @@ __global__ __launch_bounds__(64) void k_dart_count(const uint64_t* __restrict__ 
     // launch is only a couple of waves per SIMD, so a tile row's time is its chain of round trips to memory -- five of them
     // now, overlapped with the bit work, instead of ten
     constexpr int kAhead = 16;
-    static_assert(kTileRows % kAhead == 0, "whole batches of rows");
+    static_assert(kRows % kAhead == 0, "whole batches of rows");
     Row3 up, cur;
     uint64_t nxt[kAhead], ahead[kAhead];
     up.c = word(y0 - 1);
@@ -205,8 +215,8 @@ __global__ __launch_bounds__(64) void k_dart_count(const uint64_t* __restrict__ 
     edge_bits(cur.c, &cur.lbit, &cur.rbit);
     uint32_t nd = 0;
 #pragma unroll
-    for (int r0 = 0; r0 < kTileRows; r0 += kAhead) {
-        if (r0 + kAhead < kTileRows) {
+    for (int r0 = 0; r0 < kRows; r0 += kAhead) {
+        if (r0 + kAhead < kRows) {
 #pragma unroll
             for (int u = 0; u < kAhead; u++) ahead[u] = word(y0 + r0 + kAhead + u + 1);
         }
@@ -244,7 +254,8 @@ __global__ __launch_bounds__(64) void k_dart_count(const uint64_t* __restrict__ 
         const uint32_t tx = (uint32_t)(cx * kTilesPerGroup + gl);
         if (tx < tiles_x) {
             total = s_tile[grp][gl];
-            tile_darts[(size_t)(first_frame + f) * (tiles_x * tiles_y) + ty * tiles_x + tx] = total;   // lets k_dart_assign skip empty tiles
+            // part 0 goes to tile_darts itself, part z > 0 to the z-th array behind tile_off; k_tile_scan adds them up
+            (blockIdx.z ? tile_darts_h1 + (size_t)(blockIdx.z - 1) * gridDim.y * (tiles_x * tiles_y) : tile_darts)[(size_t)(first_frame + f) * (tiles_x * tiles_y) + ty * tiles_x + tx] = total;
         }
     }
     for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
@@ -294,7 +305,7 @@ __device__ void plan_frames(const unsigned long long* __restrict__ frame_darts, 
 // (and dart numbering no longer depends on scheduling).  grid: frames; tiles per frame is a few hundred.
 // (Workgroup n_frames of the launch, when there is one, does the device-side plan: it needs the per-frame totals k_dart_count
 // has just added up and nothing of this kernel, and a launch of its own costs 6 us for 2 us of work.)
-__global__ __launch_bounds__(256) void k_tile_scan(const uint32_t* __restrict__ tile_darts, uint32_t tiles, uint32_t first_frame,
+__global__ __launch_bounds__(256) void k_tile_scan(uint32_t* __restrict__ tile_darts, const uint32_t* __restrict__ tile_darts_h1, uint32_t tiles, uint32_t first_frame,
                                                    uint32_t* __restrict__ tile_off, uint32_t n_frames,
                                                    const unsigned long long* __restrict__ frame_darts, unsigned long long cap,
                                                    uint32_t* __restrict__ frame_base, uint32_t* __restrict__ plan) {
@@ -306,7 +317,13 @@ __global__ __launch_bounds__(256) void k_tile_scan(const uint32_t* __restrict__ 
     __syncthreads();
     for (uint32_t t0 = 0; t0 < tiles; t0 += 256) {
         const uint32_t t = t0 + threadIdx.x;
-        const uint32_t v = t < tiles ? tile_darts[base + t] : 0u;
+        uint32_t v = 0;
+        if (t < tiles) {   // the parts of k_dart_count
+            v = tile_darts[base + t];
+#pragma unroll
+            for (int z = 1; z < kCountHalves; z++) v += tile_darts_h1[(size_t)(z - 1) * n_frames * tiles + base + t];
+        }
+        if (t < tiles) tile_darts[base + t] = v;   // lets k_dart_assign skip empty tiles
         uint32_t total;
         const uint32_t excl = block_excl_scan_256(v, s_wave, &total);
         if (t < tiles) tile_off[base + t] = s_run + excl;
@@ -1474,19 +1491,22 @@ hipError_t launch_zero(hipStream_t st, void* p, size_t bytes /* multiple of 16, 
 }
 
 // tile_darts[frames * tiles] followed by tile_off[frames * tiles]
-size_t tile_darts_bytes(uint32_t W, uint32_t H, uint32_t n_frames) { return (size_t)dart_tiles(W, H) * n_frames * 4 * 2; }
+// tile_darts[frames * tiles] | tile_off[frames * tiles] | second-half counts of k_dart_count[frames * tiles]
+size_t tile_darts_bytes(uint32_t W, uint32_t H, uint32_t n_frames) { return (size_t)dart_tiles(W, H) * n_frames * 4 * (1 + kCountHalves); }
+size_t tile_off_offset(uint32_t W, uint32_t H, uint32_t n_frames) { return (size_t)dart_tiles(W, H) * n_frames; }
 
 // plan != nullptr: the launch of k_tile_scan also plans the batch on the device (frame_base[0..n_frames], plan[0..3])
 hipError_t launch_dart_count(hipStream_t st, const uint64_t* bits, int W, int H, uint32_t first_frame, uint32_t n_frames,
                              unsigned long long* frame_darts, uint32_t* tile_darts, uint64_t plan_cap, uint32_t* frame_base, uint32_t* plan) {
     const uint32_t tiles_x = dart_tiles_x((uint32_t)W), tiles_y = ((uint32_t)H + kTileRows - 1) / kTileRows;
     const uint32_t wpr = words_per_row((uint32_t)W);
+    uint32_t* h1 = tile_darts + (size_t)tiles_x * tiles_y * n_frames * 2;
     if (wpr <= 30)   // two tile rows per wave
-        hipLaunchKernelGGL(k_dart_count<32>, dim3((tiles_y + 1) / 2, n_frames), dim3(64), 0, st, bits, W, H, first_frame, frame_darts, tile_darts);
+        hipLaunchKernelGGL(k_dart_count<32>, dim3((tiles_y + 1) / 2, n_frames, kCountHalves), dim3(64), 0, st, bits, W, H, first_frame, frame_darts, tile_darts, h1);
     else
-        hipLaunchKernelGGL(k_dart_count<64>, dim3(((wpr + kCountLanes - 1) / kCountLanes) * tiles_y, n_frames), dim3(64), 0, st, bits, W, H, first_frame,
-                           frame_darts, tile_darts);
-    hipLaunchKernelGGL(k_tile_scan, dim3(n_frames + (plan ? 1u : 0u)), dim3(256), 0, st, tile_darts, tiles_x * tiles_y, first_frame,
+        hipLaunchKernelGGL(k_dart_count<64>, dim3(((wpr + kCountLanes - 1) / kCountLanes) * tiles_y, n_frames, kCountHalves), dim3(64), 0, st, bits, W, H, first_frame,
+                           frame_darts, tile_darts, h1);
+    hipLaunchKernelGGL(k_tile_scan, dim3(n_frames + (plan ? 1u : 0u)), dim3(256), 0, st, tile_darts, h1, tiles_x * tiles_y, first_frame,
                        tile_darts + (size_t)tiles_x * tiles_y * n_frames, n_frames, frame_darts, (unsigned long long)plan_cap, frame_base, plan);
     return hipGetLastError();
 }
