@@ -395,7 +395,7 @@ __device__ __forceinline__ void rotated_source(uint32_t r, uint32_t n, uint32_t 
 #define A3_D_THREADS 256   // threads that sample one candidate (large batches; small ones: 256 throughout)
 #endif
 #ifndef A3_D_WAVES256
-#define A3_D_WAVES256 3   // workgroups of 256 threads per CU-quarter (= waves per SIMD)
+#define A3_D_WAVES256 5   // workgroups of 256 threads per CU-quarter (= waves per SIMD)
 #endif
 #ifndef A3_D_DB
 #define A3_D_DB 8     // dictionary codes per lane and trip in the nearest-code scan
