@@ -568,7 +568,13 @@ __global__ __launch_bounds__(256) void k_dart_link(int W, int H, uint32_t first_
 // A window is a path [d, ptr): `dist` hops long, `key` = smallest (event key, dart) on it, `off` = hops from d to that
 // dart.  Joining window(d) with window(ptr) doubles the path; once a window wraps a whole cycle its key is the cycle's
 // leader and off the hop distance to it.
-constexpr int kLT = 2048;                     // darts per local tile (consecutive indices = neighbouring pixels)
+// Darts per local tile (consecutive indices = neighbouring pixels): k_local_contract<LT>.  2048 with the global doubling rounds
+// (noise-like frames: every tile boundary a chain crosses makes an entry, and there the entries are the expensive part: 1024
+// costs the reference's noise recipe 19 %), 1024 with the per-frame entry resolution of clean frames, where the entries are
+// cheap and the smaller tile saves a doubling round and half of the LDS per workgroup (72 -> 60 us on BASELINE config 2;
+// 512: 68 us, 4096: 103 us).
+constexpr int kLT = 2048;                     // the larger of the two: sizes the entry slot space of the global rounds
+constexpr int kLTFrame = 1024;
 // Entry slots are handed out from 16 counters (one same-address atomic costs ~11 ns and they serialise): tile t uses
 // shard t & 15, whose slots are [shard * cap, shard * cap + count[shard]); a tile holds at most kLT entries, so
 // cap = ceil(tiles / 16) * kLT can never overflow.
@@ -618,7 +624,8 @@ __device__ __forceinline__ void lds_barrier() {
 
 // Phase 1: 11 doubling rounds inside one tile, entirely in LDS.  A window stops growing ("freezes") when its end leaves
 // the tile; cycles that close inside the tile finish here.  Darts that some frozen window ends on become "entries".
-__global__ __launch_bounds__(256, 4) void k_local_contract(uint32_t n_darts, int W, const uint64_t* __restrict__ d_rec,
+template <int LT>
+__global__ __launch_bounds__(256, LT >= 2048 ? 4 : 8) void k_local_contract(uint32_t n_darts, int W, const uint64_t* __restrict__ d_rec,
                                                         const uint32_t* __restrict__ d_succ,
                                                         JumpState* __restrict__ loc,
                                                         uint32_t* __restrict__ entry_list,
@@ -630,17 +637,17 @@ __global__ __launch_bounds__(256, 4) void k_local_contract(uint32_t n_darts, int
     // dbg (a3_debug_kernel_time only; 0 in the product path): n > 0 runs n doubling rounds instead of 11; -1 = none
     // one 16-byte record per dart (a single ds_read_b128 fetches the next window): off <= 2047 and dist <= 2048 share a word
     struct __attribute__((aligned(16))) Win { uint64_t key; uint32_t ptr; uint32_t offdist; };
-    __shared__ Win s_win[kLT];
+    __shared__ Win s_win[LT];
     constexpr uint32_t kFrameWin = 64;               // frames a tile may span with block-aggregated counting (beyond: direct atomics)
     __shared__ uint32_t s_fcnt[kFrameWin], s_fbase[kFrameWin];
     __shared__ uint32_t s_new_count, s_new_base, s_f0;
     if (n_live) n_darts = min(n_darts, *n_live);
-    const uint32_t lo = blockIdx.x * kLT;
+    const uint32_t lo = blockIdx.x * LT;
     if (lo >= n_darts) return;   // the grid covers the pool's capacity, the graph may be smaller
-    const uint32_t cnt = min((uint32_t)kLT, n_darts - lo);
+    const uint32_t cnt = min((uint32_t)LT, n_darts - lo);
     // every lane owns 8 darts (i = lane + 256 u) and keeps their window state in registers across the rounds; LDS holds the
     // copy the other lanes read (per dart and round: one 16-byte read of the next window, one 16-byte write)
-    constexpr int PER = kLT / 256;
+    constexpr int PER = LT / 256;
     uint64_t nk[PER]; uint32_t np[PER], no[PER], nd[PER], succ0[PER], frm[PER];
     if (threadIdx.x == 0) s_new_count = 0;
     if (threadIdx.x < kFrameWin) s_fcnt[threadIdx.x] = 0;
@@ -706,7 +713,8 @@ __global__ __launch_bounds__(256, 4) void k_local_contract(uint32_t n_darts, int
     }
     // (Skipping windows that are already final -- frozen, or wrapped, visible as "the next window has the same minimum" --
     // was tried: most windows of a clean frame only become final in the last rounds, and the extra flags made it 20 % slower.)
-    const int n_rounds = dbg == 0 ? 11 : (dbg < 0 ? 0 : dbg);
+    constexpr int kLocalRounds = LT == 4096 ? 12 : (LT == 2048 ? 11 : (LT == 1024 ? 10 : 9));   // 2^rounds >= LT
+    const int n_rounds = dbg == 0 ? kLocalRounds : (dbg < 0 ? 0 : dbg);
     for (int round = 0; round < n_rounds; round++) {
         uint32_t upd = 0;   // bit u: window u was joined with its successor window in this round (a frozen one is not: its
                             // LDS copy stays as it is and need not be written again)
@@ -1534,8 +1542,12 @@ hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uin
                               const uint32_t* frame_base, uint32_t* frame_entries /*nullptr: global rounds*/, uint32_t n_frames) {
     // entry_count[16] and leader_count[16] arrive zeroed (the caller's per-batch / per-chunk memset)
     const uint32_t ecap = entry_shard_cap(n_darts);
-    hipLaunchKernelGGL(k_local_contract, dim3((n_darts + kLT - 1) / kLT), dim3(256), 0, st, n_darts, W, d_rec, d_succ, loc,
-                       entry_list, entry_pos, entry_count, ecap, frame_base, frame_entries, n_live, dbg);
+    if (frame_entries)
+        hipLaunchKernelGGL(k_local_contract<kLTFrame>, dim3((n_darts + kLTFrame - 1) / kLTFrame), dim3(256), 0, st, n_darts, W, d_rec, d_succ, loc,
+                           entry_list, entry_pos, entry_count, ecap, frame_base, frame_entries, n_live, dbg);
+    else
+        hipLaunchKernelGGL(k_local_contract<kLT>, dim3((n_darts + kLT - 1) / kLT), dim3(256), 0, st, n_darts, W, d_rec, d_succ, loc,
+                           entry_list, entry_pos, entry_count, ecap, frame_base, frame_entries, n_live, dbg);
     if (dbg) return hipGetLastError();
     EntryState* a = reinterpret_cast<EntryState*>(es_a);
     EntryState* b = reinterpret_cast<EntryState*>(es_b);
