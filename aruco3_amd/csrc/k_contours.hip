@@ -782,22 +782,24 @@ __global__ __launch_bounds__(256) void k_entry_frame(const uint32_t* __restrict_
     const uint32_t cnt = frame_entries[f], base = frame_base[f];
     if (cnt == 0) return;
     if (cnt > kEntryLdsCap) { if (threadIdx.x == 0) ctr->entry_overflow = 1u; return; }
-    // the three dependent loads (entry -> its local state -> slot of the entry it froze at) for two entries per lane at a time:
-    // a clean frame has a few hundred entries, i.e. one trip of this loop
-    for (uint32_t i0 = threadIdx.x; i0 < cnt + threadIdx.x; i0 += 512) {   // (uniform trip count)
-        uint32_t e[2], pos[2];
-        JumpState l[2];
+    // the three dependent loads (entry -> its local state -> slot of the entry it froze at) for four entries per lane at a time:
+    // a clean frame has several hundred entries, i.e. one trip of this loop
+    constexpr int EB = 4;
+    for (uint32_t i0 = threadIdx.x; i0 < cnt + threadIdx.x; i0 += 256 * EB) {   // (uniform trip count)
+        uint32_t e[EB], pos[EB];
+        JumpState l[EB];
 #pragma unroll
-        for (int u = 0; u < 2; u++) e[u] = entry_list[base + min(i0 + 256u * u, cnt - 1u)];
+        for (int u = 0; u < EB; u++) e[u] = entry_list[base + min(i0 + 256u * u, cnt - 1u)];
 #pragma unroll
-        for (int u = 0; u < 2; u++) l[u] = loc[e[u]];
+        for (int u = 0; u < EB; u++) l[u] = loc[e[u]];
 #pragma unroll
-        for (int u = 0; u < 2; u++) pos[u] = entry_pos[l[u].ptr];   // (some dart, and ignored, when the window did not freeze)
-        // (the values are "used" here so that the compiler cannot sink entry 1's loads into the `i < cnt` test below, which
-        // would turn two overlapped chains of three round trips into six in a row)
-        asm volatile("" : "+v"(pos[0]), "+v"(pos[1]), "+v"(l[0].key), "+v"(l[1].key), "+v"(l[0].off), "+v"(l[1].off));
+        for (int u = 0; u < EB; u++) pos[u] = entry_pos[l[u].ptr];   // (some dart, and ignored, when the window did not freeze)
+        // (the values are "used" here so that the compiler cannot sink the later entries' loads into the `i < cnt` test below,
+        // which would turn overlapped chains of three round trips into chains in a row)
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < EB; u++) asm volatile("" : "+v"(pos[u]), "+v"(l[u].key), "+v"(l[u].off));
+#pragma unroll
+        for (int u = 0; u < EB; u++) {
             const uint32_t i = i0 + 256u * u;
             if (i >= cnt) break;
             s_key[i] = l[u].key; s_off[i] = loc_off(l[u].off); s_dist[i] = loc_dist(l[u].off);
