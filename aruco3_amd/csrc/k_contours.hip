@@ -1555,7 +1555,7 @@ hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uin
     EntryState* b = reinterpret_cast<EntryState*>(es_b);
     if (frame_entries) {   // clean frames: every frame's entry list fits LDS, one launch instead of ~9
         hipLaunchKernelGGL(k_entry_frame, dim3(n_frames), dim3(256), 0, st, entry_list, frame_entries, frame_base, loc, entry_pos, a, ctr);
-        const int fin_blocks = std::max(blocks_for(n_darts, 256, env_cap("A3_FIN_BLOCKS", 2048)), (int)(((uint64_t)n_darts + 256ull * 32 - 1) / (256ull * 32)));
+        const int fin_blocks = std::max(blocks_for(n_darts, 256, env_cap("A3_FIN_BLOCKS", 1536)), (int)(((uint64_t)n_darts + 256ull * 32 - 1) / (256ull * 32)));
         hipLaunchKernelGGL(k_jump_finalize, dim3(fin_blocks), dim3(256), 0, st, n_darts, loc, entry_pos, a, fin,
                            leader_list, leader_count, leader_shard_cap(n_darts), n_live, ctr);
         return hipGetLastError();
@@ -1566,7 +1566,7 @@ hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uin
         hipLaunchKernelGGL(k_entry_jump, grid, block, 0, st, a, b, entry_count, ecap, r, ctr);
         EntryState* t = a; a = b; b = t;
     }
-    const int fin_blocks = std::max(blocks_for(n_darts, 256, env_cap("A3_FIN_BLOCKS", 2048)), (int)(((uint64_t)n_darts + 256ull * 32 - 1) / (256ull * 32)));
+    const int fin_blocks = std::max(blocks_for(n_darts, 256, env_cap("A3_FIN_BLOCKS", 1536)), (int)(((uint64_t)n_darts + 256ull * 32 - 1) / (256ull * 32)));
     hipLaunchKernelGGL(k_jump_finalize, dim3(fin_blocks), block, 0, st, n_darts, loc, entry_pos, a, fin,
                        leader_list, leader_count, leader_shard_cap(n_darts), n_live, ctr);
     return hipGetLastError();
