@@ -17,7 +17,7 @@ namespace a3 {
 // k_threshold.hip
 hipError_t launch_grey_threshold(hipStream_t, const uint8_t*, int, size_t, size_t, int, int, uint32_t, uint32_t, uint8_t*, uint64_t*);
 // k_contours.hip
-hipError_t launch_dart_count(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, unsigned long long*, uint32_t*, uint64_t, uint32_t*, uint32_t*);
+hipError_t launch_dart_count(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, unsigned long long*, uint32_t*, uint64_t, uint32_t*, uint32_t*, void*, size_t);
 size_t tile_darts_bytes(uint32_t W, uint32_t H, uint32_t n_frames);
 size_t tile_off_offset(uint32_t W, uint32_t H, uint32_t n_frames);
 hipError_t launch_dart_build(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*, const uint32_t*,
@@ -152,7 +152,7 @@ struct a3_ctx {
     // last batch geometry (for the debug downloads)
     uint32_t W = 0, H = 0, frames = 0;
 
-    DevBuf dict, in, grey, bin, frame_darts, frame_base, pix_base, tile_darts;
+    DevBuf dict, in, grey, bin, frame_darts, frame_darts_dev, frame_base, pix_base, tile_darts;
     DevBuf d_xy, d_succ, stA, stB, t_cur, t_next, cyc_slot;
     DevBuf leader_list, leader_keep, entry_list, entry_pos, es_a, es_b;
     DevBuf contours, cyc_start_off, points;
@@ -160,7 +160,7 @@ struct a3_ctx {
     // one allocation zeroed by one memset per batch and read back with one copy: [scratch 256 B | counters | per_frame | frame_cursor | cand_count]
     DevBuf zero_blk;
     a3_marker* markers_ptr = nullptr;                // the compacted marker list, right behind the read-back head in the zero block
-    unsigned long long* frame_darts_ptr = nullptr;   // inside the zero block (device plan) or the frame_darts buffer (host plan)
+    unsigned long long* frame_darts_ptr = nullptr;   // frame_darts_dev (device plan: kept zero by its reader) or the frame_darts buffer (host plan)
     unsigned int* scratch_u32 = nullptr; DeviceCounters* counters = nullptr; uint32_t* per_frame = nullptr; uint32_t* frame_cursor = nullptr; uint32_t* cand_count = nullptr;
     uint32_t last_marker_total = 0;   // sizes the speculative marker read-back of the next batch
     DevBuf tmp_a, tmp_b, tmp_c, tmp_d;
@@ -304,29 +304,38 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     // memset zeroes it up to the end of HEAD = [scratch 256 B | counters | per_frame]; HEAD and the marker list that follows it
     // come back to the host in one copy.
     size_t ctr_bytes = 0, head_bytes = 0, head_off = 0;
-    auto layout_zero_block = [&](size_t n_chunks, uint32_t chunk_frames, bool with_frame_darts) -> hipError_t {
+    void* zero_p = nullptr; size_t zero_bytes = 0;
+    auto layout_zero_block = [&](size_t n_chunks, uint32_t chunk_frames, bool launch) -> hipError_t {
         ctr_bytes = sizeof(DeviceCounters) * n_chunks;
         head_bytes = (256 + ctr_bytes + (size_t)n * 4 + 7) & ~(size_t)7;     // what the host reads back ahead of the markers
         const size_t fd_off = ((size_t)chunk_frames * 4 + (size_t)n * 4 + 15) & ~(size_t)15;
-        head_off = (fd_off + (with_frame_darts ? (size_t)n * 8 : 0) + 255) & ~(size_t)255;
+        head_off = (fd_off + 255) & ~(size_t)255;
         const hipError_t e = ctx->zero_blk.ensure(head_off + head_bytes + (size_t)marker_cap * sizeof(a3_marker));
         if (e != hipSuccess) return e;
         uint8_t* z = ctx->zero_blk.as<uint8_t>();
         ctx->frame_cursor = reinterpret_cast<uint32_t*>(z);
         ctx->cand_count = ctx->frame_cursor + chunk_frames;
-        ctx->frame_darts_ptr = with_frame_darts ? reinterpret_cast<unsigned long long*>(z + fd_off) : ctx->frame_darts.as<unsigned long long>();
         ctx->scratch_u32 = reinterpret_cast<unsigned int*>(z + head_off);
         ctx->counters = reinterpret_cast<DeviceCounters*>(z + head_off + 256);
         ctx->per_frame = reinterpret_cast<uint32_t*>(z + head_off + 256 + ctr_bytes);
         ctx->markers_ptr = reinterpret_cast<a3_marker*>(z + head_off + head_bytes);
-        return launch_zero(st, z, (head_off + head_bytes + 15) & ~(size_t)15);   // (may run a few bytes into the marker area: not yet written)
+        zero_p = z; zero_bytes = (head_off + head_bytes + 15) & ~(size_t)15;   // (may run a few bytes into the marker area: not yet written)
+        return launch ? launch_zero(st, zero_p, zero_bytes) : hipSuccess;
     };
     std::vector<Chunk> chunks;
     std::vector<uint64_t> fd;
     A3_HIP(ctx->tile_darts.ensure(tile_darts_bytes(W, H, n)));
     if (device_plan) {
         chunks.push_back(Chunk{0, n, cap_d, (uint32_t)std::min<uint64_t>(cap_d, 0xFFFFFFFFu)});
-        A3_HIP(layout_zero_block(1, n, true));
+        // The plan workgroup (last of k_tile_scan's launch) zeroes the block before it writes the plan into it: nothing earlier
+        // touches it, and a launch of its own costs 4 us for a few KB.  The per-frame dart totals k_dart_count adds up live in a
+        // buffer of their own that the plan workgroup hands back zeroed.
+        A3_HIP(layout_zero_block(1, n, false));
+        if (ctx->frame_darts_dev.cap < (size_t)n * 8) {
+            A3_HIP(ctx->frame_darts_dev.ensure((size_t)n * 8));
+            A3_HIP(hipMemsetAsync(ctx->frame_darts_dev.p, 0, ctx->frame_darts_dev.cap, st));
+        }
+        ctx->frame_darts_ptr = ctx->frame_darts_dev.as<unsigned long long>();
     } else {
         ctx->frame_darts_ptr = ctx->frame_darts.as<unsigned long long>();
         A3_HIP(hipMemsetAsync(ctx->frame_darts.p, 0, (size_t)n * 8, st));
@@ -334,7 +343,8 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     // device plan: frame bases and the dart total come out of the same launch sequence (scratch words 8..11, read back with the results)
     if (device_plan) A3_HIP(ctx->frame_base.ensure((size_t)(n + 1) * 4));
     A3_HIP(launch_dart_count(st, ctx->bin.as<uint64_t>(), (int)W, (int)H, 0, n, ctx->frame_darts_ptr, ctx->tile_darts.as<uint32_t>(), cap_d,
-                             device_plan ? ctx->frame_base.as<uint32_t>() : nullptr, device_plan ? ctx->scratch_u32 + 8 : nullptr));
+                             device_plan ? ctx->frame_base.as<uint32_t>() : nullptr, device_plan ? ctx->scratch_u32 + 8 : nullptr,
+                             device_plan ? zero_p : nullptr, device_plan ? zero_bytes : 0));
     if (!device_plan) {
         if (int rc = ensure_pinned(ctx, std::max<size_t>((size_t)n * 8, 1 << 16))) return rc;
         A3_HIP(hipMemcpyAsync(ctx->pinned, ctx->frame_darts.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
@@ -360,7 +370,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     if (int rc = ensure_dart_pool(ctx, pool_darts)) return rc;
     A3_HIP(ctx->pix_base.ensure((size_t)max_chunk_frames * npx * 4));
     A3_HIP(ctx->frame_base.ensure((size_t)(max_chunk_frames + 1) * 4 * chunks.size()));
-    if (!device_plan) A3_HIP(layout_zero_block(chunks.size(), max_chunk_frames, false));
+    if (!device_plan) A3_HIP(layout_zero_block(chunks.size(), max_chunk_frames, true));
     A3_HIP(ctx->contours.ensure((size_t)ctx->max_contours * sizeof(ContourRec)));
     A3_HIP(ctx->cyc_start_off.ensure((size_t)ctx->max_contours * 4));
     A3_HIP(ctx->points.ensure(ctx->max_points * 4));
@@ -673,7 +683,7 @@ void a3_destroy(a3_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
-    DevBuf* bufs[] = {&ctx->dict, &ctx->in, &ctx->grey, &ctx->bin, &ctx->frame_darts, &ctx->frame_base, &ctx->pix_base,
+    DevBuf* bufs[] = {&ctx->dict, &ctx->in, &ctx->grey, &ctx->bin, &ctx->frame_darts, &ctx->frame_darts_dev, &ctx->frame_base, &ctx->pix_base,
                       &ctx->tile_darts, &ctx->d_xy, &ctx->d_succ, &ctx->stA, &ctx->stB, &ctx->t_cur, &ctx->t_next, &ctx->cyc_slot,
                       &ctx->leader_list, &ctx->leader_keep, &ctx->entry_list, &ctx->entry_pos, &ctx->es_a, &ctx->es_b,
                       &ctx->contours, &ctx->cyc_start_off, &ctx->points, &ctx->zero_blk, &ctx->cands,
@@ -831,7 +841,7 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
         if (kernel == 0) {
             A3_HIP(hipMemsetAsync(ctx->frame_darts.p, 0, (size_t)ctx->frames * 8, st));
             A3_HIP(launch_dart_count(st, ctx->bin.as<uint64_t>(), (int)ctx->W, (int)ctx->H, 0, ctx->frames, ctx->frame_darts.as<unsigned long long>(),
-                                     ctx->tile_darts.as<uint32_t>(), 0, nullptr, nullptr));
+                                     ctx->tile_darts.as<uint32_t>(), 0, nullptr, nullptr, nullptr, 0));
         } else if (kernel == 1) {
             A3_HIP(launch_dart_build(st, ctx->bin.as<uint64_t>(), (int)ctx->W, (int)ctx->H, 0, ctx->dbg_frames, ctx->frame_base.as<uint32_t>(),
                                      ctx->tile_darts.as<uint32_t>() + tile_off_offset(ctx->W, ctx->H, ctx->frames), ctx->pix_base.as<uint32_t>(),

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64) void k_dart_count(const uint64_t* __restrict__ 
 // batch): exclusive prefix sums of the per-frame dart counts -> frame_base[0..n], total -> plan[0] (0 and plan[1] = 1 when
 // the total exceeds `cap`, which makes every later kernel a no-op; the host then re-plans with a read-back), largest
 // frame -> plan[2].  One workgroup of 256 threads (the last one of k_tile_scan's launch); n_frames is small.
-__device__ void plan_frames(const unsigned long long* __restrict__ frame_darts, uint32_t n_frames, unsigned long long cap,
+__device__ void plan_frames(unsigned long long* __restrict__ frame_darts, uint32_t n_frames, unsigned long long cap,
                             uint32_t* __restrict__ frame_base, uint32_t* __restrict__ plan) {
     __shared__ unsigned long long s_pw[4];
     __shared__ unsigned long long s_run;
@@ -277,6 +277,7 @@ __device__ void plan_frames(const unsigned long long* __restrict__ frame_darts, 
     for (uint32_t base = 0; base < n_frames; base += 256) {
         const uint32_t i = base + threadIdx.x;
         const unsigned long long v = i < n_frames ? frame_darts[i] : 0ull;
+        if (i < n_frames) frame_darts[i] = 0ull;   // handed back zeroed: the next batch's k_dart_count adds to it again
         unsigned long long inc = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const unsigned long long t = __shfl_up(inc, o); if (lane >= o) inc += t; }
@@ -307,9 +308,16 @@ __device__ void plan_frames(const unsigned long long* __restrict__ frame_darts, 
 // has just added up and nothing of this kernel, and a launch of its own costs 6 us for 2 us of work.)
 __global__ __launch_bounds__(256) void k_tile_scan(uint32_t* __restrict__ tile_darts, const uint32_t* __restrict__ tile_darts_h1, uint32_t tiles, uint32_t first_frame,
                                                    uint32_t* __restrict__ tile_off, uint32_t n_frames,
-                                                   const unsigned long long* __restrict__ frame_darts, unsigned long long cap,
-                                                   uint32_t* __restrict__ frame_base, uint32_t* __restrict__ plan) {
-    if (blockIdx.x == n_frames) { plan_frames(frame_darts, n_frames, cap, frame_base, plan); return; }
+                                                   unsigned long long* __restrict__ frame_darts, unsigned long long cap,
+                                                   uint32_t* __restrict__ frame_base, uint32_t* __restrict__ plan,
+                                                   uint4* __restrict__ zero_p, uint32_t zero_n16) {
+    if (blockIdx.x == n_frames) {
+        // the batch's block of counters (a3_api's zero block, which also holds `plan`): zeroed here, ahead of its first use
+        for (uint32_t i = threadIdx.x; i < zero_n16; i += 256) zero_p[i] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        plan_frames(frame_darts, n_frames, cap, frame_base, plan);
+        return;
+    }
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_run;
     const size_t base = (size_t)(first_frame + blockIdx.x) * tiles;
@@ -1507,7 +1515,8 @@ size_t tile_off_offset(uint32_t W, uint32_t H, uint32_t n_frames) { return (size
 
 // plan != nullptr: the launch of k_tile_scan also plans the batch on the device (frame_base[0..n_frames], plan[0..3])
 hipError_t launch_dart_count(hipStream_t st, const uint64_t* bits, int W, int H, uint32_t first_frame, uint32_t n_frames,
-                             unsigned long long* frame_darts, uint32_t* tile_darts, uint64_t plan_cap, uint32_t* frame_base, uint32_t* plan) {
+                             unsigned long long* frame_darts, uint32_t* tile_darts, uint64_t plan_cap, uint32_t* frame_base, uint32_t* plan,
+                             void* zero_p, size_t zero_bytes /* with plan: the counter block to zero, a multiple of 16 bytes */) {
     const uint32_t tiles_x = dart_tiles_x((uint32_t)W), tiles_y = ((uint32_t)H + kTileRows - 1) / kTileRows;
     const uint32_t wpr = words_per_row((uint32_t)W);
     uint32_t* h1 = tile_darts + (size_t)tiles_x * tiles_y * n_frames * 2;
@@ -1517,7 +1526,8 @@ hipError_t launch_dart_count(hipStream_t st, const uint64_t* bits, int W, int H,
         hipLaunchKernelGGL(k_dart_count<64>, dim3(((wpr + kCountLanes - 1) / kCountLanes) * tiles_y, n_frames, kCountHalves), dim3(64), 0, st, bits, W, H, first_frame,
                            frame_darts, tile_darts, h1);
     hipLaunchKernelGGL(k_tile_scan, dim3(n_frames + (plan ? 1u : 0u)), dim3(256), 0, st, tile_darts, h1, tiles_x * tiles_y, first_frame,
-                       tile_darts + (size_t)tiles_x * tiles_y * n_frames, n_frames, frame_darts, (unsigned long long)plan_cap, frame_base, plan);
+                       tile_darts + (size_t)tiles_x * tiles_y * n_frames, n_frames, frame_darts, (unsigned long long)plan_cap, frame_base, plan,
+                       reinterpret_cast<uint4*>(zero_p), (uint32_t)(zero_bytes / 16));
     return hipGetLastError();
 }
 
