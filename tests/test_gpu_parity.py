@@ -620,6 +620,28 @@ def test_randomised_structured_frames_full_parity(dicts, oracle, seed):
         _check(det, oracle, frames if c > 1 else frames[..., 0][..., None])
 
 
+@pytest.mark.parametrize("shape", [(96, 16448), (16448, 96)])
+def test_frames_wider_or_taller_than_16384(dicts, oracle, shape):
+    """Coordinates beyond 2^14: k_contour_quads then takes its 64-bit distance numerators (the 24-bit multiply-adds are only exact
+    below), k_dart_count its several-waves-per-row shape; 257 packed words per row.  Every stage against the oracle."""
+    h, w = shape
+    rng = np.random.default_rng(16448)
+    det = _detector(dicts, "ARUCO")
+    frames = np.stack([np.repeat(_fuzz_frame(rng, h, w, kind)[..., None], 3, axis=2) for kind in ("quads", "rects")])
+    # a few big quads that reach into the far end, so that candidates with coordinates > 16384 exist
+    for f in range(2):
+        for k in range(3):
+            if w > h:
+                x0 = w - 110 - 150 * k; frames[f, 20:76, x0:x0 + 90] = 15 if (f + k) % 2 else 240
+                frames[f, 30:66, x0 + 15:x0 + 75] = 240 if (f + k) % 2 else 15
+            else:
+                y0 = h - 110 - 150 * k; frames[f, y0:y0 + 90, 20:76] = 15 if (f + k) % 2 else 240
+                frames[f, y0 + 15:y0 + 75, 30:66] = 240 if (f + k) % 2 else 15
+    ctx = _check(det, oracle, frames, check_patches=False)
+    cands = np.concatenate([np.asarray(ctx.candidates(f, before_discard=True)).reshape(-1, 8) for f in range(2)])
+    assert cands.size and cands.max() > 16384      # the test is about those
+
+
 def test_many_small_frames_in_one_batch(dicts, oracle):
     """Per-frame bookkeeping under load: 600 frames of 96x80 (several per wave everywhere), a sample checked in full,
     every frame's marker list against the oracle."""
