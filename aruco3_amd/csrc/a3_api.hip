@@ -20,8 +20,9 @@ hipError_t launch_grey_threshold(hipStream_t, const uint8_t*, int, size_t, size_
 hipError_t launch_dart_count(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, unsigned long long*, uint32_t*, uint64_t, uint32_t*, uint32_t*, void*, size_t);
 size_t tile_darts_bytes(uint32_t W, uint32_t H, uint32_t n_frames);
 size_t tile_off_offset(uint32_t W, uint32_t H, uint32_t n_frames);
+size_t tile_mask_offset_bytes(uint32_t W, uint32_t H, uint32_t n_frames);
 hipError_t launch_dart_build(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*, const uint32_t*,
-                             uint64_t*, uint32_t*, uint32_t, const uint32_t*, int);
+                             uint64_t*, uint32_t*, uint32_t, const uint32_t*, int, const unsigned long long*);
 hipError_t launch_zero(hipStream_t, void*, size_t);
 size_t entry_state_bytes();
 size_t entry_slots(uint32_t);
@@ -417,7 +418,8 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
         }
         const uint32_t* tile_off = ctx->tile_darts.as<uint32_t>() + tile_off_offset(W, H, n);
         A3_HIP(launch_dart_build(st, d_bin, (int)W, (int)H, c.first, c.count, fb, tile_off, ctx->pix_base.as<uint32_t>(),
-                                 ctx->tile_darts.as<uint32_t>(), ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), nd, n_live, 0));
+                                 ctx->tile_darts.as<uint32_t>(), ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), nd, n_live, 0,
+                                 reinterpret_cast<const unsigned long long*>(ctx->tile_darts.as<uint8_t>() + tile_mask_offset_bytes(W, H, n))));
         int rounds = 1;
         while ((1ull << rounds) < (uint64_t)c.max_frame_darts && rounds < 31) rounds++;
         rounds += 1;  // the round that observes "nothing moved"
@@ -846,7 +848,8 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
             A3_HIP(launch_dart_build(st, ctx->bin.as<uint64_t>(), (int)ctx->W, (int)ctx->H, 0, ctx->dbg_frames, ctx->frame_base.as<uint32_t>(),
                                      ctx->tile_darts.as<uint32_t>() + tile_off_offset(ctx->W, ctx->H, ctx->frames), ctx->pix_base.as<uint32_t>(),
                                      ctx->tile_darts.as<uint32_t>(), ctx->d_xy.as<uint64_t>(),
-                                     ctx->d_succ.as<uint32_t>(), ctx->dbg_nd, nullptr, dbg ? dbg : 5));
+                                     ctx->d_succ.as<uint32_t>(), ctx->dbg_nd, nullptr, dbg ? dbg : 5,
+                                     reinterpret_cast<const unsigned long long*>(ctx->tile_darts.as<uint8_t>() + tile_mask_offset_bytes(ctx->W, ctx->H, ctx->frames))));
         } else if (kernel == 2) {
             A3_HIP(launch_rank_cycles(st, ctx->dbg_nd, (int)ctx->W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), ctx->stA.as<JumpState>(),
                                       ctx->entry_list.as<uint32_t>(),

@@ -73,12 +73,17 @@ __device__ __forceinline__ void pdart_words(const Nb8& nb, uint64_t p[8]) {
 
 __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* s_wave, uint32_t* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // inclusive scan over the wave with DPP row shifts and row broadcasts (VALU only; a __shfl_up ladder is six ds_bpermute
+    // round trips through the LDS crossbar)
     uint32_t inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(inc, o);
-        if (lane >= o) inc += t;
-    }
+#define A3_DPP_ADD(CTRL, ROWMASK) inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, CTRL, ROWMASK, 0xF, false);
+    A3_DPP_ADD(0x111, 0xF)   // row_shr:1, 2, 4, 8: inclusive sums inside each row of 16 lanes
+    A3_DPP_ADD(0x112, 0xF)
+    A3_DPP_ADD(0x114, 0xF)
+    A3_DPP_ADD(0x118, 0xF)
+    A3_DPP_ADD(0x142, 0xA)   // row_bcast:15: rows 1 and 3 add the totals of rows 0 and 2
+    A3_DPP_ADD(0x143, 0xC)   // row_bcast:31: rows 2 and 3 add the total of rows 0-1
+#undef A3_DPP_ADD
     if (lane == 63) s_wave[wave] = inc;
     __syncthreads();
     uint32_t base = 0, tot = 0;
@@ -108,8 +113,7 @@ __device__ __forceinline__ bool tile_word(int W, int H, int* j, int* y) {
 
 // The tile's words plus a one-word / one-row apron are staged in LDS with row-contiguous loads (6 words per row,
 // 66 rows) instead of nine strided 8-byte loads per lane.
-__device__ __forceinline__ Nb8 tile_nb8(const uint64_t* __restrict__ img, int W, int H, uint64_t (*s_t)[kTileWords + 2], bool* active, int* jo,
-                                        int* yo) {
+__device__ __forceinline__ void tile_stage(const uint64_t* __restrict__ img, int W, int H, uint64_t (*s_t)[kTileWords + 2]) {
     const int wpr = (int)words_per_row((uint32_t)W);
     const int tx = blockIdx.x % dart_tiles_x((uint32_t)W), ty = blockIdx.x / dart_tiles_x((uint32_t)W);
     const int j0 = tx * kTileWords - 1, y0 = ty * kTileRows - 1;
@@ -131,10 +135,9 @@ __device__ __forceinline__ Nb8 tile_nb8(const uint64_t* __restrict__ img, int W,
         const int i = (int)threadIdx.x + 256 * k;
         if (i < kStage) (&s_t[0][0])[i] = v[k];
     }
-    __syncthreads();
-    const int jl = threadIdx.x & (kTileWords - 1), rl = threadIdx.x >> 2;
-    *jo = j0 + 1 + jl; *yo = y0 + 1 + rl;
-    *active = *jo < wpr && *yo < H;
+}
+// the word (rl, jl) of the staged tile and its eight neighbour words' bits, aligned to it
+__device__ __forceinline__ Nb8 tile_nb8(const uint64_t (*s_t)[kTileWords + 2], int rl, int jl) {
     Nb8 r;
     const uint64_t al = s_t[rl][jl], a = s_t[rl][jl + 1], ar = s_t[rl][jl + 2];
     const uint64_t cl = s_t[rl + 1][jl], c = s_t[rl + 1][jl + 1], cr = s_t[rl + 1][jl + 2];
@@ -173,8 +176,12 @@ constexpr int kCountHalves = A3_COUNT_PARTS;
 template <int G>
 __global__ __launch_bounds__(64) void k_dart_count(const uint64_t* __restrict__ bits, int W, int H, uint32_t first_frame,
                                                    unsigned long long* __restrict__ frame_darts, uint32_t* __restrict__ tile_darts,
-                                                   uint32_t* __restrict__ tile_darts_h1) {
+                                                   uint32_t* __restrict__ tile_darts_h1, unsigned long long* __restrict__ tile_mask) {
+    // tile_mask[(frame * tiles + tile) * kCountHalves + part]: bit r * 4 + jl = word jl of row r of this part owns darts.  A part
+    // is 16 rows x 4 words = the 64 words that one wave of k_dart_assign's phase 1 would look at: the mask lets that kernel
+    // hand only the words that own darts to its lanes.
     static_assert(kCountLanes % kTileWords == 0, "a wave counts whole tiles");
+    static_assert((kTileRows / kCountHalves) * kTileWords == 64, "one 64-bit mask per tile and part");
     constexpr int kGroups = 64 / G, kOwners = G == 64 ? kCountLanes : 30, kTilesPerGroup = (kOwners + kTileWords - 1) / kTileWords;
     __shared__ uint32_t s_tile[kGroups][kTilesPerGroup];
     const int wpr = (int)words_per_row((uint32_t)W);
@@ -214,6 +221,7 @@ __global__ __launch_bounds__(64) void k_dart_count(const uint64_t* __restrict__ 
     edge_bits(up.c, &up.lbit, &up.rbit);
     edge_bits(cur.c, &cur.lbit, &cur.rbit);
     uint32_t nd = 0;
+    unsigned long long acc = 0;   // (lanes holding the first word column of a tile) the mask of this tile and part
 #pragma unroll
     for (int r0 = 0; r0 < kRows; r0 += kAhead) {
         if (r0 + kAhead < kRows) {
@@ -228,6 +236,7 @@ __global__ __launch_bounds__(64) void k_dart_count(const uint64_t* __restrict__ 
             // no foreground pixel, or a word in the middle of a white area (the word, the words above and below and the
             // six neighbour bits all ones: most words of a frame on white paper): no dart
             const bool white = (c & up.c & dn.c) == ~0ull && (cur.lbit & cur.rbit & up.lbit & up.rbit & dn.lbit & dn.rbit) != 0u;
+            uint32_t ndw = 0;
             if (c != 0ull && !white) {
                 Nb8 nb;
                 nb.c = c;
@@ -238,8 +247,12 @@ __global__ __launch_bounds__(64) void k_dart_count(const uint64_t* __restrict__ 
                 uint64_t p[8];
                 pdart_words(nb, p);
 #pragma unroll
-                for (int q = 0; q < 8; q++) nd += __popcll(p[q]);
+                for (int q = 0; q < 8; q++) ndw += __popcll(p[q]);
+                nd += ndw;
             }
+            // the four words of a tile sit in four consecutive lanes: their "owns darts" bits are a nibble of the ballot
+            const unsigned long long bal = __ballot(owner && ndw != 0u);
+            acc |= ((bal >> lane) & 0xFull) << (4 * (r0 + u));
             up = cur; cur = dn;
         }
 #pragma unroll
@@ -257,6 +270,10 @@ __global__ __launch_bounds__(64) void k_dart_count(const uint64_t* __restrict__ 
             // part 0 goes to tile_darts itself, part z > 0 to the z-th array behind tile_off; k_tile_scan adds them up
             (blockIdx.z ? tile_darts_h1 + (size_t)(blockIdx.z - 1) * gridDim.y * (tiles_x * tiles_y) : tile_darts)[(size_t)(first_frame + f) * (tiles_x * tiles_y) + ty * tiles_x + tx] = total;
         }
+    }
+    if (gl >= 1 && gl <= kOwners && ((gl - 1) & (kTileWords - 1)) == 0 && ty < (int)tiles_y) {
+        const uint32_t tx = (uint32_t)(cx * kTilesPerGroup + (gl - 1) / kTileWords);
+        if (tx < tiles_x) tile_mask[((size_t)(first_frame + f) * (tiles_x * tiles_y) + ty * tiles_x + tx) * kCountHalves + blockIdx.z] = acc;
     }
     for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
     if (lane == 0 && total) atomicAdd(&frame_darts[f], (unsigned long long)total);
@@ -388,7 +405,8 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
                                                      const uint32_t* __restrict__ frame_base, const uint32_t* __restrict__ tile_off,
                                                      uint32_t* __restrict__ pix_base, const uint32_t* __restrict__ tile_darts,
                                                      uint64_t* __restrict__ d_rec, uint32_t* __restrict__ d_succ,
-                                                     const uint32_t* __restrict__ n_live, int dbg) {
+                                                     const uint32_t* __restrict__ n_live, int dbg,
+                                                     const unsigned long long* __restrict__ tile_mask) {
     // dbg (a3_debug_kernel_time only; 0 in the product path): stop after 1 = the empty-tile test, 2 = phase 1 and its scans,
     // 3 = the range allocation; 4 = run phase 2 without its global stores
     __shared__ uint32_t s_wave[4];
@@ -402,33 +420,43 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
     if (n_live && *n_live == 0u) return;   // device-side plan: the graph does not fit the pool, the host re-plans
     const uint32_t dart0 = frame_base[f] + tile_off[(size_t)(first_frame + f) * gridDim.x + blockIdx.x];
     if (dbg == 1) return;
-    int j, y;
-    bool active;
-    const Nb8 nb = tile_nb8(bits + (size_t)(first_frame + f) * wpr * H, W, H, s_t, &active, &j, &y);
-    uint64_t nodes = 0, c0 = 0, c1 = 0, c2 = 0;
-    uint32_t nd = 0;
-    // only a foreground pixel with a background neighbour can own a dart: most words of a frame on white paper have none
-    if (active && (nb.c & ~(nb.n[0] & nb.n[1] & nb.n[2] & nb.n[3] & nb.n[4] & nb.n[5] & nb.n[6] & nb.n[7]))) {
+    // Phase 1 works on the words that own darts only (k_dart_count's masks say which: typically 60 of a tile's 256, so one wave
+    // does what four did -- the kernel is bound by its instruction count), lane k taking the k-th of them; every word's entry
+    // in the per-word arrays starts at zero.
+    __shared__ uint32_t s_cnt[256];   // per word: darts (low 17 bits) | border pixels << 17
+    const unsigned long long* tm = tile_mask + ((size_t)(first_frame + f) * gridDim.x + blockIdx.x) * kCountHalves;
+    static_assert(kCountHalves == 4, "four 64-bit word masks per tile");
+    const unsigned long long m0 = tm[0], m1 = tm[1], m2 = tm[2], m3 = tm[3];
+    tile_stage(bits + (size_t)(first_frame + f) * wpr * H, W, H, s_t);
+    s_nodes[threadIdx.x] = 0; s_c0[threadIdx.x] = 0; s_c1[threadIdx.x] = 0; s_c2[threadIdx.x] = 0; s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t a0 = (uint32_t)__popcll(m0), a1 = a0 + (uint32_t)__popcll(m1), a2 = a1 + (uint32_t)__popcll(m2), n_act = a2 + (uint32_t)__popcll(m3);
+    for (uint32_t k = threadIdx.x; k < n_act; k += 256) {
+        const uint32_t part = (k >= a0) + (k >= a1) + (k >= a2);
+        const unsigned long long mm = part == 0 ? m0 : (part == 1 ? m1 : (part == 2 ? m2 : m3));
+        const uint32_t w = part * 64u + (uint32_t)select_bit(mm, k - (part == 0 ? 0u : (part == 1 ? a0 : (part == 2 ? a1 : a2))));
+        const Nb8 nb = tile_nb8(s_t, (int)(w >> 2), (int)(w & (kTileWords - 1)));
         uint64_t p[8];
         pdart_words(nb, p);
+        uint64_t nodes = 0;
+        uint32_t nd = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) { nd += __popcll(p[k]); nodes |= p[k]; }
+        for (int q = 0; q < 8; q++) { nd += __popcll(p[q]); nodes |= p[q]; }
         // bit-sliced sum of the eight direction planes (a pixel owns at most 4 darts)
         const uint64_t s1 = p[0] ^ p[1] ^ p[2], k1 = (p[0] & p[1]) | (p[2] & (p[0] ^ p[1]));
         const uint64_t s2 = p[3] ^ p[4] ^ p[5], k2 = (p[3] & p[4]) | (p[5] & (p[3] ^ p[4]));
         const uint64_t s3 = p[6] ^ p[7], k3 = p[6] & p[7];
-        c0 = s1 ^ s2 ^ s3;
         const uint64_t k4 = (s1 & s2) | (s3 & (s1 ^ s2));
         const uint64_t t = k1 ^ k2 ^ k3, q1 = (k1 & k2) | (k3 & (k1 ^ k2));
-        c1 = t ^ k4;
-        c2 = q1 | (t & k4);
+        s_nodes[w] = nodes;
+        s_c0[w] = s1 ^ s2 ^ s3; s_c1[w] = t ^ k4; s_c2[w] = q1 | (t & k4);
+        s_cnt[w] = nd | ((uint32_t)__popcll(nodes) << 17);
     }
+    __syncthreads();
     // one block scan for both counts: darts (<= 65536 per tile) in the low 17 bits, border pixels (<= 16384) above
     uint32_t total_p;
-    const uint32_t excl_p = block_excl_scan_256(nd | ((uint32_t)__popcll(nodes) << 17), s_wave, &total_p);
+    const uint32_t excl_p = block_excl_scan_256(s_cnt[threadIdx.x], s_wave, &total_p);
     const uint32_t excl_d = excl_p & 0x1FFFFu, excl_n = excl_p >> 17, total_n = total_p >> 17;
-    s_nodes[threadIdx.x] = nodes;
-    s_c0[threadIdx.x] = c0; s_c1[threadIdx.x] = c1; s_c2[threadIdx.x] = c2;
     s_dbase[threadIdx.x] = excl_d;
     s_nbase[threadIdx.x] = excl_n;
     if (dbg == 2) return;
@@ -1510,8 +1538,11 @@ hipError_t launch_zero(hipStream_t st, void* p, size_t bytes /* multiple of 16, 
 
 // tile_darts[frames * tiles] followed by tile_off[frames * tiles]
 // tile_darts[frames * tiles] | tile_off[frames * tiles] | second-half counts of k_dart_count[frames * tiles]
-size_t tile_darts_bytes(uint32_t W, uint32_t H, uint32_t n_frames) { return (size_t)dart_tiles(W, H) * n_frames * 4 * (1 + kCountHalves); }
+size_t tile_mask_offset_bytes(uint32_t W, uint32_t H, uint32_t n_frames);
+size_t tile_darts_bytes(uint32_t W, uint32_t H, uint32_t n_frames) { return tile_mask_offset_bytes(W, H, n_frames) + (size_t)dart_tiles(W, H) * n_frames * kCountHalves * 8; }
 size_t tile_off_offset(uint32_t W, uint32_t H, uint32_t n_frames) { return (size_t)dart_tiles(W, H) * n_frames; }
+// ... followed (8-byte aligned) by the word masks, kCountHalves 64-bit words per tile
+size_t tile_mask_offset_bytes(uint32_t W, uint32_t H, uint32_t n_frames) { return ((size_t)dart_tiles(W, H) * n_frames * 4 * (1 + kCountHalves) + 7) & ~(size_t)7; }
 
 // plan != nullptr: the launch of k_tile_scan also plans the batch on the device (frame_base[0..n_frames], plan[0..3])
 hipError_t launch_dart_count(hipStream_t st, const uint64_t* bits, int W, int H, uint32_t first_frame, uint32_t n_frames,
@@ -1520,11 +1551,12 @@ hipError_t launch_dart_count(hipStream_t st, const uint64_t* bits, int W, int H,
     const uint32_t tiles_x = dart_tiles_x((uint32_t)W), tiles_y = ((uint32_t)H + kTileRows - 1) / kTileRows;
     const uint32_t wpr = words_per_row((uint32_t)W);
     uint32_t* h1 = tile_darts + (size_t)tiles_x * tiles_y * n_frames * 2;
+    unsigned long long* tmask = reinterpret_cast<unsigned long long*>(reinterpret_cast<uint8_t*>(tile_darts) + tile_mask_offset_bytes((uint32_t)W, (uint32_t)H, n_frames));
     if (wpr <= 30)   // two tile rows per wave
-        hipLaunchKernelGGL(k_dart_count<32>, dim3((tiles_y + 1) / 2, n_frames, kCountHalves), dim3(64), 0, st, bits, W, H, first_frame, frame_darts, tile_darts, h1);
+        hipLaunchKernelGGL(k_dart_count<32>, dim3((tiles_y + 1) / 2, n_frames, kCountHalves), dim3(64), 0, st, bits, W, H, first_frame, frame_darts, tile_darts, h1, tmask);
     else
         hipLaunchKernelGGL(k_dart_count<64>, dim3(((wpr + kCountLanes - 1) / kCountLanes) * tiles_y, n_frames, kCountHalves), dim3(64), 0, st, bits, W, H, first_frame,
-                           frame_darts, tile_darts, h1);
+                           frame_darts, tile_darts, h1, tmask);
     hipLaunchKernelGGL(k_tile_scan, dim3(n_frames + (plan ? 1u : 0u)), dim3(256), 0, st, tile_darts, h1, tiles_x * tiles_y, first_frame,
                        tile_darts + (size_t)tiles_x * tiles_y * n_frames, n_frames, frame_darts, (unsigned long long)plan_cap, frame_base, plan,
                        reinterpret_cast<uint4*>(zero_p), (uint32_t)(zero_bytes / 16));
@@ -1533,9 +1565,9 @@ hipError_t launch_dart_count(hipStream_t st, const uint64_t* bits, int W, int H,
 
 hipError_t launch_dart_build(hipStream_t st, const uint64_t* bits, int W, int H, uint32_t first_frame, uint32_t n_frames,
                              const uint32_t* frame_base, const uint32_t* tile_off, uint32_t* pix_base, const uint32_t* tile_darts, uint64_t* d_rec,
-                             uint32_t* d_succ, uint32_t n_darts, const uint32_t* n_live, int dbg) {
+                             uint32_t* d_succ, uint32_t n_darts, const uint32_t* n_live, int dbg, const unsigned long long* tile_mask) {
     hipLaunchKernelGGL(k_dart_assign, dim3(dart_tiles((uint32_t)W, (uint32_t)H), n_frames), dim3(256), 0, st, bits, W, H, first_frame, frame_base, tile_off,
-                       pix_base, tile_darts, d_rec, d_succ, n_live, dbg);
+                       pix_base, tile_darts, d_rec, d_succ, n_live, dbg, tile_mask);
     if (dbg && dbg != 5) return hipGetLastError();   // 5 = everything (the probe's reference point), others leave d_succ alone
     hipLaunchKernelGGL(k_dart_link, dim3(blocks_for(n_darts, 256, env_cap("A3_LINK_BLOCKS", 4096))), dim3(256), 0, st, W, H, first_frame, pix_base, bits, d_rec, d_succ, n_darts, n_live);
     return hipGetLastError();
