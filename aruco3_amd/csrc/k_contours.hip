@@ -275,8 +275,11 @@ __global__ __launch_bounds__(64) void k_dart_count(const uint64_t* __restrict__ 
         const uint32_t tx = (uint32_t)(cx * kTilesPerGroup + (gl - 1) / kTileWords);
         if (tx < tiles_x) tile_mask[((size_t)(first_frame + f) * (tiles_x * tiles_y) + ty * tiles_x + tx) * kCountHalves + blockIdx.z] = acc;
     }
-    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
-    if (lane == 0 && total) atomicAdd(&frame_darts[f], (unsigned long long)total);
+    // the wave's total: DPP row shifts and broadcasts leave it in lane 63
+#define A3_DPP_ADD(CTRL, ROWMASK) total += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)total, CTRL, ROWMASK, 0xF, false);
+    A3_DPP_ADD(0x111, 0xF) A3_DPP_ADD(0x112, 0xF) A3_DPP_ADD(0x114, 0xF) A3_DPP_ADD(0x118, 0xF) A3_DPP_ADD(0x142, 0xA) A3_DPP_ADD(0x143, 0xC)
+#undef A3_DPP_ADD
+    if (lane == 63 && total) atomicAdd(&frame_darts[f], (unsigned long long)total);
 }
 
 // Device-side plan for a batch whose contour graph is expected to fit one chunk (the host learnt its size from the previous

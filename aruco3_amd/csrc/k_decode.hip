@@ -400,6 +400,43 @@ __device__ __forceinline__ void rotated_source(uint32_t r, uint32_t n, uint32_t 
 #ifndef A3_D_DB
 #define A3_D_DB 8     // dictionary codes per lane and trip in the nearest-code scan
 #endif
+// Wave-wide scans and reductions by DPP row shifts (row_shr:1,2,4,8 inside rows of 16 lanes) and row broadcasts (row_bcast:15 into
+// rows 1 and 3, row_bcast:31 into rows 2 and 3): pure VALU, the result of a reduction ends up in lane 63.  The shuffle ladders
+// they replace are six ds_bpermute round trips each.  `OLD` is what a lane without a source combines with: the identity.
+#define A3_DPP_STEPS(STEP) STEP(0x111, 0xF) STEP(0x112, 0xF) STEP(0x114, 0xF) STEP(0x118, 0xF) STEP(0x142, 0xA) STEP(0x143, 0xC)
+__device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
+#define A3_S(CTRL, RM) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, RM, 0xF, false);
+    A3_DPP_STEPS(A3_S)
+#undef A3_S
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64_to63(unsigned long long v) {
+#define A3_S(CTRL, RM)                                                                                                  \
+    {                                                                                                                    \
+        const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)v, CTRL, RM, 0xF, false);           \
+        const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)(v >> 32), CTRL, RM, 0xF, false);    \
+        const unsigned long long o_ = ((unsigned long long)hi_ << 32) | lo_;                                             \
+        v = o_ < v ? o_ : v;                                                                                             \
+    }
+    A3_DPP_STEPS(A3_S)
+#undef A3_S
+    return v;
+}
+// largest variance, lowest threshold among equals (the Otsu scan's first strict maximum); identity: (-1.0, INT_MAX)
+__device__ __forceinline__ void wave_best_var_to63(double& var, int& best_t) {
+#define A3_S(CTRL, RM)                                                                                                  \
+    {                                                                                                                    \
+        const unsigned long long vb_ = (unsigned long long)__double_as_longlong(var);                                    \
+        const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)vb_, CTRL, RM, 0xF, false);           \
+        const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp((int)0xBFF00000u, (int)(uint32_t)(vb_ >> 32), CTRL, RM, 0xF, false); \
+        const int ot_ = __builtin_amdgcn_update_dpp(0x7FFFFFFF, best_t, CTRL, RM, 0xF, false);                             \
+        const double ov_ = __longlong_as_double((long long)(((unsigned long long)hi_ << 32) | lo_));                     \
+        if (ov_ > var || (ov_ == var && ot_ < best_t)) { var = ov_; best_t = ot_; }                                      \
+    }
+    A3_DPP_STEPS(A3_S)
+#undef A3_S
+}
+
 // NT threads sample one candidate, PT of them (64, or all) run the stages after the sampling.  History of the shape, on the
 // 2.5 k candidates of BASELINE config 2 (tools/tune_decode.sh): 256 threads throughout, 4 samples "in flight" per lane, row-major
 // sample order (round 1): 116 us; 64 threads, 8 x 8 blocked order: 98 us; 256 threads sampling, the first wave doing the rest:
@@ -551,12 +588,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? A3_D_WAVES : A3_D_WAVES256) void k_d
                     rw += hcnt; rs += t * hcnt;
                     cw[k] = rw; cs[k] = rs;
                 }
-                uint32_t bw = rw, bs = rs;                  // inclusive prefix sums over lanes
-    #pragma unroll
-                for (int o2 = 1; o2 < 64; o2 <<= 1) {
-                    const uint32_t a = __shfl_up(bw, o2), b = __shfl_up(bs, o2);
-                    if ((tid & 63) >= o2) { bw += a; bs += b; }
-                }
+                uint32_t bw = wave_incl_add(rw), bs = wave_incl_add(rs);   // inclusive prefix sums over lanes
                 if ((tid & 63) == 63) { s_scan_w[tid >> 6] = bw; s_scan_s[tid >> 6] = bs; }
                 POST_SYNC();
                 uint32_t total_sum_u = 0;
@@ -584,12 +616,8 @@ __global__ __launch_bounds__(NT, NT == 64 ? A3_D_WAVES : A3_D_WAVES256) void k_d
                         if (v > var) { var = v; best_t = tid * B + k; }   // ascending k: the first strict maximum of the run
                     }
                 }
-                for (int o2 = 32; o2 > 0; o2 >>= 1) {
-                    const double ov = __shfl_xor(var, o2);
-                    const int ot = __shfl_xor(best_t, o2);
-                    if (ov > var || (ov == var && ot < best_t)) { var = ov; best_t = ot; }
-                }
-                if ((tid & 63) == 0) { s_var[tid >> 6] = var; s_vt[tid >> 6] = best_t; }
+                wave_best_var_to63(var, best_t);
+                if ((tid & 63) == 63) { s_var[tid >> 6] = var; s_vt[tid >> 6] = best_t; }
                 POST_SYNC();
                 if (tid == 0) {
                     double bv = s_var[0]; int bt = s_vt[0];
@@ -681,12 +709,8 @@ __global__ __launch_bounds__(NT, NT == 64 ? A3_D_WAVES : A3_D_WAVES256) void k_d
                     }
                 }
     #pragma unroll
-                for (int r = 0; r < 4; r++)
-                    for (int o2 = 32; o2 > 0; o2 >>= 1) {
-                        const unsigned long long other = __shfl_xor(best[r], o2);
-                        best[r] = other < best[r] ? other : best[r];
-                    }
-                if ((tid & 63) == 0)
+                for (int r = 0; r < 4; r++) best[r] = wave_min_u64_to63(best[r]);
+                if ((tid & 63) == 63)
                     for (int r = 0; r < 4; r++) s_best[tid >> 6][r] = best[r];
             }
             POST_SYNC();
