@@ -815,20 +815,29 @@ __global__ __launch_bounds__(256) void k_entry_frame(const uint32_t* __restrict_
                                                      const uint32_t* __restrict__ frame_base, const JumpState* __restrict__ loc,
                                                      const uint32_t* __restrict__ entry_pos,
                                                      EntryState* __restrict__ es, DeviceCounters* __restrict__ ctr) {
-    __shared__ uint64_t s_key[kEntryLdsCap];
-    __shared__ uint32_t s_ptr[kEntryLdsCap], s_off[kEntryLdsCap], s_dist[kEntryLdsCap];
+    // one 16-byte record per entry (a single ds_read_b128 fetches the window an entry is joined with) + its length
+    struct __attribute__((aligned(16))) Rec { uint64_t key; uint32_t ptr; uint32_t off; };
+    __shared__ Rec s_rec[kEntryLdsCap];
+    __shared__ uint32_t s_dist[kEntryLdsCap];
     const uint32_t f = blockIdx.x;
     const uint32_t cnt = frame_entries[f], base = frame_base[f];
     if (cnt == 0) return;
     if (cnt > kEntryLdsCap) { if (threadIdx.x == 0) ctr->entry_overflow = 1u; return; }
+    // every lane owns up to 8 entries (i = lane + 256 u) and keeps their windows in registers across the rounds; LDS holds the
+    // copy the other lanes read
+    constexpr int PER = kEntryLdsCap / 256;
+    uint64_t nk[PER]; uint32_t np[PER], no[PER], nd[PER];
     // the three dependent loads (entry -> its local state -> slot of the entry it froze at) for four entries per lane at a time:
     // a clean frame has several hundred entries, i.e. one trip of this loop
     constexpr int EB = 4;
-    for (uint32_t i0 = threadIdx.x; i0 < cnt + threadIdx.x; i0 += 256 * EB) {   // (uniform trip count)
+    static_assert(PER % EB == 0, "whole batches");
+#pragma unroll
+    for (int u0 = 0; u0 < PER; u0 += EB) {
+        if ((uint32_t)u0 * 256u >= cnt) break;   // uniform
         uint32_t e[EB], pos[EB];
         JumpState l[EB];
 #pragma unroll
-        for (int u = 0; u < EB; u++) e[u] = entry_list[base + min(i0 + 256u * u, cnt - 1u)];
+        for (int u = 0; u < EB; u++) e[u] = entry_list[base + min(threadIdx.x + 256u * (uint32_t)(u0 + u), cnt - 1u)];
 #pragma unroll
         for (int u = 0; u < EB; u++) l[u] = loc[e[u]];
 #pragma unroll
@@ -839,43 +848,45 @@ __global__ __launch_bounds__(256) void k_entry_frame(const uint32_t* __restrict_
         for (int u = 0; u < EB; u++) asm volatile("" : "+v"(pos[u]), "+v"(l[u].key), "+v"(l[u].off));
 #pragma unroll
         for (int u = 0; u < EB; u++) {
-            const uint32_t i = i0 + 256u * u;
-            if (i >= cnt) break;
-            s_key[i] = l[u].key; s_off[i] = loc_off(l[u].off); s_dist[i] = loc_dist(l[u].off);
+            const uint32_t i = threadIdx.x + 256u * (uint32_t)(u0 + u);
+            nk[u0 + u] = l[u].key; no[u0 + u] = loc_off(l[u].off); nd[u0 + u] = loc_dist(l[u].off);
             // an entry's local window always freezes (its predecessor lies in another tile) unless its chain dead-ends in the tile
-            s_ptr[i] = (l[u].off & kFrozen) ? pos[u] - base : i;
+            np[u0 + u] = (l[u].off & kFrozen) ? pos[u] - base : i;
+            if (i < cnt) { s_rec[i] = Rec{nk[u0 + u], np[u0 + u], no[u0 + u]}; s_dist[i] = nd[u0 + u]; }
         }
     }
     __syncthreads();
-    constexpr int PER = kEntryLdsCap / 256;
     for (int round = 0; round < 12; round++) {   // 2^11 = kEntryLdsCap hops, + the round that sees nothing move
-        uint64_t nk[PER]; uint32_t np[PER], no[PER], nd[PER];
         int changed = 0;
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             const uint32_t i = threadIdx.x + u * 256;
             if (i < cnt) {
-                nk[u] = s_key[i]; np[u] = s_ptr[i]; no[u] = s_off[i]; nd[u] = s_dist[i];
                 const uint32_t t = np[u] < cnt ? np[u] : i;   // (a corrupt pointer cannot leave the frame's slots)
-                const uint64_t tk = s_key[t];
-                if (tk < nk[u]) { nk[u] = tk; no[u] = nd[u] + s_off[t]; changed = 1; }
-                nd[u] += s_dist[t];
-                np[u] = s_ptr[t];
+                const Rec w = s_rec[t];
+                const uint32_t wd = s_dist[t];
+                if (w.key < nk[u]) { nk[u] = w.key; no[u] = nd[u] + w.off; changed = 1; }
+                nd[u] += wd;
+                np[u] = w.ptr;
             }
         }
         const int any = __syncthreads_or(changed);
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             const uint32_t i = threadIdx.x + u * 256;
-            if (i < cnt) { s_key[i] = nk[u]; s_ptr[i] = np[u]; s_off[i] = no[u]; s_dist[i] = nd[u]; }
+            if (i < cnt) { s_rec[i] = Rec{nk[u], np[u], no[u]}; s_dist[i] = nd[u]; }
         }
         __syncthreads();
         if (!any) break;   // no key moved: every window wraps its cycle
     }
-    for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
-        EntryState o;
-        o.key = s_key[i]; o.ptr = base + s_ptr[i]; o.off = s_off[i]; o.dist = s_dist[i]; o.pad = 0;
-        es[base + i] = o;
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const uint32_t i = threadIdx.x + u * 256;
+        if (i < cnt) {
+            EntryState o;
+            o.key = nk[u]; o.ptr = base + np[u]; o.off = no[u]; o.dist = nd[u]; o.pad = 0;
+            es[base + i] = o;
+        }
     }
 }
 
