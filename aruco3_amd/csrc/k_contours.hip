@@ -1205,12 +1205,20 @@ __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restric
     // exclusive scans of (keep count, point count) over the workgroup
     uint32_t inc_k = my_keep, inc_t = my_traced;
     unsigned long long inc_p = my_points;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t a = __shfl_up(inc_k, o), c = __shfl_up(inc_t, o);
-        const unsigned long long b2 = __shfl_up(inc_p, o);
-        if (lane >= o) { inc_k += a; inc_p += b2; inc_t += c; }
+    // inclusive scans over the wave by DPP row shifts / broadcasts (for the 64-bit one both halves of the source lane's value
+    // are moved, then added as one number)
+#define A3_DPP_ADD64(V, CTRL, RM)                                                                                       \
+    {                                                                                                                    \
+        const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(V), CTRL, RM, 0xF, false);           \
+        const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)((V) >> 32), CTRL, RM, 0xF, false);    \
+        (V) += ((unsigned long long)hi_ << 32) | lo_;                                                                    \
     }
+#define A3_DPP_ADD32(V, CTRL, RM) (V) += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(V), CTRL, RM, 0xF, false);
+#define A3_STEP(CTRL, RM) A3_DPP_ADD32(inc_k, CTRL, RM) A3_DPP_ADD32(inc_t, CTRL, RM) A3_DPP_ADD64(inc_p, CTRL, RM)
+    A3_STEP(0x111, 0xF) A3_STEP(0x112, 0xF) A3_STEP(0x114, 0xF) A3_STEP(0x118, 0xF) A3_STEP(0x142, 0xA) A3_STEP(0x143, 0xC)
+#undef A3_STEP
+#undef A3_DPP_ADD32
+#undef A3_DPP_ADD64
     if (lane == 63) { s_wave[wave] = inc_k; s_wave_p[wave] = inc_p; s_wave_t[wave] = inc_t; }
     __syncthreads();
     uint32_t base_k = 0, tot_k = 0;
