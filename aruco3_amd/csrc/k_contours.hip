@@ -1657,7 +1657,8 @@ hipError_t launch_select_scatter(hipStream_t st, const JumpState* fin, uint32_t 
                                  double eps_factor, double image_diag, uint32_t* cyc_slot, ContourRec* contours, uint32_t* cyc_start_off,
                                  uint32_t max_contours, uint64_t max_points, DeviceCounters* ctr, const uint64_t* d_rec, uint32_t* points,
                                  const uint32_t* n_live, int inline_resolve_W, uint32_t* keep_tmp, int keep_all) {
-    const dim3 grid(blocks_for(n_darts, 256, env_cap("A3_SCATTER_BLOCKS", 8192))), block(256);
+    // 8192 workgroups for the graphs of clean frames (6-8 M darts), more for the tens of millions of darts of noise-like ones
+    const dim3 grid(blocks_for(n_darts, 256, env_cap("A3_SCATTER_BLOCKS", (int)std::min<uint32_t>(65536u, std::max<uint32_t>(8192u, n_darts / 1024u))))), block(256);
     hipLaunchKernelGGL(k_cycle_select, dim3(blocks_for(n_darts / 64 + 1, 256, env_cap("A3_SELECT_BLOCKS", 1024))), block, 0, st, fin, leader_list, leader_count, d_succ, t_cur,
                        frame_base, n_frames, first_frame, min_edge_length,
                        eps_factor, image_diag, cyc_slot, contours, cyc_start_off, max_contours, max_points, ctr, leader_shard_cap(n_darts), d_rec,
