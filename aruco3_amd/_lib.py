@@ -9,8 +9,12 @@ from pathlib import Path
 
 import numpy as np
 
+import os
+
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libaruco3_hip.so"
+# A3_HIP_LIB: the sweep scripts under tools/ point this at a `make tuning` build (build/tuning/libaruco3_hip.so, -DA3_TUNING);
+# everything else loads the product library next to this file.
+LIB_PATH = Path(os.environ["A3_HIP_LIB"]).resolve() if os.environ.get("A3_HIP_LIB") else _HERE / "libaruco3_hip.so"
 
 OK, ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_INTERNAL, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
 FMT_RGB8, FMT_RGBA8, FMT_L8, FMT_BGRA8 = 0, 1, 2, 3
@@ -20,8 +24,9 @@ STAGE_THRESHOLD, STAGE_CONTOUR, STAGE_DECODE = 0, 1, 2
 
 # every symbol include/aruco3_hip.h declares
 SYMBOLS = [
-    "a3_abi_version", "a3_default_config", "a3_create", "a3_destroy", "a3_last_error", "a3_set_stream", "a3_set_pool_limits",
-    "a3_get_tau", "a3_set_debug_taps", "a3_detect_batch", "a3_detect_batch_pose", "a3_detect_batch_submit", "a3_detect_batch_collect", "a3_get_stats", "a3_synth_render", "a3_download_grey", "a3_download_thresholded",
+    "a3_abi_version", "a3_default_config", "a3_create", "a3_destroy", "a3_last_error", "a3_set_stream", "a3_get_stream", "a3_set_pool_limits",
+    "a3_get_tau", "a3_set_debug_taps", "a3_detect_batch", "a3_detect_batch_pose", "a3_detect_batch_submit", "a3_detect_batch_collect", "a3_detect_batch_pose_submit", "a3_detect_batch_pose_collect",
+    "a3_host_alloc", "a3_host_free", "a3_host_register", "a3_host_unregister", "a3_get_stats", "a3_synth_render", "a3_download_grey", "a3_download_thresholded",
     "a3_candidate_count", "a3_download_candidates", "a3_download_homographies", "a3_estimate_pose", "a3_estimate_pose_normalized",
     "a3_find_nearest", "a3_calculate_tau", "a3_set_profiling", "a3_get_profile",
     "a3_contour_count", "a3_download_contours", "a3_detection_record_bytes", "a3_pack_detections",
@@ -113,6 +118,21 @@ def load():
     L.a3_last_error.argtypes = [vp]
     L.a3_set_stream.restype = C.c_int
     L.a3_set_stream.argtypes = [vp, vp]
+    L.a3_get_stream.restype = C.c_int
+    L.a3_get_stream.argtypes = [vp, C.POINTER(vp)]
+    L.a3_detect_batch_pose_submit.restype = C.c_int
+    L.a3_detect_batch_pose_submit.argtypes = [vp, vp, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_size_t, C.c_size_t, C.c_uint32, C.c_float,
+                                              C.POINTER(Intrinsics), C.c_size_t]
+    L.a3_detect_batch_pose_collect.restype = C.c_int
+    L.a3_detect_batch_pose_collect.argtypes = [vp, vp, vp, C.c_size_t, u32p, C.POINTER(C.c_size_t)]
+    L.a3_host_alloc.restype = C.c_int
+    L.a3_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.a3_host_free.restype = C.c_int
+    L.a3_host_free.argtypes = [vp]
+    L.a3_host_register.restype = C.c_int
+    L.a3_host_register.argtypes = [vp, C.c_size_t]
+    L.a3_host_unregister.restype = C.c_int
+    L.a3_host_unregister.argtypes = [vp]
     L.a3_set_pool_limits.restype = C.c_int
     L.a3_set_pool_limits.argtypes = [vp, C.c_uint64, C.c_uint64]
     L.a3_get_tau.restype = C.c_int
@@ -178,6 +198,30 @@ def load():
     return L
 
 
+class PinnedBuffer:
+    """a3_host_alloc as a numpy uint8 array (`.array`): frames placed here cross the link asynchronously and at its full rate"""
+
+    def __init__(self, nbytes: int):
+        p = C.c_void_p()
+        rc = load().a3_host_alloc(nbytes, C.byref(p))
+        if rc != OK:
+            raise A3Error(rc, load().a3_last_error(None).decode("utf-8", "replace"))
+        self.ptr, self.nbytes = p.value, nbytes
+        self.array = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(p.value))
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            load().a3_host_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
@@ -237,6 +281,13 @@ class Context:
 
     def set_stream(self, stream_ptr: int):
         check(load().a3_set_stream(self.handle, C.c_void_p(stream_ptr)), self.handle)
+
+    @property
+    def stream_ptr(self) -> int:
+        """hipStream_t the context enqueues on (a3_get_stream): wrap it with torch.cuda.ExternalStream to order torch work after it"""
+        p = C.c_void_p()
+        check(load().a3_get_stream(self.handle, C.byref(p)), self.handle)
+        return int(p.value or 0)
 
     def set_debug_taps(self, on: bool):
         check(load().a3_set_debug_taps(self.handle, int(on)), self.handle)
@@ -302,6 +353,23 @@ class Context:
                                          marker_size_mm, C.byref(intrinsics) if intrinsics else None, out.ctypes.data_as(C.c_void_p),
                                          poses.ctypes.data_as(C.c_void_p), cap, _p(per, C.c_uint32), C.byref(n))
         check(rc, self.handle)
+        return out[: n.value], per[:n_frames], poses[: n.value]
+
+    def submit_pose(self, pixels_ptr: int, memory: int, fmt: int, width: int, height: int, row_stride: int, frame_stride: int, n_frames: int,
+                    marker_size_mm: float, intrinsics: "Intrinsics" = None, out_cap: int = 0):
+        """a3_detect_batch_pose_submit; `collect_pose()` returns what detect_batch_pose would."""
+        self._pending = (out_cap or max(64 * n_frames, 64), n_frames)
+        check(load().a3_detect_batch_pose_submit(self.handle, C.c_void_p(pixels_ptr), memory, fmt, width, height, row_stride, frame_stride, n_frames,
+                                                 marker_size_mm, C.byref(intrinsics) if intrinsics else None, self._pending[0]), self.handle)
+
+    def collect_pose(self):
+        cap, n_frames = self._pending
+        out = np.empty(cap, dtype=MARKER_DTYPE)
+        poses = np.zeros((cap, 2, 13), dtype=np.float32)
+        per = np.zeros(max(n_frames, 1), dtype=np.uint32)
+        n = C.c_size_t()
+        check(load().a3_detect_batch_pose_collect(self.handle, out.ctypes.data_as(C.c_void_p), poses.ctypes.data_as(C.c_void_p), cap,
+                                                  _p(per, C.c_uint32), C.byref(n)), self.handle)
         return out[: n.value], per[:n_frames], poses[: n.value]
 
     # ---- Detection.grey / thresholded / candidates / homographies of the last batch ----

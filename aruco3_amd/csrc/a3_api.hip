@@ -53,6 +53,7 @@ hipError_t launch_compact_markers(hipStream_t, const void*, const uint16_t*, con
                                   uint32_t, uint32_t*, unsigned int*, unsigned int*, const uint32_t*, unsigned int*);
 hipError_t launch_pack_detections(hipStream_t, const a3_marker*, const a3_pose*, const uint32_t*, uint32_t, uint32_t, uint32_t, void*, unsigned int*);
 hipError_t launch_debug_rotate_bits(hipStream_t, const uint8_t*, uint32_t, uint32_t, uint8_t*);
+hipError_t launch_gather_patches(hipStream_t, const void*, uint32_t, const uint8_t*, uint32_t, uint32_t, uint8_t*, unsigned int*);
 hipError_t launch_pose(hipStream_t, const uint32_t*, uint32_t, const float*, uint32_t, const unsigned int*, int, float, float, float, float,
                        float, float, float, a3_pose*);
 hipError_t launch_find_nearest(hipStream_t, const uint64_t*, uint32_t, const uint64_t*, uint32_t, uint32_t*, uint8_t*);
@@ -66,16 +67,24 @@ using namespace a3;
 
 namespace {
 
-std::string g_create_error;
+// message of the last failed context-less call (a3_create, a3_calculate_tau) ON THIS THREAD: contexts for different GPUs may be
+// created concurrently from different threads
+thread_local std::string g_create_error;
 
-constexpr uint32_t kMaxCand = 1024;          // quad candidates kept per frame
+// Quad candidates kept per frame.  The reference is unbounded (src/aruco.rs:124-166 pushes into a Vec); here the tables start at
+// kMaxCandDefault per frame and a batch that overflows them is re-run with tables twice the size, up to kMaxCandLimit (the
+// per-frame ordering + discard_too_near kernel keeps a frame's candidates in LDS: 21 bytes each); beyond that: A3_ERR_CAPACITY.
+constexpr uint32_t kMaxCandDefault = 1024, kMaxCandLimit = 6144;
 constexpr uint32_t kMaxContoursDefault = 1u << 20;
 constexpr uint64_t kMaxDartsDefault = 48ull << 20;
 constexpr uint64_t kMaxPointsDefault = 64ull << 20;
 constexpr uint64_t kHardMaxDarts = 3ull << 30;   // 32-bit dart indices
 constexpr uint64_t kHardMaxPoints = 3ull << 30;
 constexpr int kResolveItersMax = 16;        // == DeviceCounters::resolve_changed slots
-constexpr uint32_t kPatchCap = 32768;        // debug taps: warped patches kept per batch (one per candidate that reaches the decode stage)
+// debug taps: warped patches kept per batch (one per candidate that reaches the decode stage).  The tap holds a patch for every
+// candidate the batch can have (frames x kMaxCand) up to kPatchCapMax patches (2.4 GB at 49 x 49); a binding that populates
+// Detection.homographies for more than 1024 frames per call splits the call (integration/aruco3_hip.rs does).
+constexpr uint32_t kPatchCapMin = 32768, kPatchCapMax = 1u << 20;
 
 // grow-only device buffer
 struct DevBuf {
@@ -100,8 +109,10 @@ struct Pending {
     uint64_t chunk0_darts = 0;
     uint32_t marker_cap = 0, guess = 0, n = 0, W = 0, H = 0;
     int rounds_max = 0, profiling = 0;
+    bool taps = false;   // debug taps were on: the per-frame candidate counts came back with the results
     // the submitted call, for the synchronous re-run when the device asks for one
     const uint8_t* pixels = nullptr; int fmt = 0; size_t row_stride = 0, frame_stride = 0;
+    bool want_pose = false;   // a3_detect_batch_pose_submit: the re-run must solve the poses again
 };
 
 }  // namespace
@@ -109,6 +120,10 @@ struct Pending {
 struct a3_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    // host frames (A3_MEM_HOST) are copied on a stream of their own, the compute stream waits for the copy through ev_in: with two
+    // contexts in flight (submit / collect) the H2D of batch i+1 runs under the kernels of batch i
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_in = nullptr;
     a3_config cfg{};
     uint8_t num_bits = 0, tau = 0;
     uint32_t n_codes = 0, mark_size = 0;
@@ -116,6 +131,7 @@ struct a3_ctx {
 
     uint64_t max_darts = kMaxDartsDefault, max_points = kMaxPointsDefault;
     uint32_t max_contours = kMaxContoursDefault;
+    uint32_t max_cand = kMaxCandDefault;   // candidate slots per frame (grows on overflow, see kMaxCandLimit)
     // launch-count hints (every pass past convergence is an empty launch of ~5 us): start low, retry the batch with the
     // maximum if a pass count turns out too small
     int jump_rounds_hint = 10, resolve_iters_hint = 4;
@@ -137,6 +153,7 @@ struct a3_ctx {
     a3_intrinsics pose_intr{};
     a3_pose* pose_out = nullptr;
     bool debug_taps = false;
+    uint32_t patch_cap = 0;    // patches the tap of the last tapped batch could hold
     bool grey_valid = false;   // the last batch wrote the grey plane
     // a3_download_contours: the last batch ran with debug taps in one chunk, so its contour table and point pool are whole
     bool contours_valid = false;
@@ -170,6 +187,12 @@ struct a3_ctx {
     bool poses_valid = false;
     void* pinned = nullptr;
     size_t pinned_cap = 0;
+    // debug taps: per-frame candidate counts of the last batch (before / after discard_too_near), read back with the results so
+    // that a3_candidate_count and the a3_download_* calls that start with it need no device round trip of their own
+    void* pinned_counts = nullptr;
+    size_t pinned_counts_cap = 0;
+    std::vector<uint32_t> h_cand_pre, h_cand_fin;
+    bool counts_valid = false;
 };
 
 namespace {
@@ -264,6 +287,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     const uint32_t min_edge_length = (uint32_t)((float)minwh * ctx->cfg.min_side_length_factor);   // src/aruco.rs:55
     const float min_corner_separation = (float)minwh * ctx->cfg.min_corner_separation_factor;       // src/aruco.rs:56
     const uint32_t S = ctx->cfg.homography_sample_size;
+    const uint32_t kMaxCand = ctx->max_cand;
 
     // the grey plane is materialised only for readers outside the fused path: Detection.grey (debug taps) and the generic
     // threshold kernels of other window sizes; the decode stage otherwise samples the caller's frames directly
@@ -281,7 +305,8 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     A3_HIP(ctx->outs.ensure((size_t)n * kMaxCand * decode_out_bytes()));
     A3_HIP(ctx->proj.ensure((size_t)n * kMaxCand * proj_rec_bytes()));
     const uint32_t marker_cap = (uint32_t)std::min<size_t>(std::max<size_t>(out_cap, 1), (size_t)n * kMaxCand);
-    if (ctx->debug_taps) A3_HIP(ctx->patches.ensure((size_t)kPatchCap * S * S));
+    const uint32_t patch_cap = (uint32_t)std::min<uint64_t>(kPatchCapMax, std::max<uint64_t>(kPatchCapMin, (uint64_t)n * kMaxCand));
+    if (ctx->debug_taps) { A3_HIP(ctx->patches.ensure((size_t)patch_cap * S * S)); ctx->patch_cap = patch_cap; }
     ctx->W = W; ctx->H = H; ctx->frames = n;
     ctx->stats = a3_stats{};
     ctx->contours_valid = false; ctx->markers_valid = false; ctx->poses_valid = false;
@@ -455,7 +480,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
                                    : PixelSrc{pixels, row_stride, frame_stride, fmt};
     A3_HIP(launch_decode(st, src, (int)W, (int)H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), d_work_count,
                          kMaxCand, S, ctx->mark_size, S, ctx->dict.as<uint64_t>(), ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors,
-                         ctx->proj.p, ctx->wtab.as<float>(), ctx->outs.p, ctx->debug_taps ? ctx->patches.as<uint8_t>() : nullptr, kPatchCap, ctx->per_frame, 4096, 0, n <= 64u ? 1 : 0));
+                         ctx->proj.p, ctx->wtab.as<float>(), ctx->outs.p, ctx->debug_taps ? ctx->patches.as<uint8_t>() : nullptr, patch_cap, ctx->per_frame, 4096, 0, n <= 64u ? 1 : 0));
     ctx->dbg_src = src;
     A3_HIP(launch_compact_markers(st, ctx->outs.p, ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(), n, 0, kMaxCand,
                                   ctx->markers_ptr, marker_cap, ctx->per_frame, d_marker_total, d_err, ctx->cand_count, ctx->scratch_u32 + 2));
@@ -469,7 +494,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     if (ctx->profiling >= 2) A3_HIP(hipEventRecord(ctx->ev[3], st));
 
     // ---- results: one copy of [scratch | counters | per-frame counts], one speculative copy of the marker list ----
-    const size_t pose_bytes = (ctx->want_pose && ctx->pose_out) ? 2 * sizeof(a3_pose) : 0;
+    const size_t pose_bytes = ctx->want_pose ? 2 * sizeof(a3_pose) : 0;
     const uint32_t guess = (uint32_t)std::min<size_t>(marker_cap, (size_t)ctx->last_marker_total + ctx->last_marker_total / 4 + 64);
     const size_t head_pad = head_bytes;   // the markers follow the head directly, on the device and in the staging buffer
     // pinned staging for the head and `guess` markers (+ poses); a longer list is fetched by finish_batch after growing it
@@ -478,11 +503,22 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     a3_pose* h_poses = reinterpret_cast<a3_pose*>(hp + head_pad + (size_t)guess * sizeof(a3_marker));
     A3_HIP(hipMemcpyAsync(hp, ctx->scratch_u32, head_bytes + (size_t)guess * sizeof(a3_marker), hipMemcpyDeviceToHost, st));
     if (pose_bytes) A3_HIP(hipMemcpyAsync(h_poses, ctx->pose_buf.p, (size_t)guess * pose_bytes, hipMemcpyDeviceToHost, st));
+    ctx->counts_valid = false;
+    if (ctx->debug_taps) {   // Detection.candidates / .homographies will be asked for frame by frame: their counts travel now
+        if (ctx->pinned_counts_cap < (size_t)n * 8) {
+            if (ctx->pinned_counts) (void)hipHostFree(ctx->pinned_counts);
+            ctx->pinned_counts = nullptr; ctx->pinned_counts_cap = 0;
+            A3_HIP(hipHostMalloc(&ctx->pinned_counts, (size_t)n * 8, hipHostMallocDefault));
+            ctx->pinned_counts_cap = (size_t)n * 8;
+        }
+        A3_HIP(hipMemcpyAsync(ctx->pinned_counts, ctx->cand_count, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        A3_HIP(hipMemcpyAsync((uint8_t*)ctx->pinned_counts + (size_t)n * 4, ctx->fin_count.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    }
     A3_HIP(hipEventRecord(ctx->ev[4], st));
     Pending& pd = ctx->pending;
     pd.active = true; pd.n_chunks = chunks.size(); pd.chunk0_darts = chunks.empty() ? 0 : chunks[0].darts; pd.ctr_bytes = ctr_bytes;
     pd.head_pad = head_pad; pd.marker_cap = marker_cap; pd.guess = guess; pd.pose_bytes = pose_bytes; pd.device_plan = device_plan;
-    pd.rounds_max = rounds_max; pd.n = n; pd.W = W; pd.H = H; pd.profiling = ctx->profiling;
+    pd.rounds_max = rounds_max; pd.n = n; pd.W = W; pd.H = H; pd.profiling = ctx->profiling; pd.taps = ctx->debug_taps;
     return A3_OK;
 }
 
@@ -547,7 +583,12 @@ int finish_batch(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_fram
     }
     if (flags & kErrBrokenEvent) return fail(ctx, A3_ERR_INTERNAL, "contour graph: a start event lies on an open chain");
     if (flags & kErrResolve) return fail(ctx, A3_ERR_INTERNAL, "contour start resolution did not converge");
-    if (flags & kErrCandTable) return fail(ctx, A3_ERR_CAPACITY, "more candidates / markers than the output tables hold");
+    if (flags & kErrCandTable) {   // a frame has more quad candidates than its table: twice the table and again
+        if (ctx->max_cand >= kMaxCandLimit) return fail(ctx, A3_ERR_CAPACITY, "a frame holds more than 6144 quad candidates");
+        ctx->max_cand = std::min(kMaxCandLimit, ctx->max_cand * 2);
+        return 1;
+    }
+    if (flags & kErrMarkerCap) return fail(ctx, A3_ERR_CAPACITY, "out_cap is smaller than the number of markers found");
     const uint32_t total = hs[1];
     if (total > out_cap) return fail(ctx, A3_ERR_CAPACITY, "out_cap is smaller than the number of markers found");
     const uint32_t* hpf = reinterpret_cast<const uint32_t*>(hp + 256 + ctr_bytes);
@@ -566,7 +607,14 @@ int finish_batch(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_fram
     }
     if (total) {
         memcpy(out, h_markers, (size_t)total * sizeof(a3_marker));
-        if (pose_bytes) memcpy(ctx->pose_out, h_poses, (size_t)total * pose_bytes);
+        if (pose_bytes && ctx->pose_out) memcpy(ctx->pose_out, h_poses, (size_t)total * pose_bytes);
+    }
+    if (pd.taps) {
+        const uint32_t* hc32 = reinterpret_cast<const uint32_t*>(ctx->pinned_counts);
+        ctx->h_cand_pre.assign(hc32, hc32 + n);
+        ctx->h_cand_fin.assign(hc32 + n, hc32 + 2 * (size_t)n);
+        for (auto& v : ctx->h_cand_pre) v = std::min(v, ctx->max_cand);
+        ctx->counts_valid = true;
     }
     ctx->last_marker_total = total;
     *out_n = total;
@@ -659,6 +707,9 @@ int a3_create(int device, const a3_config* cfg, const uint64_t* codes, size_t n_
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; ctx = nullptr; return fail(ctx, A3_ERR_HIP, "hipStreamCreate", e); }
     c->stream = c->own_stream;
+    e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
+    if (e != hipSuccess) { a3_destroy(c); ctx = nullptr; return fail(ctx, A3_ERR_HIP, "copy stream", e); }
     for (auto& ev : c->ev) {
         e = hipEventCreate(&ev);
         if (e != hipSuccess) { a3_destroy(c); ctx = nullptr; return fail(ctx, A3_ERR_HIP, "hipEventCreate", e); }
@@ -693,7 +744,10 @@ void a3_destroy(a3_ctx* ctx) {
                       &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_d, &ctx->pose_buf, &ctx->wtab};
     for (DevBuf* b : bufs) b->release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->pinned_counts) (void)hipHostFree(ctx->pinned_counts);
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+    if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
+    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -701,6 +755,36 @@ void a3_destroy(a3_ctx* ctx) {
 int a3_set_stream(a3_ctx* ctx, void* hip_stream) {
     if (!ctx) return A3_ERR_INVALID;
     ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return A3_OK;
+}
+
+// pinned host memory for frames: from it the H2D copy of a3_detect_batch(_submit) is asynchronous and runs at the link's rate
+int a3_host_alloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) return A3_ERR_INVALID;
+    *out = nullptr;
+    const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(nullptr, A3_ERR_HIP, "hipHostMalloc", e);
+    return A3_OK;
+}
+int a3_host_free(void* p) {
+    if (!p) return A3_OK;
+    const hipError_t e = hipHostFree(p);
+    return e == hipSuccess ? A3_OK : fail(nullptr, A3_ERR_HIP, "hipHostFree", e);
+}
+int a3_host_register(void* p, size_t bytes) {
+    if (!p || bytes == 0) return A3_ERR_INVALID;
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    return e == hipSuccess ? A3_OK : fail(nullptr, A3_ERR_HIP, "hipHostRegister", e);
+}
+int a3_host_unregister(void* p) {
+    if (!p) return A3_ERR_INVALID;
+    const hipError_t e = hipHostUnregister(p);
+    return e == hipSuccess ? A3_OK : fail(nullptr, A3_ERR_HIP, "hipHostUnregister", e);
+}
+
+int a3_get_stream(const a3_ctx* ctx, void** hip_stream) {
+    if (!ctx || !hip_stream) return A3_ERR_INVALID;
+    *hip_stream = reinterpret_cast<void*>(ctx->stream);
     return A3_OK;
 }
 
@@ -745,7 +829,13 @@ static int stage_input(a3_ctx* ctx, const void* pixels, int memory, int fmt, uin
     if (memory == A3_MEM_HOST) {
         const size_t bytes = *frame_stride * (n_frames - 1) + *row_stride * (height - 1) + (size_t)width * bpp;
         A3_HIP(ctx->in.ensure(bytes));
-        A3_HIP(hipMemcpyAsync(ctx->in.p, pixels, bytes, hipMemcpyHostToDevice, ctx->stream));
+        // On the copy stream, not the compute stream: the kernels of another context's batch (submit / collect with two
+        // contexts) keep running while these frames cross the link.  Pageable memory is staged by the runtime and the call
+        // returns when the caller's buffer has been read; pinned memory (a3_host_alloc / a3_host_register) makes the copy
+        // asynchronous and the buffer must then stay untouched until the batch is collected.
+        A3_HIP(hipMemcpyAsync(ctx->in.p, pixels, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+        A3_HIP(hipEventRecord(ctx->ev_in, ctx->copy_stream));
+        A3_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_in, 0));
         *d_pixels = ctx->in.as<uint8_t>();
     } else if (memory != A3_MEM_DEVICE) return fail(ctx, A3_ERR_INVALID, "memory must be A3_MEM_HOST or A3_MEM_DEVICE");
     return A3_OK;
@@ -777,24 +867,21 @@ int a3_detect_batch(a3_ctx* ctx, const void* pixels, int memory, int fmt, uint32
     return run_batch_with_retries(ctx, d_pixels, fmt, width, height, row_stride, frame_stride, n_frames, out, out_cap, per_frame_count, out_n);
 }
 
-int a3_detect_batch_submit(a3_ctx* ctx, const void* pixels, int memory, int fmt, uint32_t width, uint32_t height, size_t row_stride,
-                           size_t frame_stride, uint32_t n_frames, size_t out_cap) {
-    if (!ctx) return A3_ERR_INVALID;
+static int submit_common(a3_ctx* ctx, const void* pixels, int memory, int fmt, uint32_t width, uint32_t height, size_t row_stride,
+                         size_t frame_stride, uint32_t n_frames, size_t out_cap, bool want_pose) {
     if (ctx->pending.active || ctx->pending_trivial) return fail(ctx, A3_ERR_INVALID, "a submitted batch has not been collected");
     const uint8_t* d_pixels = nullptr;
     const int rc = stage_input(ctx, pixels, memory, fmt, width, height, &row_stride, &frame_stride, n_frames, &d_pixels);
     if (rc == kNothingToDo) { ctx->pending_trivial = true; ctx->pending.n = n_frames; return A3_OK; }
     if (rc != A3_OK) return rc;
     ctx->force_host_plan = false;
-    ctx->want_pose = false;
+    ctx->want_pose = want_pose;
     Pending& pd = ctx->pending;
-    pd.pixels = d_pixels; pd.fmt = fmt; pd.row_stride = row_stride; pd.frame_stride = frame_stride;
+    pd.pixels = d_pixels; pd.fmt = fmt; pd.row_stride = row_stride; pd.frame_stride = frame_stride; pd.want_pose = want_pose;
     return enqueue_batch(ctx, d_pixels, fmt, width, height, row_stride, frame_stride, n_frames, out_cap);
 }
 
-int a3_detect_batch_collect(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_frame_count, size_t* out_n) {
-    if (!ctx) return A3_ERR_INVALID;
-    if (!out_n || (!out && out_cap)) return fail(ctx, A3_ERR_INVALID, "a3_detect_batch_collect: null output");
+static int collect_common(a3_ctx* ctx, a3_marker* out, a3_pose* poses, size_t out_cap, uint32_t* per_frame_count, size_t* out_n) {
     *out_n = 0;
     if (ctx->pending_trivial) {
         ctx->pending_trivial = false;
@@ -803,10 +890,47 @@ int a3_detect_batch_collect(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_
     }
     A3_HIP(hipSetDevice(ctx->device));
     const Pending pd = ctx->pending;   // finish_batch clears .active
-    const int rc = finish_batch(ctx, out, out_cap, per_frame_count, out_n);
-    if (rc != 1) return rc;
+    ctx->want_pose = pd.want_pose;     // (the other half of the pair may have been a different kind of call on this context)
+    ctx->pose_out = pd.want_pose ? poses : nullptr;
+    int rc = finish_batch(ctx, out, out_cap, per_frame_count, out_n);
     // the device asked for a re-run (pool growth, more passes, host-side plan): do it synchronously
-    return run_batch_with_retries(ctx, pd.pixels, pd.fmt, pd.W, pd.H, pd.row_stride, pd.frame_stride, pd.n, out, out_cap, per_frame_count, out_n);
+    if (rc == 1) rc = run_batch_with_retries(ctx, pd.pixels, pd.fmt, pd.W, pd.H, pd.row_stride, pd.frame_stride, pd.n, out, out_cap, per_frame_count, out_n);
+    ctx->want_pose = false;
+    ctx->pose_out = nullptr;
+    return rc;
+}
+
+int a3_detect_batch_submit(a3_ctx* ctx, const void* pixels, int memory, int fmt, uint32_t width, uint32_t height, size_t row_stride,
+                           size_t frame_stride, uint32_t n_frames, size_t out_cap) {
+    if (!ctx) return A3_ERR_INVALID;
+    return submit_common(ctx, pixels, memory, fmt, width, height, row_stride, frame_stride, n_frames, out_cap, false);
+}
+
+int a3_detect_batch_collect(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_frame_count, size_t* out_n) {
+    if (!ctx) return A3_ERR_INVALID;
+    if (!out_n || (!out && out_cap)) return fail(ctx, A3_ERR_INVALID, "a3_detect_batch_collect: null output");
+    return collect_common(ctx, out, nullptr, out_cap, per_frame_count, out_n);
+}
+
+// detect + pose in two halves (BASELINE config 5 pipelined like config 2): the pose request travels with the submitted batch
+int a3_detect_batch_pose_submit(a3_ctx* ctx, const void* pixels, int memory, int fmt, uint32_t width, uint32_t height, size_t row_stride,
+                                size_t frame_stride, uint32_t n_frames, float marker_size_mm, const a3_intrinsics* intr, size_t out_cap) {
+    if (!ctx) return A3_ERR_INVALID;
+    if (ctx->pending.active || ctx->pending_trivial) return fail(ctx, A3_ERR_INVALID, "a submitted batch has not been collected");
+    ctx->pose_size_mm = marker_size_mm;
+    ctx->pose_has_intr = intr != nullptr;
+    if (intr) ctx->pose_intr = *intr;
+    const int rc = submit_common(ctx, pixels, memory, fmt, width, height, row_stride, frame_stride, n_frames, out_cap, true);
+    ctx->want_pose = false;   // (enqueue_batch has read it; a plain call in between must not inherit it)
+    return rc;
+}
+
+int a3_detect_batch_pose_collect(a3_ctx* ctx, a3_marker* out, a3_pose* poses, size_t out_cap, uint32_t* per_frame_count, size_t* out_n) {
+    if (!ctx) return A3_ERR_INVALID;
+    if (!out_n || (!out && out_cap) || (!poses && out_cap)) return fail(ctx, A3_ERR_INVALID, "a3_detect_batch_pose_collect: null output");
+    if (!ctx->pending_trivial && ctx->pending.active && !ctx->pending.want_pose)
+        return fail(ctx, A3_ERR_INVALID, "a3_detect_batch_pose_collect: the submitted batch was not an a3_detect_batch_pose_submit call");
+    return collect_common(ctx, out, poses, out_cap, per_frame_count, out_n);
 }
 
 int a3_detect_batch_pose(a3_ctx* ctx, const void* pixels, int memory, int fmt, uint32_t width, uint32_t height, size_t row_stride,
@@ -832,8 +956,13 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
     if (ctx->dbg_chunks != 1 || ctx->dbg_nd == 0) return fail(ctx, A3_ERR_INVALID, "needs a preceding single-chunk batch");
     A3_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    hipEvent_t e0, e1;
-    A3_HIP(hipEventCreate(&e0)); A3_HIP(hipEventCreate(&e1));
+    // the events are owned by a guard: every early return below (A3_HIP) destroys them
+    struct EventPair {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~EventPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+    } evp;
+    A3_HIP(hipEventCreate(&evp.e0)); A3_HIP(hipEventCreate(&evp.e1));
+    const hipEvent_t e0 = evp.e0, e1 = evp.e1;
     double total = 0.0;
     unsigned int* d_entry_count = ctx->scratch_u32 + 32;
     unsigned int* d_leader_count = ctx->scratch_u32 + 16;
@@ -857,7 +986,7 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
                                       ctx->leader_list.as<uint32_t>(), d_leader_count, 0, ctx->counters, nullptr, dbg ? dbg : 11, ctx->frame_base.as<uint32_t>(), nullptr, ctx->dbg_frames));
         } else if (kernel == 3) {   // dbg < 0: k_decode alone (variant -dbg), dbg >= 0: k_projection + k_decode
             A3_HIP(launch_decode(st, ctx->dbg_src, (int)ctx->W, (int)ctx->H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), ctx->scratch_u32,
-                                 kMaxCand, ctx->cfg.homography_sample_size, ctx->mark_size, ctx->cfg.homography_sample_size, ctx->dict.as<uint64_t>(),
+                                 ctx->max_cand, ctx->cfg.homography_sample_size, ctx->mark_size, ctx->cfg.homography_sample_size, ctx->dict.as<uint64_t>(),
                                  ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors, ctx->proj.p, ctx->wtab.as<float>(), ctx->outs.p, nullptr, 0u, nullptr, 4096,
                                  dbg == 0 ? -1000 : dbg, ctx->frames <= 64u ? 1 : 0));   // 0: k_projection + k_decode, < 0: k_decode alone (variant -dbg)
         } else return fail(ctx, A3_ERR_INVALID, "kernel: 0 dart_count, 1 dart_assign, 2 local_contract, 3 decode");
@@ -867,7 +996,6 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
         A3_HIP(hipEventElapsedTime(&ms, e0, e1));
         total += ms;
     }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *avg_ms = (float)(total / reps);
     return A3_OK;
 }
@@ -884,7 +1012,7 @@ int a3_synth_render(int device, void* hip_stream, const a3_synth_frame* frames, 
     for (uint32_t f = 0; f < n_frames; f++)
         if ((uint64_t)frames[f].first_marker + frames[f].n_markers > n_markers) return A3_ERR_INVALID;
     for (uint32_t m = 0; m < n_markers; m++)
-        if (markers[m].n == 0 || markers[m].n > 8) return A3_ERR_INVALID;
+        if (markers[m].n == 0 || markers[m].n > 11) return A3_ERR_INVALID;   // 121 cells in two words (CHILITAGS: 10 x 10)
     if (hipSetDevice(device) != hipSuccess) return A3_ERR_NO_DEVICE;
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
     a3_synth_frame* d_frames = nullptr; a3_synth_marker* d_markers = nullptr;
@@ -935,11 +1063,16 @@ int a3_download_thresholded(a3_ctx* ctx, uint32_t frame, uint8_t* dst) {
 int a3_candidate_count(a3_ctx* ctx, uint32_t frame, uint32_t* n_pre, uint32_t* n_final) {
     if (!ctx) return A3_ERR_INVALID;
     if (frame >= ctx->frames) return fail(ctx, A3_ERR_INVALID, "frame index outside the last batch");
+    if (ctx->counts_valid && frame < ctx->h_cand_fin.size()) {   // the tapped batch brought them along
+        if (n_pre) *n_pre = ctx->h_cand_pre[frame];
+        if (n_final) *n_final = ctx->h_cand_fin[frame];
+        return A3_OK;
+    }
     A3_HIP(hipSetDevice(ctx->device));
     uint32_t a = 0, b = 0;
     A3_HIP(hipMemcpy(&a, ctx->cand_count + frame, 4, hipMemcpyDeviceToHost));
     A3_HIP(hipMemcpy(&b, ctx->fin_count.as<uint32_t>() + frame, 4, hipMemcpyDeviceToHost));
-    if (n_pre) *n_pre = std::min(a, kMaxCand);
+    if (n_pre) *n_pre = std::min(a, ctx->max_cand);
     if (n_final) *n_final = b;
     return A3_OK;
 }
@@ -952,7 +1085,7 @@ int a3_download_candidates(a3_ctx* ctx, uint32_t frame, int before_discard, uint
     if (cnt > cap_quads) return fail(ctx, A3_ERR_CAPACITY, "cap_quads too small");
     std::vector<uint16_t> tmp((size_t)cnt * 8);
     const DevBuf& src = before_discard ? ctx->pre_xy : ctx->fin_xy;
-    if (cnt) A3_HIP(hipMemcpy(tmp.data(), src.as<uint16_t>() + (size_t)frame * kMaxCand * 8, tmp.size() * 2, hipMemcpyDeviceToHost));
+    if (cnt) A3_HIP(hipMemcpy(tmp.data(), src.as<uint16_t>() + (size_t)frame * ctx->max_cand * 8, tmp.size() * 2, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < tmp.size(); i++) dst_xy[i] = tmp[i];
     return A3_OK;
 }
@@ -965,20 +1098,40 @@ int a3_download_homographies(a3_ctx* ctx, uint32_t frame, uint8_t* dst, uint8_t*
     if (int rc = a3_candidate_count(ctx, frame, nullptr, &b)) return rc;
     if (b > cap) return fail(ctx, A3_ERR_CAPACITY, "cap too small");
     if (sizeof(DecodeOutHost) != decode_out_bytes()) return fail(ctx, A3_ERR_INTERNAL, "DecodeOut layout mismatch");
-    std::vector<DecodeOutHost> o(b);
-    if (b) A3_HIP(hipMemcpy(o.data(), (uint8_t*)ctx->outs.p + (size_t)frame * kMaxCand * sizeof(DecodeOutHost), (size_t)b * sizeof(DecodeOutHost),
-                            hipMemcpyDeviceToHost));
+    if (dst && !ctx->debug_taps) return fail(ctx, A3_ERR_INVALID, "patches are only kept after a3_set_debug_taps(ctx, 1)");
+    if (ctx->pending.active) return fail(ctx, A3_ERR_INVALID, "a submitted batch has not been collected");   // (its staging buffer is in use)
+    if (b == 0) return A3_OK;
+    A3_HIP(hipSetDevice(ctx->device));
     const uint32_t S = ctx->cfg.homography_sample_size;
+    const size_t S2 = (size_t)S * S, rec_bytes = (size_t)b * sizeof(DecodeOutHost);
+    const uint8_t* d_outs = (const uint8_t*)ctx->outs.p + (size_t)frame * ctx->max_cand * sizeof(DecodeOutHost);
+    // One trip: the frame's decode records, and its patches gathered by a kernel into one dense array, land in pinned memory
+    // through two copies on the stream and one wait (it was a blocking copy per candidate).
+    const size_t flag_off = (rec_bytes + 15) & ~(size_t)15, patch_off = flag_off + 16;
+    const size_t total = patch_off + (dst ? (size_t)b * S2 : 0);
+    A3_HIP(ctx->tmp_a.ensure(total));
+    uint8_t* d_tmp = ctx->tmp_a.as<uint8_t>();
+    unsigned int* d_missing = reinterpret_cast<unsigned int*>(d_tmp + flag_off);
+    hipStream_t st = ctx->stream;
+    if (dst) {
+        A3_HIP(hipMemsetAsync(d_missing, 0, 4, st));
+        A3_HIP(launch_gather_patches(st, d_outs, b, ctx->patches.as<uint8_t>(), ctx->patch_cap, (uint32_t)S2, d_tmp + patch_off, d_missing));
+    }
+    if (int rc = ensure_pinned(ctx, total + (1 << 16))) return rc;
+    uint8_t* hp = (uint8_t*)ctx->pinned;
+    A3_HIP(hipMemcpyAsync(hp, d_outs, rec_bytes, hipMemcpyDeviceToHost, st));
+    if (dst) A3_HIP(hipMemcpyAsync(hp + flag_off, d_tmp + flag_off, 16 + (size_t)b * S2, hipMemcpyDeviceToHost, st));
+    A3_HIP(wait_stream(st));
+    const DecodeOutHost* o = reinterpret_cast<const DecodeOutHost*>(hp);
     for (uint32_t k = 0; k < b; k++) {
         if (ok) ok[k] = o[k].hom_ok;
         if (decode_ok) decode_ok[k] = o[k].decode_ok;
         if (codes4) for (int r = 0; r < 4; r++) codes4[4 * k + r] = o[k].codes[r];
-        if (dst) {
-            if (!ctx->debug_taps) return fail(ctx, A3_ERR_INVALID, "patches are only kept after a3_set_debug_taps(ctx, 1)");
-            const size_t slot = o[k].patch;   // where k_decode kept this candidate's patch (kNone: the tap was full)
-            if (slot >= kPatchCap) return fail(ctx, A3_ERR_CAPACITY, "the patch tap holds 32768 patches per batch; this candidate's was not kept");
-            A3_HIP(hipMemcpy(dst + (size_t)k * S * S, ctx->patches.as<uint8_t>() + slot * S * S, (size_t)S * S, hipMemcpyDeviceToHost));
-        }
+    }
+    if (dst) {
+        memcpy(dst, hp + patch_off, (size_t)b * S2);
+        if (*reinterpret_cast<const unsigned int*>(hp + flag_off))
+            return fail(ctx, A3_ERR_CAPACITY, "the patch tap was full: a candidate's patch was not kept (split the batch: at most 1024 frames per tapped call)");
     }
     return A3_OK;
 }
@@ -1088,6 +1241,7 @@ int a3_debug_discard_too_near(a3_ctx* ctx, const uint32_t* quads_xy, size_t n, f
     if (!ctx || !quads_xy || !out_xy || !n_out) return A3_ERR_INVALID;
     *n_out = 0;
     if (n == 0) return A3_OK;
+    constexpr uint32_t kMaxCand = kMaxCandDefault;
     if (n > kMaxCand) return fail(ctx, A3_ERR_CAPACITY, "a3_debug_discard_too_near: at most 1024 quads");
     A3_HIP(hipSetDevice(ctx->device));
     std::vector<CandRec> h(n);

@@ -3,12 +3,23 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#ifdef A3_TUNING
+#include <cstdlib>
+#endif
 
 #include "../../include/aruco3_hip.h"
 
 namespace a3 {
 
 constexpr int WAVE = 64;
+
+// Tuning knobs exist only in -DA3_TUNING builds (`make tuning` -> build/tuning/libaruco3_hip.so, used by tools/ sweeps):
+// the product library never reads the environment, and no knob that changes results can be compiled into it.
+#ifdef A3_TUNING
+inline int tuning_knob(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#else
+constexpr int tuning_knob(const char*, int dflt) { return dflt; }
+#endif
 
 // ---- contour graph ("darts") ------------------------------------------------------------
 // A dart is (pixel, direction of a foreground 8-neighbour).  Directions are numbered
@@ -98,6 +109,6 @@ struct DeviceCounters {
     unsigned int pad[1];
 };
 
-constexpr unsigned kErrBrokenEvent = 1u, kErrPointPool = 2u, kErrContourTable = 4u, kErrCandTable = 8u, kErrResolve = 16u;
+constexpr unsigned kErrBrokenEvent = 1u, kErrPointPool = 2u, kErrContourTable = 4u, kErrCandTable = 8u, kErrResolve = 16u, kErrMarkerCap = 32u;
 
 }  // namespace a3

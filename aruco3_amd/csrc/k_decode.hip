@@ -832,7 +832,7 @@ __global__ __launch_bounds__(256) void k_compact_markers_par(const DecodeOut* __
                 mk.rotation = o.rotation;
                 mk.candidate_index = (uint16_t)k;
                 markers[p] = mk;
-            } else atomicOr(err_flags, kErrCandTable);
+            } else atomicOr(err_flags, kErrMarkerCap);
         }
         pos += (uint32_t)__popcll(m);
     }
@@ -894,7 +894,7 @@ __global__ __launch_bounds__(256) void k_compact_markers(const DecodeOut* __rest
                     m.rotation = o.rotation;
                     m.candidate_index = (uint16_t)k;
                     markers[pos] = m;
-                } else atomicOr(err_flags, kErrCandTable);
+                } else atomicOr(err_flags, kErrMarkerCap);
                 pos++;
             }
         }
@@ -938,6 +938,28 @@ __global__ __launch_bounds__(256) void k_pack_detections(const a3_marker* __rest
         uint32_t* pd = rec + 2u + maxm * kMarkerWords;
         for (uint32_t w = lane; w < maxm * kPoseWords; w += 64) pd[w] = w < kept * kPoseWords ? ps[w] : 0u;
     }
+}
+
+// Detection.homographies of one frame in one piece (debug taps): the frame's candidates keep their patches wherever their work
+// items fell in the tap; one workgroup per candidate copies its patch into a dense array that leaves in a single D2H copy
+// (a copy per patch was a blocking hipMemcpy per candidate).  A candidate whose patch was not kept gets zeros and sets *missing.
+__global__ __launch_bounds__(256) void k_gather_patches(const DecodeOut* __restrict__ outs, uint32_t n_cand, const uint8_t* __restrict__ patches,
+                                                        uint32_t patch_cap, uint32_t S2, uint8_t* __restrict__ dst, unsigned int* __restrict__ missing) {
+    const uint32_t k = blockIdx.x;
+    if (k >= n_cand) return;
+    const uint32_t slot = outs[k].patch;
+    const bool have = slot < patch_cap;
+    if (!have && threadIdx.x == 0) atomicOr(missing, 1u);
+    const uint8_t* src = patches + (size_t)(have ? slot : 0u) * S2;
+    for (uint32_t i = threadIdx.x; i < S2; i += blockDim.x) dst[(size_t)k * S2 + i] = have ? src[i] : (uint8_t)0;
+}
+
+hipError_t launch_gather_patches(hipStream_t st, const void* outs_frame, uint32_t n_cand, const uint8_t* patches, uint32_t patch_cap, uint32_t S2,
+                                 uint8_t* dst, unsigned int* missing) {
+    if (n_cand == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gather_patches, dim3(n_cand), dim3(256), 0, st, reinterpret_cast<const DecodeOut*>(outs_frame), n_cand, patches, patch_cap, S2,
+                       dst, missing);
+    return hipGetLastError();
 }
 
 // the bit-matrix rotation of the decode kernel on its own (reference vectors: src/aruco.rs:414-444)
@@ -1155,6 +1177,10 @@ hipError_t launch_frame_candidates(hipStream_t st, const CandRec* cands, const u
                                    float min_distance, uint16_t* pre_xy, uint16_t* fin_xy, uint32_t* fin_count, uint32_t* work,
                                    unsigned int* work_count, uint32_t S, void* proj) {
     const size_t lds = (size_t)max_cand * 21 + 16;
+    if (lds > 48 * 1024) {   // tables grown past the default (a3_api.hip: kMaxCandLimit keeps this under the CU's 160 KB)
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_frame_candidates), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(k_frame_candidates, dim3(n_frames), dim3(64), lds, st, cands, cand_count, max_cand, min_distance, pre_xy, fin_xy,
                        fin_count, work, work_count, S, reinterpret_cast<ProjRec*>(proj));
     return hipGetLastError();
@@ -1179,7 +1205,7 @@ hipError_t launch_decode(hipStream_t st, PixelSrc src, int W, int H, uint32_t fi
     // frames against 39), and on one wave -- no workgroup barriers -- when thousands of candidates are in flight and only the
     // throughput counts (BASELINE config 2: decode stage 0.123 ms against 0.130 with one wave per candidate throughout).
     const int d = dbg == -1000 ? 0 : (dbg < 0 ? -dbg : dbg);
-    if (const char* ev = getenv("A3_DECODE_WIDE")) few = atoi(ev);   // tuning knob
+    few = tuning_knob("A3_DECODE_WIDE", few);   // (-DA3_TUNING builds only)
     if (few)
         hipLaunchKernelGGL((k_decode<256, 256>), dim3(grid_blocks), dim3(256), decode_lds_bytes(S, n, max_taps), st, src, W, H, first_frame, fin_xy, work, work_count,
                            max_cand, S, n, max_taps, dict, n_codes, tau, filter, recs, wtab, reinterpret_cast<DecodeOut*>(outs), patches, patch_cap, per_frame, d);

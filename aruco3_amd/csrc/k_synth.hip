@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256) void k_synth_render(const a3_synth_frame* __re
                 if (!inside) continue;
                 const int ui = (int)floorf(u), vi = (int)floorf(v);   // cell coordinates; -1 and n are the white quiet zone
                 const bool in_cells = ui >= 0 && ui < n && vi >= 0 && vi < n;
-                const float val = in_cells ? (float)((m.cells >> (vi * n + ui)) & 1ull) : 1.0f;
+                const int cell = vi * n + ui;   // < 121: two words
+                const float val = in_cells ? (float)((m.cells[cell >> 6] >> (cell & 63)) & 1ull) : 1.0f;
                 if (paper) { if (val == 0.0f) { acc += black; cov += 1.0f; } }
                 else { acc += black + (white - black) * val; cov += 1.0f; }
             }
@@ -66,4 +67,4 @@ hipError_t launch_synth_render(hipStream_t st, const a3_synth_frame* frames, uin
 }
 
 }  // namespace a3
-static_assert(sizeof(a3_synth_marker) == 72 && sizeof(a3_synth_frame) == 32, "record layouts mirrored in aruco3_amd/synth.py");
+static_assert(sizeof(a3_synth_marker) == 80 && sizeof(a3_synth_frame) == 32, "record layouts mirrored in aruco3_amd/synth.py");

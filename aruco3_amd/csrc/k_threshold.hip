@@ -385,7 +385,11 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
             // the bits of pixels 0 .. T_NP-1 sit in the low half of acc, those of pixels T_NP .. in the high half
             const uint32_t outb = T_LPX == 16 ? __builtin_amdgcn_perm(0u, acc, 0x0C0C0200u) : ((acc | (acc >> 12)) & 0xFFu);
             if (flush_rows <= 0) {
-                if (owner && (flush_rows == 0 || outb == 0x12345u))   // (-1: tuning probe, no stores)
+#ifdef A3_TUNING
+                if (owner && (flush_rows == 0 || outb == 0x12345u))   // (-1: timing probe, no stores)
+#else
+                if (owner)
+#endif
                     *reinterpret_cast<out_bits_t*>(bout + (size_t)y * bpr + (x0 >> 3)) = (out_bits_t)outb;
             } else {
                 if (n_buf == 0) y_buf0 = y;
@@ -465,17 +469,21 @@ hipError_t launch_grey_threshold(hipStream_t st, const uint8_t* pixels, int fmt,
             if (cost < best_cost - 1e-9) { best_cost = cost; best_sy = sy; }
         }
         int rows_per_wave = (H + best_sy - 1) / best_sy;
-        if (const char* ev = getenv("A3_ROWS_PER_WAVE")) rows_per_wave = atoi(ev) > 0 ? atoi(ev) : rows_per_wave;  // tuning knob
+        if (const int rv = tuning_knob("A3_ROWS_PER_WAVE", 0); rv > 0) rows_per_wave = rv;   // (-DA3_TUNING builds only)
         const int strips_y = (H + rows_per_wave - 1) / rows_per_wave;
         const int n_pairs = (int)n * strips_x;
-        const char* mv = getenv("A3_K1_MAP");
         // every strip of a frame on one XCD (1) or every (frame, column strip) pair on its own XCD (0).  By frame is ~3 % faster:
         // the two column strips of a frame overlap by 32 columns and write the same lines of the packed image
-        const int map_by_frame = mv ? atoi(mv) : 1;   // tuning knob
+        const int map_by_frame = tuning_knob("A3_K1_MAP", 1);
         // rows of results a wave parks in LDS before it writes them out (0: store row by row): 128 (+15) rows x 64 lanes x 1 or 2
         // bytes = 9 or 18 KB per wave; twelve resp. eight waves per CU fit the 160 KB
-        const char* fv = getenv("A3_K1_FLUSH");
-        const int flush_rows = fv && atoi(fv) < 0 ? -1 : std::min(fv ? atoi(fv) : 128, rows_per_wave);   // tuning knob
+        // (-1 = "no stores at all" is a timing probe that leaves the binary image stale: it exists in -DA3_TUNING builds only)
+        const int fv = tuning_knob("A3_K1_FLUSH", 128);
+#ifdef A3_TUNING
+        const int flush_rows = fv < 0 ? -1 : std::min(fv, rows_per_wave);
+#else
+        const int flush_rows = std::min(fv < 0 ? 128 : fv, rows_per_wave);
+#endif
         const size_t lds_bytes = flush_rows > 0 ? (size_t)(flush_rows + 15) * 64 * sizeof(out_bits_t) : 0;
         dim3 grid(map_by_frame ? 8 * (((int)n + 7) / 8) * strips_x * strips_y : 8 * ((n_pairs + 7) / 8) * strips_y), block(64);
         const bool fast = aligned_in && aligned_out;   // W % 16 == 0: a lane's 16 pixels are all inside or all outside

@@ -148,8 +148,25 @@ def pack_detections_device(ctx: "_lib.Context", n_frames: int, first_frame: int,
 def gather_detections_device(ctx: "_lib.Context", n_frames: int, first_frame: int, device, coll_device=None, rows: int = None,
                              maxm: int = MAXM, with_poses: bool = False) -> torch.Tensor:
     """Per batch: device-packed records of this rank's frames, all-gathered (RCCL all-gather over xGMI with backend "nccl").
-    coll_device = "cpu" moves the packed tensor to the host first (gloo rehearsal on a box with fewer GPUs than ranks)."""
-    rec = pack_detections_device(ctx, n_frames, first_frame, device, maxm, with_poses)
-    if coll_device is not None and torch.device(coll_device).type == "cpu":
-        rec = rec.cpu()
-    return _all_gather(rec, rows if rows is not None else n_frames)
+    coll_device = "cpu" moves the packed tensor to the host first (gloo rehearsal on a box with fewer GPUs than ranks).
+
+    Ordering: a3_pack_detections enqueues its kernel on the CONTEXT's stream (a3_get_stream: its own non-blocking stream unless
+    a3_set_stream changed it), which torch knows nothing about.  The record tensor is therefore allocated, packed and handed to
+    the copy / collective under that stream wrapped as a torch stream, and torch's current stream waits for it before the
+    result is returned -- the pack can neither race the allocation nor be read before it has run."""
+    cs = torch.cuda.ExternalStream(ctx.stream_ptr, device=device) if ctx.stream_ptr else None
+    cur = torch.cuda.current_stream(device)
+    if cs is None:           # the context runs on the legacy default stream: torch's default stream is that very stream
+        cs = torch.cuda.default_stream(device)
+    cs.wait_stream(cur)      # (memory the caching allocator hands out may still be in use on the current stream)
+    with torch.cuda.stream(cs):
+        rec = pack_detections_device(ctx, n_frames, first_frame, device, maxm, with_poses)
+        if coll_device is not None and torch.device(coll_device).type == "cpu":
+            rec = rec.cpu()              # ordered behind the pack on cs, and synchronous for the host
+            out = _all_gather(rec, rows if rows is not None else n_frames)
+        else:
+            out = _all_gather(rec, rows if rows is not None else n_frames)   # RCCL orders itself after cs's pending work
+            rec.record_stream(cs)
+            out.record_stream(cur)
+    cur.wait_stream(cs)
+    return out

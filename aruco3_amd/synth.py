@@ -216,7 +216,7 @@ def render_frame(spec: SynthSpec, codes: np.ndarray, num_bits: int, seed: int):
 
 
 SYNTH_MARKER_DTYPE = np.dtype([("hinv", np.float32, 9), ("x0", np.int32), ("y0", np.int32), ("x1", np.int32), ("y1", np.int32),
-                               ("cells", np.uint64), ("n", np.uint32), ("reserved", np.uint32)], align=True)   # C layout: 72 bytes
+                               ("cells", np.uint64, 2), ("n", np.uint32), ("reserved", np.uint32)], align=True)   # C layout: 80 bytes
 SYNTH_FRAME_DTYPE = np.dtype([("base", np.float32), ("gx", np.float32), ("gy", np.float32), ("noise_sigma", np.float32),
                               ("first_marker", np.uint32), ("n_markers", np.uint32), ("seed", np.uint64)], align=True)       # 32 bytes
 
@@ -243,7 +243,7 @@ def device_layout(spec: SynthSpec, codes: np.ndarray, num_bits: int, seeds):
             for r in range(n):
                 for c in range(n):
                     bits |= int(cells[r, c]) << (r * n + c)
-            recs.append((np.linalg.inv(H).astype(np.float32).reshape(9), x0, y0, x1, y1, bits, n, 0))
+            recs.append((np.linalg.inv(H).astype(np.float32).reshape(9), x0, y0, x1, y1, (bits & _M64, bits >> 64), n, 0))   # n <= 11
             truth.append(TruthMarker(mid_, quad))
         truths.append(truth)
     marr = np.zeros(max(len(recs), 1), dtype=SYNTH_MARKER_DTYPE)

@@ -69,21 +69,29 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
                                                        "multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--synth-workers", type=int, default=0, help="host processes rendering frames (0 = auto)")
-    ap.add_argument("--repeats", type=int, default=25, help="the timed region (exactly --steps steps between barrier + synchronize) is run "
-                                                            "this many times back to back; the median is reported, every value listed "
-                                                            "(20 steps are 20 ms: one region alone measures clocks ramping)")
+    ap.add_argument("--repeats", type=int, default=0, help="the timed region (exactly --steps steps between barrier + synchronize) is run "
+                                                           "this many times back to back; the median is reported, every value listed "
+                                                           "(20 steps are 16 ms: one region alone measures clocks ramping).  0 = as many as "
+                                                           "make the timed regions total --min-timed-s seconds, at least 25")
+    ap.add_argument("--min-timed-s", type=float, default=3.0, help="with --repeats 0: seconds the timed regions add up to (the GPU is busy that long)")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path (process group, dictionary broadcast, device-packed "
                                                                 "records, all-gather) even with one rank: lets a 1-GPU box exercise the RCCL branch")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the other_workloads block (reference bench recipe, configs 4 and 5)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="N > 1 started without a launcher: seconds the parent waits for its ranks")
     ap.add_argument("--frames-cache", default="", help="npz path: reuse rendered frames between runs (profiling runs use it so that "
                                                         "nothing forks under the profiler)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` typed as is: this process becomes the launcher.  It has not imported torch and never touches
+        # HIP; it starts N FRESH child processes (one rank per GPU) and relays rank 0's JSON line.
+        raise SystemExit(launch_ranks(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 through torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus must agree")
 
     # host-side frame synthesis first (forks a pool; nothing has touched the GPU yet)
     workers = args.synth_workers or max(1, min(16, (os.cpu_count() or 8) // max(1, world)))
@@ -154,38 +162,48 @@ def main():
     batch_args = (d_frames.data_ptr(), _lib.MEM_DEVICE, _lib.FMT_RGB8, w, h, w * c, h * w * c, n)
 
     last_gather = [None]
-    side = torch.cuda.Stream(device=dev)   # the collective runs beside the detection stream, not in it
+    side = torch.cuda.Stream(device=dev)   # pack + collective run beside the detection stream, not in it
+    pack_done = {}                         # context -> event after its pack: the context's next batch overwrites the marker list
 
     def gather(cx):
-        # Per batch: fixed-capacity records written by a kernel from the device-resident marker list (a3_pack_detections, on the
-        # contexts' stream), then all-gathered over RCCL on a side stream that waits for the pack: the detection stream goes on
-        # with the next batch instead of waiting for the collective; no host copy in between.
-        with torch.cuda.stream(stream):
-            rec = shard.pack_detections_device(cx, n, first_frame, dev)
-            if coll_dev.type == "cpu":                  # gloo rehearsal: host tensors (the copy is ordered on the same stream)
-                rec = rec.cpu()
-        if coll_dev.type == "cpu":
-            last_gather[0] = shard._all_gather(rec, n)
-            return
-        side.wait_stream(stream)
-        with torch.cuda.stream(side):
-            last_gather[0] = shard._all_gather(rec, n)
-        rec.record_stream(side)
+        # Per batch: fixed-capacity records written by a kernel from the device-resident marker list (a3_pack_detections), then
+        # all-gathered over RCCL; no host copy in between.  collect() has returned, so batch i is complete: its pack needs no
+        # ordering against the detection stream and goes to the side stream AT ONCE, beside the kernels of batch i+1 that were
+        # submitted before the collect -- queued on the detection stream it would start a whole step late.
+        cx.set_stream(side.cuda_stream)
+        try:
+            with torch.cuda.stream(side):
+                rec = shard.pack_detections_device(cx, n, first_frame, dev)
+                pack_done[id(cx)] = side.record_event()
+                if coll_dev.type == "cpu":                  # gloo rehearsal: host tensors (the copy waits for the pack on `side`)
+                    rec = rec.cpu()
+                last_gather[0] = shard._all_gather(rec, n)
+        finally:
+            cx.set_stream(stream.cuda_stream)
+
+    def submit(cx):
+        ev = pack_done.pop(id(cx), None)
+        if ev is not None:
+            stream.wait_event(ev)        # the pack of this context's previous batch has read the marker list
+        cx.submit(*batch_args, out_cap=n * 64)
 
     def run_steps(k):
         """k steps; a step = one pass of Detector::detect over the rank's batch, results on the host (and all-gathered)."""
         markers, per = None, None
         if args.no_pipeline:
             for _ in range(k):
+                ev = pack_done.pop(id(ctx), None)
+                if ev is not None:
+                    stream.wait_event(ev)
                 markers, per = ctx.detect_batch(*batch_args, out_cap=n * 64)
                 if use_dist:
                     gather(ctx)
             return markers, per
         if k > 0:
-            ctxs[0].submit(*batch_args, out_cap=n * 64)
+            submit(ctxs[0])
         for i in range(k):
             if i + 1 < k:
-                ctxs[(i + 1) % 2].submit(*batch_args, out_cap=n * 64)
+                submit(ctxs[(i + 1) % 2])
             markers, per = ctxs[i % 2].collect()
             if use_dist:
                 gather(ctxs[i % 2])
@@ -214,22 +232,50 @@ def main():
 
     # The timed region: EXACTLY --steps steps between barrier + synchronize on both sides, max over ranks.  It is run
     # --repeats times back to back and the median region is the one reported (all are listed in ms_per_step_all).
-    regions = []
-    for _ in range(max(1, args.repeats)):
+    regions, k1_region_ms = [], []
+
+    def k1_totals():
+        tot = cnt = 0
+        for cx in ctxs:
+            a, b = cx.profile(_lib.STAGE_THRESHOLD); tot += a; cnt += b
+        return tot, cnt
+
+    def one_region():
+        k0 = k1_totals()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        markers, per = run_steps(args.steps)
+        res = run_steps(args.steps)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         regions.append(time.perf_counter() - t0)
+        k1 = k1_totals()
+        k1_region_ms.append((k1[0] - k0[0]) / max(k1[1] - k0[1], 1))
+        return res
+
+    n_regions = max(1, args.repeats)
+    if args.repeats <= 0:
+        # as many regions as make the timed time add up to --min-timed-s (every rank must run the same number: the count comes
+        # from the slowest rank's first five regions)
+        for _ in range(5):
+            markers, per = one_region()
+        pilot = torch.tensor([sum(regions) / len(regions)], dtype=torch.float64, device=coll_dev if use_dist else "cpu")
+        if use_dist:
+            dist.all_reduce(pilot, op=dist.ReduceOp.MAX)
+        n_regions = int(min(2000, max(25, np.ceil(args.min_timed_s / max(float(pilot[0]), 1e-6)))))
+    while len(regions) < n_regions:
+        markers, per = one_region()
     if use_dist:
         t = torch.tensor(regions, dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         regions = [float(v) for v in t.tolist()]
     elapsed = sorted(regions)[len(regions) // 2]
+    # regions far off the median (a one-off stall somewhere): counted and located, with the threshold kernel's own average in
+    # that region beside it -- a normal kernel time there says the stall was not on the GPU's side of K1
+    outliers = [{"region": i, "ms_per_step": round(r / args.steps * 1e3, 4), "k1_ms_in_region": round(k1_region_ms[i], 4)}
+                for i, r in enumerate(regions) if r > 1.5 * elapsed]
 
     # sanity: what was rendered is what was read (ids per frame), on this rank's last step
     pos, id_ok = 0, 0
@@ -279,7 +325,9 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "repeats": len(regions),
-            "ms_per_step_all": [round(r / args.steps * 1e3, 4) for r in regions],
+            "ms_per_step_all": [round(r / args.steps * 1e3, 3) for r in regions],
+            "ms_per_step_min_max": [round(min(regions) / args.steps * 1e3, 4), round(max(regions) / args.steps * 1e3, 4)],
+            "outlier_regions": {"count": len(outliers), "threshold": "1.5 x median", "first": outliers[:8]},
             "timed_region_s_total": round(sum(regions), 3),
             "higher_is_better": True,
             "scaling": "weak",
@@ -322,6 +370,10 @@ def main():
         }
         if gathered is not None:
             out["gathered"] = gathered
+        if use_dist:   # what the ranks themselves saw
+            out["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                           "launcher": os.environ.get("A3_BENCH_LAUNCHER", "external (torch.distributed.run)"),
+                           "pack_and_collective": "side stream, started when collect() returns (beside the next batch's kernels)"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames, d)
         if not args.no_other_workloads and world == 1:
@@ -330,6 +382,66 @@ def main():
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def launch_ranks(args):
+    """The front door for N > 1 without a launcher: start one child per rank -- `python bench.py <same flags>` with RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, exactly what torch.distributed.run would hand them -- wait for all
+    of them, pass on rank 0's JSON line.  Returns the exit code: non-zero if any rank fails or the launch times out (the
+    children that are still alive are then killed by PID).  The parent itself never initialises the GPU, and no process that
+    has is ever re-executed."""
+    import socket
+    import subprocess
+
+    n = args.gpus
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()   # a free rendezvous port
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    base["A3_BENCH_LAUNCHER"] = "bench.py --gpus N (self-launched child ranks)"
+    base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, str(Path(__file__).resolve())] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        # rank 0's stdout carries the JSON line; the other ranks' stdout goes to our stderr so that the line stays alone
+        procs.append(subprocess.Popen(cmd, env=env, cwd=str(ROOT), stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)   # drain rank 0's pipe while we wait
+    reader.start()
+    deadline = time.time() + args.launch_timeout
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        failed = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if failed:      # one rank down: the others would wait for it at the next collective until their own timeout
+            r, c = failed[0]
+            print(f"bench.py: rank {r} exited with {c}", file=sys.stderr)
+            rc = c if c > 0 else 1
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            print(f"bench.py: launch of {n} ranks timed out after {args.launch_timeout} s", file=sys.stderr)
+            rc = 124
+            break
+        time.sleep(0.05)
+    for p in procs:
+        if p.poll() is None:     # still running after a failure / timeout: kill exactly that PID
+            p.kill()
+        p.wait()
+    reader.join(timeout=10)
+    out0 = chunks[0] if chunks else ""
+    lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    for ln in (out0 or "").splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if rc == 0 and not lines:
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
+        rc = 1
+    if lines:
+        print(lines[-1], flush=True)
+    return rc
 
 
 def pmc_traffic_bytes():
@@ -445,10 +557,13 @@ def other_workloads(device, with_cpu=True, budget_s=60.0):
         ctx.close()
 
     g = torch.Generator(device=dev); g.manual_seed(20261004)
-    noise = torch.randint(0, 256, (32, 1080, 1920, 3), dtype=torch.uint8, device=dev, generator=g)
-    run("C0_reference_bench_noise_1080p", noise, "ARUCO", cpu_frames=2,
-        note="benches/detect_markers.rs:29-51 recipe: every channel of every pixel uniform random u8; no markers, ~1.6 M darts per frame")
-    del noise
+    # the reference's bench matrix, benches/detect_markers.rs:29: 1920x1080, 1280x720, 960x540, 512x512 uniform noise
+    for (nw, nh), nb in (((1920, 1080), 32), ((1280, 720), 32), ((960, 540), 32), ((512, 512), 32)):
+        noise = torch.randint(0, 256, (nb, nh, nw, 3), dtype=torch.uint8, device=dev, generator=g)
+        run(f"C0_reference_bench_noise_{nw}x{nh}" if (nw, nh) != (1920, 1080) else "C0_reference_bench_noise_1080p", noise, "ARUCO",
+            cpu_frames=2 if nw >= 1280 else 4, reps=5,
+            note="benches/detect_markers.rs:29-51 recipe: every channel of every pixel uniform random u8; no markers")
+        del noise
     spec4, name4 = synth.config_spec(4)
     d4 = ARDictionary.new_from_named_dict(name4)
     f4, t4 = synth.render_frames_device(spec4, d4.code_list, d4.num_bits, [synth.frame_seed(4, i) for i in range(32)], device=device)
@@ -459,7 +574,122 @@ def other_workloads(device, with_cpu=True, budget_s=60.0):
     f5, t5 = synth.render_frames_device(spec5, d5.code_list, d5.num_bits, [synth.frame_seed(5, i) for i in range(16)], device=device)
     run("C5_4k_16_markers_detect_plus_pose", f5, name5, pose_mm=40.0, cpu_frames=2, truths=t5,
         note="BASELINE config 5 on one GPU: detect + solve_with_undistorted_points of every marker in one call")
+    del f5
+    try:
+        res["C1_single_frame_from_host"] = caller_latency(device, with_cpu)
+        if time.perf_counter() - t_start < budget_s + 30.0:
+            res["C2_from_host_frames"] = host_ingest(device)
+    except Exception as e:   # the headline must not die with a side measurement
+        res["caller_path_error"] = repr(e)
     return res
+
+
+def caller_latency(device, with_cpu=True, calls=200):
+    """BASELINE config 1 the way the reference's own caller meets it (benches/detect_markers.rs:25,48-50: one host image per
+    `detect` call): ONE 640x480 frame with 4 ARUCO_DEFAULT markers in host memory through a3_detect_batch(A3_MEM_HOST, n = 1) --
+    H2D copy, every kernel, marker read-back -- as a LATENCY, with the debug taps off (Detection.markers only) and on
+    (Detection.grey / .candidates / .homographies filled like src/aruco.rs:115-120, each download included), beside the
+    single-thread oracle on the same frame."""
+    import torch
+
+    from aruco3_amd import _lib, synth
+    from aruco3_amd.aruco import Detector, DetectorConfig
+    from aruco3_amd.dictionaries import ARDictionary
+
+    frames, truth = synth.config_frames(1, 1)
+    d = ARDictionary.new_from_named_dict("ARUCO_DEFAULT")
+    ctx = Detector(DetectorConfig.default(), d, device=device)._context()
+    n, h, w, c = frames.shape
+    pinned = _lib.PinnedBuffer(frames.nbytes)
+    pinned.array[:] = frames.reshape(-1)
+    out = {"workload": "BASELINE config 1: one 640x480 RGB frame, 4 ARUCO_DEFAULT markers, host memory, n = 1 per call", "calls": calls}
+
+    def timeit(fn, k=calls):
+        fn(); fn(); fn()
+        ts = []
+        for _ in range(k):
+            t0 = time.perf_counter(); r = fn(); ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return r, {"median_ms": round(ts[len(ts) // 2] * 1e3, 4), "p10_ms": round(ts[len(ts) // 10] * 1e3, 4), "p90_ms": round(ts[(9 * len(ts)) // 10] * 1e3, 4)}
+
+    for label, ptr in (("pageable", frames.ctypes.data), ("pinned", pinned.ptr)):
+        a = (ptr, _lib.MEM_HOST, _lib.FMT_RGB8, w, h, w * c, h * w * c, 1)
+        ctx.set_debug_taps(False)
+        r, t = timeit(lambda: ctx.detect_batch(*a, out_cap=64))
+        t["markers"] = int(len(r[0])); t["ids_correct"] = sorted(int(m["id"]) for m in r[0]) == sorted(x.id for x in truth[0])
+        out[f"markers_only_{label}"] = t
+        ctx.set_debug_taps(True)
+
+        def populated():
+            res = ctx.detect_batch(*a, out_cap=64)
+            grey = ctx.download_grey(0, w, h); cand = ctx.candidates(0); hom = ctx.homographies(0)
+            return res, grey, cand, hom
+
+        r, t = timeit(populated, max(20, calls // 4))
+        t["candidates"] = int(len(r[2])); t["patches"] = int(len(r[3][0]))
+        out[f"detection_fully_populated_{label}"] = t
+    ctx.set_debug_taps(False)
+    if with_cpu:
+        from oracle import a3oracle
+        a3oracle.build()
+        codes = np.ascontiguousarray(d.code_list)
+        _, t = timeit(lambda: a3oracle.detect_markers_only(frames[0], codes, d.num_bits, d._tau), 20)
+        out["cpu_baseline"] = dict(t, cores=1, kind="port", sample="the same frame, single thread, 20 calls (markers only)")
+    pinned.close(); ctx.close()
+    return out
+
+
+def host_ingest(device, batches=6, frames_per_batch=256):
+    """BASELINE config 2 from HOST frames (H2D inclusive; never the headline `value`): 256-frame batches of the 1080p workload in
+    pageable and in pinned host memory, two contexts in submit / collect so that the copy of batch i+1 (each context's copy
+    stream) runs under the kernels of batch i, beside the bare pinned-H2D rate of the same bytes on this box."""
+    import torch
+
+    from aruco3_amd import _lib, synth
+    from aruco3_amd.aruco import Detector, DetectorConfig
+    from aruco3_amd.dictionaries import ARDictionary
+
+    dev = torch.device("cuda", device)
+    spec, name = synth.config_spec(2)
+    d = ARDictionary.new_from_named_dict(name)
+    seeds = [synth.frame_seed(2, i) for i in range(frames_per_batch)]
+    d_frames, _ = synth.render_frames_device(spec, d.code_list, d.num_bits, seeds, device=device)
+    n, h, w, c = d_frames.shape
+    nbytes = d_frames.numel()
+    pageable = d_frames.cpu().numpy()                      # ordinary host memory, as a caller's Vec<u8> would be
+    pinned = _lib.PinnedBuffer(nbytes)
+    pinned.array[:] = pageable.reshape(-1)
+    # the link itself: hipMemcpyAsync of the same bytes from pinned memory, nothing else running
+    t_pin = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+    t_pin.copy_(torch.from_numpy(pageable.reshape(-1)))
+    dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ts = []
+    for _ in range(4):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        dst.copy_(t_pin, non_blocking=True)
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    link_s = sorted(ts)[1]
+    out = {"workload": f"BASELINE config 2 from host memory: {frames_per_batch} x 1920x1080 RGB per batch, two contexts, submit / collect",
+           "pinned_h2d_alone": {"GBps": round(nbytes / link_s / 1e9, 2), "frames_per_s": round(n / link_s, 1)}}
+    del dst, t_pin
+    ctxs = [Detector(DetectorConfig.default(), d, device=device)._context() for _ in range(2)]
+    for label, ptr in (("pageable", pageable.ctypes.data), ("pinned", pinned.ptr)):
+        a = (ptr, _lib.MEM_HOST, _lib.FMT_RGB8, w, h, w * c, h * w * c, n)
+        for cx in ctxs:
+            cx.detect_batch(*a, out_cap=n * 64)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ctxs[0].submit(*a, out_cap=n * 64)
+        for i in range(batches):
+            if i + 1 < batches:
+                ctxs[(i + 1) % 2].submit(*a, out_cap=n * 64)
+            markers, per = ctxs[i % 2].collect()
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        out[label] = {"value": round(batches * n / dt, 1), "unit": "frames/s", "GBps_over_the_link": round(batches * nbytes / dt / 1e9, 2),
+                      "fraction_of_pinned_h2d_alone": round((batches * n / dt) / (n / link_s), 3), "markers_last_batch": int(len(markers))}
+    for cx in ctxs:
+        cx.close()
+    pinned.close()
+    return out
 
 
 if __name__ == "__main__":

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define A3_ABI_VERSION 2
+#define A3_ABI_VERSION 3
 
 enum {
     A3_OK = 0,
@@ -99,6 +99,9 @@ void a3_destroy(a3_ctx *ctx);
 const char *a3_last_error(const a3_ctx *ctx); /* ctx may be NULL: message of the last failed a3_create */
 /* run on the caller's HIP stream (hipStream_t as void*); NULL = the context's own stream */
 int  a3_set_stream(a3_ctx *ctx, void *hip_stream);
+/* the stream the context enqueues on (its own unless a3_set_stream changed it): a caller that follows a batch or
+ * a3_pack_detections with work of its own orders that work after this stream */
+int  a3_get_stream(const a3_ctx *ctx, void **hip_stream);
 /* total darts / contour points the device pools may hold (0 keeps the default); call before detect */
 int  a3_set_pool_limits(a3_ctx *ctx, uint64_t max_darts, uint64_t max_points);
 int  a3_get_tau(const a3_ctx *ctx, uint8_t *tau);
@@ -123,11 +126,27 @@ int  a3_detect_batch_pose(a3_ctx *ctx, const void *pixels, int memory, int fmt, 
 /* The same call in two halves, for callers that keep the GPU fed: submit enqueues the whole batch and returns without
  * waiting; collect waits for it and hands out the results (re-running the batch synchronously in the rare cases a
  *3_detect_batch would).  One batch may be in flight per context; with two contexts on one stream, batch i+1 is
- * submitted before batch i is collected.  Device-resident frames must stay valid until collect; host frames are
- * copied during submit.  out_cap of submit bounds the marker list; collect's must not be smaller than what was found. */
+ * submitted before batch i is collected.  Device-resident frames and pinned host frames must stay valid until collect;
+ * pageable host frames have been read when submit returns.  out_cap of submit bounds the marker list; collect's must not be smaller than what was found. */
 int  a3_detect_batch_submit(a3_ctx *ctx, const void *pixels, int memory, int fmt, uint32_t width, uint32_t height,
                             size_t row_stride, size_t frame_stride, uint32_t n_frames, size_t out_cap);
 int  a3_detect_batch_collect(a3_ctx *ctx, a3_marker *out, size_t out_cap, uint32_t *per_frame_count, size_t *out_n);
+/* a3_detect_batch_pose in the same two halves (BASELINE config 5 pipelined like config 2) */
+int  a3_detect_batch_pose_submit(a3_ctx *ctx, const void *pixels, int memory, int fmt, uint32_t width, uint32_t height,
+                                 size_t row_stride, size_t frame_stride, uint32_t n_frames, float marker_size_mm,
+                                 const a3_intrinsics *intr, size_t out_cap);
+int  a3_detect_batch_pose_collect(a3_ctx *ctx, a3_marker *out, a3_pose *poses, size_t out_cap, uint32_t *per_frame_count,
+                                  size_t *out_n);
+
+/* Host frames (A3_MEM_HOST) cross the link on a copy stream of the context, beside the kernels of whatever batch another
+ * context has in flight.  From pageable memory the runtime stages the copy and the call returns once the caller's buffer has
+ * been read.  From PINNED memory -- allocated with a3_host_alloc, or the caller's own ring pinned once with a3_host_register
+ * (a webcam loop's frame buffers, examples/webcam_kamera.rs:36-71) -- the copy is asynchronous and runs at the link's rate:
+ * a3_detect_batch_submit returns at once, and the buffer must then stay untouched until the batch is collected. */
+int  a3_host_alloc(size_t bytes, void **out);
+int  a3_host_free(void *p);
+int  a3_host_register(void *p, size_t bytes);
+int  a3_host_unregister(void *p);
 int  a3_get_stats(const a3_ctx *ctx, a3_stats *stats);
 
 /* Detection.grey / .candidates / .homographies of the last batch (src/aruco.rs:16-21,115-120),
@@ -182,11 +201,11 @@ int  a3_get_profile(a3_ctx *ctx, int stage, double *total_ms, uint64_t *launches
 /* Synthetic frames rendered on the device (the reference's counterparts are its test renderer
  * and ARDictionary::make_binary_image, src/dictionaries.rs:209-232).  The caller lays the frames out -- background
  * gradient, and per marker the inverse homography image -> cell coordinates, a bounding box and the n x n cell bitmap
- * (bit r*n+c = 1: white; n = code side + 2 <= 8) -- and the kernel paints RGB8 frames into device memory `out`. */
+ * (bit r*n+c = 1: white; n = code side + 2 <= 11: CHILITAGS is 10 x 10) -- and the kernel paints RGB8 frames into device memory `out`. */
 typedef struct a3_synth_marker {
     float    hinv[9];            /* image (x, y, 1) -> marker cells (u, v, w), row-major */
     int32_t  x0, y0, x1, y1;     /* pixels the marker (with its one-cell quiet zone) can touch: [x0,x1) x [y0,y1) */
-    uint64_t cells;
+    uint64_t cells[2];           /* bit r*n+c of the 128 = cell (r, c); 1: white */
     uint32_t n, reserved;
 } a3_synth_marker;
 typedef struct a3_synth_frame {

@@ -15,7 +15,7 @@
 //! lives in a process-wide registry keyed by the detector's VALUE (config bits + dictionary identity),
 //! see `registry()`.
 //!
-//! Status: written against include/aruco3_hip.h ABI version 2; NOT compiled in the build image (no
+//! Status: written against include/aruco3_hip.h ABI version 3; NOT compiled in the build image (no
 //! Rust toolchain there).  tests/test_rust_shim.py checks that every entry point of the header is
 //! declared here with the same number of parameters and that the `#[repr(C)]` structs list the
 //! header's fields in order.
@@ -42,7 +42,7 @@ use crate::pose::MarkerPose;
 // 1. The C ABI, one declaration per entry point of include/aruco3_hip.h
 // =====================================================================================================
 
-pub const A3_ABI_VERSION: c_int = 2;
+pub const A3_ABI_VERSION: c_int = 3;
 
 pub const A3_OK: c_int = 0;
 pub const A3_ERR_INVALID: c_int = -1;
@@ -137,7 +137,7 @@ pub struct A3SynthMarker {
     pub y0: i32,
     pub x1: i32,
     pub y1: i32,
-    pub cells: u64,
+    pub cells: [u64; 2],
     pub n: u32,
     pub reserved: u32,
 }
@@ -167,6 +167,7 @@ extern "C" {
     pub fn a3_destroy(ctx: *mut A3Ctx);
     pub fn a3_last_error(ctx: *const A3Ctx) -> *const c_char;
     pub fn a3_set_stream(ctx: *mut A3Ctx, hip_stream: *mut c_void) -> c_int;
+    pub fn a3_get_stream(ctx: *const A3Ctx, hip_stream: *mut *mut c_void) -> c_int;
     pub fn a3_set_pool_limits(ctx: *mut A3Ctx, max_darts: u64, max_points: u64) -> c_int;
     pub fn a3_get_tau(ctx: *const A3Ctx, tau: *mut u8) -> c_int;
     pub fn a3_set_debug_taps(ctx: *mut A3Ctx, enabled: c_int) -> c_int;
@@ -181,6 +182,15 @@ extern "C" {
                                   row_stride: usize, frame_stride: usize, n_frames: u32, out_cap: usize) -> c_int;
     pub fn a3_detect_batch_collect(ctx: *mut A3Ctx, out: *mut A3Marker, out_cap: usize, per_frame_count: *mut u32,
                                    out_n: *mut usize) -> c_int;
+    pub fn a3_detect_batch_pose_submit(ctx: *mut A3Ctx, pixels: *const c_void, memory: c_int, fmt: c_int, width: u32, height: u32,
+                                       row_stride: usize, frame_stride: usize, n_frames: u32, marker_size_mm: f32,
+                                       intr: *const A3Intrinsics, out_cap: usize) -> c_int;
+    pub fn a3_detect_batch_pose_collect(ctx: *mut A3Ctx, out: *mut A3Marker, poses: *mut A3Pose, out_cap: usize,
+                                        per_frame_count: *mut u32, out_n: *mut usize) -> c_int;
+    pub fn a3_host_alloc(bytes: usize, out: *mut *mut c_void) -> c_int;
+    pub fn a3_host_free(p: *mut c_void) -> c_int;
+    pub fn a3_host_register(p: *mut c_void, bytes: usize) -> c_int;
+    pub fn a3_host_unregister(p: *mut c_void) -> c_int;
     pub fn a3_get_stats(ctx: *const A3Ctx, stats: *mut A3Stats) -> c_int;
     pub fn a3_download_grey(ctx: *mut A3Ctx, frame: u32, dst: *mut u8) -> c_int;
     pub fn a3_download_thresholded(ctx: *mut A3Ctx, frame: u32, dst: *mut u8) -> c_int;
@@ -216,6 +226,9 @@ extern "C" {
 /// through the `Mutex` of its registry slot; that keeps `&Detector` `Sync`, as the reference's plain struct is.
 pub struct HipCtx {
     raw: *mut A3Ctx,
+    /// pinned staging for the frames of a call, grow-only and re-used from call to call (page-locking memory costs far more
+    /// than a frame's copy: it is not done per `detect()`)
+    staging: PinnedBytes,
 }
 // the raw pointer is only dereferenced by the library, under the slot's Mutex
 unsafe impl Send for HipCtx {}
@@ -231,7 +244,7 @@ impl HipCtx {
             // (src/dictionaries.rs:144); a missing GPU has no precedent and panics with the library's message
             panic!("aruco3_hip: a3_create failed ({}): {}", rc, last_error(std::ptr::null()));
         }
-        HipCtx { raw }
+        HipCtx { raw, staging: PinnedBytes::empty() }
     }
     fn check(&self, rc: c_int, what: &str) {
         if rc != A3_OK {
@@ -364,19 +377,69 @@ fn slot_for(d: &Detector) -> Slot {
 // 3. Detector::detect (replaces src/aruco.rs:52-121) + the batch form the GPU wants
 // =====================================================================================================
 
-/// One batch as the library wants it: frames of one size and one layout, back to back.
+/// Page-locked host memory from `a3_host_alloc`: frames packed here cross the link asynchronously and at its full rate
+/// (include/aruco3_hip.h, "Host frames").  Falls back to nothing: an allocation failure panics like every other error.
+struct PinnedBytes {
+    ptr: *mut u8,
+    len: usize,
+    cap: usize,
+}
+// only ever touched under the Mutex of the context that owns it
+unsafe impl Send for PinnedBytes {}
+impl PinnedBytes {
+    fn empty() -> PinnedBytes {
+        PinnedBytes { ptr: std::ptr::null_mut(), len: 0, cap: 0 }
+    }
+    /// empty the buffer and make room for `cap` bytes (re-allocating only when it has to grow)
+    fn reset(&mut self, cap: usize) {
+        self.len = 0;
+        if cap <= self.cap {
+            return;
+        }
+        if !self.ptr.is_null() {
+            unsafe { a3_host_free(self.ptr as *mut c_void) };
+            self.ptr = std::ptr::null_mut();
+            self.cap = 0;
+        }
+        let mut p: *mut c_void = std::ptr::null_mut();
+        let rc = unsafe { a3_host_alloc(cap, &mut p) };
+        if rc != A3_OK || p.is_null() {
+            panic!("aruco3_hip: a3_host_alloc({}) failed ({}): {}", cap, rc, last_error(std::ptr::null()));
+        }
+        self.ptr = p as *mut u8;
+        self.cap = cap;
+    }
+    fn extend_from_slice(&mut self, src: &[u8]) {
+        assert!(self.len + src.len() <= self.cap, "aruco3_hip: packed batch larger than computed");
+        unsafe { std::ptr::copy_nonoverlapping(src.as_ptr(), self.ptr.add(self.len), src.len()) };
+        self.len += src.len();
+    }
+    fn as_ptr(&self) -> *const u8 {
+        self.ptr
+    }
+}
+impl Drop for PinnedBytes {
+    fn drop(&mut self) {
+        if !self.ptr.is_null() {
+            unsafe { a3_host_free(self.ptr as *mut c_void) };
+            self.ptr = std::ptr::null_mut();
+        }
+    }
+}
+
+/// One batch as the library wants it: frames of one size and one layout, back to back, in the context's pinned staging buffer.
 struct Packed {
     fmt: c_int,
     bpp: usize,
     width: u32,
     height: u32,
-    bytes: Vec<u8>,
+    bytes: *const u8,
 }
 
 /// `DynamicImage` -> raw bytes without touching pixel values.  Rgb8 / Rgba8 / Luma8 buffers are handed over as they are
 /// (the kernel applies `into_luma8`'s integer formula itself, src/aruco.rs:60); every other variant (16-bit, float,
 /// LumaA) goes through the crate's own `into_luma8()` on the CPU first, so its result is the reference's by construction.
-fn pack(images: &[DynamicImage]) -> Packed {
+fn pack(images: &[DynamicImage], staging: &mut PinnedBytes) -> Packed {
     assert!(!images.is_empty(), "aruco3_hip: empty batch");
     let (width, height) = (images[0].width(), images[0].height());
     let kind = |im: &DynamicImage| -> (c_int, usize) {
@@ -389,7 +452,8 @@ fn pack(images: &[DynamicImage]) -> Packed {
     let (fmt, bpp) = kind(&images[0]);
     let uniform = images.iter().all(|im| kind(im).0 == fmt);
     let (fmt, bpp) = if uniform { (fmt, bpp) } else { (A3_FMT_L8, 1) }; // mixed layouts: everything to Luma8
-    let mut bytes = Vec::with_capacity(images.len() * width as usize * height as usize * bpp);
+    staging.reset(images.len() * width as usize * height as usize * bpp);
+    let bytes = staging;
     for im in images {
         assert!(im.width() == width && im.height() == height, "aruco3_hip: all frames of a batch must have one size");
         match (fmt, im) {
@@ -399,7 +463,7 @@ fn pack(images: &[DynamicImage]) -> Packed {
             (_, other) => bytes.extend_from_slice(other.clone().into_luma8().as_raw()),
         }
     }
-    Packed { fmt, bpp, width, height, bytes }
+    Packed { fmt, bpp, width, height, bytes: bytes.as_ptr() }
 }
 
 fn marker_of(m: &A3Marker) -> Marker {
@@ -436,6 +500,10 @@ fn fill_debug_outputs(ctx: &HipCtx, f: u32, width: u32, height: u32, sample: u32
     }).collect();
 }
 
+/// With `Detection.homographies` populated the library keeps one patch per candidate of the batch; its tap is sized for
+/// 1024 frames x 1024 candidates, so a populated call never carries more frames than this (larger batches are split).
+const MAX_TAPPED_FRAMES: usize = 1024;
+
 impl Detector {
     /// src/aruco.rs:52-121, same signature.  One frame = a batch of one.
     pub fn detect(&self, image: DynamicImage) -> Detection {
@@ -448,10 +516,13 @@ impl Detector {
         if images.is_empty() {
             return Vec::new();
         }
-        let p = pack(images);
-        let slot = slot_for(self);
-        let ctx = slot.lock().unwrap();
         let populate = POPULATE.load(Ordering::Relaxed);
+        if populate && images.len() > MAX_TAPPED_FRAMES {
+            return images.chunks(MAX_TAPPED_FRAMES).flat_map(|c| self.detect_batch(c)).collect();
+        }
+        let slot = slot_for(self);
+        let mut ctx = slot.lock().unwrap();
+        let p = pack(images, &mut ctx.staging);
         ctx.check(unsafe { a3_set_debug_taps(ctx.raw, populate as c_int) }, "a3_set_debug_taps");
         let n = images.len();
         let mut markers = vec![A3Marker::default(); 64 * n];
@@ -459,7 +530,7 @@ impl Detector {
         let mut found = 0usize;
         loop {
             let rc = unsafe {
-                a3_detect_batch(ctx.raw, p.bytes.as_ptr() as *const c_void, A3_MEM_HOST, p.fmt, p.width, p.height,
+                a3_detect_batch(ctx.raw, p.bytes as *const c_void, A3_MEM_HOST, p.fmt, p.width, p.height,
                                 p.width as usize * p.bpp, p.width as usize * p.height as usize * p.bpp, n as u32,
                                 markers.as_mut_ptr(), markers.len(), per.as_mut_ptr(), &mut found)
             };
@@ -492,23 +563,34 @@ impl Detector {
         if images.is_empty() {
             return Vec::new();
         }
-        let p = pack(images);
         let slot = slot_for(self);
-        let ctx = slot.lock().unwrap();
+        let mut ctx = slot.lock().unwrap();
+        let p = pack(images, &mut ctx.staging);
         ctx.check(unsafe { a3_set_debug_taps(ctx.raw, 0) }, "a3_set_debug_taps");
         let n = images.len();
-        let cap = 64 * n;
+        let mut cap = 64 * n;
         let mut markers = vec![A3Marker::default(); cap];
         let mut poses = vec![A3Pose::default(); 2 * cap];
         let mut per = vec![0u32; n];
         let mut found = 0usize;
         let intr = intrinsics.map(to_a3_intrinsics);
         let intr_ptr = intr.as_ref().map_or(std::ptr::null(), |i| i as *const A3Intrinsics);
-        ctx.check(unsafe {
-            a3_detect_batch_pose(ctx.raw, p.bytes.as_ptr() as *const c_void, A3_MEM_HOST, p.fmt, p.width, p.height,
-                                 p.width as usize * p.bpp, p.width as usize * p.height as usize * p.bpp, n as u32, marker_size_mm,
-                                 intr_ptr, markers.as_mut_ptr(), poses.as_mut_ptr(), cap, per.as_mut_ptr(), &mut found)
-        }, "a3_detect_batch_pose");
+        loop {
+            let rc = unsafe {
+                a3_detect_batch_pose(ctx.raw, p.bytes as *const c_void, A3_MEM_HOST, p.fmt, p.width, p.height,
+                                     p.width as usize * p.bpp, p.width as usize * p.height as usize * p.bpp, n as u32, marker_size_mm,
+                                     intr_ptr, markers.as_mut_ptr(), poses.as_mut_ptr(), cap, per.as_mut_ptr(), &mut found)
+            };
+            // the reference has no marker limit: lists that do not fit are grown and the batch re-run (as in detect_batch)
+            if rc == A3_ERR_CAPACITY && cap < 1024 * n {
+                cap *= 4;
+                markers.resize(cap, A3Marker::default());
+                poses.resize(2 * cap, A3Pose::default());
+                continue;
+            }
+            ctx.check(rc, "a3_detect_batch_pose");
+            break;
+        }
         let mut out = Vec::with_capacity(n);
         let mut pos = 0usize;
         for f in 0..n {
@@ -553,7 +635,7 @@ fn pose_slot() -> &'static Mutex<HipCtx> {
         if rc != A3_OK {
             panic!("aruco3_hip: a3_create (pose context) failed ({}): {}", rc, last_error(std::ptr::null()));
         }
-        Mutex::new(HipCtx { raw })
+        Mutex::new(HipCtx { raw, staging: PinnedBytes::empty() })
     })
 }
 

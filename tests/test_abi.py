@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), n
     assert sorted(_lib.SYMBOLS) == names
-    assert L.a3_abi_version() == 2
+    assert L.a3_abi_version() == 3
     # tuning probes and single-stage hooks live in an internal header, out of the binding surface
     internal = _declared(ROOT / "aruco3_amd" / "csrc" / "a3_internal.h")
     assert sorted(_lib.INTERNAL_SYMBOLS) == internal and not set(internal) & set(names)
@@ -62,3 +62,25 @@ def test_no_device_fails_loudly():
 
     with pytest.raises(_lib.A3Error):
         ARDictionary.new_from_named_dict("ARUCO").find_nearest(0x1084210)
+
+
+def test_product_library_reads_no_environment():
+    """Tuning knobs are compile-time (-DA3_TUNING, `make tuning` into build/tuning/): the product library must not import
+    getenv, and the only getenv in the sources sits inside the A3_TUNING block of a3_common.h."""
+    import subprocess
+
+    from aruco3_amd import _lib
+
+    csrc = ROOT / "aruco3_amd" / "csrc"
+    hits = []
+    for f in sorted(csrc.glob("*.hip")) + sorted(csrc.glob("*.h")):
+        for i, line in enumerate(f.read_text().splitlines(), 1):
+            if "getenv" in line:
+                hits.append((f.name, i))
+    assert [h[0] for h in hits] == ["a3_common.h"], hits
+    text = (csrc / "a3_common.h").read_text()
+    block = text[text.index("#ifdef A3_TUNING\ninline int tuning_knob"): text.index("#else\nconstexpr int tuning_knob")]
+    assert "getenv" in block
+    assert _lib.LIB_PATH == ROOT / "aruco3_amd" / "libaruco3_hip.so"        # (A3_HIP_LIB is for the sweep scripts only)
+    syms = subprocess.run(["nm", "-D", "--undefined-only", str(_lib.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in syms
