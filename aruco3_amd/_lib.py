@@ -32,7 +32,7 @@ SYMBOLS = [
     "a3_contour_count", "a3_download_contours", "a3_detection_record_bytes", "a3_pack_detections",
 ]
 # aruco3_amd/csrc/a3_internal.h: probes and single-stage hooks for this repository's tests and tools, not for bindings
-INTERNAL_SYMBOLS = ["a3_debug_kernel_time", "a3_selftest_ieee", "a3_debug_clockwise", "a3_debug_rotate_bits", "a3_debug_discard_too_near"]
+INTERNAL_SYMBOLS = ["a3_debug_set_overlap", "a3_debug_kernel_time", "a3_selftest_ieee", "a3_debug_clockwise", "a3_debug_rotate_bits", "a3_debug_discard_too_near"]
 
 
 class A3Error(RuntimeError):
@@ -152,6 +152,8 @@ def load():
     L.a3_synth_render.restype = C.c_int
     L.a3_synth_render.argtypes = [C.c_int, vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_float, C.c_float, C.c_int,
                                   vp, C.c_size_t, C.c_size_t]
+    L.a3_debug_set_overlap.restype = C.c_int
+    L.a3_debug_set_overlap.argtypes = [C.c_int]
     L.a3_debug_kernel_time.restype = C.c_int
     L.a3_debug_kernel_time.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.a3_get_stats.restype = C.c_int

@@ -7,6 +7,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -29,13 +30,13 @@ size_t entry_slots(uint32_t);
 size_t leader_list_bytes(uint32_t);
 hipError_t launch_rank_cycles(hipStream_t, uint32_t, int, const uint64_t*, const uint32_t*, JumpState*,
                               uint32_t*, uint32_t*, unsigned int*, void*, void*, JumpState*, uint32_t*, unsigned int*, int, DeviceCounters*, const uint32_t*, int,
-                              const uint32_t*, uint32_t*, uint32_t);
+                              const uint32_t*, uint32_t*, uint32_t, const SelectArgs&, int);
 hipError_t launch_resolve(hipStream_t, const JumpState*, uint32_t, int, const uint64_t*, const uint32_t*, const unsigned int*, uint64_t*, uint64_t*,
                           DeviceCounters*, int, const uint32_t*);
 hipError_t launch_select_scatter(hipStream_t, const JumpState*, uint32_t, const uint32_t*, const unsigned int*, const uint32_t*, const uint64_t*,
                                  const uint32_t*, uint32_t, uint32_t,
                                  uint32_t, double, double, uint32_t*, ContourRec*, uint32_t*, uint32_t, uint64_t, DeviceCounters*,
-                                 const uint64_t*, uint32_t*, const uint32_t*, int, uint32_t*, int);
+                                 const uint64_t*, uint32_t*, const uint32_t*, int, uint32_t*, int, int);
 hipError_t launch_debug_clockwise(hipStream_t, const int32_t*, uint32_t, int32_t*);
 hipError_t launch_unpack_bits(hipStream_t, const uint64_t*, int, int, uint8_t*);
 hipError_t launch_contour_quads(hipStream_t, const ContourRec*, const DeviceCounters*, uint32_t, const uint32_t*, double, uint32_t, uint32_t,
@@ -102,6 +103,19 @@ struct DevBuf {
 };
 
 struct Chunk { uint32_t first, count; uint64_t darts; uint32_t max_frame_darts; };
+// The second half of a batch (candidates -> markers -> read-back), kept aside when its enqueue is deferred: everything
+// enqueue_back needs besides the context's buffers.
+struct BackArgs {
+    uint32_t n = 0, W = 0, H = 0, S = 0, max_cand = 0, patch_cap = 0, marker_cap = 0, guess = 0;
+    float min_corner_separation = 0.0f;
+    PixelSrc src{};
+    size_t head_bytes = 0, pose_bytes = 0;
+    bool taps = false, want_pose = false, pose_has_intr = false;
+    float pose_size_mm = 0.0f;
+    a3_intrinsics pose_intr{};
+    int profiling = 0;
+};
+
 // what finish_batch needs to know about the batch enqueue_batch put on the stream
 struct Pending {
     bool active = false, device_plan = false;
@@ -124,6 +138,14 @@ struct a3_ctx {
     // contexts in flight (submit / collect) the H2D of batch i+1 runs under the kernels of batch i
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_in = nullptr;
+    // Deferred decode (submit / collect with more than one context, see enqueue_batch): the decode stage of a submitted batch
+    // runs on a stream of its own, released behind the threshold kernel of the NEXT submitted batch, so that it shares the GPU
+    // with that batch's contour stage (both are latency-bound and leave the chip mostly idle) instead of standing in line.
+    hipStream_t decode_stream = nullptr;
+    hipEvent_t ev_contours = nullptr, ev_k1 = nullptr;
+    bool back_deferred = false;      // guarded by g_defer_mu
+    bool allow_defer = false;        // set by the submit entry points for the batch being enqueued
+    BackArgs back;
     a3_config cfg{};
     uint8_t num_bits = 0, tau = 0;
     uint32_t n_codes = 0, mark_size = 0;
@@ -275,6 +297,64 @@ int ensure_dart_pool(a3_ctx* ctx, uint64_t darts) {
     return A3_OK;
 }
 
+// ---- deferred decode: contexts whose submitted batch has its contour stage enqueued and its decode stage not yet ----
+std::mutex g_defer_mu;
+std::vector<a3_ctx*> g_deferred;
+// 0: no deferral; 1: release a waiting decode stage behind the next batch's threshold kernel; 2 (default): behind the next batch's
+// k_local_contract -- the kernels that follow it (entry resolution, finalize, scatter, quads) are latency-bound like the decode
+// stage and share the chip with it, whereas the dart kernels before it are bound by VALU and LDS throughput and only get slower
+// in company.  Measured in one process (tools/ab_overlap.py, BASELINE config 2, two contexts): 0.820 / 0.769 / 0.762 ms per step
+// for modes 0 / 1 / 2.  Deferring the second half of the contour stage as well (entry resolution ... quads, released with the
+// decode stage behind the next threshold kernel) was built and measured: 0.777 with two contexts, 0.821 with three -- dropped.
+// (a3_debug_set_overlap in a3_internal.h switches modes for the A/B measurements of tools/.)
+int g_overlap_mode = 2;
+
+// candidates -> markers -> read-back of one batch, on stream `st` (the context's stream, or its decode stream when deferred)
+int enqueue_back(a3_ctx* ctx, hipStream_t st, const BackArgs& b) {
+    unsigned int* d_work_count = ctx->scratch_u32 + 0;
+    unsigned int* d_marker_total = ctx->scratch_u32 + 1;
+    unsigned int* d_err = ctx->scratch_u32 + 4;
+    A3_HIP(launch_frame_candidates(st, ctx->cands.as<CandRec>(), ctx->cand_count, b.n, b.max_cand, b.min_corner_separation,
+                                   ctx->pre_xy.as<uint16_t>(), ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(),
+                                   ctx->work.as<uint32_t>(), d_work_count, b.S, ctx->proj.p));
+    A3_HIP(launch_decode(st, b.src, (int)b.W, (int)b.H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), d_work_count,
+                         b.max_cand, b.S, ctx->mark_size, b.S, ctx->dict.as<uint64_t>(), ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors,
+                         ctx->proj.p, ctx->wtab.as<float>(), ctx->outs.p, b.taps ? ctx->patches.as<uint8_t>() : nullptr, b.patch_cap, ctx->per_frame, 4096, 0,
+                         b.n <= 64u ? 1 : 0));
+    A3_HIP(launch_compact_markers(st, ctx->outs.p, ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(), b.n, 0, b.max_cand,
+                                  ctx->markers_ptr, b.marker_cap, ctx->per_frame, d_marker_total, d_err, ctx->cand_count, ctx->scratch_u32 + 2));
+    if (b.want_pose) {   // IPPE on the device-resident marker list (src/pose.rs:52-81), no extra round trip
+        const a3_intrinsics& in = b.pose_intr;
+        A3_HIP(launch_pose(st, reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(ctx->markers_ptr) + offsetof(a3_marker, corners)),
+                           (uint32_t)(sizeof(a3_marker) / 4), nullptr, b.marker_cap, d_marker_total, b.pose_has_intr ? 1 : 0, b.pose_size_mm,
+                           (float)b.W, (float)b.H, in.focal_x, in.focal_y, in.principal_x, in.principal_y, ctx->pose_buf.as<a3_pose>()));
+    }
+    if (b.profiling >= 2) A3_HIP(hipEventRecord(ctx->ev[3], st));
+    // ---- results: one copy of [scratch | counters | per-frame counts | `guess` markers], then the poses and (taps) the counts ----
+    uint8_t* hp = (uint8_t*)ctx->pinned;
+    a3_pose* h_poses = reinterpret_cast<a3_pose*>(hp + b.head_bytes + (size_t)b.guess * sizeof(a3_marker));
+    A3_HIP(hipMemcpyAsync(hp, ctx->scratch_u32, b.head_bytes + (size_t)b.guess * sizeof(a3_marker), hipMemcpyDeviceToHost, st));
+    if (b.pose_bytes) A3_HIP(hipMemcpyAsync(h_poses, ctx->pose_buf.p, (size_t)b.guess * b.pose_bytes, hipMemcpyDeviceToHost, st));
+    if (b.taps) {   // Detection.candidates / .homographies will be asked for frame by frame: their counts travel now
+        A3_HIP(hipMemcpyAsync(ctx->pinned_counts, ctx->cand_count, (size_t)b.n * 4, hipMemcpyDeviceToHost, st));
+        A3_HIP(hipMemcpyAsync((uint8_t*)ctx->pinned_counts + (size_t)b.n * 4, ctx->fin_count.p, (size_t)b.n * 4, hipMemcpyDeviceToHost, st));
+    }
+    A3_HIP(hipEventRecord(ctx->ev[4], st));
+    return A3_OK;
+}
+
+// Enqueue the deferred second half of `ctx`'s batch on its decode stream: after its own contour stage and, when `after` is
+// given, after that event (the threshold kernel of the batch another context has just submitted).  g_defer_mu is held.
+int flush_deferred_locked(a3_ctx* ctx, hipEvent_t after) {
+    if (!ctx->back_deferred) return A3_OK;
+    ctx->back_deferred = false;
+    for (size_t i = 0; i < g_deferred.size(); i++)
+        if (g_deferred[i] == ctx) { g_deferred.erase(g_deferred.begin() + (long)i); break; }
+    A3_HIP(hipStreamWaitEvent(ctx->decode_stream, ctx->ev_contours, 0));
+    if (after) A3_HIP(hipStreamWaitEvent(ctx->decode_stream, after, 0));
+    return enqueue_back(ctx, ctx->decode_stream, ctx->back);
+}
+
 // the whole pipeline for one batch; `pixels` is a device pointer here
 // One batch = enqueue_batch (every launch and the read-back copies, then an event) + finish_batch (wait for the event, check
 // the device's verdict, hand out the markers).  a3_detect_batch runs them back to back; a3_detect_batch_submit / _collect
@@ -316,6 +396,24 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     A3_HIP(launch_grey_threshold(st, pixels, fmt, row_stride, frame_stride, (int)W, (int)H, n, ctx->cfg.threshold_window,
                                  need_grey ? ctx->grey.as<uint8_t>() : nullptr, ctx->bin.as<uint64_t>()));
     if (ctx->profiling) A3_HIP(hipEventRecord(ctx->ev[1], st));
+    // batches of OTHER contexts (same device) that wait with their decode stage are released from inside this batch's launch
+    // sequence (see g_overlap_mode): `release_point(true)` records the event they wait for and enqueues them
+    bool released = false;
+    auto release_waiting = [&]() -> int {
+        if (released) return A3_OK;
+        std::lock_guard<std::mutex> lk(g_defer_mu);
+        bool any = false;
+        for (a3_ctx* o : g_deferred) any |= (o != ctx && o->device == ctx->device);
+        if (!any) return A3_OK;
+        released = true;
+        A3_HIP(hipEventRecord(ctx->ev_k1, st));
+        const std::vector<a3_ctx*> list = g_deferred;   // (flush edits g_deferred)
+        for (a3_ctx* o : list)
+            if (o != ctx && o->device == ctx->device)
+                if (int rc = flush_deferred_locked(o, ctx->ev_k1)) { ctx->err = "deferred decode of another context: " + o->err; return rc; }
+        return A3_OK;
+    };
+    if (g_overlap_mode == 1) { if (int rc = release_waiting()) return rc; }
 
     // ---- contour graph size per frame -> chunk plan ----
     // A batch shaped like the previous one is planned on the device: no read-back, no idle GPU while the host thinks.
@@ -401,9 +499,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     A3_HIP(ctx->cyc_start_off.ensure((size_t)ctx->max_contours * 4));
     A3_HIP(ctx->points.ensure(ctx->max_points * 4));
 
-    unsigned int* d_work_count = ctx->scratch_u32 + 0;
-    unsigned int* d_marker_total = ctx->scratch_u32 + 1;
-    unsigned int* d_err = ctx->scratch_u32 + 4;
+    unsigned int* d_err = ctx->scratch_u32 + 4;             // ([0] work count, [1] marker total: enqueue_back)
     unsigned int* d_entry_count = ctx->scratch_u32 + 32;    // [32..47]
     unsigned int* d_leader_count = ctx->scratch_u32 + 16;   // [16..31]
 
@@ -450,71 +546,86 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
         rounds += 1;  // the round that observes "nothing moved"
         rounds = std::min(rounds, ctx->jump_rounds_hint);
         rounds_max = std::max(rounds_max, rounds);
-        A3_HIP(launch_rank_cycles(st, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(),
-                                  ctx->stA.as<JumpState>(),
+        // The usual case -- no start-resolution passes in the launch sequence -- selects the borders inside k_jump_finalize; with
+        // the passes (a recent batch had a component whose first pixel lies in column 0) the per-leader kernels do it after them.
+        const bool fused_select = ctx->resolve_full_ttl <= 0;
+        SelectArgs sel{};
+        sel.enabled = fused_select ? 1 : 0;
+        sel.d_succ = ctx->d_succ.as<uint32_t>(); sel.d_rec = ctx->d_xy.as<uint64_t>();
+        sel.first_frame = c.first; sel.min_edge_length = min_edge_length;
+        sel.eps_factor = ctx->cfg.contour_simplification_epsilon; sel.image_diag = image_diag;
+        sel.cyc_slot = ctx->cyc_slot.as<uint32_t>(); sel.contours = ctx->contours.as<ContourRec>();
+        sel.max_contours = ctx->max_contours; sel.max_points = ctx->max_points; sel.keep_all = ctx->debug_taps ? 1 : 0;
+        uint32_t* const frame_entries = ctx->entry_global_ttl > 0 ? nullptr : ctx->frame_cursor;   // per-frame entry counts
+        const int resolve_iters = ctx->resolve_full_ttl > 0 ? ctx->resolve_iters_hint : 0;
+        const int inline_resolve_W = ctx->resolve_full_ttl > 0 ? 0 : (int)W;
+        const int keep_all = ctx->debug_taps ? 1 : 0;
+        const Chunk cc = c;
+        // first half: the doubling rounds inside LDS tiles
+        A3_HIP(launch_rank_cycles(st, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), ctx->stA.as<JumpState>(),
                                   ctx->entry_list.as<uint32_t>(), ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
-                                  ctx->stA.as<JumpState>() /* final states in place */, ctx->leader_list.as<uint32_t>(), d_leader_count, rounds, ctr, n_live, 0, fb,
-                                  ctx->entry_global_ttl > 0 ? nullptr : ctx->frame_cursor /* per-frame entry counts */, c.count));
+                                  ctx->stA.as<JumpState>(), ctx->leader_list.as<uint32_t>(), d_leader_count, rounds, ctr, n_live, 0, fb,
+                                  frame_entries, cc.count, sel, 1));
+        if (g_overlap_mode == 2) { if (int rc = release_waiting()) return rc; }   // waiting decode stages go out behind this k_local_contract
         ctx->dbg_nd = nd; ctx->dbg_frames = c.count; ctx->dbg_chunks = (uint32_t)chunks.size();
-        const JumpState* fin = ctx->stA.as<JumpState>();
-        A3_HIP(launch_resolve(st, fin, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->leader_list.as<uint32_t>(), d_leader_count,
-                              ctx->t_cur.as<uint64_t>(), ctx->t_next.as<uint64_t>(), ctr, ctx->resolve_full_ttl > 0 ? ctx->resolve_iters_hint : 0, n_live));
-        A3_HIP(launch_select_scatter(st, fin, nd, ctx->leader_list.as<uint32_t>(), d_leader_count, ctx->d_succ.as<uint32_t>(), ctx->t_cur.as<uint64_t>(), fb, c.count, c.first, min_edge_length,
-                                     ctx->cfg.contour_simplification_epsilon, image_diag, ctx->cyc_slot.as<uint32_t>(),
-                                     ctx->contours.as<ContourRec>(),
-                                     ctx->cyc_start_off.as<uint32_t>(), ctx->max_contours, ctx->max_points, ctr, ctx->d_xy.as<uint64_t>(),
-                                     ctx->points.as<uint32_t>(), n_live, ctx->resolve_full_ttl > 0 ? 0 : (int)W, ctx->leader_keep.as<uint32_t>(),
-                                     ctx->debug_taps ? 1 : 0));
-        A3_HIP(launch_contour_quads(st, ctx->contours.as<ContourRec>(), ctr, ctx->max_contours, ctx->points.as<uint32_t>(),
-                                    ctx->cfg.contour_simplification_epsilon, min_edge_length, c.first, kMaxCand,
-                                    ctx->cands.as<CandRec>() + (size_t)c.first * kMaxCand, ctx->cand_count + c.first, d_err,
-                                    W <= 16384u && H <= 16384u ? 1 : 0));
+        // second half: entry resolution, final states (+ border selection), point scatter, quads -- on `s2`
+        auto chunk_back = [=](hipStream_t s2) -> int {
+            A3_HIP(launch_rank_cycles(s2, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), ctx->stA.as<JumpState>(),
+                                      ctx->entry_list.as<uint32_t>(), ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
+                                      ctx->stA.as<JumpState>() /* final states in place */, ctx->leader_list.as<uint32_t>(), d_leader_count, rounds, ctr,
+                                      n_live, 0, fb, frame_entries, cc.count, sel, 2));
+            const JumpState* fin = ctx->stA.as<JumpState>();
+            A3_HIP(launch_resolve(s2, fin, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->leader_list.as<uint32_t>(), d_leader_count,
+                                  ctx->t_cur.as<uint64_t>(), ctx->t_next.as<uint64_t>(), ctr, resolve_iters, n_live));
+            A3_HIP(launch_select_scatter(s2, fin, nd, ctx->leader_list.as<uint32_t>(), d_leader_count, ctx->d_succ.as<uint32_t>(), ctx->t_cur.as<uint64_t>(), fb,
+                                         cc.count, cc.first, min_edge_length, sel.eps_factor, image_diag, ctx->cyc_slot.as<uint32_t>(),
+                                         ctx->contours.as<ContourRec>(), ctx->cyc_start_off.as<uint32_t>(), sel.max_contours, sel.max_points, ctr,
+                                         ctx->d_xy.as<uint64_t>(), ctx->points.as<uint32_t>(), n_live, inline_resolve_W, ctx->leader_keep.as<uint32_t>(),
+                                         keep_all, fused_select ? 1 : 0));
+            A3_HIP(launch_contour_quads(s2, ctx->contours.as<ContourRec>(), ctr, sel.max_contours, ctx->points.as<uint32_t>(),
+                                        sel.eps_factor, min_edge_length, cc.first, kMaxCand,
+                                        ctx->cands.as<CandRec>() + (size_t)cc.first * kMaxCand, ctx->cand_count + cc.first, d_err,
+                                        W <= 16384u && H <= 16384u ? 1 : 0));
+            return A3_OK;
+        };
+        if (int rc = chunk_back(st)) return rc;
     }
+    if (g_overlap_mode != 0) { if (int rc = release_waiting()) return rc; }   // (a batch without a contour graph releases here)
     if (ctx->profiling >= 2) A3_HIP(hipEventRecord(ctx->ev[2], st));
 
-    // ---- candidates -> markers, all frames at once ----
-    A3_HIP(launch_frame_candidates(st, ctx->cands.as<CandRec>(), ctx->cand_count, n, kMaxCand, min_corner_separation,
-                                   ctx->pre_xy.as<uint16_t>(), ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(),
-                                   ctx->work.as<uint32_t>(), d_work_count, S, ctx->proj.p));
+    // ---- candidates -> markers -> read-back: enqueued now, or deferred behind the next submitted batch's threshold kernel ----
     const PixelSrc src = need_grey ? PixelSrc{ctx->grey.as<uint8_t>(), W, (unsigned long long)npx, kFmtGreyPlane}
                                    : PixelSrc{pixels, row_stride, frame_stride, fmt};
-    A3_HIP(launch_decode(st, src, (int)W, (int)H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), d_work_count,
-                         kMaxCand, S, ctx->mark_size, S, ctx->dict.as<uint64_t>(), ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors,
-                         ctx->proj.p, ctx->wtab.as<float>(), ctx->outs.p, ctx->debug_taps ? ctx->patches.as<uint8_t>() : nullptr, patch_cap, ctx->per_frame, 4096, 0, n <= 64u ? 1 : 0));
     ctx->dbg_src = src;
-    A3_HIP(launch_compact_markers(st, ctx->outs.p, ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(), n, 0, kMaxCand,
-                                  ctx->markers_ptr, marker_cap, ctx->per_frame, d_marker_total, d_err, ctx->cand_count, ctx->scratch_u32 + 2));
-    if (ctx->want_pose) {   // IPPE on the device-resident marker list (src/pose.rs:52-81), no extra round trip
-        A3_HIP(ctx->pose_buf.ensure((size_t)marker_cap * 2 * sizeof(a3_pose)));
-        const a3_intrinsics& in = ctx->pose_intr;
-        A3_HIP(launch_pose(st, reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(ctx->markers_ptr) + offsetof(a3_marker, corners)),
-                           (uint32_t)(sizeof(a3_marker) / 4), nullptr, marker_cap, d_marker_total, ctx->pose_has_intr ? 1 : 0, ctx->pose_size_mm,
-                           (float)W, (float)H, in.focal_x, in.focal_y, in.principal_x, in.principal_y, ctx->pose_buf.as<a3_pose>()));
-    }
-    if (ctx->profiling >= 2) A3_HIP(hipEventRecord(ctx->ev[3], st));
-
-    // ---- results: one copy of [scratch | counters | per-frame counts], one speculative copy of the marker list ----
     const size_t pose_bytes = ctx->want_pose ? 2 * sizeof(a3_pose) : 0;
     const uint32_t guess = (uint32_t)std::min<size_t>(marker_cap, (size_t)ctx->last_marker_total + ctx->last_marker_total / 4 + 64);
     const size_t head_pad = head_bytes;   // the markers follow the head directly, on the device and in the staging buffer
-    // pinned staging for the head and `guess` markers (+ poses); a longer list is fetched by finish_batch after growing it
+    // every allocation of the second half happens here, at submit time: pose buffer, pinned staging for the head and `guess`
+    // markers (+ poses; a longer list is fetched by finish_batch after growing it), pinned staging for the tap counts
+    if (ctx->want_pose) A3_HIP(ctx->pose_buf.ensure((size_t)marker_cap * 2 * sizeof(a3_pose)));
     if (int rc = ensure_pinned(ctx, head_pad + (size_t)guess * (sizeof(a3_marker) + 2 * sizeof(a3_pose)) + (1 << 16))) return rc;
-    uint8_t* hp = (uint8_t*)ctx->pinned;
-    a3_pose* h_poses = reinterpret_cast<a3_pose*>(hp + head_pad + (size_t)guess * sizeof(a3_marker));
-    A3_HIP(hipMemcpyAsync(hp, ctx->scratch_u32, head_bytes + (size_t)guess * sizeof(a3_marker), hipMemcpyDeviceToHost, st));
-    if (pose_bytes) A3_HIP(hipMemcpyAsync(h_poses, ctx->pose_buf.p, (size_t)guess * pose_bytes, hipMemcpyDeviceToHost, st));
     ctx->counts_valid = false;
-    if (ctx->debug_taps) {   // Detection.candidates / .homographies will be asked for frame by frame: their counts travel now
-        if (ctx->pinned_counts_cap < (size_t)n * 8) {
-            if (ctx->pinned_counts) (void)hipHostFree(ctx->pinned_counts);
-            ctx->pinned_counts = nullptr; ctx->pinned_counts_cap = 0;
-            A3_HIP(hipHostMalloc(&ctx->pinned_counts, (size_t)n * 8, hipHostMallocDefault));
-            ctx->pinned_counts_cap = (size_t)n * 8;
-        }
-        A3_HIP(hipMemcpyAsync(ctx->pinned_counts, ctx->cand_count, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-        A3_HIP(hipMemcpyAsync((uint8_t*)ctx->pinned_counts + (size_t)n * 4, ctx->fin_count.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    if (ctx->debug_taps && ctx->pinned_counts_cap < (size_t)n * 8) {
+        if (ctx->pinned_counts) (void)hipHostFree(ctx->pinned_counts);
+        ctx->pinned_counts = nullptr; ctx->pinned_counts_cap = 0;
+        A3_HIP(hipHostMalloc(&ctx->pinned_counts, (size_t)n * 8, hipHostMallocDefault));
+        ctx->pinned_counts_cap = (size_t)n * 8;
     }
-    A3_HIP(hipEventRecord(ctx->ev[4], st));
+    BackArgs& bk = ctx->back;
+    bk.n = n; bk.W = W; bk.H = H; bk.S = S; bk.max_cand = kMaxCand; bk.patch_cap = patch_cap; bk.marker_cap = marker_cap; bk.guess = guess;
+    bk.min_corner_separation = min_corner_separation; bk.src = src; bk.head_bytes = head_bytes; bk.pose_bytes = pose_bytes;
+    bk.taps = ctx->debug_taps; bk.want_pose = ctx->want_pose; bk.pose_has_intr = ctx->pose_has_intr; bk.pose_size_mm = ctx->pose_size_mm;
+    bk.pose_intr = ctx->pose_intr; bk.profiling = ctx->profiling;
+    // Deferral: only for submitted batches (somebody will submit again or collect), and not while every stage is being timed
+    // (the stage times are those of stages that run alone).  The decode stage then waits on the context's decode stream until
+    // (a) another context submits a batch -- it is released behind that batch's threshold kernel and shares the GPU with its
+    // contour stage -- or (b) this batch is collected first.
+    if (ctx->allow_defer && ctx->profiling < 2 && g_overlap_mode != 0) {
+        A3_HIP(hipEventRecord(ctx->ev_contours, st));
+        std::lock_guard<std::mutex> lk(g_defer_mu);
+        ctx->back_deferred = true;
+        g_deferred.push_back(ctx);
+    } else if (int rc = enqueue_back(ctx, st, bk)) return rc;
     Pending& pd = ctx->pending;
     pd.active = true; pd.n_chunks = chunks.size(); pd.chunk0_darts = chunks.empty() ? 0 : chunks[0].darts; pd.ctr_bytes = ctr_bytes;
     pd.head_pad = head_pad; pd.marker_cap = marker_cap; pd.guess = guess; pd.pose_bytes = pose_bytes; pd.device_plan = device_plan;
@@ -535,6 +646,10 @@ int finish_batch(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_fram
     a3_marker* h_markers = reinterpret_cast<a3_marker*>(hp + head_pad);
     a3_pose* h_poses = reinterpret_cast<a3_pose*>(hp + head_pad + (size_t)guess * sizeof(a3_marker));
     (void)marker_cap;
+    {   // nobody submitted behind this batch: its decode stage goes out now
+        std::lock_guard<std::mutex> lk(g_defer_mu);
+        if (int rc = flush_deferred_locked(ctx, nullptr)) return rc;
+    }
     A3_HIP(wait_event(ctx->ev[4], st));
     const unsigned int* hs = reinterpret_cast<const unsigned int*>(hp);
     const DeviceCounters* hc = reinterpret_cast<const DeviceCounters*>(hp + 256);
@@ -709,7 +824,10 @@ int a3_create(int device, const a3_config* cfg, const uint64_t* codes, size_t n_
     c->stream = c->own_stream;
     e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
-    if (e != hipSuccess) { a3_destroy(c); ctx = nullptr; return fail(ctx, A3_ERR_HIP, "copy stream", e); }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->decode_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_contours, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_k1, hipEventDisableTiming);
+    if (e != hipSuccess) { a3_destroy(c); ctx = nullptr; return fail(ctx, A3_ERR_HIP, "copy / decode streams", e); }
     for (auto& ev : c->ev) {
         e = hipEventCreate(&ev);
         if (e != hipSuccess) { a3_destroy(c); ctx = nullptr; return fail(ctx, A3_ERR_HIP, "hipEventCreate", e); }
@@ -735,6 +853,14 @@ int a3_create(int device, const a3_config* cfg, const uint64_t* codes, size_t n_
 void a3_destroy(a3_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    {   // a submitted batch that was never collected: its deferred half is dropped
+        std::lock_guard<std::mutex> lk(g_defer_mu);
+        for (size_t i = 0; i < g_deferred.size(); i++)
+            if (g_deferred[i] == ctx) { g_deferred.erase(g_deferred.begin() + (long)i); break; }
+        ctx->back_deferred = false;
+    }
+    if (ctx->stream && ctx->stream != ctx->own_stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->decode_stream) (void)hipStreamSynchronize(ctx->decode_stream);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     DevBuf* bufs[] = {&ctx->dict, &ctx->in, &ctx->grey, &ctx->bin, &ctx->frame_darts, &ctx->frame_darts_dev, &ctx->frame_base, &ctx->pix_base,
                       &ctx->tile_darts, &ctx->d_xy, &ctx->d_succ, &ctx->stA, &ctx->stB, &ctx->t_cur, &ctx->t_next, &ctx->cyc_slot,
@@ -747,6 +873,9 @@ void a3_destroy(a3_ctx* ctx) {
     if (ctx->pinned_counts) (void)hipHostFree(ctx->pinned_counts);
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
     if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
+    if (ctx->ev_contours) (void)hipEventDestroy(ctx->ev_contours);
+    if (ctx->ev_k1) (void)hipEventDestroy(ctx->ev_k1);
+    if (ctx->decode_stream) (void)hipStreamDestroy(ctx->decode_stream);
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -878,7 +1007,10 @@ static int submit_common(a3_ctx* ctx, const void* pixels, int memory, int fmt, u
     ctx->want_pose = want_pose;
     Pending& pd = ctx->pending;
     pd.pixels = d_pixels; pd.fmt = fmt; pd.row_stride = row_stride; pd.frame_stride = frame_stride; pd.want_pose = want_pose;
-    return enqueue_batch(ctx, d_pixels, fmt, width, height, row_stride, frame_stride, n_frames, out_cap);
+    ctx->allow_defer = true;    // (a synchronous call, or a re-run, enqueues both halves at once)
+    const int erc = enqueue_batch(ctx, d_pixels, fmt, width, height, row_stride, frame_stride, n_frames, out_cap);
+    ctx->allow_defer = false;
+    return erc;
 }
 
 static int collect_common(a3_ctx* ctx, a3_marker* out, a3_pose* poses, size_t out_cap, uint32_t* per_frame_count, size_t* out_n) {
@@ -983,7 +1115,7 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
             A3_HIP(launch_rank_cycles(st, ctx->dbg_nd, (int)ctx->W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), ctx->stA.as<JumpState>(),
                                       ctx->entry_list.as<uint32_t>(),
                                       ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p, ctx->stB.as<JumpState>(),
-                                      ctx->leader_list.as<uint32_t>(), d_leader_count, 0, ctx->counters, nullptr, dbg ? dbg : 11, ctx->frame_base.as<uint32_t>(), nullptr, ctx->dbg_frames));
+                                      ctx->leader_list.as<uint32_t>(), d_leader_count, 0, ctx->counters, nullptr, dbg ? dbg : 11, ctx->frame_base.as<uint32_t>(), nullptr, ctx->dbg_frames, SelectArgs{}, 0));
         } else if (kernel == 3) {   // dbg < 0: k_decode alone (variant -dbg), dbg >= 0: k_projection + k_decode
             A3_HIP(launch_decode(st, ctx->dbg_src, (int)ctx->W, (int)ctx->H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), ctx->scratch_u32,
                                  ctx->max_cand, ctx->cfg.homography_sample_size, ctx->mark_size, ctx->cfg.homography_sample_size, ctx->dict.as<uint64_t>(),
@@ -997,6 +1129,15 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
         total += ms;
     }
     *avg_ms = (float)(total / reps);
+    return A3_OK;
+}
+
+// internal (a3_internal.h): where a submitted batch's decode stage is released (0 not deferred, 1 behind the next batch's
+// threshold kernel, 2 behind its k_local_contract); process-wide, for A/B measurements
+int a3_debug_set_overlap(int mode) {
+    if (mode < 0 || mode > 2) return A3_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(g_defer_mu);
+    g_overlap_mode = mode;
     return A3_OK;
 }
 

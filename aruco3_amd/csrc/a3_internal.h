@@ -17,6 +17,12 @@ extern "C" {
  * The internal contour buffers hold garbage afterwards; results already returned are unaffected. */
 int  a3_debug_kernel_time(a3_ctx *ctx, int kernel, int dbg, int reps, float *avg_ms);
 
+/* Where the decode stage of a SUBMITTED batch is released when another context submits behind it (see a3_api.hip,
+ * "deferred decode"): 0 = never deferred (both halves of a batch enqueued at once, as a3_detect_batch always does), 1 = behind
+ * the next batch's threshold kernel, 2 = behind its k_local_contract (the default).  Process-wide; results are identical in
+ * every mode -- tools/ use it for A/B timing inside one process, since two boxes of the pool differ by more than the effect. */
+int  a3_debug_set_overlap(int mode);
+
 /* numerics self-check used by the GPU tests: evaluates the IEEE operations the kernels rely on (f64 sqrt/div, f32 sqrt/div)
  * for n inputs so that the host can compare them bit for bit */
 int  a3_selftest_ieee(a3_ctx *ctx, const double *a, const double *b, size_t n, double *sqrt_a, double *a_div_b,

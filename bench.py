@@ -233,6 +233,14 @@ def main():
     # The timed region: EXACTLY --steps steps between barrier + synchronize on both sides, max over ranks.  It is run
     # --repeats times back to back and the median region is the one reported (all are listed in ms_per_step_all).
     regions, k1_region_ms = [], []
+    # The one slow region that showed up at the same index in every run of rounds 1 and 2 (one region of ~60 ms among ~16 ms ones,
+    # with a normal threshold-kernel time inside it): a full collection of Python's cyclic garbage collector, triggered by
+    # allocation count -- host time, nothing of the detector's.  Collect once here and keep the collector out of the timed
+    # regions (the steps allocate nothing cyclic).
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
 
     def k1_totals():
         tot = cnt = 0
@@ -271,6 +279,7 @@ def main():
         t = torch.tensor(regions, dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         regions = [float(v) for v in t.tolist()]
+    gc.enable()
     elapsed = sorted(regions)[len(regions) // 2]
     # regions far off the median (a one-off stall somewhere): counted and located, with the threshold kernel's own average in
     # that region beside it -- a normal kernel time there says the stall was not on the GPU's side of K1
