@@ -152,8 +152,9 @@ def load():
     L.a3_synth_render.restype = C.c_int
     L.a3_synth_render.argtypes = [C.c_int, vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_float, C.c_float, C.c_int,
                                   vp, C.c_size_t, C.c_size_t]
-    L.a3_debug_set_overlap.restype = C.c_int
-    L.a3_debug_set_overlap.argtypes = [C.c_int]
+    if hasattr(L, "a3_debug_set_overlap"):      # (older builds loaded through A3_HIP_LIB for A/B runs lack it)
+        L.a3_debug_set_overlap.restype = C.c_int
+        L.a3_debug_set_overlap.argtypes = [C.c_int]
     L.a3_debug_kernel_time.restype = C.c_int
     L.a3_debug_kernel_time.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.a3_get_stats.restype = C.c_int

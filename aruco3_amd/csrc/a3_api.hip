@@ -30,13 +30,13 @@ size_t entry_slots(uint32_t);
 size_t leader_list_bytes(uint32_t);
 hipError_t launch_rank_cycles(hipStream_t, uint32_t, int, const uint64_t*, const uint32_t*, JumpState*,
                               uint32_t*, uint32_t*, unsigned int*, void*, void*, JumpState*, uint32_t*, unsigned int*, int, DeviceCounters*, const uint32_t*, int,
-                              const uint32_t*, uint32_t*, uint32_t, const SelectArgs&, int);
+                              const uint32_t*, uint32_t*, uint32_t, int);
 hipError_t launch_resolve(hipStream_t, const JumpState*, uint32_t, int, const uint64_t*, const uint32_t*, const unsigned int*, uint64_t*, uint64_t*,
                           DeviceCounters*, int, const uint32_t*);
 hipError_t launch_select_scatter(hipStream_t, const JumpState*, uint32_t, const uint32_t*, const unsigned int*, const uint32_t*, const uint64_t*,
                                  const uint32_t*, uint32_t, uint32_t,
                                  uint32_t, double, double, uint32_t*, ContourRec*, uint32_t*, uint32_t, uint64_t, DeviceCounters*,
-                                 const uint64_t*, uint32_t*, const uint32_t*, int, uint32_t*, int, int);
+                                 const uint64_t*, uint32_t*, const uint32_t*, int, uint32_t*, int);
 hipError_t launch_debug_clockwise(hipStream_t, const int32_t*, uint32_t, int32_t*);
 hipError_t launch_unpack_bits(hipStream_t, const uint64_t*, int, int, uint8_t*);
 hipError_t launch_contour_quads(hipStream_t, const ContourRec*, const DeviceCounters*, uint32_t, const uint32_t*, double, uint32_t, uint32_t,
@@ -546,17 +546,10 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
         rounds += 1;  // the round that observes "nothing moved"
         rounds = std::min(rounds, ctx->jump_rounds_hint);
         rounds_max = std::max(rounds_max, rounds);
-        // The usual case -- no start-resolution passes in the launch sequence -- selects the borders inside k_jump_finalize; with
-        // the passes (a recent batch had a component whose first pixel lies in column 0) the per-leader kernels do it after them.
-        const bool fused_select = ctx->resolve_full_ttl <= 0;
-        SelectArgs sel{};
-        sel.enabled = fused_select ? 1 : 0;
-        sel.d_succ = ctx->d_succ.as<uint32_t>(); sel.d_rec = ctx->d_xy.as<uint64_t>();
-        sel.first_frame = c.first; sel.min_edge_length = min_edge_length;
-        sel.eps_factor = ctx->cfg.contour_simplification_epsilon; sel.image_diag = image_diag;
-        sel.cyc_slot = ctx->cyc_slot.as<uint32_t>(); sel.contours = ctx->contours.as<ContourRec>();
-        sel.max_contours = ctx->max_contours; sel.max_points = ctx->max_points; sel.keep_all = ctx->debug_taps ? 1 : 0;
         uint32_t* const frame_entries = ctx->entry_global_ttl > 0 ? nullptr : ctx->frame_cursor;   // per-frame entry counts
+        const double eps_factor = ctx->cfg.contour_simplification_epsilon;
+        const uint32_t max_contours = ctx->max_contours;
+        const uint64_t max_points = ctx->max_points;
         const int resolve_iters = ctx->resolve_full_ttl > 0 ? ctx->resolve_iters_hint : 0;
         const int inline_resolve_W = ctx->resolve_full_ttl > 0 ? 0 : (int)W;
         const int keep_all = ctx->debug_taps ? 1 : 0;
@@ -565,7 +558,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
         A3_HIP(launch_rank_cycles(st, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), ctx->stA.as<JumpState>(),
                                   ctx->entry_list.as<uint32_t>(), ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
                                   ctx->stA.as<JumpState>(), ctx->leader_list.as<uint32_t>(), d_leader_count, rounds, ctr, n_live, 0, fb,
-                                  frame_entries, cc.count, sel, 1));
+                                  frame_entries, cc.count, 1));
         if (g_overlap_mode == 2) { if (int rc = release_waiting()) return rc; }   // waiting decode stages go out behind this k_local_contract
         ctx->dbg_nd = nd; ctx->dbg_frames = c.count; ctx->dbg_chunks = (uint32_t)chunks.size();
         // second half: entry resolution, final states (+ border selection), point scatter, quads -- on `s2`
@@ -573,17 +566,17 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
             A3_HIP(launch_rank_cycles(s2, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), ctx->stA.as<JumpState>(),
                                       ctx->entry_list.as<uint32_t>(), ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
                                       ctx->stA.as<JumpState>() /* final states in place */, ctx->leader_list.as<uint32_t>(), d_leader_count, rounds, ctr,
-                                      n_live, 0, fb, frame_entries, cc.count, sel, 2));
+                                      n_live, 0, fb, frame_entries, cc.count, 2));
             const JumpState* fin = ctx->stA.as<JumpState>();
             A3_HIP(launch_resolve(s2, fin, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->leader_list.as<uint32_t>(), d_leader_count,
                                   ctx->t_cur.as<uint64_t>(), ctx->t_next.as<uint64_t>(), ctr, resolve_iters, n_live));
             A3_HIP(launch_select_scatter(s2, fin, nd, ctx->leader_list.as<uint32_t>(), d_leader_count, ctx->d_succ.as<uint32_t>(), ctx->t_cur.as<uint64_t>(), fb,
-                                         cc.count, cc.first, min_edge_length, sel.eps_factor, image_diag, ctx->cyc_slot.as<uint32_t>(),
-                                         ctx->contours.as<ContourRec>(), ctx->cyc_start_off.as<uint32_t>(), sel.max_contours, sel.max_points, ctr,
+                                         cc.count, cc.first, min_edge_length, eps_factor, image_diag, ctx->cyc_slot.as<uint32_t>(),
+                                         ctx->contours.as<ContourRec>(), ctx->cyc_start_off.as<uint32_t>(), max_contours, max_points, ctr,
                                          ctx->d_xy.as<uint64_t>(), ctx->points.as<uint32_t>(), n_live, inline_resolve_W, ctx->leader_keep.as<uint32_t>(),
-                                         keep_all, fused_select ? 1 : 0));
-            A3_HIP(launch_contour_quads(s2, ctx->contours.as<ContourRec>(), ctr, sel.max_contours, ctx->points.as<uint32_t>(),
-                                        sel.eps_factor, min_edge_length, cc.first, kMaxCand,
+                                         keep_all));
+            A3_HIP(launch_contour_quads(s2, ctx->contours.as<ContourRec>(), ctr, max_contours, ctx->points.as<uint32_t>(),
+                                        eps_factor, min_edge_length, cc.first, kMaxCand,
                                         ctx->cands.as<CandRec>() + (size_t)cc.first * kMaxCand, ctx->cand_count + cc.first, d_err,
                                         W <= 16384u && H <= 16384u ? 1 : 0));
             return A3_OK;
@@ -1115,7 +1108,7 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
             A3_HIP(launch_rank_cycles(st, ctx->dbg_nd, (int)ctx->W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), ctx->stA.as<JumpState>(),
                                       ctx->entry_list.as<uint32_t>(),
                                       ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p, ctx->stB.as<JumpState>(),
-                                      ctx->leader_list.as<uint32_t>(), d_leader_count, 0, ctx->counters, nullptr, dbg ? dbg : 11, ctx->frame_base.as<uint32_t>(), nullptr, ctx->dbg_frames, SelectArgs{}, 0));
+                                      ctx->leader_list.as<uint32_t>(), d_leader_count, 0, ctx->counters, nullptr, dbg ? dbg : 11, ctx->frame_base.as<uint32_t>(), nullptr, ctx->dbg_frames, 0));
         } else if (kernel == 3) {   // dbg < 0: k_decode alone (variant -dbg), dbg >= 0: k_projection + k_decode
             A3_HIP(launch_decode(st, ctx->dbg_src, (int)ctx->W, (int)ctx->H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), ctx->scratch_u32,
                                  ctx->max_cand, ctx->cfg.homography_sample_size, ctx->mark_size, ctx->cfg.homography_sample_size, ctx->dict.as<uint64_t>(),

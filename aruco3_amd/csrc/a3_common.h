@@ -89,23 +89,6 @@ struct ContourRec {
     uint32_t n;           // number of points
 };
 
-// What k_jump_finalize needs to SELECT borders on the spot (the usual case: every border starts at its smallest event, no
-// start-resolution passes in the launch sequence): the leader of a cycle with a start event works out the cycle's length,
-// decides whether the border is worth materialising and, after one block-wide allocation, writes the border's record -- the
-// separate per-leader kernel (k_cycle_select: leader list, another launch) is then not needed.
-struct SelectArgs {
-    int enabled;                    // 0: collect the leader list instead (start-resolution passes follow; k_cycle_select selects)
-    const uint32_t* d_succ;
-    const uint64_t* d_rec;
-    uint32_t first_frame, min_edge_length;
-    double eps_factor, image_diag;
-    uint32_t* cyc_slot;             // per leader dart: slot of its border in `contours`, kNone if it is not materialised
-    ContourRec* contours;
-    uint32_t max_contours;
-    uint64_t max_points;
-    int keep_all;                   // debug taps: materialise every traced border
-};
-
 // a quad candidate (contours_to_candidates + enforce_clockwise, src/aruco.rs:124-185)
 struct CandRec {
     uint32_t start_key;

@@ -935,37 +935,23 @@ constexpr uint32_t kLeaderShards = 16;
 // darts handled by the blocks of one shard: n/16 plus at most one 256-dart slice per block of the shard and iteration
 __host__ __device__ inline uint32_t leader_shard_cap(uint32_t n_darts) { return n_darts / kLeaderShards + n_darts / 64u + 262144u; }
 
-// Parity-safe pruning (src/aruco.rs:133-158), shared by both selection paths:
-//  (1) a candidate keeps 4 points whose hull-adjacent pairs are >= sqrt(min_edge_length) apart; two border points i < j are at
-//      most min(j-i, n-(j-i)) 8-connected steps apart, i.e. dist^2 <= 2*(n/2)^2, so n^2 >= 2*min_edge_length is necessary;
-//  (2) Douglas-Peucker splits only when a point is further than eps = eps_factor*n from a chord, and no two pixels are further
-//      apart than the image diagonal (+1 slack for rounding).
-__device__ __forceinline__ bool border_worth_keeping(uint32_t n, uint32_t min_edge_length, double eps_factor, double image_diag, int keep_all) {
-    const double eps = (double)n * eps_factor;
-    return keep_all || (n >= 5u && (uint64_t)n * n >= 2ull * min_edge_length && eps < image_diag + 1.0);
-}
-
-// ... and either (sel.enabled) the borders are selected on the spot, or the leaders of cycles that carry at least one start
-// event are collected (one atomic per workgroup) for the per-border kernels that follow.
+// ... and the leaders of cycles that carry at least one start event are collected (one atomic per wave) for the
+// per-border kernels that follow.
 __global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const JumpState* loc,
                                                        const uint32_t* __restrict__ entry_pos, const EntryState* __restrict__ es,
                                                        JumpState* fin /* may be loc: only the states that change are then written */,
                                                        uint32_t* __restrict__ leader_list,
                                                        unsigned int* __restrict__ leader_count /*[kLeaderShards]*/, uint32_t shard_cap,
-                                                       const uint32_t* __restrict__ n_live, DeviceCounters* __restrict__ ctr, const SelectArgs sel) {
+                                                       const uint32_t* __restrict__ n_live, const DeviceCounters* __restrict__ ctr) {
     // a frame's entries did not fit k_entry_frame's LDS: their states were never written and the batch is re-run; with no
     // leaders listed and no points scattered everything downstream is a no-op
     if (ctr->entry_overflow) return;
     if (n_live) n_darts = min(n_darts, *n_live);
-    __shared__ uint32_t s_wave[4], s_wave_t[4];
-    __shared__ unsigned long long s_wave_p[4];
+    __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_base;
-    __shared__ unsigned long long s_pbase;
     const uint32_t shard = blockIdx.x & (kLeaderShards - 1);   // spread the slot counter over 16 addresses
     const uint32_t stride = gridDim.x * blockDim.x;            // the launcher keeps ceil(n_darts / stride) <= 32
-    uint32_t mask = 0;    // bit i: my i-th dart leads a cycle that has a start event
-    uint32_t my_keep = 0, my_traced = 0;
-    unsigned long long my_points = 0;
+    uint32_t mask = 0;                                          // bit i: my i-th dart leads a cycle that has a start event
     // B darts per lane at a time, each of the three dependent loads (local state -> slot of the entry the window froze at ->
     // that entry's state) issued for all of them before the first is used: the kernel is a chain of round trips to memory, and
     // one dart at a time it is three of them per dart.  Loads are unconditional from clamped indices (slot 0 for windows that
@@ -991,106 +977,19 @@ __global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const J
             const bool better = (od[u] & kFrozen) && g[u].key < s[u].key;
             if (better) { s[u].key = g[u].key; s[u].off = (loc_dist(od[u]) + g[u].off) | kFinal; }
             if (better || fin != loc) fin[d] = s[u];
-            if ((uint32_t)s[u].key == d && (uint32_t)(s[u].key >> 32) != kNoKey) mask |= 1u << (it + u);   // a leader with a start event
+            if ((uint32_t)s[u].key == d && (uint32_t)(s[u].key >> 32) != kNoKey) mask |= 1u << (it + u);
         }
     }
-    if (!sel.enabled) {
-        // one global atomic per workgroup: leaders are counted in a block scan first
-        uint32_t total;
-        const uint32_t excl = block_excl_scan_256((uint32_t)__popc(mask), s_wave, &total);
-        if (threadIdx.x == 0) s_base = total ? atomicAdd(&leader_count[shard], total) : 0u;
-        __syncthreads();
-        uint32_t slot = s_base + excl;
-        while (mask) {
-            const int i = __ffs(mask) - 1;
-            mask &= mask - 1;
-            leader_list[(size_t)shard * shard_cap + slot++] = blockIdx.x * blockDim.x + threadIdx.x + (uint32_t)i * stride;
-        }
-        return;
-    }
-    // Select mode.  A border's length is known to the dart right behind its leader (hop distance to the leader + 1), whose
-    // final state may not have been written yet -- another thread of this launch owns it.  The leader's thread therefore works
-    // that one state out again from the same read-only inputs: the local state (or, if the owner was faster, the final one:
-    // kFinal marks it; states are single aligned 16-byte accesses), the entry it froze at, that entry's state.  Rare lanes: one
-    // dart in a few hundred leads a border on clean frames.
-    auto border_length = [&](uint32_t d, bool* broken) -> uint32_t {
-        const uint32_t sl = sel.d_succ[d];
-        JumpState t = loc[sl];
-        if (!(t.off & kFinal) && (t.off & kFrozen)) {
-            const EntryState g = es[entry_pos[t.ptr]];
-            if (g.key < t.key) { t.key = g.key; t.off = (loc_dist(t.off) + g.off) | kFinal; }
-        }
-        // the successor's window must have wrapped around to this leader, else this is a chain, not a cycle
-        if (sl == d || (uint32_t)t.key != d) { *broken = true; return 0u; }
-        return fin_off(t.off) + 1u;
-    };
-    bool broken = false;
-    for (uint32_t m = mask; m; m &= m - 1) {
-        const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x + (uint32_t)(__ffs(m) - 1) * stride;
-        bool bad = false;
-        const uint32_t n = border_length(d, &bad);
-        broken |= bad;
-        if (bad) continue;
-        const bool keep = border_worth_keeping(n, sel.min_edge_length, sel.eps_factor, sel.image_diag, sel.keep_all);
-        my_traced++; my_keep += keep; my_points += keep ? n : 0u;
-    }
-    if (broken) atomicOr(&ctr->err_flags, kErrBrokenEvent);
-    // Border slots and point ranges: exclusive scans of (kept borders, their points) over the workgroup, then ONE bump of each of
-    // the two global counters per workgroup (per-wave bumps of one address serialise at ~11 ns each: on noise frames, 140 k
-    // borders per frame, that was most of the old per-leader kernel's time).
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc_k = my_keep, inc_t = my_traced;
-    unsigned long long inc_p = my_points;
-#define A3_DPP_ADD64(V, CTRL, RM)                                                                                       \
-    {                                                                                                                    \
-        const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(V), CTRL, RM, 0xF, false);           \
-        const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)((V) >> 32), CTRL, RM, 0xF, false);    \
-        (V) += ((unsigned long long)hi_ << 32) | lo_;                                                                    \
-    }
-#define A3_DPP_ADD32(V, CTRL, RM) (V) += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(V), CTRL, RM, 0xF, false);
-#define A3_STEP(CTRL, RM) A3_DPP_ADD32(inc_k, CTRL, RM) A3_DPP_ADD32(inc_t, CTRL, RM) A3_DPP_ADD64(inc_p, CTRL, RM)
-    A3_STEP(0x111, 0xF) A3_STEP(0x112, 0xF) A3_STEP(0x114, 0xF) A3_STEP(0x118, 0xF) A3_STEP(0x142, 0xA) A3_STEP(0x143, 0xC)
-#undef A3_STEP
-#undef A3_DPP_ADD32
-#undef A3_DPP_ADD64
-    if (lane == 63) { s_wave[wave] = inc_k; s_wave_p[wave] = inc_p; s_wave_t[wave] = inc_t; }
+    // one global atomic per workgroup: leaders are counted in a block scan first
+    uint32_t total;
+    const uint32_t excl = block_excl_scan_256((uint32_t)__popc(mask), s_wave, &total);
+    if (threadIdx.x == 0) s_base = total ? atomicAdd(&leader_count[shard], total) : 0u;
     __syncthreads();
-    uint32_t base_k = 0, tot_k = 0;
-    unsigned long long base_p = 0, tot_p = 0;
-    for (int w = 0; w < 4; w++) {
-        if (w < wave) { base_k += s_wave[w]; base_p += s_wave_p[w]; }
-        tot_k += s_wave[w]; tot_p += s_wave_p[w];
-    }
-    if (threadIdx.x == 0) {
-        const uint32_t tot_t = s_wave_t[0] + s_wave_t[1] + s_wave_t[2] + s_wave_t[3];
-        if (tot_t) atomicAdd(&ctr->traced, tot_t);
-        s_base = tot_k ? atomicAdd(&ctr->contours, tot_k) : 0u;
-        s_pbase = tot_k ? atomicAdd(&ctr->points, tot_p) : 0ull;
-    }
-    __syncthreads();
-    uint32_t c = s_base + base_k + (inc_k - my_keep);
-    unsigned long long pb = s_pbase + base_p + (inc_p - my_points);
-    for (uint32_t m = mask; m; m &= m - 1) {
-        const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x + (uint32_t)(__ffs(m) - 1) * stride;
-        bool bad = false;
-        const uint32_t n = border_length(d, &bad);     // (the same loads again: cache hits)
-        uint32_t slot = kNone;
-        if (!bad && border_worth_keeping(n, sel.min_edge_length, sel.eps_factor, sel.image_diag, sel.keep_all)) {
-            if (c >= sel.max_contours) atomicOr(&ctr->err_flags, kErrContourTable);
-            else if (pb + n > sel.max_points) atomicOr(&ctr->err_flags, kErrPointPool);
-            else {
-                const JumpState sd = fin[d];   // this thread's own dart: final
-                ContourRec r;
-                r.frame = sel.first_frame + rec_frame(sel.d_rec[d]);   // a border never leaves its frame
-                r.start_key = (uint32_t)(sd.key >> 32);                // every border starts at its smallest event (checked by k_scatter_points)
-                r.point_base = (uint32_t)pb;
-                r.n = n;
-                sel.contours[c] = r;
-                slot = c;
-            }
-            c++; pb += n;
-        }
-        sel.cyc_slot[d] = slot;
+    uint32_t slot = s_base + excl;
+    while (mask) {
+        const int i = __ffs(mask) - 1;
+        mask &= mask - 1;
+        leader_list[(size_t)shard * shard_cap + slot++] = blockIdx.x * blockDim.x + threadIdx.x + (uint32_t)i * stride;
     }
 }
 
@@ -1273,7 +1172,14 @@ __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restric
         const uint32_t sl = d_succ[e.d];
         if (sl == e.d || (uint32_t)st[sl].key != e.d) { e.broken = true; return e; }
         e.n = fin_off(st[sl].off) + 1u;
-        e.keep = border_worth_keeping(e.n, min_edge_length, eps_factor, image_diag, keep_all);   // parity-safe pruning
+        // Parity-safe pruning (src/aruco.rs:133-158):
+        //  (1) a candidate keeps 4 points whose hull-adjacent pairs are >= sqrt(min_edge_length) apart; two
+        //      border points i < j are at most min(j-i, n-(j-i)) 8-connected steps apart, i.e.
+        //      dist^2 <= 2*(n/2)^2, so n^2 >= 2*min_edge_length is necessary;
+        //  (2) Douglas-Peucker splits only when a point is further than eps = eps_factor*n from a chord,
+        //      and no two pixels are further apart than the image diagonal (+1 slack for rounding).
+        const double eps = (double)e.n * eps_factor;
+        e.keep = keep_all || (e.n >= 5u && (uint64_t)e.n * e.n >= 2ull * min_edge_length && eps < image_diag + 1.0);
         return e;
     };
 
@@ -1361,25 +1267,16 @@ __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restric
     }
 }
 
-// FUSED: the borders were selected by k_jump_finalize itself (natural starts).  A dart's border slot then needs no second
-// opinion from the leader's state: the slot is valid iff it lies inside this batch's table and the record there is this
-// border's (frame, start key) -- stale slots of earlier batches fail that test -- and the border starts at its leader, so
-// the rank along the border follows from the dart's own hop distance.  The check the per-leader kernel used to make rides
-// along on the leader darts: the border's smallest event must fire (else the batch is re-run with the start-resolution passes).
-template <bool FUSED>
 __global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restrict__ st, uint32_t n_darts, const uint64_t* __restrict__ d_rec,
                                                         const uint32_t* __restrict__ cyc_slot, const ContourRec* __restrict__ contours,
                                                         const uint32_t* __restrict__ cyc_start_off, uint32_t* __restrict__ points,
-                                                        const uint32_t* __restrict__ n_live, DeviceCounters* __restrict__ ctr,
-                                                        const uint32_t* __restrict__ d_succ, uint32_t first_frame, uint32_t max_contours, int W) {
+                                                        const uint32_t* __restrict__ n_live, const DeviceCounters* __restrict__ ctr) {
     if (ctr->entry_overflow) return;
     if (n_live) n_darts = min(n_darts, *n_live);
-    const uint32_t n_contours = FUSED ? min(ctr->contours, max_contours) : 0u;
     // B darts per lane at a time, three rounds of loads instead of five per dart: {state, record} -> {leader's key, border
     // slot of the leader} -> {border record, start offset}.  Unconditional loads from clamped indices, see k_jump_finalize.
     constexpr int B = A3_SCAT_B;
     const uint32_t stride = gridDim.x * blockDim.x;
-    bool moved = false;
     for (uint32_t d0 = blockIdx.x * blockDim.x + threadIdx.x; d0 < n_darts; d0 += B * stride) {
         JumpState s[B];
         uint64_t rec[B];
@@ -1397,39 +1294,24 @@ __global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restr
             live[u] = d0 + (uint32_t)u * stride < n_darts && (uint32_t)(s[u].key >> 32) != kNoKey;   // else: no start event on this cycle
             const uint32_t leader = live[u] ? (uint32_t)s[u].key : 0u;
             c[u] = cyc_slot[leader];
-            if constexpr (!FUSED) lk[u] = st[leader].key;
+            lk[u] = st[leader].key;
         }
 #pragma unroll
         for (int u = 0; u < B; u++) {
-            if constexpr (FUSED) {
-                live[u] = live[u] && c[u] < n_contours;
-                r[u] = contours[live[u] ? c[u] : 0u];
-                live[u] = live[u] && r[u].start_key == (uint32_t)(s[u].key >> 32) && r[u].frame == first_frame + rec_frame(rec[u]);
-                so[u] = 0u;
-            } else {
-                // a leader that does not hold its own key: an open chain, or states of a run that has not converged (the batch is
-                // then re-run) -- its slot was never written this batch
-                live[u] = live[u] && (uint32_t)lk[u] == (uint32_t)s[u].key && c[u] != kNone;
-                r[u] = contours[live[u] ? c[u] : 0u];
-                so[u] = cyc_start_off[live[u] ? c[u] : 0u];
-            }
+            // a leader that does not hold its own key: an open chain, or states of a run that has not converged (the batch is
+            // then re-run) -- its slot was never written this batch
+            live[u] = live[u] && (uint32_t)lk[u] == (uint32_t)s[u].key && c[u] != kNone;
+            r[u] = contours[live[u] ? c[u] : 0u];
+            so[u] = cyc_start_off[live[u] ? c[u] : 0u];
         }
 #pragma unroll
         for (int u = 0; u < B; u++) {
-            if constexpr (FUSED) {
-                const uint32_t d = d0 + (uint32_t)u * stride;
-                // a leader with a start event (rare lanes): does the border's smallest event fire?
-                if (d < n_darts && (uint32_t)s[u].key == d && (uint32_t)(s[u].key >> 32) != kNoKey && !natural_start_fires(d, s[u].key, st, d_rec, W)) moved = true;
-            }
             if (!live[u]) continue;
             // off = hops forward to the leader; position along the border counted from the start dart
             const uint32_t off = fin_off(s[u].off);
             const uint32_t rank = so[u] >= off ? so[u] - off : so[u] + r[u].n - off;
             points[r[u].point_base + rank] = rec_xy(rec[u]);
         }
-    }
-    if constexpr (FUSED) {
-        if (moved) ctr->resolve_needed = 1u;
     }
 }
 
@@ -1724,7 +1606,7 @@ hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uin
                               unsigned int* entry_count, void* es_a, void* es_b, JumpState* fin, uint32_t* leader_list,
                               unsigned int* leader_count, int max_rounds, DeviceCounters* ctr, const uint32_t* n_live, int dbg,
                               const uint32_t* frame_base, uint32_t* frame_entries /*nullptr: global rounds*/, uint32_t n_frames,
-                              const SelectArgs& sel, int phase /* 0: everything, 1: k_local_contract only, 2: what follows it */) {
+                              int phase /* 0: everything, 1: k_local_contract only, 2: what follows it */) {
     // entry_count[16] and leader_count[16] arrive zeroed (the caller's per-batch / per-chunk memset)
     const uint32_t ecap = entry_shard_cap(n_darts);
     if (phase != 2) {
@@ -1742,7 +1624,7 @@ hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uin
         hipLaunchKernelGGL(k_entry_frame, dim3(n_frames), dim3(256), 0, st, entry_list, frame_entries, frame_base, loc, entry_pos, a, ctr);
         const int fin_blocks = std::max(blocks_for(n_darts, 256, env_cap("A3_FIN_BLOCKS", 1536)), (int)(((uint64_t)n_darts + 256ull * 32 - 1) / (256ull * 32)));
         hipLaunchKernelGGL(k_jump_finalize, dim3(fin_blocks), dim3(256), 0, st, n_darts, loc, entry_pos, a, fin,
-                           leader_list, leader_count, leader_shard_cap(n_darts), n_live, ctr, sel);
+                           leader_list, leader_count, leader_shard_cap(n_darts), n_live, ctr);
         return hipGetLastError();
     }
     const dim3 grid(blocks_for(n_darts / 16 + 1, 256, 1024)), block(256);   // entries are a few % of the darts on clean frames
@@ -1753,7 +1635,7 @@ hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uin
     }
     const int fin_blocks = std::max(blocks_for(n_darts, 256, env_cap("A3_FIN_BLOCKS", 1536)), (int)(((uint64_t)n_darts + 256ull * 32 - 1) / (256ull * 32)));
     hipLaunchKernelGGL(k_jump_finalize, dim3(fin_blocks), block, 0, st, n_darts, loc, entry_pos, a, fin,
-                       leader_list, leader_count, leader_shard_cap(n_darts), n_live, ctr, sel);
+                       leader_list, leader_count, leader_shard_cap(n_darts), n_live, ctr);
     return hipGetLastError();
 }
 
@@ -1777,20 +1659,14 @@ hipError_t launch_select_scatter(hipStream_t st, const JumpState* fin, uint32_t 
                                  const uint32_t* frame_base, uint32_t n_frames, uint32_t first_frame, uint32_t min_edge_length,
                                  double eps_factor, double image_diag, uint32_t* cyc_slot, ContourRec* contours, uint32_t* cyc_start_off,
                                  uint32_t max_contours, uint64_t max_points, DeviceCounters* ctr, const uint64_t* d_rec, uint32_t* points,
-                                 const uint32_t* n_live, int inline_resolve_W, uint32_t* keep_tmp, int keep_all, int fused) {
+                                 const uint32_t* n_live, int inline_resolve_W, uint32_t* keep_tmp, int keep_all) {
     // 8192 workgroups for the graphs of clean frames (6-8 M darts), more for the tens of millions of darts of noise-like ones
     const dim3 grid(blocks_for(n_darts, 256, env_cap("A3_SCATTER_BLOCKS", (int)std::min<uint32_t>(65536u, std::max<uint32_t>(8192u, n_darts / 1024u))))), block(256);
-    if (fused) {   // k_jump_finalize selected the borders itself (launch_rank_cycles with sel.enabled)
-        hipLaunchKernelGGL(k_scatter_points<true>, grid, block, 0, st, fin, n_darts, d_rec, cyc_slot, contours, cyc_start_off, points, n_live, ctr,
-                           d_succ, first_frame, max_contours, inline_resolve_W);
-        return hipGetLastError();
-    }
     hipLaunchKernelGGL(k_cycle_select, dim3(blocks_for(n_darts / 64 + 1, 256, env_cap("A3_SELECT_BLOCKS", 1024))), block, 0, st, fin, leader_list, leader_count, d_succ, t_cur,
                        frame_base, n_frames, first_frame, min_edge_length,
                        eps_factor, image_diag, cyc_slot, contours, cyc_start_off, max_contours, max_points, ctr, leader_shard_cap(n_darts), d_rec,
                        inline_resolve_W, keep_tmp, keep_all);
-    hipLaunchKernelGGL(k_scatter_points<false>, grid, block, 0, st, fin, n_darts, d_rec, cyc_slot, contours, cyc_start_off, points, n_live, ctr,
-                       d_succ, first_frame, max_contours, inline_resolve_W);
+    hipLaunchKernelGGL(k_scatter_points, grid, block, 0, st, fin, n_darts, d_rec, cyc_slot, contours, cyc_start_off, points, n_live, ctr);
     return hipGetLastError();
 }
 

@@ -9,7 +9,8 @@
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-template <int PAT, int PF, int WORK, int STORE>
+// HALO > 0: like K1, every wave also reads HALO rows above and below its strip (clamped to the frame): 14 more rows per 270
+template <int PAT, int PF, int WORK, int STORE, int HALO = 0>
 __global__ __launch_bounds__(64) void k_read(const uint8_t* __restrict__ base, size_t row_stride, int rows, int strips_x, int strips_y, uint32_t* __restrict__ out, uint16_t* __restrict__ bits) {
     extern __shared__ uint8_t lds[];
     const int lane = threadIdx.x;
@@ -17,6 +18,18 @@ __global__ __launch_bounds__(64) void k_read(const uint8_t* __restrict__ base, s
     const int pair = (k / strips_y) * 8 + xcd, sy = k % strips_y;
     const int sx = pair % strips_x, f = pair / strips_x;
     const uint8_t* p = base + (size_t)f * row_stride * (size_t)(rows * strips_y) + (size_t)sy * rows * row_stride + (size_t)sx * 2976;
+    if (HALO) {   // the halo rows: 2 * HALO clamped row reads before the strip's own (no stores for them)
+        const int H = rows * strips_y;
+        uint32_t hacc = 0;
+        for (int h = 0; h < 2 * HALO; h++) {
+            const int y = sy * rows + (h < HALO ? -HALO + h : rows + h - HALO);
+            const uint8_t* rp = base + (size_t)f * row_stride * (size_t)H + (size_t)min(max(y, 0), H - 1) * row_stride + (size_t)sx * 2976;
+            const uint4* v = reinterpret_cast<const uint4*>(rp + lane * 48);
+            const uint4 a = v[0], b = v[1], c = v[2];
+            hacc += a.x ^ a.w ^ b.y ^ c.z;
+        }
+        if (hacc == 0x12345678u) out[blockIdx.x * 64 + lane] = hacc;
+    }
     uint32_t acc = 0;
     uint4 q[PF][3];
     auto issue = [&](int r, uint4* d) {
@@ -101,17 +114,17 @@ __global__ __launch_bounds__(64) void k_read(const uint8_t* __restrict__ base, s
     if (acc == 0x12345678u) out[blockIdx.x * 64 + lane] = acc + lds[lane];
 }
 
-template <int PAT, int PF, int WORK, int STORE>
+template <int PAT, int PF, int WORK, int STORE, int HALO = 0>
 float run(const uint8_t* d, size_t row_stride, int frames, int H, int strips_y, size_t lds, uint32_t* out, int reps) {
     uint16_t* bits = reinterpret_cast<uint16_t*>(out + (8 << 20));
     const int strips_x = 2, rows = H / strips_y;
     const int n_pairs = frames * strips_x;
     dim3 grid(8 * ((n_pairs + 7) / 8) * strips_y), block(64);
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    hipLaunchKernelGGL((k_read<PAT, PF, WORK, STORE>), grid, block, lds, 0, d, row_stride, rows, strips_x, strips_y, out, bits);
+    hipLaunchKernelGGL((k_read<PAT, PF, WORK, STORE, HALO>), grid, block, lds, 0, d, row_stride, rows, strips_x, strips_y, out, bits);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(a));
-    for (int i = 0; i < reps; i++) hipLaunchKernelGGL((k_read<PAT, PF, WORK, STORE>), grid, block, lds, 0, d, row_stride, rows, strips_x, strips_y, out, bits);
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL((k_read<PAT, PF, WORK, STORE, HALO>), grid, block, lds, 0, d, row_stride, rows, strips_x, strips_y, out, bits);
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b));
     return ms / reps;
@@ -150,5 +163,10 @@ int main() {
             fflush(stdout);
         }
     }
+    // K1's own shape, arithmetic stripped: 4 strips of 270 rows per frame column, 14 halo rows per strip, result bits parked in LDS
+    // and written in bursts of 128 rows; beside it the same without the halo and without the stores
+    printf("K1 shape (occ 2, strips_y 4): reads only %.3f | + 14 halo rows %.3f | + halo + stores in bursts of 128 rows %.3f | no halo, bursts of 128 rows %.3f\n",
+           run<0, 3, 0, 0>(d, row_stride, frames, H, 4, 19000, out, 20), run<0, 3, 0, 0, 7>(d, row_stride, frames, H, 4, 19000, out, 20),
+           run<0, 3, 0, 228, 7>(d, row_stride, frames, H, 4, 19000, out, 20), run<0, 3, 0, 228>(d, row_stride, frames, H, 4, 19000, out, 20));
     return 0;
 }
