@@ -141,7 +141,7 @@ struct a3_ctx {
     // Deferred decode (submit / collect with more than one context, see enqueue_batch): the decode stage of a submitted batch
     // runs on a stream of its own, released behind the threshold kernel of the NEXT submitted batch, so that it shares the GPU
     // with that batch's contour stage (both are latency-bound and leave the chip mostly idle) instead of standing in line.
-    hipStream_t decode_stream = nullptr;
+    hipStream_t decode_stream = nullptr;   // lowest priority: the contour kernels it shares the chip with get free slots first
     hipEvent_t ev_contours = nullptr, ev_k1 = nullptr;
     bool back_deferred = false;      // guarded by g_defer_mu
     bool allow_defer = false;        // set by the submit entry points for the batch being enqueued
@@ -304,7 +304,8 @@ std::vector<a3_ctx*> g_deferred;
 // k_local_contract -- the kernels that follow it (entry resolution, finalize, scatter, quads) are latency-bound like the decode
 // stage and share the chip with it, whereas the dart kernels before it are bound by VALU and LDS throughput and only get slower
 // in company.  Measured in one process (tools/ab_overlap.py, BASELINE config 2, two contexts): 0.820 / 0.769 / 0.762 ms per step
-// for modes 0 / 1 / 2.  Deferring the second half of the contour stage as well (entry resolution ... quads, released with the
+// for modes 0 / 1 / 2 with a decode stream of default priority; with the LOWEST priority (what the contexts create) 0.797 / 0.744
+// / 0.745 on another box, and smaller decode grids (2048 ... 512 workgroups) only lose.  Deferring the second half of the contour stage as well (entry resolution ... quads, released with the
 // decode stage behind the next threshold kernel) was built and measured: 0.777 with two contexts, 0.821 with three -- dropped.
 // (a3_debug_set_overlap in a3_internal.h switches modes for the A/B measurements of tools/.)
 int g_overlap_mode = 2;
@@ -817,7 +818,11 @@ int a3_create(int device, const a3_config* cfg, const uint64_t* codes, size_t n_
     c->stream = c->own_stream;
     e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->decode_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {   // the decode stream: lowest priority, so that the contour kernels it shares the chip with get free slots first
+        int lo = 0, hi = 0;
+        e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->decode_stream, hipStreamNonBlocking, lo);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_contours, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_k1, hipEventDisableTiming);
     if (e != hipSuccess) { a3_destroy(c); ctx = nullptr; return fail(ctx, A3_ERR_HIP, "copy / decode streams", e); }

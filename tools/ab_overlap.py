@@ -48,9 +48,10 @@ def main():
             m, per = ctxs[i % len(ctxs)].collect()
         return m, per
 
-    res = {0: [], 1: [], 2: []}
+    modes = [0, 1, 2]
+    res = {m: [] for m in modes}
     for r in range(rounds):
-        for mode in (0, 1, 2):
+        for mode in modes:
             assert L.a3_debug_set_overlap(mode) == 0
             run(6)
             torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -58,7 +59,7 @@ def main():
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
             assert len(m) == len(ref[0]) and np.array_equal(per, ref[1])
             res[mode].append(dt / steps * 1e3)
-    for mode in (0, 1, 2):
+    for mode in modes:
         v = sorted(res[mode])
         print(f"overlap mode {mode}: median {v[len(v) // 2]:.4f} ms/step  ({n / v[len(v) // 2] * 1e3:.0f} frames/s)  all {[round(x, 4) for x in res[mode]]}")
     L.a3_debug_set_overlap(2)
