@@ -19,7 +19,7 @@ LIB_PATH = Path(os.environ["A3_HIP_LIB"]).resolve() if os.environ.get("A3_HIP_LI
 OK, ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_INTERNAL, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
 FMT_RGB8, FMT_RGBA8, FMT_L8, FMT_BGRA8 = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
-PROFILE_OFF, PROFILE_STAGES, PROFILE_THRESHOLD_ONLY = 0, 1, 2
+PROFILE_OFF, PROFILE_STAGES, PROFILE_THRESHOLD_ONLY, PROFILE_THRESHOLD_SAMPLED = 0, 1, 2, 3
 STAGE_THRESHOLD, STAGE_CONTOUR, STAGE_DECODE = 0, 1, 2
 
 # every symbol include/aruco3_hip.h declares

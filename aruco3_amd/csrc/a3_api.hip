@@ -184,6 +184,8 @@ struct a3_ctx {
     bool markers_valid = false;
     uint32_t last_n = 0, last_max_per_frame = 0;
     int profiling = 0;   // 0 off, 1 threshold stage only, 2 every stage (an event record between kernels costs ~6 us of device time)
+    int profile_every = 1;   // threshold-only mode: time every k-th batch (A3_PROFILE_THRESHOLD_SAMPLED: 4)
+    uint32_t batch_seq = 0;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double prof_ms[A3_STAGE_COUNT] = {0, 0, 0};
     uint64_t prof_n[A3_STAGE_COUNT] = {0, 0, 0};
@@ -393,10 +395,12 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     ctx->contours_valid = false; ctx->markers_valid = false; ctx->poses_valid = false;
 
     // ---- K1 ----
-    if (ctx->profiling) A3_HIP(hipEventRecord(ctx->ev[0], st));
+    // (level in force for THIS batch: the sampled threshold-only mode times one batch in profile_every)
+    const int prof = ctx->profiling == 1 && (ctx->batch_seq++ % (uint32_t)ctx->profile_every) != 0 ? 0 : ctx->profiling;
+    if (prof) A3_HIP(hipEventRecord(ctx->ev[0], st));
     A3_HIP(launch_grey_threshold(st, pixels, fmt, row_stride, frame_stride, (int)W, (int)H, n, ctx->cfg.threshold_window,
                                  need_grey ? ctx->grey.as<uint8_t>() : nullptr, ctx->bin.as<uint64_t>()));
-    if (ctx->profiling) A3_HIP(hipEventRecord(ctx->ev[1], st));
+    if (prof) A3_HIP(hipEventRecord(ctx->ev[1], st));
     // batches of OTHER contexts (same device) that wait with their decode stage are released from inside this batch's launch
     // sequence (see g_overlap_mode): `release_point(true)` records the event they wait for and enqueues them
     bool released = false;
@@ -585,7 +589,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
         if (int rc = chunk_back(st)) return rc;
     }
     if (g_overlap_mode != 0) { if (int rc = release_waiting()) return rc; }   // (a batch without a contour graph releases here)
-    if (ctx->profiling >= 2) A3_HIP(hipEventRecord(ctx->ev[2], st));
+    if (prof >= 2) A3_HIP(hipEventRecord(ctx->ev[2], st));
 
     // ---- candidates -> markers -> read-back: enqueued now, or deferred behind the next submitted batch's threshold kernel ----
     const PixelSrc src = need_grey ? PixelSrc{ctx->grey.as<uint8_t>(), W, (unsigned long long)npx, kFmtGreyPlane}
@@ -609,7 +613,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     bk.n = n; bk.W = W; bk.H = H; bk.S = S; bk.max_cand = kMaxCand; bk.patch_cap = patch_cap; bk.marker_cap = marker_cap; bk.guess = guess;
     bk.min_corner_separation = min_corner_separation; bk.src = src; bk.head_bytes = head_bytes; bk.pose_bytes = pose_bytes;
     bk.taps = ctx->debug_taps; bk.want_pose = ctx->want_pose; bk.pose_has_intr = ctx->pose_has_intr; bk.pose_size_mm = ctx->pose_size_mm;
-    bk.pose_intr = ctx->pose_intr; bk.profiling = ctx->profiling;
+    bk.pose_intr = ctx->pose_intr; bk.profiling = prof;
     // Deferral: only for submitted batches (somebody will submit again or collect), and not while every stage is being timed
     // (the stage times are those of stages that run alone).  The decode stage then waits on the context's decode stream until
     // (a) another context submits a batch -- it is released behind that batch's threshold kernel and shares the GPU with its
@@ -623,7 +627,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     Pending& pd = ctx->pending;
     pd.active = true; pd.n_chunks = chunks.size(); pd.chunk0_darts = chunks.empty() ? 0 : chunks[0].darts; pd.ctr_bytes = ctr_bytes;
     pd.head_pad = head_pad; pd.marker_cap = marker_cap; pd.guess = guess; pd.pose_bytes = pose_bytes; pd.device_plan = device_plan;
-    pd.rounds_max = rounds_max; pd.n = n; pd.W = W; pd.H = H; pd.profiling = ctx->profiling; pd.taps = ctx->debug_taps;
+    pd.rounds_max = rounds_max; pd.n = n; pd.W = W; pd.H = H; pd.profiling = prof; pd.taps = ctx->debug_taps;
     return A3_OK;
 }
 
@@ -1458,7 +1462,8 @@ int a3_find_nearest(a3_ctx* ctx, const uint64_t* bits, size_t n, uint32_t* idx, 
 
 int a3_set_profiling(a3_ctx* ctx, int enabled) {
     if (!ctx) return A3_ERR_INVALID;
-    ctx->profiling = enabled == A3_PROFILE_STAGES ? 2 : (enabled == A3_PROFILE_THRESHOLD_ONLY ? 1 : 0);
+    ctx->profiling = enabled == A3_PROFILE_STAGES ? 2 : ((enabled == A3_PROFILE_THRESHOLD_ONLY || enabled == A3_PROFILE_THRESHOLD_SAMPLED) ? 1 : 0);
+    ctx->profile_every = enabled == A3_PROFILE_THRESHOLD_SAMPLED ? 4 : 1;
     return A3_OK;
 }
 

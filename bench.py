@@ -27,7 +27,7 @@ WIDTH, HEIGHT = 1920, 1080
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 K1_BYTES_PER_PIXEL = 3.125         # what K1 has to move: 3 B RGB read + 1/8 B bit-packed binary written; NO grey plane is written
 K1_SURVEY_BYTES_PER_PIXEL = 5      # SURVEY.md section 8d's figure (3 B read + 1 B grey + 1 B byte-wide binary): reported separately
-PROFILE_TAG = "r02"                # profiles/<tag>_pmc_bench_c2.json holds the PMC passes of this same command
+PROFILE_TAGS = ("r03", "r02")      # profiles/<tag>_pmc_bench_c2.json holds the PMC passes of this same command (newest first)
 
 
 def _render(args):
@@ -217,8 +217,8 @@ def main():
         for st_id in (_lib.STAGE_THRESHOLD, _lib.STAGE_CONTOUR, _lib.STAGE_DECODE):
             cx.profile(st_id, reset=True)
     # Warm-up with every stage timed (the breakdown reported as stage_ms_per_step); the timed steps keep only the two event
-    # records around the threshold kernel -- the roofline figure must be measured live -- because each record between two
-    # kernels costs ~6 us of device time.
+    # records around the threshold kernel, on every 4th batch of a context -- the roofline figure must be measured live, but
+    # each record between two kernels costs ~6 us of device time.
     markers, per = run_steps(args.warmup)
     stage_ms = {}
     for name, st_id in (("threshold", _lib.STAGE_THRESHOLD), ("contour", _lib.STAGE_CONTOUR), ("decode", _lib.STAGE_DECODE)):
@@ -228,7 +228,7 @@ def main():
         stage_ms[name] = round(tot / cnt, 3) if cnt else None
     if args.warmup > 0:
         for cx in ctxs:
-            cx.set_profiling(_lib.PROFILE_THRESHOLD_ONLY)
+            cx.set_profiling(_lib.PROFILE_THRESHOLD_SAMPLED)   # the kernel of every 4th batch of a context is timed
 
     # The timed region: EXACTLY --steps steps between barrier + synchronize on both sides, max over ranks.  It is run
     # --repeats times back to back and the median region is the one reported (all are listed in ms_per_step_all).
@@ -455,16 +455,17 @@ def launch_ranks(args):
 
 def pmc_traffic_bytes():
     """HBM bytes per K1 launch from the committed PMC passes of this same workload (tools/pmc_k1.sh ->
-    profiles/<PROFILE_TAG>_pmc_bench_c2.json): (2 x FETCH_SIZE + WRITE_SIZE) KiB, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    profiles/<tag>_pmc_bench_c2.json): (2 x FETCH_SIZE + WRITE_SIZE) KiB, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
     for wide coalesced reads on gfx950.  Counters cannot be read inside this process, so this is the profiled value for the
     default 256-frame batch, or None when the summary is missing."""
-    path = ROOT / "profiles" / f"{PROFILE_TAG}_pmc_bench_c2.json"
-    try:
-        pmc = json.loads(path.read_text())
-        k1 = next(v for k, v in pmc.items() if "k_grey_threshold7" in k)
-        return int((2.0 * k1["FETCH_SIZE"] + k1["WRITE_SIZE"]) * 1024)
-    except Exception:
-        return None
+    for tag in PROFILE_TAGS:
+        try:
+            pmc = json.loads((ROOT / "profiles" / f"{tag}_pmc_bench_c2.json").read_text())
+            k1 = next(v for k, v in pmc.items() if "k_grey_threshold7" in k)
+            return int((2.0 * k1["FETCH_SIZE"] + k1["WRITE_SIZE"]) * 1024)
+        except Exception:
+            continue
+    return None
 
 
 def cpu_baseline(frames, d):

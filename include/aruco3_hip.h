@@ -194,7 +194,8 @@ int  a3_calculate_tau(int device, const uint64_t *codes, size_t n_codes, uint8_t
 enum { A3_STAGE_THRESHOLD = 0, A3_STAGE_CONTOUR = 1, A3_STAGE_DECODE = 2, A3_STAGE_COUNT = 3 };
 /* mode: stage times are taken with HIP events on the context's stream; an event record between two kernels costs about
  * 6 us of device time, so the lighter mode times the threshold stage only (two records per batch instead of four) */
-enum { A3_PROFILE_OFF = 0, A3_PROFILE_STAGES = 1, A3_PROFILE_THRESHOLD_ONLY = 2 };
+enum { A3_PROFILE_OFF = 0, A3_PROFILE_STAGES = 1, A3_PROFILE_THRESHOLD_ONLY = 2,
+       A3_PROFILE_THRESHOLD_SAMPLED = 3 /* the threshold stage of every 4th batch: a quarter of the records' cost */ };
 int  a3_set_profiling(a3_ctx *ctx, int mode);
 int  a3_get_profile(a3_ctx *ctx, int stage, double *total_ms, uint64_t *launches, int reset);
 

@@ -65,6 +65,7 @@ pub const A3_STAGE_DECODE: c_int = 2;
 pub const A3_PROFILE_OFF: c_int = 0;
 pub const A3_PROFILE_STAGES: c_int = 1;
 pub const A3_PROFILE_THRESHOLD_ONLY: c_int = 2;
+pub const A3_PROFILE_THRESHOLD_SAMPLED: c_int = 3;
 
 /// a3_config <-> DetectorConfig, src/aruco.rs:23-30
 #[repr(C)]

@@ -314,3 +314,70 @@ def test_chilitags_rendered_on_the_device(dicts, oracle):
         assert markers_of_hip(got) == markers_of_oracle(res)
         found += len(set(int(x["id"]) for x in got) & set(tm.id for tm in truths[f]))
     assert found >= 8       # of the 12 drawn
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# deferred decode (submit / collect): the decode stage of a submitted batch waits on the context's low-priority stream until
+# another context submits behind it (released behind that batch's k_local_contract) or the batch is collected
+# ------------------------------------------------------------------------------------------------------------------
+def test_deferred_decode_in_every_order_of_calls(dicts):
+    import torch
+
+    from aruco3_amd import _lib, synth
+
+    frames_a, _ = synth.config_frames(1, 5)
+    frames_b, _ = synth.config_frames(1, 5, first=5)
+    da, db = torch.from_numpy(frames_a).cuda(), torch.from_numpy(frames_b).cuda()
+    ctxs = [_detector(dicts, "ARUCO_DEFAULT")._context() for _ in range(3)]
+    aa, ab = _args(frames_a, _lib.MEM_DEVICE, da.data_ptr()), _args(frames_b, _lib.MEM_DEVICE, db.data_ptr())
+    L = _lib.load()
+    want = {}
+    assert L.a3_debug_set_overlap(0) == 0
+    want["a"], want["b"] = ctxs[0].detect_batch(*aa), ctxs[0].detect_batch(*ab)
+    same = lambda got, w: marker_tuples(got[0]) == marker_tuples(w[0]) and np.array_equal(got[1], w[1])
+    try:
+        for mode in (0, 1, 2):
+            assert L.a3_debug_set_overlap(mode) == 0
+            # (1) collected in the order of submission, and in the opposite order
+            ctxs[0].submit(*aa); ctxs[1].submit(*ab)
+            assert same(ctxs[0].collect(), want["a"]) and same(ctxs[1].collect(), want["b"])
+            ctxs[0].submit(*aa); ctxs[1].submit(*ab)
+            assert same(ctxs[1].collect(), want["b"]) and same(ctxs[0].collect(), want["a"])
+            # (2) a lone submit: nobody releases it, collect does
+            ctxs[2].submit(*ab)
+            assert same(ctxs[2].collect(), want["b"])
+            # (3) a synchronous call on another context while a batch waits: it releases the waiting decode stage and is itself complete
+            ctxs[0].submit(*aa)
+            assert same(ctxs[1].detect_batch(*ab), want["b"])
+            assert same(ctxs[0].collect(), want["a"])
+            # (4) three in flight, with debug taps on one of them
+            ctxs[1].set_debug_taps(True)
+            ctxs[0].submit(*aa); ctxs[1].submit(*ab); ctxs[2].submit(*aa)
+            assert same(ctxs[0].collect(), want["a"]) and same(ctxs[1].collect(), want["b"]) and same(ctxs[2].collect(), want["a"])
+            assert ctxs[1].candidates(0).shape[0] > 0
+            ctxs[1].set_debug_taps(False)
+        # (5) a context destroyed with its submitted batch never collected
+        extra = _detector(dicts, "ARUCO_DEFAULT")._context()
+        extra.submit(*aa)
+        extra.close()
+        ctxs[0].submit(*aa)
+        assert same(ctxs[0].collect(), want["a"])
+    finally:
+        L.a3_debug_set_overlap(2)
+
+
+def test_sampled_threshold_profiling_counts_every_fourth_batch(dicts):
+    from aruco3_amd import _lib, synth
+
+    frames, _ = synth.config_frames(1, 2)
+    ctx = _detector(dicts, "ARUCO_DEFAULT")._context()
+    a = _args(frames, _lib.MEM_HOST)
+    ctx.set_profiling(_lib.PROFILE_THRESHOLD_SAMPLED)
+    for _ in range(12):
+        ctx.detect_batch(*a)
+    ms, n = ctx.profile(_lib.STAGE_THRESHOLD)
+    assert n == 3 and ms > 0.0
+    assert ctx.profile(_lib.STAGE_DECODE)[1] == 0
+    ctx.set_profiling(_lib.PROFILE_STAGES)
+    ctx.detect_batch(*a)
+    assert ctx.profile(_lib.STAGE_DECODE)[1] == 1 and ctx.profile(_lib.STAGE_THRESHOLD)[1] == 4

@@ -5,7 +5,7 @@ microbenchmark and the 2-rank rehearsal line.  The bench line's roofline.traffic
 run (bench.py read the previously committed summary when it ran).  Usage: python tools/install_profiles.py [tag]"""
 import csv, json, pathlib, shutil, subprocess, sys
 ROOT = pathlib.Path(__file__).resolve().parent.parent
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 prof, new = ROOT / "profiles", ROOT / "gpurun_out" / "refresh"
 shutil.copy(new / "stats_kernel_stats.csv", prof / f"{tag}_bench_c2_kernel_stats.csv")
 subprocess.check_call([sys.executable, str(ROOT / "tools" / "pmc_aggregate.py"), str(ROOT / "gpurun_out" / "pmc"), str(prof / f"{tag}_pmc_bench_c2.json")])
@@ -14,8 +14,9 @@ pmc = json.loads((prof / f"{tag}_pmc_bench_c2.json").read_text())
 k1 = next(v for k, v in pmc.items() if "k_grey_threshold7" in k)
 d["roofline"]["traffic"] = int((2 * k1["FETCH_SIZE"] + k1["WRITE_SIZE"]) * 1024)
 (prof / f"{tag}_bench_c2.json.log").write_text(json.dumps(d) + "\n")
-if (new / "readbench.txt").exists():
-    shutil.copy(new / "readbench.txt", prof / f"{tag}_readbench.txt")
+for name in ("readbench.txt", "scatterbench.txt", "ab_overlap.txt", "pmc_issue.txt"):
+    if (new / name).exists():
+        shutil.copy(new / name, prof / f"{tag}_{name}")
 for line in (new / "rehearsal_n2_gloo.log").read_text().splitlines():
     if line.startswith("{"):
         (prof / f"{tag}_rehearsal_n2_gloo.json.log").write_text(line + "\n")

@@ -16,7 +16,10 @@ tail -c 400 "$OUT/stats.log"; echo
 bash "$ROOT/tools/pmc_k1.sh" > "$OUT/pmc.log" 2>&1 || exit 3
 cd "$ROOT"
 [ -x tools/micro/readbench ] && timeout -k 5 120 ./tools/micro/readbench > "$OUT/readbench.txt" 2>&1
-HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29555 \
-    bench.py --gpus 2 --steps 20 --warmup 5 --backend gloo --device-synth --no-cpu-baseline > "$OUT/rehearsal_n2_gloo.log" 2> "$OUT/rehearsal_n2_gloo.err" || echo "rehearsal failed"
+[ -x tools/micro/scatterbench ] && timeout -k 5 120 ./tools/micro/scatterbench > "$OUT/scatterbench.txt" 2>&1
+# the N = 2 line through the bench's own front door (no launcher in the command): two child ranks on the one leased GPU, gloo
+timeout -k 10 400 python3 bench.py --gpus 2 --steps 20 --warmup 5 --backend gloo --device-synth --no-cpu-baseline > "$OUT/rehearsal_n2_gloo.log" 2> "$OUT/rehearsal_n2_gloo.err" || echo "rehearsal failed"
+timeout -k 10 300 python3 tools/ab_overlap.py 256 40 5 2 > "$OUT/ab_overlap.txt" 2>&1
+bash "$ROOT/tools/pmc_issue.sh" > "$OUT/pmc_issue.txt" 2>&1
 grep '^{' "$OUT/rehearsal_n2_gloo.log" | cut -c1-300
 ls "$OUT" "$ROOT/gpurun_out/pmc"

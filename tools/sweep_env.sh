@@ -1,7 +1,10 @@
 #!/bin/bash
-# On the GPU box: the bench under each of a list of environment settings (tuning knobs are read per launch), interleaved REPS
-# times so that drift of the box shows.  ENVS="A=1;A=2 B=3;..."  (an empty entry = defaults)
+# On the GPU box: the bench under each of a list of environment settings, interleaved REPS times so that drift of the box shows.
+# The knobs are only read by a -DA3_TUNING build: this script makes one (build/tuning/, `make tuning`) and loads it through
+# A3_HIP_LIB; the product library ignores the environment.  ENVS="A=1;A=2 B=3;..."  (an empty entry = defaults)
 ROOT=$(cd "$(dirname "$0")/.." && pwd); export TMPDIR=/tmp
+make -C "$ROOT/aruco3_amd/csrc" tuning > /dev/null 2>&1 || exit 1
+export A3_HIP_LIB=$ROOT/build/tuning/libaruco3_hip.so
 cd "$ROOT"
 B="python3 bench.py --device-synth --no-cpu-baseline --no-other-workloads --repeats ${REPEATS:-7} --steps 20 --warmup 3"
 IFS=';' read -ra LIST <<< "${ENVS:-;}"
