@@ -35,7 +35,7 @@ hipError_t launch_resolve(hipStream_t, const JumpState*, uint32_t, int, const ui
                           DeviceCounters*, int, const uint32_t*);
 hipError_t launch_select_scatter(hipStream_t, const JumpState*, uint32_t, const uint32_t*, const unsigned int*, const uint32_t*, const uint64_t*,
                                  const uint32_t*, uint32_t, uint32_t,
-                                 uint32_t, double, double, uint32_t*, ContourRec*, uint32_t*, uint32_t, uint64_t, DeviceCounters*,
+                                 uint32_t, double, double, ContourRec*, uint32_t*, uint32_t, uint64_t, DeviceCounters*,
                                  const uint64_t*, uint32_t*, const uint32_t*, int, uint32_t*, int);
 hipError_t launch_debug_clockwise(hipStream_t, const int32_t*, uint32_t, int32_t*);
 hipError_t launch_unpack_bits(hipStream_t, const uint64_t*, int, int, uint8_t*);
@@ -195,7 +195,7 @@ struct a3_ctx {
     uint32_t W = 0, H = 0, frames = 0;
 
     DevBuf dict, in, grey, bin, frame_darts, frame_darts_dev, frame_base, pix_base, tile_darts;
-    DevBuf d_xy, d_succ, stA, stB, t_cur, t_next, cyc_slot;
+    DevBuf d_xy, d_succ, stA, stB, t_cur, t_next;
     DevBuf leader_list, leader_keep, entry_list, entry_pos, es_a, es_b;
     DevBuf contours, cyc_start_off, points;
     DevBuf cands, pre_xy, fin_xy, fin_count, work, outs, proj, patches;
@@ -286,7 +286,6 @@ int ensure_dart_pool(a3_ctx* ctx, uint64_t darts) {
     A3_HIP(ctx->stB.ensure(darts * sizeof(JumpState)));
     A3_HIP(ctx->t_cur.ensure(darts * 8));
     A3_HIP(ctx->t_next.ensure(darts * 8));
-    A3_HIP(ctx->cyc_slot.ensure(darts * 4));
     A3_HIP(ctx->leader_list.ensure(leader_list_bytes((uint32_t)darts)));   // leaders of cycles with a start event, 16 shards
     A3_HIP(ctx->leader_keep.ensure(leader_list_bytes((uint32_t)darts)));   // k_cycle_select: pass-1 verdict per leader slot
     const size_t eslots = entry_slots((uint32_t)darts);   // sharded slot space: darts + at most 16 tiles of padding
@@ -576,7 +575,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
             A3_HIP(launch_resolve(s2, fin, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->leader_list.as<uint32_t>(), d_leader_count,
                                   ctx->t_cur.as<uint64_t>(), ctx->t_next.as<uint64_t>(), ctr, resolve_iters, n_live));
             A3_HIP(launch_select_scatter(s2, fin, nd, ctx->leader_list.as<uint32_t>(), d_leader_count, ctx->d_succ.as<uint32_t>(), ctx->t_cur.as<uint64_t>(), fb,
-                                         cc.count, cc.first, min_edge_length, eps_factor, image_diag, ctx->cyc_slot.as<uint32_t>(),
+                                         cc.count, cc.first, min_edge_length, eps_factor, image_diag,
                                          ctx->contours.as<ContourRec>(), ctx->cyc_start_off.as<uint32_t>(), max_contours, max_points, ctr,
                                          ctx->d_xy.as<uint64_t>(), ctx->points.as<uint32_t>(), n_live, inline_resolve_W, ctx->leader_keep.as<uint32_t>(),
                                          keep_all));
@@ -865,7 +864,7 @@ void a3_destroy(a3_ctx* ctx) {
     if (ctx->decode_stream) (void)hipStreamSynchronize(ctx->decode_stream);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     DevBuf* bufs[] = {&ctx->dict, &ctx->in, &ctx->grey, &ctx->bin, &ctx->frame_darts, &ctx->frame_darts_dev, &ctx->frame_base, &ctx->pix_base,
-                      &ctx->tile_darts, &ctx->d_xy, &ctx->d_succ, &ctx->stA, &ctx->stB, &ctx->t_cur, &ctx->t_next, &ctx->cyc_slot,
+                      &ctx->tile_darts, &ctx->d_xy, &ctx->d_succ, &ctx->stA, &ctx->stB, &ctx->t_cur, &ctx->t_next,
                       &ctx->leader_list, &ctx->leader_keep, &ctx->entry_list, &ctx->entry_pos, &ctx->es_a, &ctx->es_b,
                       &ctx->contours, &ctx->cyc_start_off, &ctx->points, &ctx->zero_blk, &ctx->cands,
                       &ctx->pre_xy, &ctx->fin_xy, &ctx->fin_count, &ctx->work, &ctx->outs, &ctx->proj, &ctx->patches,

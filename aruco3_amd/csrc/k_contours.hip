@@ -1135,11 +1135,15 @@ __global__ void k_resolve_commit(const JumpState* __restrict__ st, uint32_t n_da
 // ---------------------------------------------------------------------------------------
 // select the borders worth materialising, then write their points in traversal order
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restrict__ st, const uint32_t* __restrict__ leader_list,
+// The border slot of a listed leader (kNone: not materialised) is written into the `ptr` word of the leader's OWN state -- nothing
+// reads that word after k_jump_finalize -- so that k_scatter_points finds "is my leader's window intact" and "where do its points
+// go" in one 16-byte load per dart instead of two scattered ones (on noise-like frames, 50 M darts, the scattered loads are the
+// kernel).
+__global__ __launch_bounds__(256) void k_cycle_select(JumpState* st, const uint32_t* __restrict__ leader_list,
                                                       const unsigned int* __restrict__ leader_count, const uint32_t* __restrict__ d_succ,
                                                       const uint64_t* __restrict__ t_cur, const uint32_t* __restrict__ frame_base,
                                                       uint32_t n_frames, uint32_t first_frame, uint32_t min_edge_length, double eps_factor,
-                                                      double image_diag, uint32_t* __restrict__ cyc_slot, ContourRec* __restrict__ contours,
+                                                      double image_diag, ContourRec* __restrict__ contours,
                                                       uint32_t* __restrict__ cyc_start_off, uint32_t max_contours, uint64_t max_points,
                                                       DeviceCounters* __restrict__ ctr, uint32_t shard_cap, const uint64_t* __restrict__ d_rec,
                                                       int W /* > 0: no resolve kernel ran; borders start naturally, checked here */,
@@ -1241,7 +1245,7 @@ __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restric
         {
             const uint32_t sh = i0 / span, i = i0 - sh * span;
             if (i >= leader_count[sh]) continue;
-            if (!keep_tmp[(size_t)sh * shard_cap + i]) { cyc_slot[leader_list[(size_t)sh * shard_cap + i]] = kNone; continue; }
+            if (!keep_tmp[(size_t)sh * shard_cap + i]) { st[leader_list[(size_t)sh * shard_cap + i]].ptr = kNone; continue; }
         }
         const Eval e = eval(i0);
         if (!e.valid) continue;
@@ -1263,12 +1267,12 @@ __global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restric
             }
             c++; pb += e.n;
         }
-        cyc_slot[e.d] = slot;
+        st[e.d].ptr = slot;
     }
 }
 
 __global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restrict__ st, uint32_t n_darts, const uint64_t* __restrict__ d_rec,
-                                                        const uint32_t* __restrict__ cyc_slot, const ContourRec* __restrict__ contours,
+                                                        const ContourRec* __restrict__ contours,
                                                         const uint32_t* __restrict__ cyc_start_off, uint32_t* __restrict__ points,
                                                         const uint32_t* __restrict__ n_live, const DeviceCounters* __restrict__ ctr) {
     if (ctr->entry_overflow) return;
@@ -1281,7 +1285,7 @@ __global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restr
         JumpState s[B];
         uint64_t rec[B];
         uint32_t c[B], so[B];
-        uint64_t lk[B];
+        JumpState ls[B];
         ContourRec r[B];
         bool live[B];
 #pragma unroll
@@ -1293,14 +1297,14 @@ __global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restr
         for (int u = 0; u < B; u++) {
             live[u] = d0 + (uint32_t)u * stride < n_darts && (uint32_t)(s[u].key >> 32) != kNoKey;   // else: no start event on this cycle
             const uint32_t leader = live[u] ? (uint32_t)s[u].key : 0u;
-            c[u] = cyc_slot[leader];
-            lk[u] = st[leader].key;
+            ls[u] = st[leader];    // key: is the leader's window intact; ptr: its border slot (k_cycle_select)
+            c[u] = ls[u].ptr;
         }
 #pragma unroll
         for (int u = 0; u < B; u++) {
             // a leader that does not hold its own key: an open chain, or states of a run that has not converged (the batch is
             // then re-run) -- its slot was never written this batch
-            live[u] = live[u] && (uint32_t)lk[u] == (uint32_t)s[u].key && c[u] != kNone;
+            live[u] = live[u] && (uint32_t)ls[u].key == (uint32_t)s[u].key && c[u] != kNone;
             r[u] = contours[live[u] ? c[u] : 0u];
             so[u] = cyc_start_off[live[u] ? c[u] : 0u];
         }
@@ -1657,16 +1661,16 @@ hipError_t launch_resolve(hipStream_t st, const JumpState* fin, uint32_t n_darts
 hipError_t launch_select_scatter(hipStream_t st, const JumpState* fin, uint32_t n_darts, const uint32_t* leader_list,
                                  const unsigned int* leader_count, const uint32_t* d_succ, const uint64_t* t_cur,
                                  const uint32_t* frame_base, uint32_t n_frames, uint32_t first_frame, uint32_t min_edge_length,
-                                 double eps_factor, double image_diag, uint32_t* cyc_slot, ContourRec* contours, uint32_t* cyc_start_off,
+                                 double eps_factor, double image_diag, ContourRec* contours, uint32_t* cyc_start_off,
                                  uint32_t max_contours, uint64_t max_points, DeviceCounters* ctr, const uint64_t* d_rec, uint32_t* points,
                                  const uint32_t* n_live, int inline_resolve_W, uint32_t* keep_tmp, int keep_all) {
     // 8192 workgroups for the graphs of clean frames (6-8 M darts), more for the tens of millions of darts of noise-like ones
     const dim3 grid(blocks_for(n_darts, 256, env_cap("A3_SCATTER_BLOCKS", (int)std::min<uint32_t>(65536u, std::max<uint32_t>(8192u, n_darts / 1024u))))), block(256);
-    hipLaunchKernelGGL(k_cycle_select, dim3(blocks_for(n_darts / 64 + 1, 256, env_cap("A3_SELECT_BLOCKS", 1024))), block, 0, st, fin, leader_list, leader_count, d_succ, t_cur,
+    hipLaunchKernelGGL(k_cycle_select, dim3(blocks_for(n_darts / 64 + 1, 256, env_cap("A3_SELECT_BLOCKS", 1024))), block, 0, st, const_cast<JumpState*>(fin), leader_list, leader_count, d_succ, t_cur,
                        frame_base, n_frames, first_frame, min_edge_length,
-                       eps_factor, image_diag, cyc_slot, contours, cyc_start_off, max_contours, max_points, ctr, leader_shard_cap(n_darts), d_rec,
+                       eps_factor, image_diag, contours, cyc_start_off, max_contours, max_points, ctr, leader_shard_cap(n_darts), d_rec,
                        inline_resolve_W, keep_tmp, keep_all);
-    hipLaunchKernelGGL(k_scatter_points, grid, block, 0, st, fin, n_darts, d_rec, cyc_slot, contours, cyc_start_off, points, n_live, ctr);
+    hipLaunchKernelGGL(k_scatter_points, grid, block, 0, st, fin, n_darts, d_rec, contours, cyc_start_off, points, n_live, ctr);
     return hipGetLastError();
 }
 
