@@ -134,14 +134,13 @@ struct Pending {
 struct a3_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    // host frames (A3_MEM_HOST) are copied on a stream of their own, the compute stream waits for the copy through ev_in: with two
-    // contexts in flight (submit / collect) the H2D of batch i+1 runs under the kernels of batch i
-    hipStream_t copy_stream = nullptr;
+    // host frames (A3_MEM_HOST) are copied on the device's copy stream (shared by the contexts of a device, see DeviceStreams), the
+    // compute stream waits for the copy through ev_in: with two contexts in flight (submit / collect) the H2D of batch i+1 runs
+    // under the kernels of batch i
     hipEvent_t ev_in = nullptr;
     // Deferred decode (submit / collect with more than one context, see enqueue_batch): the decode stage of a submitted batch
-    // runs on a stream of its own, released behind the threshold kernel of the NEXT submitted batch, so that it shares the GPU
-    // with that batch's contour stage (both are latency-bound and leave the chip mostly idle) instead of standing in line.
-    hipStream_t decode_stream = nullptr;   // lowest priority: the contour kernels it shares the chip with get free slots first
+    // runs on the device's decode stream, released from inside the launch sequence of the NEXT submitted batch, so that it shares
+    // the GPU with that batch's contour stage (both are latency-bound and leave the chip mostly idle) instead of standing in line.
     hipEvent_t ev_contours = nullptr, ev_k1 = nullptr;
     bool back_deferred = false;      // guarded by g_defer_mu
     bool allow_defer = false;        // set by the submit entry points for the batch being enqueued
@@ -298,6 +297,34 @@ int ensure_dart_pool(a3_ctx* ctx, uint64_t darts) {
     return A3_OK;
 }
 
+// ---- streams ----
+// A process has few hardware queues (the runtime multiplexes its streams onto four by default), and two streams that land on one
+// queue run in order whatever their events say: a decode stage "released beside the next batch" then simply stands in that
+// batch's line -- measured: a second set of contexts, each with three streams of its own, lost 10 % where the first set gained
+// 7 %.  So streams are few: ONE decode stream and ONE copy stream per device, shared by all contexts (their work never wants to
+// overlap with itself), created on first use; a context's own stream exists only if the caller never passed one (a3_set_stream).
+struct DeviceStreams { hipStream_t decode = nullptr, copy = nullptr; };
+std::mutex g_streams_mu;
+DeviceStreams g_dev_streams[64];
+bool g_decode_low_prio = false;   // (see a3_debug_set_overlap)
+
+hipError_t device_stream(int device, bool decode, hipStream_t* out) {
+    std::lock_guard<std::mutex> lk(g_streams_mu);
+    DeviceStreams& ds = g_dev_streams[device & 63];
+    hipStream_t& st = decode ? ds.decode : ds.copy;
+    if (!st) {
+        int lo = 0, hi = 0;
+        hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, decode && g_decode_low_prio ? lo : 0);
+        if (e != hipSuccess) { st = nullptr; return e; }
+    }
+    *out = st;
+    return hipSuccess;
+}
+
+// the stream a context enqueues on: the caller's (a3_set_stream) or, created on first need, its own
+int need_stream(a3_ctx* ctx);
+
 // ---- deferred decode: contexts whose submitted batch has its contour stage enqueued and its decode stage not yet ----
 std::mutex g_defer_mu;
 std::vector<a3_ctx*> g_deferred;
@@ -305,11 +332,12 @@ std::vector<a3_ctx*> g_deferred;
 // k_local_contract -- the kernels that follow it (entry resolution, finalize, scatter, quads) are latency-bound like the decode
 // stage and share the chip with it, whereas the dart kernels before it are bound by VALU and LDS throughput and only get slower
 // in company.  Measured in one process (tools/ab_overlap.py, BASELINE config 2, two contexts): 0.820 / 0.769 / 0.762 ms per step
-// for modes 0 / 1 / 2 with a decode stream of default priority; with the LOWEST priority (what the contexts create) 0.797 / 0.744
-// / 0.745 on another box, and smaller decode grids (2048 ... 512 workgroups) only lose.  Deferring the second half of the contour stage as well (entry resolution ... quads, released with the
+// for modes 0 / 1 / 2 (0.794 / 0.744 / 0.741 on another box); smaller decode grids (2048 ... 512 workgroups) only lose.  Deferring the second half of the contour stage as well (entry resolution ... quads, released with the
 // decode stage behind the next threshold kernel) was built and measured: 0.777 with two contexts, 0.821 with three -- dropped.
 // (a3_debug_set_overlap in a3_internal.h switches modes for the A/B measurements of tools/.)
 int g_overlap_mode = 2;
+// (The decode stream has default priority: the lowest one measured the same, and is the wrong thing to hold when two processes
+// share a GPU.)
 
 // candidates -> markers -> read-back of one batch, on stream `st` (the context's stream, or its decode stream when deferred)
 int enqueue_back(a3_ctx* ctx, hipStream_t st, const BackArgs& b) {
@@ -352,9 +380,21 @@ int flush_deferred_locked(a3_ctx* ctx, hipEvent_t after) {
     ctx->back_deferred = false;
     for (size_t i = 0; i < g_deferred.size(); i++)
         if (g_deferred[i] == ctx) { g_deferred.erase(g_deferred.begin() + (long)i); break; }
-    A3_HIP(hipStreamWaitEvent(ctx->decode_stream, ctx->ev_contours, 0));
-    if (after) A3_HIP(hipStreamWaitEvent(ctx->decode_stream, after, 0));
-    return enqueue_back(ctx, ctx->decode_stream, ctx->back);
+    hipStream_t ds = nullptr;
+    A3_HIP(device_stream(ctx->device, true, &ds));
+    A3_HIP(hipStreamWaitEvent(ds, ctx->ev_contours, 0));
+    if (after) A3_HIP(hipStreamWaitEvent(ds, after, 0));
+    return enqueue_back(ctx, ds, ctx->back);
+}
+
+int need_stream(a3_ctx* ctx) {
+    if (ctx->stream) return A3_OK;
+    if (!ctx->own_stream) {
+        A3_HIP(hipSetDevice(ctx->device));
+        A3_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    }
+    ctx->stream = ctx->own_stream;
+    return A3_OK;
 }
 
 // the whole pipeline for one batch; `pixels` is a device pointer here
@@ -816,19 +856,10 @@ int a3_create(int device, const a3_config* cfg, const uint64_t* codes, size_t n_
     c->n_codes = (uint32_t)n_codes;
     c->mark_size = mark_size_of(num_bits);
     ctx = c;
-    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete c; ctx = nullptr; return fail(ctx, A3_ERR_HIP, "hipStreamCreate", e); }
-    c->stream = c->own_stream;
-    e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
-    if (e == hipSuccess) {   // the decode stream: lowest priority, so that the contour kernels it shares the chip with get free slots first
-        int lo = 0, hi = 0;
-        e = hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->decode_stream, hipStreamNonBlocking, lo);
-    }
+    hipError_t e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_contours, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_k1, hipEventDisableTiming);
-    if (e != hipSuccess) { a3_destroy(c); ctx = nullptr; return fail(ctx, A3_ERR_HIP, "copy / decode streams", e); }
+    if (e != hipSuccess) { a3_destroy(c); ctx = nullptr; return fail(ctx, A3_ERR_HIP, "hipEventCreate", e); }
     for (auto& ev : c->ev) {
         e = hipEventCreate(&ev);
         if (e != hipSuccess) { a3_destroy(c); ctx = nullptr; return fail(ctx, A3_ERR_HIP, "hipEventCreate", e); }
@@ -837,8 +868,9 @@ int a3_create(int device, const a3_config* cfg, const uint64_t* codes, size_t n_
     if (e == hipSuccess && n_codes) e = hipMemcpy(c->dict.p, codes, n_codes * 8, hipMemcpyHostToDevice);
     if (e != hipSuccess) { a3_destroy(c); ctx = nullptr; return fail(ctx, A3_ERR_HIP, "dictionary upload", e); }
     e = c->wtab.ensure(weight_table_bytes());
-    if (e == hipSuccess) e = launch_weight_table(c->stream, cfg->homography_sample_size, c->mark_size, cfg->homography_sample_size, c->wtab.as<float>());
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    // (on the legacy default stream: a stream of the context's own is only created if the caller never passes one)
+    if (e == hipSuccess) e = launch_weight_table(nullptr, cfg->homography_sample_size, c->mark_size, cfg->homography_sample_size, c->wtab.as<float>());
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) { a3_destroy(c); ctx = nullptr; return fail(ctx, A3_ERR_HIP, "resize weight table", e); }
     if (tau == 0) {  // src/dictionaries.rs:124
         uint8_t t = 255;
@@ -861,7 +893,12 @@ void a3_destroy(a3_ctx* ctx) {
         ctx->back_deferred = false;
     }
     if (ctx->stream && ctx->stream != ctx->own_stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->decode_stream) (void)hipStreamSynchronize(ctx->decode_stream);
+    {   // the device's shared streams may still hold work of this context
+        std::lock_guard<std::mutex> lk(g_streams_mu);
+        const DeviceStreams& ds = g_dev_streams[ctx->device & 63];
+        if (ds.decode) (void)hipStreamSynchronize(ds.decode);
+        if (ds.copy) (void)hipStreamSynchronize(ds.copy);
+    }
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     DevBuf* bufs[] = {&ctx->dict, &ctx->in, &ctx->grey, &ctx->bin, &ctx->frame_darts, &ctx->frame_darts_dev, &ctx->frame_base, &ctx->pix_base,
                       &ctx->tile_darts, &ctx->d_xy, &ctx->d_succ, &ctx->stA, &ctx->stB, &ctx->t_cur, &ctx->t_next,
@@ -876,15 +913,13 @@ void a3_destroy(a3_ctx* ctx) {
     if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
     if (ctx->ev_contours) (void)hipEventDestroy(ctx->ev_contours);
     if (ctx->ev_k1) (void)hipEventDestroy(ctx->ev_k1);
-    if (ctx->decode_stream) (void)hipStreamDestroy(ctx->decode_stream);
-    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
 
 int a3_set_stream(a3_ctx* ctx, void* hip_stream) {
     if (!ctx) return A3_ERR_INVALID;
-    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;   // (may be null until first needed)
     return A3_OK;
 }
 
@@ -914,6 +949,7 @@ int a3_host_unregister(void* p) {
 
 int a3_get_stream(const a3_ctx* ctx, void** hip_stream) {
     if (!ctx || !hip_stream) return A3_ERR_INVALID;
+    if (int rc = need_stream(const_cast<a3_ctx*>(ctx))) return rc;
     *hip_stream = reinterpret_cast<void*>(ctx->stream);
     return A3_OK;
 }
@@ -955,6 +991,7 @@ static int stage_input(a3_ctx* ctx, const void* pixels, int memory, int fmt, uin
     if (*frame_stride == 0) *frame_stride = *row_stride * height;
     if (*frame_stride < *row_stride * (height - 1) + (size_t)width * bpp) return fail(ctx, A3_ERR_INVALID, "frame_stride smaller than a frame");
     A3_HIP(hipSetDevice(ctx->device));
+    if (int rcs_ = need_stream(ctx)) return rcs_;
     *d_pixels = reinterpret_cast<const uint8_t*>(pixels);
     if (memory == A3_MEM_HOST) {
         const size_t bytes = *frame_stride * (n_frames - 1) + *row_stride * (height - 1) + (size_t)width * bpp;
@@ -963,8 +1000,10 @@ static int stage_input(a3_ctx* ctx, const void* pixels, int memory, int fmt, uin
         // contexts) keep running while these frames cross the link.  Pageable memory is staged by the runtime and the call
         // returns when the caller's buffer has been read; pinned memory (a3_host_alloc / a3_host_register) makes the copy
         // asynchronous and the buffer must then stay untouched until the batch is collected.
-        A3_HIP(hipMemcpyAsync(ctx->in.p, pixels, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
-        A3_HIP(hipEventRecord(ctx->ev_in, ctx->copy_stream));
+        hipStream_t cs = nullptr;
+        A3_HIP(device_stream(ctx->device, false, &cs));
+        A3_HIP(hipMemcpyAsync(ctx->in.p, pixels, bytes, hipMemcpyHostToDevice, cs));
+        A3_HIP(hipEventRecord(ctx->ev_in, cs));
         A3_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_in, 0));
         *d_pixels = ctx->in.as<uint8_t>();
     } else if (memory != A3_MEM_DEVICE) return fail(ctx, A3_ERR_INVALID, "memory must be A3_MEM_HOST or A3_MEM_DEVICE");
@@ -1022,6 +1061,7 @@ static int collect_common(a3_ctx* ctx, a3_marker* out, a3_pose* poses, size_t ou
         return A3_OK;
     }
     A3_HIP(hipSetDevice(ctx->device));
+    if (int rcs_ = need_stream(ctx)) return rcs_;
     const Pending pd = ctx->pending;   // finish_batch clears .active
     ctx->want_pose = pd.want_pose;     // (the other half of the pair may have been a different kind of call on this context)
     ctx->pose_out = pd.want_pose ? poses : nullptr;
@@ -1088,6 +1128,7 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
     if (!ctx || !avg_ms || reps <= 0) return A3_ERR_INVALID;
     if (ctx->dbg_chunks != 1 || ctx->dbg_nd == 0) return fail(ctx, A3_ERR_INVALID, "needs a preceding single-chunk batch");
     A3_HIP(hipSetDevice(ctx->device));
+    if (int rcs_ = need_stream(ctx)) return rcs_;
     hipStream_t st = ctx->stream;
     // the events are owned by a guard: every early return below (A3_HIP) destroys them
     struct EventPair {
@@ -1135,10 +1176,11 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
 
 // internal (a3_internal.h): where a submitted batch's decode stage is released (0 not deferred, 1 behind the next batch's
 // threshold kernel, 2 behind its k_local_contract); process-wide, for A/B measurements
-int a3_debug_set_overlap(int mode) {
-    if (mode < 0 || mode > 2) return A3_ERR_INVALID;
+int a3_debug_set_overlap(int mode) {   // bits 0-7: mode; bit 8: a decode stream created from now on gets the LOWEST priority
+    if (mode < 0 || (mode & 0xFF) > 2) return A3_ERR_INVALID;
     std::lock_guard<std::mutex> lk(g_defer_mu);
-    g_overlap_mode = mode;
+    g_overlap_mode = mode & 0xFF;
+    { std::lock_guard<std::mutex> lk2(g_streams_mu); g_decode_low_prio = (mode & 0x100) != 0; }
     return A3_OK;
 }
 
@@ -1181,6 +1223,7 @@ static int download_plane(a3_ctx* ctx, const DevBuf& buf, uint32_t frame, uint8_
     if (frame >= ctx->frames) return fail(ctx, A3_ERR_INVALID, "frame index outside the last batch");
     const size_t npx = (size_t)ctx->W * ctx->H;
     A3_HIP(hipSetDevice(ctx->device));
+    if (int rcs_ = need_stream(ctx)) return rcs_;
     A3_HIP(hipMemcpy(dst, buf.as<uint8_t>() + npx * frame, npx, hipMemcpyDeviceToHost));
     return A3_OK;
 }
@@ -1195,6 +1238,7 @@ int a3_download_thresholded(a3_ctx* ctx, uint32_t frame, uint8_t* dst) {
     if (frame >= ctx->frames) return fail(ctx, A3_ERR_INVALID, "frame index outside the last batch");
     const size_t npx = (size_t)ctx->W * ctx->H, wpf = (size_t)words_per_row(ctx->W) * ctx->H;
     A3_HIP(hipSetDevice(ctx->device));
+    if (int rcs_ = need_stream(ctx)) return rcs_;
     A3_HIP(ctx->tmp_a.ensure(npx));
     A3_HIP(launch_unpack_bits(ctx->stream, ctx->bin.as<uint64_t>() + wpf * frame, (int)ctx->W, (int)ctx->H, ctx->tmp_a.as<uint8_t>()));
     A3_HIP(hipStreamSynchronize(ctx->stream));
@@ -1211,6 +1255,7 @@ int a3_candidate_count(a3_ctx* ctx, uint32_t frame, uint32_t* n_pre, uint32_t* n
         return A3_OK;
     }
     A3_HIP(hipSetDevice(ctx->device));
+    if (int rcs_ = need_stream(ctx)) return rcs_;
     uint32_t a = 0, b = 0;
     A3_HIP(hipMemcpy(&a, ctx->cand_count + frame, 4, hipMemcpyDeviceToHost));
     A3_HIP(hipMemcpy(&b, ctx->fin_count.as<uint32_t>() + frame, 4, hipMemcpyDeviceToHost));
@@ -1244,6 +1289,7 @@ int a3_download_homographies(a3_ctx* ctx, uint32_t frame, uint8_t* dst, uint8_t*
     if (ctx->pending.active) return fail(ctx, A3_ERR_INVALID, "a submitted batch has not been collected");   // (its staging buffer is in use)
     if (b == 0) return A3_OK;
     A3_HIP(hipSetDevice(ctx->device));
+    if (int rcs_ = need_stream(ctx)) return rcs_;
     const uint32_t S = ctx->cfg.homography_sample_size;
     const size_t S2 = (size_t)S * S, rec_bytes = (size_t)b * sizeof(DecodeOutHost);
     const uint8_t* d_outs = (const uint8_t*)ctx->outs.p + (size_t)frame * ctx->max_cand * sizeof(DecodeOutHost);
@@ -1298,6 +1344,7 @@ int a3_pack_detections(a3_ctx* ctx, uint32_t first_frame_global, uint32_t max_ma
         return fail(ctx, A3_ERR_CAPACITY, msg);
     }
     A3_HIP(hipSetDevice(ctx->device));
+    if (int rcs_ = need_stream(ctx)) return rcs_;
     // scratch word 3 is the kernel's overflow flag (cannot fire after the host check; kept as the device-side guard)
     A3_HIP(launch_pack_detections(ctx->stream, ctx->markers_ptr, with_poses ? ctx->pose_buf.as<a3_pose>() : nullptr, ctx->per_frame, ctx->last_n,
                                   first_frame_global, max_markers_per_frame, dst_device, ctx->scratch_u32 + 3));
@@ -1310,6 +1357,7 @@ int fetch_contours(a3_ctx* ctx, uint32_t frame, std::vector<ContourRec>* recs) {
     if (!ctx->contours_valid) return fail(ctx, A3_ERR_INVALID, "contours are only kept for a single-chunk batch run after a3_set_debug_taps(ctx, 1)");
     if (frame >= ctx->frames) return fail(ctx, A3_ERR_INVALID, "frame index outside the last batch");
     A3_HIP(hipSetDevice(ctx->device));
+    if (int rcs_ = need_stream(ctx)) return rcs_;
     std::vector<ContourRec> all(ctx->tap_contours);
     if (!all.empty()) A3_HIP(hipMemcpy(all.data(), ctx->contours.p, all.size() * sizeof(ContourRec), hipMemcpyDeviceToHost));
     recs->clear();
@@ -1359,6 +1407,7 @@ int a3_debug_clockwise(a3_ctx* ctx, const int32_t* quads_xy, size_t n, int32_t* 
     if (!ctx || !quads_xy || !out_xy) return A3_ERR_INVALID;
     if (n == 0) return A3_OK;
     A3_HIP(hipSetDevice(ctx->device));
+    if (int rcs_ = need_stream(ctx)) return rcs_;
     A3_HIP(ctx->tmp_a.ensure(n * 32)); A3_HIP(ctx->tmp_c.ensure(n * 32));
     A3_HIP(hipMemcpyAsync(ctx->tmp_a.p, quads_xy, n * 32, hipMemcpyHostToDevice, ctx->stream));
     A3_HIP(launch_debug_clockwise(ctx->stream, ctx->tmp_a.as<int32_t>(), (uint32_t)n, ctx->tmp_c.as<int32_t>()));
@@ -1370,6 +1419,7 @@ int a3_debug_clockwise(a3_ctx* ctx, const int32_t* quads_xy, size_t n, int32_t* 
 int a3_debug_rotate_bits(a3_ctx* ctx, const uint8_t* bits, uint32_t n, uint32_t times, uint8_t* out) {
     if (!ctx || !bits || !out || n == 0 || n > 16) return A3_ERR_INVALID;
     A3_HIP(hipSetDevice(ctx->device));
+    if (int rcs_ = need_stream(ctx)) return rcs_;
     A3_HIP(ctx->tmp_a.ensure(256)); A3_HIP(ctx->tmp_c.ensure(256));
     A3_HIP(hipMemcpyAsync(ctx->tmp_a.p, bits, (size_t)n * n, hipMemcpyHostToDevice, ctx->stream));
     A3_HIP(launch_debug_rotate_bits(ctx->stream, ctx->tmp_a.as<uint8_t>(), n, times & 3u, ctx->tmp_c.as<uint8_t>()));
@@ -1386,6 +1436,7 @@ int a3_debug_discard_too_near(a3_ctx* ctx, const uint32_t* quads_xy, size_t n, f
     constexpr uint32_t kMaxCand = kMaxCandDefault;
     if (n > kMaxCand) return fail(ctx, A3_ERR_CAPACITY, "a3_debug_discard_too_near: at most 1024 quads");
     A3_HIP(hipSetDevice(ctx->device));
+    if (int rcs_ = need_stream(ctx)) return rcs_;
     std::vector<CandRec> h(n);
     for (size_t i = 0; i < n; i++) {
         h[i].start_key = (uint32_t)i;   // the given order
@@ -1419,6 +1470,7 @@ static int pose_common(a3_ctx* ctx, const uint32_t* corners, const float* norm, 
     if (!ctx || !out || (!corners && !norm)) return A3_ERR_INVALID;
     if (n == 0) return A3_OK;
     A3_HIP(hipSetDevice(ctx->device));
+    if (int rcs_ = need_stream(ctx)) return rcs_;
     const size_t in_bytes = n * 8 * 4;
     A3_HIP(ctx->tmp_a.ensure(in_bytes));
     A3_HIP(ctx->tmp_b.ensure(n * 2 * sizeof(a3_pose)));
@@ -1447,6 +1499,7 @@ int a3_find_nearest(a3_ctx* ctx, const uint64_t* bits, size_t n, uint32_t* idx, 
     if (!ctx || !bits || !idx || !dist) return A3_ERR_INVALID;
     if (n == 0) return A3_OK;
     A3_HIP(hipSetDevice(ctx->device));
+    if (int rcs_ = need_stream(ctx)) return rcs_;
     A3_HIP(ctx->tmp_a.ensure(n * 8));
     A3_HIP(ctx->tmp_c.ensure(n * 4));
     A3_HIP(ctx->tmp_d.ensure(n));
@@ -1478,6 +1531,7 @@ int a3_selftest_ieee(a3_ctx* ctx, const double* a, const double* b, size_t n, do
     if (!ctx || !a || !b || !sqrt_a || !a_div_b || !sqrtf_a || !a_divf_b) return A3_ERR_INVALID;
     if (n == 0) return A3_OK;
     A3_HIP(hipSetDevice(ctx->device));
+    if (int rcs_ = need_stream(ctx)) return rcs_;
     A3_HIP(ctx->tmp_a.ensure(n * 8)); A3_HIP(ctx->tmp_b.ensure(n * 8)); A3_HIP(ctx->tmp_c.ensure(n * 16)); A3_HIP(ctx->tmp_d.ensure(n * 8));
     A3_HIP(hipMemcpy(ctx->tmp_a.p, a, n * 8, hipMemcpyHostToDevice));
     A3_HIP(hipMemcpy(ctx->tmp_b.p, b, n * 8, hipMemcpyHostToDevice));

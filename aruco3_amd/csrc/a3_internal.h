@@ -19,8 +19,8 @@ int  a3_debug_kernel_time(a3_ctx *ctx, int kernel, int dbg, int reps, float *avg
 
 /* Where the decode stage of a SUBMITTED batch is released when another context submits behind it (see a3_api.hip,
  * "deferred decode"): 0 = never deferred (both halves of a batch enqueued at once, as a3_detect_batch always does), 1 = behind
- * the next batch's threshold kernel, 2 = behind its k_local_contract (the default).  Process-wide; results are identical in
- * every mode -- tools/ use it for A/B timing inside one process, since two boxes of the pool differ by more than the effect. */
+ * the next batch's threshold kernel, 2 = behind its k_local_contract (the default); | 0x100: contexts created from now on get a
+ * decode stream of the lowest priority instead of the default one.  Process-wide; results are identical in every mode -- tools/ use it for A/B timing inside one process, since two boxes of the pool differ by more than the effect. */
 int  a3_debug_set_overlap(int mode);
 
 /* numerics self-check used by the GPU tests: evaluates the IEEE operations the kernels rely on (f64 sqrt/div, f32 sqrt/div)

@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path (process group, dictionary broadcast, device-packed "
                                                                 "records, all-gather) even with one rank: lets a 1-GPU box exercise the RCCL branch")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the other_workloads block (reference bench recipe, configs 4 and 5)")
+    ap.add_argument("--overlap", type=int, default=-1, help="measurement aid (a3_internal.h: a3_debug_set_overlap): where the decode stage of a "
+                                                            "submitted batch is released, 0 never deferred / 1 / 2; -1 = the library's default")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="N > 1 started without a launcher: seconds the parent waits for its ranks")
     ap.add_argument("--frames-cache", default="", help="npz path: reuse rendered frames between runs (profiling runs use it so that "
                                                         "nothing forks under the profiler)")
@@ -131,6 +133,8 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
+    if args.overlap >= 0:
+        assert _lib.load().a3_debug_set_overlap(args.overlap) == 0
     d = ARDictionary.new_from_named_dict("ARUCO") if rank == 0 or world == 1 else None
     if use_dist:
         d = shard.broadcast_dictionary(d, coll_dev, 0)   # RCCL broadcast, once
@@ -165,21 +169,33 @@ def main():
     side = torch.cuda.Stream(device=dev)   # pack + collective run beside the detection stream, not in it
     pack_done = {}                         # context -> event after its pack: the context's next batch overwrites the marker list
 
-    def gather(cx):
-        # Per batch: fixed-capacity records written by a kernel from the device-resident marker list (a3_pack_detections), then
-        # all-gathered over RCCL; no host copy in between.  collect() has returned, so batch i is complete: its pack needs no
-        # ordering against the detection stream and goes to the side stream AT ONCE, beside the kernels of batch i+1 that were
-        # submitted before the collect -- queued on the detection stream it would start a whole step late.
+    pinned_rec = {}
+
+    def pack(cx):
+        # Per batch: fixed-capacity records written by a kernel from the device-resident marker list (a3_pack_detections); no host
+        # copy in between.  collect() has returned, so batch i is complete: its pack needs no ordering against the detection
+        # stream and goes to the side stream AT ONCE, beside the kernels of the batches already submitted -- queued on the
+        # detection stream it would start a whole step late.  Only the enqueue happens here; the collective follows
+        # in all_gather(), after the next batch has been submitted.
         cx.set_stream(side.cuda_stream)
         try:
             with torch.cuda.stream(side):
                 rec = shard.pack_detections_device(cx, n, first_frame, dev)
                 pack_done[id(cx)] = side.record_event()
-                if coll_dev.type == "cpu":                  # gloo rehearsal: host tensors (the copy waits for the pack on `side`)
-                    rec = rec.cpu()
-                last_gather[0] = shard._all_gather(rec, n)
         finally:
             cx.set_stream(stream.cuda_stream)
+        return rec
+
+    def all_gather(rec):
+        with torch.cuda.stream(side):
+            if coll_dev.type == "cpu":     # gloo rehearsal: host tensors, through a pinned buffer (a pageable D2H copy from a side
+                key = tuple(rec.shape)     # stream stalls for tens of milliseconds under a busy detection stream on this runtime)
+                if key not in pinned_rec:
+                    pinned_rec[key] = torch.empty(rec.shape, dtype=rec.dtype, pin_memory=True)
+                pinned_rec[key].copy_(rec, non_blocking=True)
+                side.synchronize()
+                rec = pinned_rec[key]
+            last_gather[0] = shard._all_gather(rec, n)
 
     def submit(cx):
         ev = pack_done.pop(id(cx), None)
@@ -197,16 +213,21 @@ def main():
                     stream.wait_event(ev)
                 markers, per = ctx.detect_batch(*batch_args, out_cap=n * 64)
                 if use_dist:
-                    gather(ctx)
+                    all_gather(pack(ctx))
             return markers, per
-        if k > 0:
-            submit(ctxs[0])
+        # Two batches ahead of the host: batch i+2 goes out (on the context batch i has just been collected from) before anything
+        # else happens, so the GPU always finds the next threshold kernel queued when a contour stage ends, however long the host
+        # takes over the results, the pack and the collective.
+        for i in range(min(2, k)):
+            submit(ctxs[i % 2])
         for i in range(k):
-            if i + 1 < k:
-                submit(ctxs[(i + 1) % 2])
-            markers, per = ctxs[i % 2].collect()
+            cx = ctxs[i % 2]
+            markers, per = cx.collect()
+            rec = pack(cx) if use_dist else None
+            if i + 2 < k:
+                submit(cx)
             if use_dist:
-                gather(ctxs[i % 2])
+                all_gather(rec)
         return markers, per
 
     # set-up, not steps: every context allocates its device buffers on its first batches (hipMalloc is slow and synchronous)
@@ -372,7 +393,7 @@ def main():
             },
             # threshold: the timed steps; contour / decode: the warm-up steps (every stage timed there, see above)
             "stage_ms_per_step": {"threshold": round(k1_avg_ms, 3), "contour": stage_ms.get("contour"), "decode": stage_ms.get("decode")},
-            "stepping": "one context, synchronous" if args.no_pipeline else "two contexts on one stream: step i+1 submitted before step i is collected",
+            "stepping": "one context, synchronous" if args.no_pipeline else "two contexts on one stream, two batches ahead: step i+2 is submitted as soon as step i is collected",
             "stats": stats,
             "frames_with_all_ids_correct": f"{id_ok}/{n}",
             "frame_synthesis_s": round(t_gen, 1),

@@ -30,38 +30,41 @@ def main():
     d_frames, _ = synth.render_frames_device(spec, d.code_list, d.num_bits, [synth.frame_seed(2, i) for i in range(frames)])
     n, h, w, c = d_frames.shape
     a = (d_frames.data_ptr(), _lib.MEM_DEVICE, _lib.FMT_RGB8, w, h, w * c, h * w * c, n)
-    ctxs = [Detector(DetectorConfig.default(), d)._context() for _ in range(n_ctx)]
-    stream = torch.cuda.Stream()
-    for cx in ctxs:
-        cx.set_stream(stream.cuda_stream)
-        for _ in range(3):
-            ref = cx.detect_batch(*a, out_cap=n * 64)
     L = _lib.load()
+    stream = torch.cuda.Stream()
+    sets = {}
+    for label, flag in (("default-priority decode stream", 0), ("lowest-priority decode stream", 0x100)):
+        assert L.a3_debug_set_overlap(2 | flag) == 0     # (priority of the decode stream of contexts created from now on)
+        sets[label] = [Detector(DetectorConfig.default(), d)._context() for _ in range(n_ctx)]
+        for cx in sets[label]:
+            cx.set_stream(stream.cuda_stream)
+            for _ in range(3):
+                ref = cx.detect_batch(*a, out_cap=n * 64)
 
-    def run(k):
-        depth = len(ctxs) - 1
-        for i in range(min(depth, k)):
-            ctxs[i % len(ctxs)].submit(*a, out_cap=n * 64)
+    def run(k, ctxs):
+        nc = len(ctxs)       # as bench.py steps: every context has a batch out; the one just collected submits the next at once
+        for i in range(min(nc, k)):
+            ctxs[i % nc].submit(*a, out_cap=n * 64)
         for i in range(k):
-            if i + depth < k:
-                ctxs[(i + depth) % len(ctxs)].submit(*a, out_cap=n * 64)
-            m, per = ctxs[i % len(ctxs)].collect()
+            m, per = ctxs[i % nc].collect()
+            if i + nc < k:
+                ctxs[i % nc].submit(*a, out_cap=n * 64)
         return m, per
 
-    modes = [0, 1, 2]
+    modes = [(m, lab) for lab in sets for m in (0, 1, 2)]
     res = {m: [] for m in modes}
     for r in range(rounds):
         for mode in modes:
-            assert L.a3_debug_set_overlap(mode) == 0
-            run(6)
+            assert L.a3_debug_set_overlap(mode[0]) == 0
+            run(6, sets[mode[1]])
             torch.cuda.synchronize(); t0 = time.perf_counter()
-            m, per = run(steps)
+            m, per = run(steps, sets[mode[1]])
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
             assert len(m) == len(ref[0]) and np.array_equal(per, ref[1])
             res[mode].append(dt / steps * 1e3)
     for mode in modes:
         v = sorted(res[mode])
-        print(f"overlap mode {mode}: median {v[len(v) // 2]:.4f} ms/step  ({n / v[len(v) // 2] * 1e3:.0f} frames/s)  all {[round(x, 4) for x in res[mode]]}")
+        print(f"overlap mode {mode[0]}, {mode[1]}: median {v[len(v) // 2]:.4f} ms/step  ({n / v[len(v) // 2] * 1e3:.0f} frames/s)  all {[round(x, 4) for x in res[mode]]}")
     L.a3_debug_set_overlap(2)
 
 
