@@ -393,7 +393,8 @@ def main():
             },
             # threshold: the timed steps; contour / decode: the warm-up steps (every stage timed there, see above)
             "stage_ms_per_step": {"threshold": round(k1_avg_ms, 3), "contour": stage_ms.get("contour"), "decode": stage_ms.get("decode")},
-            "stepping": "one context, synchronous" if args.no_pipeline else "two contexts on one stream, two batches ahead: step i+2 is submitted as soon as step i is collected",
+            "stepping": "one context, synchronous" if args.no_pipeline else "two contexts on one stream, two batches ahead: step i+2 is submitted as soon as step i is collected; "
+                        "the decode stage of a submitted batch runs on the device's decode stream, released behind the next batch's k_local_contract",
             "stats": stats,
             "frames_with_all_ids_correct": f"{id_ok}/{n}",
             "frame_synthesis_s": round(t_gen, 1),
