@@ -32,9 +32,9 @@ def main():
     a = (d_frames.data_ptr(), _lib.MEM_DEVICE, _lib.FMT_RGB8, w, h, w * c, h * w * c, n)
     L = _lib.load()
     stream = torch.cuda.Stream()
+    # two sets of contexts, created one after the other: their buffers lie elsewhere, and that alone moves a step by ~2 %
     sets = {}
-    for label, flag in (("default-priority decode stream", 0), ("lowest-priority decode stream", 0x100)):
-        assert L.a3_debug_set_overlap(2 | flag) == 0     # (priority of the decode stream of contexts created from now on)
+    for label in ("first set of contexts", "second set of contexts"):
         sets[label] = [Detector(DetectorConfig.default(), d)._context() for _ in range(n_ctx)]
         for cx in sets[label]:
             cx.set_stream(stream.cuda_stream)
