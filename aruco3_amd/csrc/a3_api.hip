@@ -384,7 +384,9 @@ int flush_deferred_locked(a3_ctx* ctx, hipEvent_t after) {
     A3_HIP(device_stream(ctx->device, true, &ds));
     A3_HIP(hipStreamWaitEvent(ds, ctx->ev_contours, 0));
     if (after) A3_HIP(hipStreamWaitEvent(ds, after, 0));
-    return enqueue_back(ctx, ds, ctx->back);
+    if (int rc = enqueue_back(ctx, ds, ctx->back)) return rc;
+    (void)hipStreamQuery(ds);   // hands what was just queued to the GPU now (the owner polls an event, not this stream)
+    return A3_OK;
 }
 
 int need_stream(a3_ctx* ctx) {

@@ -35,6 +35,12 @@ __global__ __launch_bounds__(64) void k_read(const uint8_t* __restrict__ base, s
     auto issue = [&](int r, uint4* d) {
         const uint8_t* rp = p + (size_t)r * row_stride;
         if (PAT == 0) { const uint4* v = reinterpret_cast<const uint4*>(rp + lane * 48); d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; }
+        else if (PAT == 3) {   // K1's pattern with non-temporal loads (streaming: the frames should not push the dirty result lines out of L2)
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4* v = reinterpret_cast<const u32x4*>(rp + lane * 48);
+            const u32x4 a = __builtin_nontemporal_load(v), b = __builtin_nontemporal_load(v + 1), c = __builtin_nontemporal_load(v + 2);
+            d[0] = make_uint4(a.x, a.y, a.z, a.w); d[1] = make_uint4(b.x, b.y, b.z, b.w); d[2] = make_uint4(c.x, c.y, c.z, c.w);
+        }
         else if (PAT == 1) { const uint4* v = reinterpret_cast<const uint4*>(rp + lane * 16); d[0] = v[0]; d[1] = v[64]; d[2] = v[128]; }
         else {
             const uint32_t* v = reinterpret_cast<const uint32_t*>(rp + lane * 12);
@@ -168,5 +174,9 @@ int main() {
     printf("K1 shape (occ 2, strips_y 4): reads only %.3f | + 14 halo rows %.3f | + halo + stores in bursts of 128 rows %.3f | no halo, bursts of 128 rows %.3f\n",
            run<0, 3, 0, 0>(d, row_stride, frames, H, 4, 19000, out, 20), run<0, 3, 0, 0, 7>(d, row_stride, frames, H, 4, 19000, out, 20),
            run<0, 3, 0, 228, 7>(d, row_stride, frames, H, 4, 19000, out, 20), run<0, 3, 0, 228>(d, row_stride, frames, H, 4, 19000, out, 20));
+    printf("the same with NON-TEMPORAL loads: reads only %.3f | + halo %.3f | + halo + stores in bursts of 128 rows %.3f | no halo, bursts of 128 rows %.3f | row-by-row stores %.3f\n",
+           run<3, 3, 0, 0>(d, row_stride, frames, H, 4, 19000, out, 20), run<3, 3, 0, 0, 7>(d, row_stride, frames, H, 4, 19000, out, 20),
+           run<3, 3, 0, 228, 7>(d, row_stride, frames, H, 4, 19000, out, 20), run<3, 3, 0, 228>(d, row_stride, frames, H, 4, 19000, out, 20),
+           run<3, 3, 0, 1, 7>(d, row_stride, frames, H, 4, 19000, out, 20));
     return 0;
 }
