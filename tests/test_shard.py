@@ -102,3 +102,27 @@ def test_broadcast_and_gather_world2_gloo():
     for p in procs:
         p.join(60)
     assert res == [(0, True), (1, True)]
+
+
+def test_bench_launcher_without_a_gpu_fails_loudly_and_cleanly():
+    """`python bench.py --gpus 2` typed as is (no launcher, no RANK in the environment) on a box WITHOUT a GPU: the parent starts
+    its two child ranks, they die at the first device call, and the parent reports it -- non-zero exit code, no JSON line, no
+    rank left running.  (With a GPU the same front door is exercised for real by tests/test_gpu_round3.py.)"""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--frames", "2", "--steps", "1", "--warmup", "0",
+                        "--device-synth", "--repeats", "1", "--no-other-workloads", "--no-cpu-baseline", "--launch-timeout", "120"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=200)
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert "rank" in p.stderr and "exited with" in p.stderr
