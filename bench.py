@@ -21,6 +21,11 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default), and two streams that
+# share a queue run in order whatever their events say.  This process has the detection stream, the library's decode and copy
+# streams, a side stream for the collective and -- for the free-running side measurement -- two more: with 4 queues some of them
+# collide (measured: the two free-running contexts then run in lock-step).  Must be set before the runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 FRAMES_PER_GPU = 256
 WIDTH, HEIGHT = 1920, 1080
@@ -77,6 +82,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path (process group, dictionary broadcast, device-packed "
                                                                 "records, all-gather) even with one rank: lets a 1-GPU box exercise the RCCL branch")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the other_workloads block (reference bench recipe, configs 4 and 5)")
+    ap.add_argument("--streams", choices=("own", "shared"), default="shared",
+                    help="shared: both contexts enqueue on ONE stream (steps run in order; only the deferred decode stage overlaps); "
+                         "own: every context on a stream of its own (consecutive steps overlap wherever the GPU has room)")
     ap.add_argument("--overlap", type=int, default=-1, help="measurement aid (a3_internal.h: a3_debug_set_overlap): where the decode stage of a "
                                                             "submitted batch is released, 0 never deferred / 1 / 2; -1 = the library's default")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="N > 1 started without a launcher: seconds the parent waits for its ranks")
@@ -143,9 +151,14 @@ def main():
     dets = [Detector(DetectorConfig.default(), d, device=local_rank) for _ in range(1 if args.no_pipeline else 2)]
     ctxs = [x._context() for x in dets]
     stream = torch.cuda.Stream(device=dev)   # an explicit stream: handle 0 (the default stream) would mean "the context's own"
+    own_streams = args.streams == "own" and not args.no_pipeline
     for ctx in ctxs:
-        ctx.set_stream(stream.cuda_stream)
+        if not own_streams:
+            ctx.set_stream(stream.cuda_stream)
         ctx.set_profiling(True)
+    # the stream every context enqueues on, as a torch stream (for the waits on the pack of its previous batch)
+    ctx_stream = {id(cx): (torch.cuda.ExternalStream(cx.stream_ptr, device=dev) if own_streams else stream) for cx in ctxs}
+    ctx_stream_ptr = {id(cx): cx.stream_ptr for cx in ctxs}
     ctx = ctxs[0]
 
     if args.device_synth:
@@ -183,7 +196,7 @@ def main():
                 rec = shard.pack_detections_device(cx, n, first_frame, dev)
                 pack_done[id(cx)] = side.record_event()
         finally:
-            cx.set_stream(stream.cuda_stream)
+            cx.set_stream(ctx_stream_ptr[id(cx)])
         return rec
 
     def all_gather(rec):
@@ -200,7 +213,7 @@ def main():
     def submit(cx):
         ev = pack_done.pop(id(cx), None)
         if ev is not None:
-            stream.wait_event(ev)        # the pack of this context's previous batch has read the marker list
+            ctx_stream[id(cx)].wait_event(ev)        # the pack of this context's previous batch has read the marker list
         cx.submit(*batch_args, out_cap=n * 64)
 
     def run_steps(k):
@@ -210,7 +223,7 @@ def main():
             for _ in range(k):
                 ev = pack_done.pop(id(ctx), None)
                 if ev is not None:
-                    stream.wait_event(ev)
+                    ctx_stream[id(ctx)].wait_event(ev)
                 markers, per = ctx.detect_batch(*batch_args, out_cap=n * 64)
                 if use_dist:
                     all_gather(pack(ctx))
@@ -317,6 +330,54 @@ def main():
     k1_ms = k1_n = 0
     for cx in ctxs:
         a, b = cx.profile(_lib.STAGE_THRESHOLD); k1_ms += a; k1_n += b
+
+    # The other way to step, measured beside the headline (one rank, both contexts on streams of their OWN, nothing deferred):
+    # consecutive batches overlap wherever the GPU has room -- the threshold kernel of batch i+1 runs beside the contour and decode
+    # stages of batch i.  More frames per second, but no kernel runs alone any more: the threshold kernel's launches then last
+    # ~0.44-0.48 ms, of which only part is its own, and a roofline fraction computed from that duration would describe the
+    # company, not the kernel.  The headline keeps the steps in order (K1 alone, timed alone) and this number is reported as what
+    # it is.
+    free_running = None
+    if not use_dist and not args.no_pipeline and not own_streams:
+        try:
+            L = _lib.load()
+            L.a3_debug_set_overlap(0)
+            fctx = [Detector(DetectorConfig.default(), d, device=local_rank)._context() for _ in range(2)]   # (never given a stream: their own)
+            for cx in fctx:
+                cx.set_profiling(_lib.PROFILE_THRESHOLD_SAMPLED)
+                for _ in range(2):
+                    cx.detect_batch(*batch_args, out_cap=n * 64)
+
+            def free_steps(k):
+                for i in range(min(2, k)):
+                    fctx[i % 2].submit(*batch_args, out_cap=n * 64)
+                res = None
+                for i in range(k):
+                    res = fctx[i % 2].collect()
+                    if i + 2 < k:
+                        fctx[i % 2].submit(*batch_args, out_cap=n * 64)
+                return res
+
+            free_steps(args.steps)
+            for cx in fctx:
+                cx.profile(_lib.STAGE_THRESHOLD, reset=True)
+            fr_regions = []
+            for _ in range(20):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                m2, p2 = free_steps(args.steps)
+                torch.cuda.synchronize(); fr_regions.append(time.perf_counter() - t0)
+            fr = sorted(fr_regions)[len(fr_regions) // 2]
+            fk = [cx.profile(_lib.STAGE_THRESHOLD) for cx in fctx]
+            free_running = {"value": round(args.frames * args.steps / fr, 2), "unit": "frames/s", "ms_per_step": round(fr / args.steps * 1e3, 4),
+                            "regions": len(fr_regions), "same_markers": bool(len(m2) == len(markers) and np.array_equal(p2, per)),
+                            "threshold_kernel_ms_in_company": round(sum(a for a, _ in fk) / max(sum(b for _, b in fk), 1), 4),
+                            "stepping": "two contexts, each on a stream of its own, two batches ahead, no deferred decode: steps overlap freely"}
+            for cx in fctx:
+                cx.close()
+        except Exception as e:   # a side measurement must not take the line down
+            free_running = {"error": repr(e)}
+        finally:
+            _lib.load().a3_debug_set_overlap(args.overlap if args.overlap >= 0 else 2)
     if args.warmup == 0:   # no warm-up to take the breakdown from: every stage was timed in the timed steps instead
         for name, st_id in (("contour", _lib.STAGE_CONTOUR), ("decode", _lib.STAGE_DECODE)):
             tot = sum(cx.profile(st_id)[0] for cx in ctxs)
@@ -399,6 +460,8 @@ def main():
             "frames_with_all_ids_correct": f"{id_ok}/{n}",
             "frame_synthesis_s": round(t_gen, 1),
         }
+        if free_running is not None:
+            out["free_running_streams"] = free_running
         if gathered is not None:
             out["gathered"] = gathered
         if use_dist:   # what the ranks themselves saw

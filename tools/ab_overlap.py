@@ -25,6 +25,7 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     n_ctx = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+    own_streams = len(sys.argv) > 5 and sys.argv[5] == "own"   # every context on a stream of its own: batches overlap freely
     d = ARDictionary.new_from_named_dict("ARUCO")
     spec, _ = synth.config_spec(2)
     d_frames, _ = synth.render_frames_device(spec, d.code_list, d.num_bits, [synth.frame_seed(2, i) for i in range(frames)])
@@ -37,7 +38,8 @@ def main():
     for label in ("first set of contexts", "second set of contexts"):
         sets[label] = [Detector(DetectorConfig.default(), d)._context() for _ in range(n_ctx)]
         for cx in sets[label]:
-            cx.set_stream(stream.cuda_stream)
+            if not own_streams:
+                cx.set_stream(stream.cuda_stream)
             for _ in range(3):
                 ref = cx.detect_batch(*a, out_cap=n * 64)
 
