@@ -338,7 +338,7 @@ def main():
     # company, not the kernel.  The headline keeps the steps in order (K1 alone, timed alone) and this number is reported as what
     # it is.
     free_running = None
-    if not use_dist and not args.no_pipeline and not own_streams:
+    if not use_dist and not args.no_pipeline and not own_streams and not args.no_other_workloads:   # (a side measurement like those)
         try:
             L = _lib.load()
             L.a3_debug_set_overlap(0)
