@@ -143,6 +143,7 @@ struct a3_ctx {
     // the GPU with that batch's contour stage (both are latency-bound and leave the chip mostly idle) instead of standing in line.
     hipEvent_t ev_contours = nullptr, ev_k1 = nullptr;
     bool back_deferred = false;      // guarded by g_defer_mu
+    int back_rc = 0;                 // a failed launch of the deferred half, whoever enqueued it (guarded by g_defer_mu): collect reports it
     bool allow_defer = false;        // set by the submit entry points for the batch being enqueued
     BackArgs back;
     a3_config cfg{};
@@ -375,7 +376,13 @@ int enqueue_back(a3_ctx* ctx, hipStream_t st, const BackArgs& b) {
 
 // Enqueue the deferred second half of `ctx`'s batch on its decode stream: after its own contour stage and, when `after` is
 // given, after that event (the threshold kernel of the batch another context has just submitted).  g_defer_mu is held.
+int flush_deferred_impl(a3_ctx* ctx, hipEvent_t after);
 int flush_deferred_locked(a3_ctx* ctx, hipEvent_t after) {
+    const int rc = flush_deferred_impl(ctx, after);
+    if (rc) ctx->back_rc = rc;   // the owner may be another thread's context: its collect must not read a batch that never ran
+    return rc;
+}
+int flush_deferred_impl(a3_ctx* ctx, hipEvent_t after) {
     if (!ctx->back_deferred) return A3_OK;
     ctx->back_deferred = false;
     for (size_t i = 0; i < g_deferred.size(); i++)
@@ -663,6 +670,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
         A3_HIP(hipEventRecord(ctx->ev_contours, st));
         std::lock_guard<std::mutex> lk(g_defer_mu);
         ctx->back_deferred = true;
+        ctx->back_rc = 0;
         g_deferred.push_back(ctx);
     } else if (int rc = enqueue_back(ctx, st, bk)) return rc;
     Pending& pd = ctx->pending;
@@ -688,6 +696,7 @@ int finish_batch(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_fram
     {   // nobody submitted behind this batch: its decode stage goes out now
         std::lock_guard<std::mutex> lk(g_defer_mu);
         if (int rc = flush_deferred_locked(ctx, nullptr)) return rc;
+        if (const int rc = ctx->back_rc) { ctx->back_rc = 0; return rc; }   // (released by another context's submit, and that failed)
     }
     A3_HIP(wait_event(ctx->ev[4], st));
     const unsigned int* hs = reinterpret_cast<const unsigned int*>(hp);
