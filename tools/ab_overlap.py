@@ -25,7 +25,8 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     n_ctx = int(sys.argv[4]) if len(sys.argv) > 4 else 2
-    own_streams = len(sys.argv) > 5 and sys.argv[5] == "own"   # every context on a stream of its own: batches overlap freely
+    own_streams = len(sys.argv) > 5 and sys.argv[5] == "own"
+    MODES = tuple(int(x) for x in sys.argv[6].split(",")) if len(sys.argv) > 6 else (0, 1, 2)   # every context on a stream of its own: batches overlap freely
     d = ARDictionary.new_from_named_dict("ARUCO")
     spec, _ = synth.config_spec(2)
     d_frames, _ = synth.render_frames_device(spec, d.code_list, d.num_bits, [synth.frame_seed(2, i) for i in range(frames)])
@@ -53,7 +54,7 @@ def main():
                 ctxs[i % nc].submit(*a, out_cap=n * 64)
         return m, per
 
-    modes = [(m, lab) for lab in sets for m in (0, 1, 2)]
+    modes = [(m, lab) for lab in sets for m in MODES]
     res = {m: [] for m in modes}
     for r in range(rounds):
         for mode in modes:
