@@ -472,7 +472,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(frames, d)
         if not args.no_other_workloads and world == 1:
             # free the headline batch first: the 4K batch below needs room only in the sense of tidiness (288 GB of HBM)
-            out["other_workloads"] = other_workloads(local_rank, with_cpu=not args.no_cpu_baseline)
+            try:
+                out["other_workloads"] = other_workloads(local_rank, with_cpu=not args.no_cpu_baseline)
+            except Exception as e:   # side measurements never take the line down
+                out["other_workloads"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
