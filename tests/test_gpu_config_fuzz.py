@@ -101,6 +101,72 @@ def test_random_config_dictionary_format_combinations(oracle, block):
     assert found >= 0
 
 
+def _projected_squares(rng, n, w, h):
+    """corners (u32, as a Marker carries them) of squares seen by a pinhole camera at random poses: the inputs k_pose meets"""
+    out = np.zeros((n, 8), dtype=np.uint32)
+    f = 0.9 * w
+    for i in range(n):
+        while True:
+            size = float(rng.uniform(20.0, 120.0))
+            ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+            ang = float(rng.uniform(0.0, 1.2))
+            K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+            R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+            R = R @ np.array([[np.cos(a := float(rng.uniform(0, 6.283))), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+            t = np.array([rng.uniform(-0.3, 0.3) * 1000, rng.uniform(-0.2, 0.2) * 1000, rng.uniform(300.0, 2500.0)])
+            sq = np.array([[-1, 1, 0], [1, 1, 0], [1, -1, 0], [-1, -1, 0]], dtype=np.float64) * size / 2
+            pc = sq @ R.T + t
+            uv = np.stack([f * pc[:, 0] / pc[:, 2] + w / 2, f * pc[:, 1] / pc[:, 2] + h / 2], axis=1)
+            if (pc[:, 2] > 50).all() and (uv >= 0).all() and (uv[:, 0] < w).all() and (uv[:, 1] < h).all():
+                out[i] = np.round(uv).astype(np.uint32).reshape(8)
+                break
+    return out
+
+
+def _same_floats(got, want, what):
+    got, want = np.asarray(got, dtype=np.float64).ravel(), np.asarray(want, dtype=np.float64).ravel()
+    assert np.array_equal(np.isnan(got), np.isnan(want)), f"{what}: NaN pattern differs"
+    ok = ~np.isnan(want)
+    fin = ok & np.isfinite(want)
+    assert np.array_equal(got[ok & ~fin], want[ok & ~fin]), f"{what}: infinities differ"
+    tol = 1e-4 * np.maximum(1.0, np.abs(want[fin]))     # north_star's pose tolerance, relative above 1
+    bad = np.abs(got[fin] - want[fin]) > tol
+    assert not bad.any(), f"{what}: {got[fin][bad][:4]} vs {want[fin][bad][:4]}"
+
+
+@pytest.mark.gpu
+def test_pose_solvers_on_random_quads(oracle):
+    """src/pose.rs:52-81 through the device: squares projected at random poses (rounded to the integer corners a Marker has), and
+    quads no camera would produce (collinear, repeated and wildly skewed corners): both solutions, their errors, with the image
+    size and with explicit intrinsics, against the oracle within 1e-4 (relative above 1); NaNs where the oracle has NaNs."""
+    from aruco3_amd import _lib
+    from aruco3_amd.aruco import Detector, DetectorConfig
+    from aruco3_amd.dictionaries import ARDictionary
+
+    rng = np.random.default_rng(4711)
+    ctx = Detector(DetectorConfig(), ARDictionary.new_from_named_dict("ARUCO"))._context()
+    w, h = 1920, 1080
+    quads = _projected_squares(rng, 600, w, h)
+    wild = rng.integers(0, 1080, size=(200, 8)).astype(np.uint32)
+    wild[:20, 2:4] = wild[:20, 0:2]                                    # a repeated corner
+    wild[20:40] = np.stack([np.arange(8, dtype=np.uint32) * 10 + i for i in range(20)])   # collinear
+    corners = np.concatenate([quads, wild])
+    size = 40.0
+    intr = _lib.Intrinsics(w, h, 1500.0, 1480.0, 955.5, 541.25)
+    for label, recs, ref in (
+        ("image size", ctx.estimate_pose(corners, size, (w, h)), lambda c: oracle.solve_with_undistorted_points(c, size, (w, h))),
+        ("intrinsics", ctx.estimate_pose(corners, size, (w, h), intr), lambda c: oracle.solve_with_intrinsics(c, size, 1500.0, 1480.0, 955.5, 541.25)),
+    ):
+        for i in range(corners.shape[0]):
+            a, b = ref(corners[i])
+            for k, want in enumerate((a, b)):
+                r = recs[2 * i + k]
+                what = f"{label}, quad {i} ({corners[i].tolist()}), solution {k}"
+                _same_floats([r.error], [want[0]], what + " error")
+                _same_floats(np.array(r.rotation), want[1], what + " rotation")
+                _same_floats(np.array(r.translation), want[2], what + " translation")
+
+
 if __name__ == "__main__":
     import time
 
