@@ -381,3 +381,64 @@ def test_sampled_threshold_profiling_counts_every_fourth_batch(dicts):
     ctx.set_profiling(_lib.PROFILE_STAGES)
     ctx.detect_batch(*a)
     assert ctx.profile(_lib.STAGE_DECODE)[1] == 1 and ctx.profile(_lib.STAGE_THRESHOLD)[1] == 4
+
+
+@pytest.mark.gpu
+def test_contexts_driven_from_concurrent_host_threads(dicts):
+    """include/aruco3_hip.h promises that contexts are independent: four host threads, a context each on the same device, frames of
+    a different size each, 40 rounds of submit / collect (the decode stage of one thread's batch is released from inside another
+    thread's submit, on the device's shared decode stream) mixed with synchronous calls and host-memory batches (shared copy
+    stream).  Every result must equal the one a single thread got for the same frames."""
+    import threading
+
+    import torch
+
+    from aruco3_amd import _lib, synth
+
+    shapes = [(640, 480), (333, 251), (800, 600), (512, 512)]
+    d = dicts.new_from_named_dict("ARUCO_DEFAULT")
+    jobs = []
+    ref_ctx = _detector(dicts, "ARUCO_DEFAULT")._context()
+    for t, (w, h) in enumerate(shapes):
+        spec = synth.SynthSpec(w, h, n_markers=(2, 3), side=(min(w, h) * 0.2, min(w, h) * 0.3), min_center_sep=min(w, h) * 0.4)
+        sets = []
+        for k in range(3):
+            fr = np.stack([synth.render_frame(spec, d.code_list, d.num_bits, 1000 * t + 10 * k + i)[0] for i in range(3)])
+            dev = torch.from_numpy(fr).cuda()
+            a_dev, a_host = _args(fr, _lib.MEM_DEVICE, dev.data_ptr()), _args(fr, _lib.MEM_HOST)
+            m, per = ref_ctx.detect_batch(*a_dev)
+            sets.append((fr, dev, a_dev, a_host, (marker_tuples(m), per.copy())))
+        assert sum(len(s[4][0]) for s in sets) > 0
+        jobs.append(sets)
+    torch.cuda.synchronize()
+    errors = []
+    start = threading.Barrier(len(shapes))
+
+    def worker(t):
+        try:
+            ctx = _detector(dicts, "ARUCO_DEFAULT")._context()
+            start.wait()
+            for it in range(40):
+                fr, dev, a_dev, a_host, (want_m, want_per) = jobs[t][it % 3]
+                how = (it + t) % 4
+                if how == 0:
+                    m, per = ctx.detect_batch(*a_dev)
+                elif how == 1:
+                    m, per = ctx.detect_batch(*a_host)
+                else:
+                    ctx.submit(*(a_dev if how == 2 else a_host))
+                    m, per = ctx.collect()
+                if marker_tuples(m) != want_m or not np.array_equal(per, want_per):
+                    errors.append(f"thread {t}, round {it}, path {how}: {len(m)} markers, expected {len(want_m)}")
+                    return
+            ctx.close()
+        except Exception as e:   # noqa: BLE001 -- reported by the main thread
+            errors.append(f"thread {t}: {e!r}")
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(len(shapes))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=120)
+    assert not any(th.is_alive() for th in threads), "a worker thread hangs"
+    assert not errors, errors
