@@ -764,7 +764,26 @@ def caller_latency(device, with_cpu=True, calls=200):
         codes = np.ascontiguousarray(d.code_list)
         _, t = timeit(lambda: a3oracle.detect_markers_only(frames[0], codes, d.num_bits, d._tau), 20)
         out["cpu_baseline"] = dict(t, cores=1, kind="port", sample="the same frame, single thread, 20 calls (markers only)")
-    pinned.close(); ctx.close()
+    pinned.close()
+    # the reference's own bench, call for call (benches/detect_markers.rs:29-51): ONE 1920x1080 uniform-noise frame per detect()
+    rng = np.random.default_rng(29)
+    noise = rng.integers(0, 256, size=(1080, 1920, 3), dtype=np.uint8)
+    ctx_n = Detector(DetectorConfig.default(), ARDictionary.new_from_named_dict("ARUCO"), device=device)._context()
+    pin_n = _lib.PinnedBuffer(noise.nbytes)
+    pin_n.array[:] = noise.reshape(-1)
+    row = {"workload": "benches/detect_markers.rs recipe as it is called: one 1920x1080 uniform-noise RGB frame in host memory per call"}
+    for label, ptr in (("pageable", noise.ctypes.data), ("pinned", pin_n.ptr)):
+        a = (ptr, _lib.MEM_HOST, _lib.FMT_RGB8, 1920, 1080, 1920 * 3, 1080 * 1920 * 3, 1)
+        r, t = timeit(lambda: ctx_n.detect_batch(*a, out_cap=64), max(20, calls // 4))
+        t["markers"] = int(len(r[0]))
+        row[f"markers_only_{label}"] = t
+    if with_cpu:
+        dn = ARDictionary.new_from_named_dict("ARUCO")
+        codes_n = np.ascontiguousarray(dn.code_list)
+        _, t = timeit(lambda: a3oracle.detect_markers_only(noise, codes_n, dn.num_bits, dn._tau), 3)
+        row["cpu_baseline"] = dict(t, cores=1, kind="port", sample="the same frame, single thread, 3 calls")
+    out["reference_bench_one_frame_per_call_1080p_noise"] = row
+    pin_n.close(); ctx_n.close(); ctx.close()
     return out
 
 

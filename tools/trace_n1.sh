@@ -1,8 +1,8 @@
 #!/bin/bash
 ROOT=$(cd "$(dirname "$0")/.." && pwd); OUT=$ROOT/gpurun_out/n1; rm -rf "$OUT"; mkdir -p "$OUT"; export TMPDIR=/tmp
 cd /tmp
-python3 "$ROOT/tools/trace_n1.py"
-rocprofv3 --kernel-trace --output-format csv -d "$OUT" -o n1 -- python3 "$ROOT/tools/trace_n1.py" > "$OUT/n1.log" 2>&1; tail -1 "$OUT/n1.log"
+python3 "$ROOT/tools/trace_n1.py" $1
+rocprofv3 --kernel-trace --output-format csv -d "$OUT" -o n1 -- python3 "$ROOT/tools/trace_n1.py" $1 > "$OUT/n1.log" 2>&1; tail -1 "$OUT/n1.log"
 python3 - "$OUT/n1_kernel_trace.csv" <<'PY'
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
