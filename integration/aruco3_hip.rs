@@ -501,9 +501,12 @@ fn fill_debug_outputs(ctx: &HipCtx, f: u32, width: u32, height: u32, sample: u32
     }).collect();
 }
 
-/// With `Detection.homographies` populated the library keeps one patch per candidate of the batch; its tap is sized for
-/// 1024 frames x 1024 candidates, so a populated call never carries more frames than this (larger batches are split).
+/// With `Detection.homographies` populated the library keeps one patch per candidate of the batch, up to 2^20 patches per call;
+/// a populated call therefore never carries more frames than this (larger batches are split).
 const MAX_TAPPED_FRAMES: usize = 1024;
+/// The library's candidate tables grow to 6144 quads per frame (beyond that a3_detect_batch reports A3_ERR_CAPACITY for good):
+/// marker lists are grown and the batch re-run up to that many markers per frame.
+const MAX_MARKERS_PER_FRAME: usize = 6144;
 
 impl Detector {
     /// src/aruco.rs:52-121, same signature.  One frame = a batch of one.
@@ -536,7 +539,7 @@ impl Detector {
                                 markers.as_mut_ptr(), markers.len(), per.as_mut_ptr(), &mut found)
             };
             // the reference has no marker limit: a list that does not fit is grown and the batch re-run
-            if rc == A3_ERR_CAPACITY && markers.len() < 1024 * n {
+            if rc == A3_ERR_CAPACITY && markers.len() < MAX_MARKERS_PER_FRAME * n {
                 markers.resize(markers.len() * 4, A3Marker::default());
                 continue;
             }
@@ -583,7 +586,7 @@ impl Detector {
                                      intr_ptr, markers.as_mut_ptr(), poses.as_mut_ptr(), cap, per.as_mut_ptr(), &mut found)
             };
             // the reference has no marker limit: lists that do not fit are grown and the batch re-run (as in detect_batch)
-            if rc == A3_ERR_CAPACITY && cap < 1024 * n {
+            if rc == A3_ERR_CAPACITY && cap < MAX_MARKERS_PER_FRAME * n {
                 cap *= 4;
                 markers.resize(cap, A3Marker::default());
                 poses.resize(2 * cap, A3Pose::default());
