@@ -184,6 +184,14 @@ __global__ __launch_bounds__(64) void k_dart_count(const uint64_t* __restrict__ 
     static_assert((kTileRows / kCountHalves) * kTileWords == 64, "one 64-bit mask per tile and part");
     constexpr int kGroups = 64 / G, kOwners = G == 64 ? kCountLanes : 30, kTilesPerGroup = (kOwners + kTileWords - 1) / kTileWords;
     __shared__ uint32_t s_tile[kGroups][kTilesPerGroup];
+    __shared__ unsigned long long s_mask[kGroups][kTilesPerGroup];
+    // Words that can own darts (not empty, not in the middle of a white area: ~5 % of a clean frame's words) are QUEUED -- the
+    // word, the words above and below, six neighbour bits, its lane and row -- and worked on 64 at a time: the bit arithmetic
+    // that finds their darts (75 instructions) then runs with every lane busy, once per 64 such words, instead of once per image
+    // row for the two or three lanes that hold one (A3_COUNT_QUEUE=0: in place).
+    constexpr uint32_t kQ = 128;                   // ring of two flushes: a row adds at most 64 entries to fewer than 64 waiting
+    __shared__ uint64_t q_c[kQ], q_up[kQ], q_dn[kQ];
+    __shared__ uint32_t q_meta[kQ];                // bits 0-5: l/r bits of the row, the row above, the row below; 8-13: lane; 16-19: row in the part
     const int wpr = (int)words_per_row((uint32_t)W);
     const uint32_t f = blockIdx.y;
     const uint32_t tiles_x = dart_tiles_x((uint32_t)W), tiles_y = ((uint32_t)H + kTileRows - 1) / kTileRows;
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(64) void k_dart_count(const uint64_t* __restrict__ 
     const int j = cx * kOwners + gl - 1;                       // this lane's word column (may lie outside the image: zeros)
     const bool owner = gl >= 1 && gl <= kOwners && j < wpr && ty < (int)tiles_y;
     const uint64_t* img = bits + (size_t)(first_frame + f) * wpr * H;
-    if (lane < kGroups * kTilesPerGroup) (&s_tile[0][0])[lane] = 0;
+    if (lane < kGroups * kTilesPerGroup) { (&s_tile[0][0])[lane] = 0; (&s_mask[0][0])[lane] = 0ull; }
     constexpr int kRows = kTileRows / kCountHalves;
     const int y0 = ty * kTileRows + (int)blockIdx.z * kRows;
     // (unconditional load from a clamped address, then a select: a load behind a branch cannot be batched with its neighbours)
@@ -202,11 +210,12 @@ __global__ __launch_bounds__(64) void k_dart_count(const uint64_t* __restrict__ 
         const uint64_t v = img[(size_t)min(max(y, 0), H - 1) * wpr + jc];
         return v & (0ull - (uint64_t)(y >= 0 && y < H && j >= 0 && j < wpr));   // (an AND, not a select: a select lets the compiler sink the load into a branch again)
     };
-    auto edge_bits = [](uint64_t c, uint32_t* lbit, uint32_t* rbit) {   // bit 63 of the word to the left, bit 0 of the word to the right
-        *lbit = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(c >> 32), 0x138 /* wave_shr:1 */, 0xF, 0xF, true) >> 31;
-        *rbit = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)c, 0x130 /* wave_shl:1 */, 0xF, 0xF, true) & 1u;
+    auto edge_bits = [](uint64_t c, uint32_t* lr) {   // bit 0: bit 63 of the word to the left; bit 1: bit 0 of the word to the right
+        const uint32_t l = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(c >> 32), 0x138 /* wave_shr:1 */, 0xF, 0xF, true) >> 31;
+        const uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)c, 0x130 /* wave_shl:1 */, 0xF, 0xF, true) & 1u;
+        *lr = l | (r << 1);
     };
-    struct Row3 { uint64_t c; uint32_t lbit, rbit; };
+    struct Row3 { uint64_t c; uint32_t lr; };
     // rows are fetched kAhead at a time, and the next kAhead rows are requested before the current ones are looked at: the
     // launch is only a couple of waves per SIMD, so a tile row's time is its chain of round trips to memory -- five of them
     // now, overlapped with the bit work, instead of ten
@@ -218,10 +227,33 @@ __global__ __launch_bounds__(64) void k_dart_count(const uint64_t* __restrict__ 
     cur.c = word(y0);
 #pragma unroll
     for (int u = 0; u < kAhead; u++) nxt[u] = word(y0 + u + 1);
-    edge_bits(up.c, &up.lbit, &up.rbit);
-    edge_bits(cur.c, &cur.lbit, &cur.rbit);
-    uint32_t nd = 0;
-    unsigned long long acc = 0;   // (lanes holding the first word column of a tile) the mask of this tile and part
+    edge_bits(up.c, &up.lr);
+    edge_bits(cur.c, &cur.lr);
+    uint32_t qhead = 0, qtail = 0;                 // wave-uniform
+    const uint32_t lane_row0 = (uint32_t)lane << 8;
+    // darts of one queued word -> its tile's count and its bit of the tile's mask (LDS atomics: a few per flush)
+    auto work = [&](uint32_t slot) {
+        const uint64_t c = q_c[slot], uc = q_up[slot], dc = q_dn[slot];
+        const uint32_t m = q_meta[slot];
+        Nb8 nb;
+        nb.c = c;
+        nb.n[0] = (c << 1) | (m & 1u);                  nb.n[4] = (c >> 1) | ((uint64_t)((m >> 1) & 1u) << 63);
+        nb.n[1] = (uc << 1) | ((m >> 2) & 1u);          nb.n[3] = (uc >> 1) | ((uint64_t)((m >> 3) & 1u) << 63);
+        nb.n[2] = uc;                                   nb.n[6] = dc;
+        nb.n[7] = (dc << 1) | ((m >> 4) & 1u);          nb.n[5] = (dc >> 1) | ((uint64_t)((m >> 5) & 1u) << 63);
+        uint64_t p[8];
+        pdart_words(nb, p);
+        uint32_t ndw = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) ndw += __popcll(p[q]);
+        if (ndw) {
+            const uint32_t src = (m >> 8) & 63u, r = (m >> 16) & 15u, sgl = src & (G - 1), sgrp = src / G;
+            const uint32_t tile = (sgl - 1u) / kTileWords, jl = (sgl - 1u) & (kTileWords - 1);
+            atomicAdd(&s_tile[sgrp][tile], ndw);
+            atomicOr(&s_mask[sgrp][tile], 1ull << (4u * r + jl));
+        }
+    };
+    auto wave_sync = []() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
 #pragma unroll
     for (int r0 = 0; r0 < kRows; r0 += kAhead) {
         if (r0 + kAhead < kRows) {
@@ -231,35 +263,36 @@ __global__ __launch_bounds__(64) void k_dart_count(const uint64_t* __restrict__ 
 #pragma unroll
         for (int u = 0; u < kAhead; u++) {
             Row3 dn;
-            dn.c = nxt[u]; edge_bits(dn.c, &dn.lbit, &dn.rbit);
+            dn.c = nxt[u]; edge_bits(dn.c, &dn.lr);
             const uint64_t c = cur.c;
             // no foreground pixel, or a word in the middle of a white area (the word, the words above and below and the
             // six neighbour bits all ones: most words of a frame on white paper): no dart
-            const bool white = (c & up.c & dn.c) == ~0ull && (cur.lbit & cur.rbit & up.lbit & up.rbit & dn.lbit & dn.rbit) != 0u;
-            uint32_t ndw = 0;
-            if (c != 0ull && !white) {
-                Nb8 nb;
-                nb.c = c;
-                nb.n[0] = (c << 1) | cur.lbit;          nb.n[4] = (c >> 1) | ((uint64_t)cur.rbit << 63);
-                nb.n[1] = (up.c << 1) | up.lbit;        nb.n[3] = (up.c >> 1) | ((uint64_t)up.rbit << 63);
-                nb.n[2] = up.c;                         nb.n[6] = dn.c;
-                nb.n[7] = (dn.c << 1) | dn.lbit;        nb.n[5] = (dn.c >> 1) | ((uint64_t)dn.rbit << 63);
-                uint64_t p[8];
-                pdart_words(nb, p);
-#pragma unroll
-                for (int q = 0; q < 8; q++) ndw += __popcll(p[q]);
-                nd += ndw;
+            const bool white = (c & up.c & dn.c) == ~0ull && (cur.lr & up.lr & dn.lr) == 3u;
+            const bool hot = owner && c != 0ull && !white;
+            const unsigned long long bal = __ballot(hot);
+            if (bal) {   // uniform
+                if (hot) {
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    const uint32_t slot = (qtail + below) & (kQ - 1);
+                    q_c[slot] = c; q_up[slot] = up.c; q_dn[slot] = dn.c;
+                    q_meta[slot] = cur.lr | (up.lr << 2) | (dn.lr << 4) | lane_row0 | ((uint32_t)(r0 + u) << 16);
+                }
+                qtail += (uint32_t)__popcll(bal);
+                if (qtail - qhead >= 64u) {   // uniform
+                    wave_sync();
+                    work((qhead + (uint32_t)lane) & (kQ - 1));
+                    qhead += 64u;
+                    wave_sync();
+                }
             }
-            // the four words of a tile sit in four consecutive lanes: their "owns darts" bits are a nibble of the ballot
-            const unsigned long long bal = __ballot(owner && ndw != 0u);
-            acc |= ((bal >> lane) & 0xFull) << (4 * (r0 + u));
             up = cur; cur = dn;
         }
 #pragma unroll
         for (int u = 0; u < kAhead; u++) nxt[u] = ahead[u];
     }
+    wave_sync();
+    if ((uint32_t)lane < qtail - qhead) work((qhead + (uint32_t)lane) & (kQ - 1));
     // a tile is four word columns: sum over its lanes through LDS (one wave per workgroup: no barrier needed)
-    if (owner && nd) atomicAdd(&s_tile[grp][(gl - 1) / kTileWords], nd);
     __builtin_amdgcn_s_waitcnt(0);   // LDS atomics of this wave have landed before it reads the totals back
     __builtin_amdgcn_wave_barrier();
     uint32_t total = 0;
@@ -273,7 +306,7 @@ __global__ __launch_bounds__(64) void k_dart_count(const uint64_t* __restrict__ 
     }
     if (gl >= 1 && gl <= kOwners && ((gl - 1) & (kTileWords - 1)) == 0 && ty < (int)tiles_y) {
         const uint32_t tx = (uint32_t)(cx * kTilesPerGroup + (gl - 1) / kTileWords);
-        if (tx < tiles_x) tile_mask[((size_t)(first_frame + f) * (tiles_x * tiles_y) + ty * tiles_x + tx) * kCountHalves + blockIdx.z] = acc;
+        if (tx < tiles_x) tile_mask[((size_t)(first_frame + f) * (tiles_x * tiles_y) + ty * tiles_x + tx) * kCountHalves + blockIdx.z] = s_mask[grp][(gl - 1) / kTileWords];
     }
     // the wave's total: DPP row shifts and broadcasts leave it in lane 63
 #define A3_DPP_ADD(CTRL, ROWMASK) total += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)total, CTRL, ROWMASK, 0xF, false);
