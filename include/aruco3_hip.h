@@ -124,8 +124,8 @@ int  a3_detect_batch_pose(a3_ctx *ctx, const void *pixels, int memory, int fmt, 
                           const a3_intrinsics *intr, a3_marker *out, a3_pose *poses, size_t out_cap,
                           uint32_t *per_frame_count, size_t *out_n);
 /* The same call in two halves, for callers that keep the GPU fed: submit enqueues the whole batch and returns without
- * waiting; collect waits for it and hands out the results (re-running the batch synchronously in the rare cases a
- *3_detect_batch would).  One batch may be in flight per context; with two contexts on one stream, batch i+1 is
+ * waiting; collect waits for it and hands out the results (re-running the batch synchronously in the rare cases
+ * a3_detect_batch would).  One batch may be in flight per context; with two contexts on one stream, batch i+1 is
  * submitted before batch i is collected.  Device-resident frames and pinned host frames must stay valid until collect;
  * pageable host frames have been read when submit returns.  out_cap of submit bounds the marker list; collect's must not be smaller than what was found. */
 int  a3_detect_batch_submit(a3_ctx *ctx, const void *pixels, int memory, int fmt, uint32_t width, uint32_t height,
@@ -138,7 +138,7 @@ int  a3_detect_batch_pose_submit(a3_ctx *ctx, const void *pixels, int memory, in
 int  a3_detect_batch_pose_collect(a3_ctx *ctx, a3_marker *out, a3_pose *poses, size_t out_cap, uint32_t *per_frame_count,
                                   size_t *out_n);
 
-/* Host frames (A3_MEM_HOST) cross the link on a copy stream of the context, beside the kernels of whatever batch another
+/* Host frames (A3_MEM_HOST) cross the link on the device's copy stream, beside the kernels of whatever batch another
  * context has in flight.  From pageable memory the runtime stages the copy and the call returns once the caller's buffer has
  * been read.  From PINNED memory -- allocated with a3_host_alloc, or the caller's own ring pinned once with a3_host_register
  * (a webcam loop's frame buffers, examples/webcam_kamera.rs:36-71) -- the copy is asynchronous and runs at the link's rate:
