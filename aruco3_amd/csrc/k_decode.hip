@@ -291,7 +291,8 @@ __device__ __forceinline__ float grey_tap(const uint8_t* __restrict__ row, uint3
 __device__ __forceinline__ uint32_t luma_px(uint32_t px, bool bgr) {
     const uint32_t lo = __builtin_amdgcn_udot4(px, bgr ? 0x004EF0D2u : 0x00D2F04Eu, 0u, false);
     const uint32_t hi = __builtin_amdgcn_udot4(px, bgr ? 0x00081B02u : 0x00021B08u, 0u, false);
-    const uint32_t l = lo + (hi << 8);
+    const uint32_t l = lo + (hi << 8);   // <= 10000 * 255 < 2^22
+    __builtin_assume(l < (1u << 22));     // both factors below 2^24: the full-rate v_mul_hi_u32_u24 instead of the quarter-rate v_mul_hi_u32
     return (uint32_t)(((uint64_t)l * 13743896ull) >> 37);
 }
 
@@ -310,26 +311,42 @@ struct TapLoad {
     uint32_t l, t;       // first tap (mode 2 only)
 };
 
-__device__ __forceinline__ void sample_issue(TapLoad& tl, const uint8_t* __restrict__ img, const uint8_t* __restrict__ safe, size_t row_stride,
+// The frame as 4-byte words in the GLOBAL address space: a pointer that went through uintptr_t arithmetic is a generic one to the
+// compiler, and loads through it are flat_load (LDS / scratch aperture checks, and every LDS wait of the loop then waits for
+// them as well); with the base uniform per workgroup and the offset 32 bits wide the tap loads are global_load ... s[base]
+// with no 64-bit address arithmetic per sample.
+typedef const uint32_t __attribute__((address_space(1)))* a3_gptr;
+
+// OffT: uint32_t when the frame's bytes (+ 16) fit 32 bits and a row's stride 24, else uint64_t.  base4 = the frame's first byte rounded down to 4
+// bytes (`mis` = what was rounded off), or any 16 readable bytes when the frame is smaller than one wide read (`tiny`: no
+// sample then takes the wide path).  wide_limit = frame bytes - 12: the last offset at which a 12-byte read ends inside the frame.
+template <typename OffT>
+__device__ __forceinline__ void sample_issue(TapLoad& tl, a3_gptr base4, uint32_t mis, OffT row_stride, OffT wide_limit, bool tiny,
                                              uint32_t bpp, uint32_t w, uint32_t h, float x, float y, bool valid) {
-    // safe: where a sample without wide taps reads instead -- the frame itself, unless it is smaller than one wide read
     const float left = floorf(x), right = left + 1.0f, top = floorf(y), bottom = top + 1.0f;
     tl.rw = x - left; tl.bw = y - top;
     // (bitwise, not short-circuit: no branches)
     const bool inside = valid & !((left < 0.0f) | (right >= (float)w) | (top < 0.0f) | (bottom >= (float)h));
-    const uint32_t l = inside ? sat_u32(left) : 0u, t = inside ? sat_u32(top) : 0u, b = inside ? sat_u32(bottom) : 0u;
+    // (converted unconditionally, selected afterwards: with the conversion inside the ternary each became an exec-mask region)
+    const uint32_t lc = sat_u32(left), tc = sat_u32(top), bc = sat_u32(bottom);
+    const uint32_t l = inside ? lc : 0u, t = inside ? tc : 0u, b = inside ? bc : 0u;
     tl.l = l; tl.t = t;
+    OffT ot, ob;
+    if constexpr (sizeof(OffT) == 4) {   // row index < 2^16, row_stride < 2^24 (the caller's condition for this path), products < 2^32: full-rate 24-bit multiplies
+        const uint32_t xl = __umul24(bpp, l);
+        ot = __umul24(t, (uint32_t)row_stride) + xl; ob = __umul24(b, (uint32_t)row_stride) + xl;
+    } else {
+        ot = (OffT)t * row_stride + (OffT)(bpp * l); ob = (OffT)b * row_stride + (OffT)(bpp * l);
+    }
     // the wide read of the bottom row must end inside this frame (running on into the next row is fine)
-    const bool wide = inside & ((size_t)b * row_stride + (size_t)bpp * l + 12u <= (size_t)(h - 1u) * row_stride + (size_t)w * bpp);
+    const bool wide = inside & !tiny & (ob <= wide_limit);
     tl.mode = inside ? (wide ? 1 : 2) : 0;
-    const uintptr_t pt = reinterpret_cast<uintptr_t>(wide ? img + (size_t)t * row_stride + (size_t)bpp * l : safe);
-    const uintptr_t pb = reinterpret_cast<uintptr_t>(wide ? img + (size_t)b * row_stride + (size_t)bpp * l : safe);
-    const uint32_t* qt = reinterpret_cast<const uint32_t*>(pt & ~(uintptr_t)3);
-    const uint32_t* qb = reinterpret_cast<const uint32_t*>(pb & ~(uintptr_t)3);
+    const OffT at = (wide ? ot : (OffT)0) + (OffT)mis, ab = (wide ? ob : (OffT)0) + (OffT)mis;
+    const a3_gptr qt = base4 + (at >> 2), qb = base4 + (ab >> 2);
     tl.top[0] = qt[0]; tl.top[1] = qt[1]; tl.top[2] = qt[2];
     tl.bot[0] = qb[0]; tl.bot[1] = qb[1]; tl.bot[2] = qb[2];
     // both rows start at the same misalignment only if row_stride % 4 == 0; keep one shift per row in sh's halves
-    tl.sh = ((uint32_t)(pt & 3u) * 8u) | (((uint32_t)(pb & 3u) * 8u) << 8);
+    tl.sh = ((uint32_t)(at & 3u) * 8u) | (((uint32_t)(ab & 3u) * 8u) << 8);
 }
 
 __device__ __forceinline__ void pair_from(const uint32_t d[3], uint32_t sh, int fmt, uint32_t bpp, float* g0, float* g1) {
@@ -553,13 +570,18 @@ __global__ __launch_bounds__(NT, NT == 64 ? A3_D_WAVES : A3_D_WAVES256) void k_d
 #endif
             const uint32_t bpp = (src.fmt == A3_FMT_RGB8) ? 3u : ((src.fmt == A3_FMT_RGBA8 || src.fmt == A3_FMT_BGRA8) ? 4u : 1u);
             // (a frame smaller than one wide read cannot hold a candidate; the weight table is merely something of 16 KB to read)
-            const uint8_t* safe = (size_t)(H - 1) * src.row_stride + (size_t)W * bpp >= 16u ? img : reinterpret_cast<const uint8_t*>(wtab);
+            const unsigned long long frame_bytes = (unsigned long long)(H - 1) * src.row_stride + (unsigned long long)W * bpp;
+            const bool tiny = frame_bytes < 16ull, off32 = frame_bytes < 0xFFFFFFE0ull && src.row_stride < (1ull << 24);
+            const uintptr_t img_u = reinterpret_cast<uintptr_t>(img);
+            const uint32_t mis = tiny ? 0u : (uint32_t)(img_u & 3u);
+            const a3_gptr base4 = reinterpret_cast<a3_gptr>(tiny ? reinterpret_cast<uintptr_t>(wtab) : img_u - mis);
             const uint32_t nbx = (S + 7u) / 8u, n_slots = A3_D_BLOCKED ? nbx * nbx * 64u : S * S;
             // slot -> (x, y); i / S by a multiply-high in the row-major order (S is uniform but not a compile-time constant)
-            const uint32_t M = S > 1 ? 0xFFFFFFFFu / S + 1u : 0u, Mb = 0xFFFFFFFFu / nbx + 1u;
+            // blk / nbx as (blk * Mb) >> 16, Mb = 2^16 / nbx + 1: exact while blk * nbx < 2^16 (blk < nbx^2 <= 625, nbx <= 25), and full rate
+            const uint32_t M = S > 1 ? 0xFFFFFFFFu / S + 1u : 0u, Mb = 65536u / nbx + 1u;
             auto slot_xy = [&](uint32_t slot, uint32_t* x, uint32_t* y) -> bool {
                 if (A3_D_BLOCKED) {
-                    const uint32_t blk = slot >> 6, l = slot & 63u, by = __umulhi(blk, Mb), bx = blk - by * nbx;   // blk < nbx^2 <= 625
+                    const uint32_t blk = slot >> 6, l = slot & 63u, by = __umul24(min(blk, 1023u), Mb) >> 16, bx = blk - __umul24(by, nbx);
                     *x = bx * 8u + (l & 7u); *y = by * 8u + (l >> 3);
                     return slot < n_slots && *x < S && *y < S;
                 }
@@ -577,14 +599,15 @@ __global__ __launch_bounds__(NT, NT == 64 ? A3_D_WAVES : A3_D_WAVES256) void k_d
                     const float d = t6 * fx + t7 * fy + t8;
                     const float px = (t0 * fx + t1 * fy + t2) / d;
                     const float py = (t3 * fx + t4 * fy + t5) / d;
-                    sample_issue(tl[u], img, safe, (size_t)src.row_stride, bpp, (uint32_t)W, (uint32_t)H, px, py, valid);
+                    if (off32) sample_issue<uint32_t>(tl[u], base4, mis, (uint32_t)src.row_stride, (uint32_t)(frame_bytes - 12ull), tiny, bpp, (uint32_t)W, (uint32_t)H, px, py, valid);
+                    else sample_issue<unsigned long long>(tl[u], base4, mis, src.row_stride, frame_bytes - 12ull, tiny, bpp, (uint32_t)W, (uint32_t)H, px, py, valid);
                 }
 #pragma unroll
                 for (int u = 0; u < kU; u++) {
                     uint32_t x, y;
                     if (slot_xy(i0 + (uint32_t)NT * u, &x, &y)) {
                         const uint8_t v = sample_finish(tl[u], img, (size_t)src.row_stride, src.fmt, bpp);
-                        s_patch[y * S + x] = v;
+                        s_patch[__umul24(y, S) + x] = v;
                         atomicAdd(&s_hist[v], 1u);
                     }
                 }
