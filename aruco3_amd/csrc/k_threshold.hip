@@ -376,12 +376,18 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
             // white iff S < (L + 1) * area, two pixels per instruction: T = L * area + area, d = saturating T - S (non-zero
             // iff S < T), bit = min(d, 1), shifted in from the last pair down to the first: acc = acc * 2 + bit
             uint32_t acc = 0u;
+#if defined(A3_TUNING) && defined(A3_K1_PROBE_SKIP_COMPARE)
+            // timing probe (wrong results): the compare stage's 40 instructions per row replaced by 8 that keep S and the centre row alive
+#pragma unroll
+            for (int j = 0; j < T_NP; j++) acc ^= S[j] + centre[j & (T_NG - 1)];
+#else
 #pragma unroll
             for (int j = T_NP - 1; j >= 0; j--) {
                 const uint32_t Lp = byte_pair(j, centre[(j + T_NP) >> 2], centre[j >> 2]);
                 const uint32_t T = pk_mad(Lp, area[j], area[j]);
                 acc = pk_shift_in(acc, pk_nonzero_diff(T, S[j]));
             }
+#endif
             // the bits of pixels 0 .. T_NP-1 sit in the low half of acc, those of pixels T_NP .. in the high half
             const uint32_t outb = T_LPX == 16 ? __builtin_amdgcn_perm(0u, acc, 0x0C0C0200u) : ((acc | (acc >> 12)) & 0xFFu);
             if (flush_rows <= 0) {
