@@ -466,7 +466,7 @@ def main():
             out["gathered"] = gathered
         if use_dist:   # what the ranks themselves saw
             out["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
-                           "launcher": os.environ.get("A3_BENCH_LAUNCHER", "external (torch.distributed.run)"),
+                           "launcher": os.environ.get("A3_BENCH_LAUNCHER", "external (torch.distributed.run)" if "RANK" in os.environ else "none (one process, --force-dist)"),
                            "pack_and_collective": "side stream, started when collect() returns (beside the next batch's kernels)"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames, d)
