@@ -32,7 +32,7 @@ SYMBOLS = [
     "a3_contour_count", "a3_download_contours", "a3_detection_record_bytes", "a3_pack_detections",
 ]
 # aruco3_amd/csrc/a3_internal.h: probes and single-stage hooks for this repository's tests and tools, not for bindings
-INTERNAL_SYMBOLS = ["a3_debug_set_overlap", "a3_debug_kernel_time", "a3_selftest_ieee", "a3_debug_clockwise", "a3_debug_rotate_bits", "a3_debug_discard_too_near"]
+INTERNAL_SYMBOLS = ["a3_debug_set_overlap", "a3_debug_set_k1_waves", "a3_debug_set_partition", "a3_debug_build_flags", "a3_debug_kernel_time", "a3_selftest_ieee", "a3_debug_clockwise", "a3_debug_rotate_bits", "a3_debug_discard_too_near"]
 
 
 class A3Error(RuntimeError):
@@ -155,6 +155,15 @@ def load():
     if hasattr(L, "a3_debug_set_overlap"):      # (older builds loaded through A3_HIP_LIB for A/B runs lack it)
         L.a3_debug_set_overlap.restype = C.c_int
         L.a3_debug_set_overlap.argtypes = [C.c_int]
+    if hasattr(L, "a3_debug_set_k1_waves"):
+        L.a3_debug_set_k1_waves.restype = C.c_int
+        L.a3_debug_set_k1_waves.argtypes = [C.c_int]
+    if hasattr(L, "a3_debug_build_flags"):
+        L.a3_debug_build_flags.restype = C.c_int
+        L.a3_debug_build_flags.argtypes = []
+    if hasattr(L, "a3_debug_set_partition"):
+        L.a3_debug_set_partition.restype = C.c_int
+        L.a3_debug_set_partition.argtypes = [C.c_int, C.c_int]
     L.a3_debug_kernel_time.restype = C.c_int
     L.a3_debug_kernel_time.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.a3_get_stats.restype = C.c_int
@@ -199,6 +208,15 @@ def load():
     L.a3_debug_discard_too_near.argtypes = [vp, u32p, C.c_size_t, C.c_float, u32p, C.POINTER(C.c_size_t)]
     _lib = L
     return L
+
+
+def library_info() -> dict:
+    """which shared library this process runs on (bench.py and the GPU tests put it into their output: a leftover A3_HIP_LIB
+    pointing at a tuning build must not pass for the product)"""
+    L = load()
+    flags = int(L.a3_debug_build_flags()) if hasattr(L, "a3_debug_build_flags") else -1
+    return {"path": str(LIB_PATH), "from_A3_HIP_LIB": bool(os.environ.get("A3_HIP_LIB")), "tuning_build": bool(flags & 1) if flags >= 0 else None,
+            "non_default_kernel_build": bool(flags & 2) if flags >= 0 else None, "abi": int(L.a3_abi_version())}
 
 
 class PinnedBuffer:

@@ -17,6 +17,9 @@
 namespace a3 {
 // k_threshold.hip
 hipError_t launch_grey_threshold(hipStream_t, const uint8_t*, int, size_t, size_t, int, int, uint32_t, uint32_t, uint8_t*, uint64_t*);
+void set_k1_waves(int);
+void set_k1_cus(int);
+bool k1_build_is_default();
 // k_contours.hip
 hipError_t launch_dart_count(hipStream_t, const uint64_t*, int, int, uint32_t, uint32_t, unsigned long long*, uint32_t*, uint64_t, uint32_t*, uint32_t*, void*, size_t);
 size_t tile_darts_bytes(uint32_t W, uint32_t H, uint32_t n_frames);
@@ -141,7 +144,7 @@ struct a3_ctx {
     // Deferred decode (submit / collect with more than one context, see enqueue_batch): the decode stage of a submitted batch
     // runs on the device's decode stream, released from inside the launch sequence of the NEXT submitted batch, so that it shares
     // the GPU with that batch's contour stage (both are latency-bound and leave the chip mostly idle) instead of standing in line.
-    hipEvent_t ev_contours = nullptr, ev_k1 = nullptr;
+    hipEvent_t ev_contours = nullptr, ev_k1 = nullptr, ev_k1_ready = nullptr, ev_k1_done = nullptr;
     bool back_deferred = false;      // guarded by g_defer_mu
     int back_rc = 0;                 // a failed launch of the deferred half, whoever enqueued it (guarded by g_defer_mu): collect reports it
     bool allow_defer = false;        // set by the submit entry points for the batch being enqueued
@@ -304,19 +307,43 @@ int ensure_dart_pool(a3_ctx* ctx, uint64_t darts) {
 // batch's line -- measured: a second set of contexts, each with three streams of its own, lost 10 % where the first set gained
 // 7 %.  So streams are few: ONE decode stream and ONE copy stream per device, shared by all contexts (their work never wants to
 // overlap with itself), created on first use; a context's own stream exists only if the caller never passed one (a3_set_stream).
-struct DeviceStreams { hipStream_t decode = nullptr, copy = nullptr; };
+struct DeviceStreams { hipStream_t decode = nullptr, copy = nullptr, k1 = nullptr; };
 std::mutex g_streams_mu;
 DeviceStreams g_dev_streams[64];
 bool g_decode_low_prio = false;   // (see a3_debug_set_overlap)
+// CU partition (a3_internal.h: a3_debug_set_partition): the threshold kernel of every batch on a device-wide stream restricted to
+// g_part_k1_cus compute units, everything else on streams restricted to the others.  0 = off.
+int g_part_k1_cus = 0, g_part_pattern = 0;
+enum { kStreamCopy = 0, kStreamDecode = 1, kStreamK1 = 2 };
 
-hipError_t device_stream(int device, bool decode, hipStream_t* out) {
+// CU masks of the partition: 256 bits, bit i = compute unit i as the runtime numbers them
+void partition_masks(uint32_t k1[8], uint32_t rest[8]) {
+    for (int i = 0; i < 8; i++) { k1[i] = 0u; rest[i] = 0u; }
+    for (int cu = 0; cu < 256; cu++) {
+        bool to_k1;
+        if (g_part_pattern == 0) to_k1 = cu < g_part_k1_cus;                                   // the first k
+        else to_k1 = ((cu % 16) * g_part_k1_cus) / 256 != (((cu % 16) + 1) * g_part_k1_cus) / 256;   // k/256 of every group of 16
+        (to_k1 ? k1 : rest)[cu >> 5] |= 1u << (cu & 31);
+    }
+}
+
+hipError_t create_stream(hipStream_t* st, int role /* 0 rest, 1 k1 */, int priority) {
+    if (g_part_k1_cus > 0) {
+        uint32_t k1[8], rest[8];
+        partition_masks(k1, rest);
+        return hipExtStreamCreateWithCUMask(st, 8, role ? k1 : rest);
+    }
+    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, priority);
+}
+
+hipError_t device_stream(int device, int kind, hipStream_t* out) {
     std::lock_guard<std::mutex> lk(g_streams_mu);
     DeviceStreams& ds = g_dev_streams[device & 63];
-    hipStream_t& st = decode ? ds.decode : ds.copy;
+    hipStream_t& st = kind == kStreamDecode ? ds.decode : (kind == kStreamK1 ? ds.k1 : ds.copy);
     if (!st) {
         int lo = 0, hi = 0;
         hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, decode && g_decode_low_prio ? lo : 0);
+        if (e == hipSuccess) e = create_stream(&st, kind == kStreamK1 ? 1 : 0, kind == kStreamDecode && g_decode_low_prio ? lo : 0);
         if (e != hipSuccess) { st = nullptr; return e; }
     }
     *out = st;
@@ -388,7 +415,7 @@ int flush_deferred_impl(a3_ctx* ctx, hipEvent_t after) {
     for (size_t i = 0; i < g_deferred.size(); i++)
         if (g_deferred[i] == ctx) { g_deferred.erase(g_deferred.begin() + (long)i); break; }
     hipStream_t ds = nullptr;
-    A3_HIP(device_stream(ctx->device, true, &ds));
+    A3_HIP(device_stream(ctx->device, kStreamDecode, &ds));
     A3_HIP(hipStreamWaitEvent(ds, ctx->ev_contours, 0));
     if (after) A3_HIP(hipStreamWaitEvent(ds, after, 0));
     if (int rc = enqueue_back(ctx, ds, ctx->back)) return rc;
@@ -400,7 +427,7 @@ int need_stream(a3_ctx* ctx) {
     if (ctx->stream) return A3_OK;
     if (!ctx->own_stream) {
         A3_HIP(hipSetDevice(ctx->device));
-        A3_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+        A3_HIP(create_stream(&ctx->own_stream, 0, 0));
     }
     ctx->stream = ctx->own_stream;
     return A3_OK;
@@ -445,10 +472,20 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     // ---- K1 ----
     // (level in force for THIS batch: the sampled threshold-only mode times one batch in profile_every)
     const int prof = ctx->profiling == 1 && (ctx->batch_seq++ % (uint32_t)ctx->profile_every) != 0 ? 0 : ctx->profiling;
-    if (prof) A3_HIP(hipEventRecord(ctx->ev[0], st));
-    A3_HIP(launch_grey_threshold(st, pixels, fmt, row_stride, frame_stride, (int)W, (int)H, n, ctx->cfg.threshold_window,
+    hipStream_t k1st = st;
+    if (g_part_k1_cus > 0) {   // CU partition: the threshold kernel runs on the device's K1 stream, between two events
+        A3_HIP(device_stream(ctx->device, kStreamK1, &k1st));
+        A3_HIP(hipEventRecord(ctx->ev_k1_ready, st));
+        A3_HIP(hipStreamWaitEvent(k1st, ctx->ev_k1_ready, 0));
+    }
+    if (prof) A3_HIP(hipEventRecord(ctx->ev[0], k1st));
+    A3_HIP(launch_grey_threshold(k1st, pixels, fmt, row_stride, frame_stride, (int)W, (int)H, n, ctx->cfg.threshold_window,
                                  need_grey ? ctx->grey.as<uint8_t>() : nullptr, ctx->bin.as<uint64_t>()));
-    if (prof) A3_HIP(hipEventRecord(ctx->ev[1], st));
+    if (prof) A3_HIP(hipEventRecord(ctx->ev[1], k1st));
+    if (k1st != st) {
+        A3_HIP(hipEventRecord(ctx->ev_k1_done, k1st));
+        A3_HIP(hipStreamWaitEvent(st, ctx->ev_k1_done, 0));
+    }
     // batches of OTHER contexts (same device) that wait with their decode stage are released from inside this batch's launch
     // sequence (see g_overlap_mode): `release_point(true)` records the event they wait for and enqueues them
     bool released = false;
@@ -870,6 +907,8 @@ int a3_create(int device, const a3_config* cfg, const uint64_t* codes, size_t n_
     hipError_t e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_contours, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_k1, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_k1_ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_k1_done, hipEventDisableTiming);
     if (e != hipSuccess) { a3_destroy(c); ctx = nullptr; return fail(ctx, A3_ERR_HIP, "hipEventCreate", e); }
     for (auto& ev : c->ev) {
         e = hipEventCreate(&ev);
@@ -909,6 +948,7 @@ void a3_destroy(a3_ctx* ctx) {
         const DeviceStreams& ds = g_dev_streams[ctx->device & 63];
         if (ds.decode) (void)hipStreamSynchronize(ds.decode);
         if (ds.copy) (void)hipStreamSynchronize(ds.copy);
+        if (ds.k1) (void)hipStreamSynchronize(ds.k1);
     }
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     DevBuf* bufs[] = {&ctx->dict, &ctx->in, &ctx->grey, &ctx->bin, &ctx->frame_darts, &ctx->frame_darts_dev, &ctx->frame_base, &ctx->pix_base,
@@ -924,6 +964,8 @@ void a3_destroy(a3_ctx* ctx) {
     if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
     if (ctx->ev_contours) (void)hipEventDestroy(ctx->ev_contours);
     if (ctx->ev_k1) (void)hipEventDestroy(ctx->ev_k1);
+    if (ctx->ev_k1_ready) (void)hipEventDestroy(ctx->ev_k1_ready);
+    if (ctx->ev_k1_done) (void)hipEventDestroy(ctx->ev_k1_done);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -1012,7 +1054,7 @@ static int stage_input(a3_ctx* ctx, const void* pixels, int memory, int fmt, uin
         // returns when the caller's buffer has been read; pinned memory (a3_host_alloc / a3_host_register) makes the copy
         // asynchronous and the buffer must then stay untouched until the batch is collected.
         hipStream_t cs = nullptr;
-        A3_HIP(device_stream(ctx->device, false, &cs));
+        A3_HIP(device_stream(ctx->device, kStreamCopy, &cs));
         A3_HIP(hipMemcpyAsync(ctx->in.p, pixels, bytes, hipMemcpyHostToDevice, cs));
         A3_HIP(hipEventRecord(ctx->ev_in, cs));
         A3_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_in, 0));
@@ -1194,6 +1236,26 @@ int a3_debug_set_overlap(int mode) {   // bits 0-7: mode; bit 8: a decode stream
     { std::lock_guard<std::mutex> lk2(g_streams_mu); g_decode_low_prio = (mode & 0x100) != 0; }
     return A3_OK;
 }
+
+// bit 0: built with -DA3_TUNING (environment knobs are read), bit 1: any other non-default build flag of the kernels
+int a3_debug_build_flags(void) {
+    int f = 0;
+#ifdef A3_TUNING
+    f |= 1;
+#endif
+    f |= k1_build_is_default() ? 0 : 2;
+    return f;
+}
+
+int a3_debug_set_partition(int k1_cus, int pattern) {   // before the first context of the process is used
+    if (k1_cus < 0 || k1_cus > 248) return A3_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(g_streams_mu);
+    g_part_k1_cus = k1_cus; g_part_pattern = pattern;
+    set_k1_cus(k1_cus > 0 ? k1_cus : 256);
+    return A3_OK;
+}
+
+int a3_debug_set_k1_waves(int waves_per_simd) { set_k1_waves(waves_per_simd); return A3_OK; }
 
 int a3_synth_render(int device, void* hip_stream, const a3_synth_frame* frames, uint32_t n_frames, const a3_synth_marker* markers,
                     uint32_t n_markers, uint32_t width, uint32_t height, int paper, float black, float white, int supersample,

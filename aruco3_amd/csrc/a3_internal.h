@@ -23,6 +23,19 @@ int  a3_debug_kernel_time(a3_ctx *ctx, int kernel, int dbg, int reps, float *avg
  * decode stream of the lowest priority instead of the default one.  Process-wide; results are identical in every mode -- tools/ use it for A/B timing inside one process, since two boxes of the pool differ by more than the effect. */
 int  a3_debug_set_overlap(int mode);
 
+/* K1 waves per SIMD the threshold kernel's strip model sizes its launches for (2: the whole chip in one round; 1: one wave per
+ * SIMD, twice as tall strips).  Process-wide; results are identical. */
+int  a3_debug_set_k1_waves(int waves_per_simd);
+
+/* which build this is: bit 0 = -DA3_TUNING (the library reads tuning knobs from the environment), bit 1 = a non-default kernel
+ * build option (A3_T_LPX, A3_T_WAVES ...).  0 for the product library; bench.py and the GPU tests report it. */
+int  a3_debug_build_flags(void);
+
+/* CU partition (measurement aid): the threshold kernel of every batch on a device-wide stream restricted to k1_cus compute units
+ * (hipExtStreamCreateWithCUMask), every other stream the library creates restricted to the remaining ones.  pattern 0: the first
+ * k1_cus units as the runtime numbers them, 1: the same share of every group of 16.  0 = off.  Call before any context is used. */
+int  a3_debug_set_partition(int k1_cus, int pattern);
+
 /* numerics self-check used by the GPU tests: evaluates the IEEE operations the kernels rely on (f64 sqrt/div, f32 sqrt/div)
  * for n inputs so that the host can compare them bit for bit */
 int  a3_selftest_ieee(a3_ctx *ctx, const double *a, const double *b, size_t n, double *sqrt_a, double *a_div_b,

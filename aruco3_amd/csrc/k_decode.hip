@@ -35,7 +35,10 @@ __device__ bool solve_projection(const float* from, float S, float* inv_out);
 // one wave per frame.  cands: unordered CandRec[max_cand] per frame (as k_contour_quads appended them).
 // proj != nullptr: the wave also solves the projection of every surviving candidate (one lane each: the 8x8 system needs
 // ~200 VGPRs, affordable in a one-wave workgroup) into proj[work index], which saves the separate k_projection launch.
-__global__ __launch_bounds__(64) void k_frame_candidates(const CandRec* __restrict__ cands, const uint32_t* __restrict__ cand_count,
+#ifndef A3_FC_WAVES
+#define A3_FC_WAVES 1
+#endif
+__global__ __launch_bounds__(64, A3_FC_WAVES) void k_frame_candidates(const CandRec* __restrict__ cands, const uint32_t* __restrict__ cand_count,
                                                          uint32_t max_cand, float min_distance, uint16_t* __restrict__ pre_xy,
                                                          uint16_t* __restrict__ fin_xy, uint32_t* __restrict__ fin_count,
                                                          uint32_t* __restrict__ work, unsigned int* __restrict__ work_count,
@@ -413,7 +416,7 @@ __global__ void k_weight_table(uint32_t S, uint32_t n, uint32_t max_taps, float*
     const uint32_t left = resize_weights(S, n, threadIdx.x, row + 2, &cnt);
     row[0] = __uint_as_float(left); row[1] = __uint_as_float(cnt);
 }
-__global__ __launch_bounds__(64) void k_projection(const uint16_t* __restrict__ fin_xy, const uint32_t* __restrict__ work,
+__global__ __launch_bounds__(64, A3_FC_WAVES) void k_projection(const uint16_t* __restrict__ fin_xy, const uint32_t* __restrict__ work,
                                                    const unsigned int* __restrict__ work_count, uint32_t S, ProjRec* __restrict__ proj) {
     const uint32_t n_work = *work_count;
     for (uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x; wi < n_work; wi += gridDim.x * blockDim.x) {

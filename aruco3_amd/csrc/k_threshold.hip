@@ -37,8 +37,11 @@ constexpr int T_R = 7;               // fast path radius (threshold_window = 7)
 #ifndef A3_T_PF
 #define A3_T_PF 3
 #endif
+#ifndef A3_T_RECOMPUTE
+#define A3_T_RECOMPUTE 0
+#endif
 #ifndef A3_T_WAVES
-#define A3_T_WAVES (A3_T_LPX == 8 ? 3 : 2)
+#define A3_T_WAVES ((A3_T_LPX == 8 || A3_T_RECOMPUTE) ? 3 : 2)
 #endif
 // Pixels per lane and row.  16 (the default): 256 VGPRs (the ring of row sums alone is 120), two waves per SIMD.  8: every
 // per-lane array halves, 144 VGPRs, three waves per SIMD -- built to see whether occupancy was what kept the kernel (stores off)
@@ -49,7 +52,6 @@ static_assert(T_LPX == 8 || T_LPX == 16, "a lane owns 8 or 16 consecutive pixels
 constexpr int T_NG = T_LPX / 4;      // grey dwords per lane and row
 constexpr int T_NP = T_LPX / 2;      // packed pairs per lane and row: pixel j with pixel j + T_NP
 constexpr int T_OUT = 62 * T_LPX;    // output columns per wave (lanes 0 and 63 only feed their neighbours)
-constexpr int T_PF = A3_T_PF;        // rows of loads kept in flight per lane
 typedef typename std::conditional<T_LPX == 16, uint16_t, uint8_t>::type out_bits_t;   // a lane's result bits of one row
 
 
@@ -238,8 +240,8 @@ __device__ __forceinline__ void row_sums(const uint32_t g[T_NG], uint32_t Hp[T_N
 // packed u16 pairs (pixel j with pixel j + T_NP); the row 7 iterations old is then thresholded: sum < (L+1)*area.
 // No barriers; T_PF rows of loads stay in flight per lane; LDS only parks the result bits between bursts of stores.
 // grid: 8 * ceil(frames / 8) * strips_x * strips_y workgroups of one wave.
-template <int FMT, bool FAST>
-__global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_t* __restrict__ pixels, size_t row_stride, size_t frame_stride,
+template <int FMT, bool FAST, int T_PF = A3_T_PF>
+__global__ __launch_bounds__(64, T_PF == A3_T_PF ? A3_T_WAVES : 1) void k_grey_threshold7(const uint8_t* __restrict__ pixels, size_t row_stride, size_t frame_stride,
                                                         int W, int H, int rows_per_wave, int strips_y, int n_pairs,
                                                         uint8_t* __restrict__ grey,
                                                         uint8_t* __restrict__ bits, int aligned_in, int aligned_out, int map_by_frame,
@@ -290,7 +292,9 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
     uint32_t ay_cur = 0;
     uint32_t gring[15][T_NG];  // grey rows; row `it` lives in slot it % 15 (static: the row loop is unrolled 15x); a row is read
                                // again 7 iterations later, so only 8 of the slots are live at any time
+#if !A3_T_RECOMPUTE
     uint32_t hring[15][T_NP];  // the last 15 rows of horizontal sums (pairs)
+#endif
     uint32_t S[T_NP];          // 15x15 window sums of the row 7 iterations old (pairs)
 #pragma unroll
     for (int i = 0; i < T_NP; i++) S[i] = 0u;
@@ -298,8 +302,10 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
     for (int q = 0; q < 15; q++) {
 #pragma unroll
         for (int i = 0; i < T_NG; i++) gring[q][i] = 0u;
+#if !A3_T_RECOMPUTE
 #pragma unroll
         for (int i = 0; i < T_NP; i++) hring[q][i] = 0u;
+#endif
     }
 
     // Odd strips walk upwards.  Strip k (going down) and strip k+1 (going up) then both reach their common boundary --
@@ -358,8 +364,17 @@ __global__ __launch_bounds__(64, A3_T_WAVES) void k_grey_threshold7(const uint8_
             // entered 15 iterations ago (they never underflow: the add comes first and the true sum is >= 0)
             uint32_t Hn[T_NP];
             row_sums(g, Hn);
+#if A3_T_RECOMPUTE
+            {   // the sums of the row that leaves the window are formed again from its grey bytes (slot k15 still holds that row)
+                uint32_t Ho[T_NP];
+                row_sums(gring[k15], Ho);
+#pragma unroll
+                for (int j = 0; j < T_NP; j++) S[j] = pk_sub(pk_add(S[j], Hn[j]), Ho[j]);
+            }
+#else
 #pragma unroll
             for (int j = 0; j < T_NP; j++) { S[j] = pk_sub(pk_add(S[j], Hn[j]), hring[k15][j]); hring[k15][j] = Hn[j]; }
+#endif
 #pragma unroll
             for (int i = 0; i < T_NG; i++) gring[k15][i] = g[i];
             const uint32_t* centre = gring[(k15 + 8) % 15];   // the row 7 iterations old: the one being thresholded
@@ -450,6 +465,15 @@ __global__ __launch_bounds__(64) void k_threshold_generic(const uint8_t* __restr
 }
 
 // ---- host launcher -------------------------------------------------------------------------
+// K1 waves per SIMD the strip model sizes a launch for (a3_internal.h: a3_debug_set_k1_waves).  2 = the whole chip in one
+// round (every register of every SIMD); 1 = one wave per SIMD, strips twice as tall: half of every SIMD's registers and wave
+// slots stay free for the kernels of another batch's contour / decode stage.
+static int g_k1_waves = A3_T_WAVES;
+void set_k1_waves(int w) { g_k1_waves = w < 1 ? 1 : (w > A3_T_WAVES ? A3_T_WAVES : w); }
+bool k1_build_is_default() { return A3_T_LPX == 16 && A3_T_PF == 3 && A3_T_WAVES == 2 && A3_T_RECOMPUTE == 0; }
+static int g_k1_cus = 256;   // compute units the kernel's stream may use (a3_debug_set_partition)
+void set_k1_cus(int c) { g_k1_cus = c < 8 ? 8 : (c > 256 ? 256 : c); }
+
 hipError_t launch_grey_threshold(hipStream_t st, const uint8_t* pixels, int fmt, size_t row_stride, size_t frame_stride, int W, int H,
                                  uint32_t n, uint32_t radius, uint8_t* grey, uint64_t* bits) {
     if (radius == (uint32_t)T_R) {
@@ -466,7 +490,7 @@ hipError_t launch_grey_threshold(hipStream_t st, const uint8_t* pixels, int fmt,
         // strip count (at least 16 rows per strip).  256 frames of 1920x1080 with 8 pixels per lane: 4 column strips x 3 strips of
         // 360 rows = 3072 waves = exactly one round of three waves per SIMD.
         const int strips_x = (W + T_OUT - 1) / T_OUT;
-        const long long slots = 256LL * 4 * A3_T_WAVES, cols = (long long)strips_x * n;
+        const long long slots = (long long)g_k1_cus * 4 * g_k1_waves, cols = (long long)strips_x * n;
         int best_sy = 1; double best_cost = 1e300;
         for (int sy = 1; sy <= std::max(1, H / 16); sy++) {
             const int rows = (H + sy - 1) / sy;
@@ -484,7 +508,9 @@ hipError_t launch_grey_threshold(hipStream_t st, const uint8_t* pixels, int fmt,
         // rows of results a wave parks in LDS before it writes them out (0: store row by row): 128 (+15) rows x 64 lanes x 1 or 2
         // bytes = 9 or 18 KB per wave; twelve resp. eight waves per CU fit the 160 KB
         // (-1 = "no stores at all" is a timing probe that leaves the binary image stale: it exists in -DA3_TUNING builds only)
-        const int fv = tuning_knob("A3_K1_FLUSH", 128);
+        // (every resident wave's parking area must fit the CU's 160 KB: 4 x A3_T_WAVES waves)
+        constexpr int flush_cap = (160 * 1024 / (4 * A3_T_WAVES)) / (64 * (int)sizeof(out_bits_t)) - 15;
+        const int fv = tuning_knob("A3_K1_FLUSH", flush_cap < 128 ? flush_cap : 128);
 #ifdef A3_TUNING
         const int flush_rows = fv < 0 ? -1 : std::min(fv, rows_per_wave);
 #else
@@ -493,9 +519,9 @@ hipError_t launch_grey_threshold(hipStream_t st, const uint8_t* pixels, int fmt,
         const size_t lds_bytes = flush_rows > 0 ? (size_t)(flush_rows + 15) * 64 * sizeof(out_bits_t) : 0;
         dim3 grid(map_by_frame ? 8 * (((int)n + 7) / 8) * strips_x * strips_y : 8 * ((n_pairs + 7) / 8) * strips_y), block(64);
         const bool fast = aligned_in && aligned_out;   // W % 16 == 0: a lane's 16 pixels are all inside or all outside
-#define A3_LAUNCH_K1(F, B) hipLaunchKernelGGL((k_grey_threshold7<F, B>), grid, block, lds_bytes, st, pixels, row_stride, frame_stride, W, H, \
+#define A3_LAUNCH_K1(F, B, ...) hipLaunchKernelGGL((k_grey_threshold7<F, B __VA_OPT__(,) __VA_ARGS__>), grid, block, lds_bytes, st, pixels, row_stride, frame_stride, W, H, \
                                               rows_per_wave, strips_y, n_pairs, grey, bin, aligned_in, aligned_out, map_by_frame, flush_rows)
-        if (fmt == A3_FMT_RGB8) { if (fast) A3_LAUNCH_K1(A3_FMT_RGB8, true); else A3_LAUNCH_K1(A3_FMT_RGB8, false); }
+        if (fmt == A3_FMT_RGB8) { if (fast && g_k1_waves == 1 && A3_T_WAVES != 1) A3_LAUNCH_K1(A3_FMT_RGB8, true, 5); else if (fast) A3_LAUNCH_K1(A3_FMT_RGB8, true); else A3_LAUNCH_K1(A3_FMT_RGB8, false); }
         else if (fmt == A3_FMT_RGBA8) { if (fast) A3_LAUNCH_K1(A3_FMT_RGBA8, true); else A3_LAUNCH_K1(A3_FMT_RGBA8, false); }
         else if (fmt == A3_FMT_BGRA8) { if (fast) A3_LAUNCH_K1(A3_FMT_BGRA8, true); else A3_LAUNCH_K1(A3_FMT_BGRA8, false); }
         else { if (fast) A3_LAUNCH_K1(A3_FMT_L8, true); else A3_LAUNCH_K1(A3_FMT_L8, false); }

@@ -27,12 +27,25 @@ sys.path.insert(0, str(ROOT))
 # collide (measured: the two free-running contexts then run in lock-step).  Must be set before the runtime starts.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-FRAMES_PER_GPU = 256
-WIDTH, HEIGHT = 1920, 1080
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 K1_BYTES_PER_PIXEL = 3.125         # what K1 has to move: 3 B RGB read + 1/8 B bit-packed binary written; NO grey plane is written
 K1_SURVEY_BYTES_PER_PIXEL = 5      # SURVEY.md section 8d's figure (3 B read + 1 B grey + 1 B byte-wide binary): reported separately
-PROFILE_TAGS = ("r03", "r02")      # profiles/<tag>_pmc_bench_c2.json holds the PMC passes of this same command (newest first)
+E2E_BYTES_PER_PIXEL = 3.25         # what one step must move end to end: K1's 3.125 B/px + the 1/8 B/px re-read of the packed image
+PROFILE_TAGS = ("r04", "r03", "r02")   # profiles/<tag>_pmc_bench_c2.json holds the PMC passes of this same command (newest first)
+
+# the workloads this file can step (BASELINE.json configs): c2 is the one the metric is quoted on and the default; c5 is the
+# 3840x2160 detect + estimate_pose configuration (BASELINE config 5: `--workload c5 --gpus 4`)
+WORKLOADS = {
+    "c2": {"config": 2, "frames": 256, "pose_mm": None,
+           "metric": "frames/sec at 1920x1080 ARUCO dict",
+           "label": "BASELINE config 2: batch of {n} x 1920x1080 synthetic RGB frames per GPU, ARUCO dict, 4-8 markers per frame, frames resident "
+                    "in HBM; Detector::detect end to end (grey, threshold, contours, quads, warp+decode, lookup) incl. D2H of the marker list"},
+    "c5": {"config": 5, "frames": 16, "pose_mm": 40.0,
+           "metric": "frames/sec at 3840x2160 ARUCO dict, detect + estimate_pose",
+           "label": "BASELINE config 5: batch of {n} x 3840x2160 synthetic RGB frames per GPU, ARUCO dict, 16 markers per frame, frames resident "
+                    "in HBM; Detector::detect + solve_with_undistorted_points of every marker (a3_detect_batch_pose_submit / _collect), "
+                    "D2H of markers and pose pairs"},
+}
 
 
 def _render(args):
@@ -46,9 +59,9 @@ def _render(args):
     return img, [t.id for t in truth]
 
 
-def make_frames(first, count, workers):
-    """Config-2 frames `first .. first+count` (seeded per frame index), rendered by a process pool on the host."""
-    jobs = [(2, first + i) for i in range(count)]
+def make_frames(config, first, count, workers):
+    """Frames `first .. first+count` of a BASELINE config (seeded per frame index), rendered by a process pool on the host."""
+    jobs = [(config, first + i) for i in range(count)]
     if workers > 1:
         with mp.get_context("fork").Pool(workers) as pool:
             res = pool.map(_render, jobs, chunksize=4)
@@ -58,39 +71,67 @@ def make_frames(first, count, workers):
     return frames, [r[1] for r in res]
 
 
+def split_by_frame(markers, per):
+    out, pos = [], 0
+    for c in per:
+        out.append(markers[pos: pos + int(c)]); pos += int(c)
+    return out
+
+
+def hip_marker_tuples(arr):
+    return [(int(m["id"]), int(m["code"]), tuple(int(v) for v in m["corners"]), int(m["hamming_distance"]), int(m["rotation"])) for m in arr]
+
+
+def oracle_marker_tuples(res):
+    return [(m["id"], m["code"], tuple(v for c in m["corners"] for v in c), m["hamming_distance"], m["rotation"]) for m in res["markers"]]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
+    ap.add_argument("--workload", choices=tuple(WORKLOADS), default="c2", help="c2 (default): BASELINE config 2, the configuration the metric is quoted "
+                                                                                "on; c5: BASELINE config 5 (3840x2160, 16 markers, detect + pose)")
+    ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (0 = the workload's: 256 for c2, 16 for c5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--device-synth", action="store_true", help="render the frames on the GPU (a3_synth_render) instead of on the host: no "
                                                                   "host rendering, no H2D copy (same layouts and ids; pixels may differ by "
                                                                   "a grey level at cell edges)")
-    ap.add_argument("--no-pipeline", action="store_true", help="one context, a3_detect_batch per step (the GPU idles while the host "
-                                                                "collects a batch); default: two contexts on one stream, step i+1 is "
-                                                                "submitted before step i is collected")
+    ap.add_argument("--no-pipeline", action="store_true", help="one context, a3_detect_batch per step: every kernel runs alone (the GPU idles "
+                                                                "while the host collects a batch)")
+    ap.add_argument("--contexts", type=int, default=0, help="contexts in flight (submit / collect in rotation); 0 = 4 with --streams own, 2 with shared")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
                                                        "multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--synth-workers", type=int, default=0, help="host processes rendering frames (0 = auto)")
     ap.add_argument("--repeats", type=int, default=0, help="the timed region (exactly --steps steps between barrier + synchronize) is run "
                                                            "this many times back to back; the median is reported, every value listed "
-                                                           "(20 steps are 16 ms: one region alone measures clocks ramping).  0 = as many as "
+                                                           "(20 steps are 13 ms: one region alone measures clocks ramping).  0 = as many as "
                                                            "make the timed regions total --min-timed-s seconds, at least 25")
     ap.add_argument("--min-timed-s", type=float, default=3.0, help="with --repeats 0: seconds the timed regions add up to (the GPU is busy that long)")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-rank code path (process group, dictionary broadcast, device-packed "
                                                                 "records, all-gather) even with one rank: lets a 1-GPU box exercise the RCCL branch")
-    ap.add_argument("--no-other-workloads", action="store_true", help="skip the other_workloads block (reference bench recipe, configs 4 and 5)")
-    ap.add_argument("--streams", choices=("own", "shared"), default="shared",
-                    help="shared: both contexts enqueue on ONE stream (steps run in order; only the deferred decode stage overlaps); "
-                         "own: every context on a stream of its own (consecutive steps overlap wherever the GPU has room)")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the other_workloads block (reference bench recipe, configs 4 and 5) and the "
+                                                                       "shared-stream A/B")
+    ap.add_argument("--streams", choices=("own", "shared"), default="own",
+                    help="own (default): every context on a stream of its own -- the threshold kernels of consecutive batches serialise (each "
+                         "fills the chip's register file), the contour / decode chains of the batches in flight overlap one another; "
+                         "shared: all contexts enqueue on ONE stream (steps run in order; only the deferred decode stage overlaps)")
     ap.add_argument("--overlap", type=int, default=-1, help="measurement aid (a3_internal.h: a3_debug_set_overlap): where the decode stage of a "
-                                                            "submitted batch is released, 0 never deferred / 1 / 2; -1 = the library's default")
+                                                            "submitted batch is released, 0 never deferred / 1 / 2; -1 = 0 with --streams own, "
+                                                            "the library's default (2) with shared")
+    ap.add_argument("--isolated-launches", type=int, default=24, help="synchronous batches run one at a time, every stage between events, before the "
+                                                                      "timed steps: the threshold kernel's launch duration ALONE (roofline) and the stage table")
+    ap.add_argument("--max-markers", type=int, default=0, help="N > 1: markers per frame a gather record holds; 0 = calibrated on the first batch "
+                                                               "(2 x the largest count on any rank, at least 8); a frame that holds more later is an error, never a clip")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="N > 1 started without a launcher: seconds the parent waits for its ranks")
     ap.add_argument("--frames-cache", default="", help="npz path: reuse rendered frames between runs (profiling runs use it so that "
                                                         "nothing forks under the profiler)")
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    if args.frames <= 0:
+        args.frames = wl["frames"]
+    pose_mm = wl["pose_mm"]
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # `python bench.py --gpus N` typed as is: this process becomes the launcher.  It has not imported torch and never touches
@@ -106,7 +147,7 @@ def main():
     # host-side frame synthesis first (forks a pool; nothing has touched the GPU yet)
     workers = args.synth_workers or max(1, min(16, (os.cpu_count() or 8) // max(1, world)))
     t0 = time.time()
-    cache = Path(f"{args.frames_cache}.n{args.frames}.r{rank}.npz") if args.frames_cache else None
+    cache = Path(f"{args.frames_cache}.{args.workload}.n{args.frames}.r{rank}.npz") if args.frames_cache else None
     if args.device_synth:
         frames, truth_ids = None, None        # rendered below, once the device is set up
     elif cache is not None and cache.exists():
@@ -114,7 +155,7 @@ def main():
         frames, truth_ids = z["frames"], [list(t) for t in z["truth"]]
         assert frames.shape[0] == args.frames
     else:
-        frames, truth_ids = make_frames(rank * args.frames, args.frames, workers)
+        frames, truth_ids = make_frames(wl["config"], rank * args.frames, args.frames, workers)
         if cache is not None:
             cache.parent.mkdir(parents=True, exist_ok=True)
             np.savez(cache, frames=frames, truth=np.array(truth_ids, dtype=object))
@@ -123,7 +164,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from aruco3_amd import _lib, shard
+    from aruco3_amd import _lib, shard, synth
     from aruco3_amd.aruco import Detector, DetectorConfig
     from aruco3_amd.dictionaries import ARDictionary
 
@@ -141,30 +182,28 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    if args.overlap >= 0:
-        assert _lib.load().a3_debug_set_overlap(args.overlap) == 0
-    d = ARDictionary.new_from_named_dict("ARUCO") if rank == 0 or world == 1 else None
+    own_streams = args.streams == "own" and not args.no_pipeline
+    n_ctx = 1 if args.no_pipeline else (args.contexts or (4 if own_streams else 2))
+    overlap_mode = args.overlap if args.overlap >= 0 else (0 if own_streams else 2)
+    L = _lib.load()
+    assert L.a3_debug_set_overlap(overlap_mode) == 0
+    spec, dict_name = synth.config_spec(wl["config"])
+    d = ARDictionary.new_from_named_dict(dict_name) if rank == 0 or world == 1 else None
     if use_dist:
         d = shard.broadcast_dictionary(d, coll_dev, 0)   # RCCL broadcast, once
-    # two contexts on ONE stream: kernels of consecutive steps never overlap (K1 is timed alone), but the host enqueues step
-    # i+1 while step i runs, so the GPU does not idle between steps
-    dets = [Detector(DetectorConfig.default(), d, device=local_rank) for _ in range(1 if args.no_pipeline else 2)]
+    dets = [Detector(DetectorConfig.default(), d, device=local_rank) for _ in range(n_ctx)]
     ctxs = [x._context() for x in dets]
     stream = torch.cuda.Stream(device=dev)   # an explicit stream: handle 0 (the default stream) would mean "the context's own"
-    own_streams = args.streams == "own" and not args.no_pipeline
     for ctx in ctxs:
         if not own_streams:
             ctx.set_stream(stream.cuda_stream)
-        ctx.set_profiling(True)
     # the stream every context enqueues on, as a torch stream (for the waits on the pack of its previous batch)
     ctx_stream = {id(cx): (torch.cuda.ExternalStream(cx.stream_ptr, device=dev) if own_streams else stream) for cx in ctxs}
     ctx_stream_ptr = {id(cx): cx.stream_ptr for cx in ctxs}
     ctx = ctxs[0]
 
     if args.device_synth:
-        from aruco3_amd import synth
-        spec, _ = synth.config_spec(2)
-        seeds = [synth.frame_seed(2, rank * args.frames + i) for i in range(args.frames)]
+        seeds = [synth.frame_seed(wl["config"], rank * args.frames + i) for i in range(args.frames)]
         t0 = time.time()
         d_frames, truths = synth.render_frames_device(spec, d.code_list, d.num_bits, seeds, device=local_rank)
         truth_ids = [[t.id for t in tr] for tr in truths]
@@ -175,25 +214,50 @@ def main():
     torch.cuda.synchronize()
     n, h, w, c = d_frames.shape
     first_frame = rank * args.frames
+    out_cap = n * 64
 
     batch_args = (d_frames.data_ptr(), _lib.MEM_DEVICE, _lib.FMT_RGB8, w, h, w * c, h * w * c, n)
 
-    last_gather = [None]
-    side = torch.cuda.Stream(device=dev)   # pack + collective run beside the detection stream, not in it
-    pack_done = {}                         # context -> event after its pack: the context's next batch overwrites the marker list
+    def detect_sync(cx):
+        if pose_mm:
+            return cx.detect_batch_pose(*batch_args, pose_mm, None, out_cap)
+        return cx.detect_batch(*batch_args, out_cap=out_cap)
 
+    def submit_raw(cx):
+        if pose_mm:
+            cx.submit_pose(*batch_args, pose_mm, None, out_cap)
+        else:
+            cx.submit(*batch_args, out_cap=out_cap)
+
+    def collect_raw(cx):
+        return cx.collect_pose() if pose_mm else cx.collect()
+
+    # set-up, not steps: every context allocates its device buffers on its first batches (hipMalloc is slow and synchronous)
+    for cx in ctxs:
+        for _ in range(2):
+            res0 = detect_sync(cx)
+
+    # markers per frame a gather record holds: from the argument, or calibrated on the first batch over all ranks
+    maxm = args.max_markers
+    if use_dist and maxm <= 0:
+        t = torch.tensor([int(res0[1].max()) if len(res0[1]) else 0], dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        maxm = max(8, 2 * int(t[0]))
+
+    last_gather = [None]
+    side = torch.cuda.Stream(device=dev)   # pack + collective run beside the detection streams, not in them
+    pack_done = {}                         # context -> event after its pack: the context's next batch overwrites the marker list
     pinned_rec = {}
 
     def pack(cx):
         # Per batch: fixed-capacity records written by a kernel from the device-resident marker list (a3_pack_detections); no host
         # copy in between.  collect() has returned, so batch i is complete: its pack needs no ordering against the detection
-        # stream and goes to the side stream AT ONCE, beside the kernels of the batches already submitted -- queued on the
-        # detection stream it would start a whole step late.  Only the enqueue happens here; the collective follows
-        # in all_gather(), after the next batch has been submitted.
+        # stream and goes to the side stream AT ONCE, beside the kernels of the batches already submitted.  Only the enqueue happens
+        # here; the collective follows in all_gather(), after the next batch has been submitted.
         cx.set_stream(side.cuda_stream)
         try:
             with torch.cuda.stream(side):
-                rec = shard.pack_detections_device(cx, n, first_frame, dev)
+                rec = shard.pack_detections_device(cx, n, first_frame, dev, maxm=maxm, with_poses=bool(pose_mm))
                 pack_done[id(cx)] = side.record_event()
         finally:
             cx.set_stream(ctx_stream_ptr[id(cx)])
@@ -214,174 +278,153 @@ def main():
         ev = pack_done.pop(id(cx), None)
         if ev is not None:
             ctx_stream[id(cx)].wait_event(ev)        # the pack of this context's previous batch has read the marker list
-        cx.submit(*batch_args, out_cap=n * 64)
+        submit_raw(cx)
 
     def run_steps(k):
         """k steps; a step = one pass of Detector::detect over the rank's batch, results on the host (and all-gathered)."""
-        markers, per = None, None
+        res = None
         if args.no_pipeline:
             for _ in range(k):
                 ev = pack_done.pop(id(ctx), None)
                 if ev is not None:
                     ctx_stream[id(ctx)].wait_event(ev)
-                markers, per = ctx.detect_batch(*batch_args, out_cap=n * 64)
+                res = detect_sync(ctx)
                 if use_dist:
                     all_gather(pack(ctx))
-            return markers, per
-        # Two batches ahead of the host: batch i+2 goes out (on the context batch i has just been collected from) before anything
-        # else happens, so the GPU always finds the next threshold kernel queued when a contour stage ends, however long the host
-        # takes over the results, the pack and the collective.
-        for i in range(min(2, k)):
-            submit(ctxs[i % 2])
+            return res
+        # n_ctx batches ahead of the host: batch i + n_ctx goes out (on the context batch i has just been collected from) before
+        # anything else happens, so the GPU always finds work queued however long the host takes over the results, the pack and
+        # the collective.
+        for i in range(min(n_ctx, k)):
+            submit(ctxs[i % n_ctx])
         for i in range(k):
-            cx = ctxs[i % 2]
-            markers, per = cx.collect()
+            cx = ctxs[i % n_ctx]
+            res = collect_raw(cx)
             rec = pack(cx) if use_dist else None
-            if i + 2 < k:
+            if i + n_ctx < k:
                 submit(cx)
             if use_dist:
                 all_gather(rec)
-        return markers, per
+        return res
 
-    # set-up, not steps: every context allocates its device buffers on its first batches (hipMalloc is slow and synchronous)
-    for cx in ctxs:
-        for _ in range(2):
-            cx.detect_batch(*batch_args, out_cap=n * 64)
-    for cx in ctxs:
-        for st_id in (_lib.STAGE_THRESHOLD, _lib.STAGE_CONTOUR, _lib.STAGE_DECODE):
-            cx.profile(st_id, reset=True)
-    # Warm-up with every stage timed (the breakdown reported as stage_ms_per_step); the timed steps keep only the two event
-    # records around the threshold kernel, on every 4th batch of a context -- the roofline figure must be measured live, but
-    # each record between two kernels costs ~6 us of device time.
-    markers, per = run_steps(args.warmup)
-    stage_ms = {}
+    # ---- isolated launches: one synchronous batch at a time, every stage between events, nothing else on the GPU ----
+    # The roofline figure of the threshold kernel is its launch duration ALONE; in the stepping below no kernel runs alone.
+    stage_ms, k1_ms, k1_n = {}, 0.0, 0
+    ctx.set_profiling(True)
+    for st_id in (_lib.STAGE_THRESHOLD, _lib.STAGE_CONTOUR, _lib.STAGE_DECODE):
+        ctx.profile(st_id, reset=True)
+    torch.cuda.synchronize()
+    for _ in range(max(1, args.isolated_launches)):
+        detect_sync(ctx)
     for name, st_id in (("threshold", _lib.STAGE_THRESHOLD), ("contour", _lib.STAGE_CONTOUR), ("decode", _lib.STAGE_DECODE)):
-        tot = cnt = 0
-        for cx in ctxs:
-            a, b = cx.profile(st_id, reset=True); tot += a; cnt += b
-        stage_ms[name] = round(tot / cnt, 3) if cnt else None
-    if args.warmup > 0:
-        for cx in ctxs:
-            cx.set_profiling(_lib.PROFILE_THRESHOLD_SAMPLED)   # the kernel of every 4th batch of a context is timed
+        a, b = ctx.profile(st_id, reset=True)
+        stage_ms[name] = round(a / b, 4) if b else None
+        if st_id == _lib.STAGE_THRESHOLD:
+            k1_ms, k1_n = a, b
+    ctx.set_profiling(0)
+
+    res = run_steps(args.warmup)
 
     # The timed region: EXACTLY --steps steps between barrier + synchronize on both sides, max over ranks.  It is run
-    # --repeats times back to back and the median region is the one reported (all are listed in ms_per_step_all).
-    regions, k1_region_ms = [], []
-    # The one slow region that showed up at the same index in every run of rounds 1 and 2 (one region of ~60 ms among ~16 ms ones,
-    # with a normal threshold-kernel time inside it): a full collection of Python's cyclic garbage collector, triggered by
-    # allocation count -- host time, nothing of the detector's.  Collect once here and keep the collector out of the timed
-    # regions (the steps allocate nothing cyclic).
+    # --repeats times back to back and the median region is the one reported (all are listed in ms_per_step_all).  No event is
+    # recorded inside it.
+    regions = []
+    # Python's cyclic garbage collector is kept out of the timed regions (a full collection triggered by allocation count was the
+    # one slow region of rounds 1 and 2); the steps allocate nothing cyclic.
     import gc
     gc.collect()
     gc.freeze()
     gc.disable()
 
-    def k1_totals():
-        tot = cnt = 0
-        for cx in ctxs:
-            a, b = cx.profile(_lib.STAGE_THRESHOLD); tot += a; cnt += b
-        return tot, cnt
-
     def one_region():
-        k0 = k1_totals()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        res = run_steps(args.steps)
+        r = run_steps(args.steps)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         regions.append(time.perf_counter() - t0)
-        k1 = k1_totals()
-        k1_region_ms.append((k1[0] - k0[0]) / max(k1[1] - k0[1], 1))
-        return res
+        return r
 
     n_regions = max(1, args.repeats)
     if args.repeats <= 0:
         # as many regions as make the timed time add up to --min-timed-s (every rank must run the same number: the count comes
         # from the slowest rank's first five regions)
         for _ in range(5):
-            markers, per = one_region()
+            res = one_region()
         pilot = torch.tensor([sum(regions) / len(regions)], dtype=torch.float64, device=coll_dev if use_dist else "cpu")
         if use_dist:
             dist.all_reduce(pilot, op=dist.ReduceOp.MAX)
         n_regions = int(min(2000, max(25, np.ceil(args.min_timed_s / max(float(pilot[0]), 1e-6)))))
     while len(regions) < n_regions:
-        markers, per = one_region()
+        res = one_region()
     if use_dist:
         t = torch.tensor(regions, dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         regions = [float(v) for v in t.tolist()]
     gc.enable()
     elapsed = sorted(regions)[len(regions) // 2]
-    # regions far off the median (a one-off stall somewhere): counted and located, with the threshold kernel's own average in
-    # that region beside it -- a normal kernel time there says the stall was not on the GPU's side of K1
-    outliers = [{"region": i, "ms_per_step": round(r / args.steps * 1e3, 4), "k1_ms_in_region": round(k1_region_ms[i], 4)}
-                for i, r in enumerate(regions) if r > 1.5 * elapsed]
+    outliers = [{"region": i, "ms_per_step": round(r / args.steps * 1e3, 4)} for i, r in enumerate(regions) if r > 1.5 * elapsed]
+    markers, per = res[0], res[1]
+    poses = res[2] if pose_mm else None
 
     # sanity: what was rendered is what was read (ids per frame), on this rank's last step
-    pos, id_ok = 0, 0
-    for f in range(n):
-        got = sorted(int(m["id"]) for m in markers[pos: pos + int(per[f])])
-        pos += int(per[f])
-        id_ok += got == sorted(truth_ids[f])
+    by_frame = split_by_frame(markers, per)
+    id_ok = sum(sorted(int(m["id"]) for m in by_frame[f]) == sorted(truth_ids[f]) for f in range(n))
 
-    k1_ms = k1_n = 0
-    for cx in ctxs:
-        a, b = cx.profile(_lib.STAGE_THRESHOLD); k1_ms += a; k1_n += b
+    # the threshold kernel's launch duration IN COMPANY (a few more steps with its launches between events, outside the timed
+    # regions): what the kernel trace of this run shows for it -- it waits for and shares the chip with the other batches
+    k1_company = None
+    if not args.no_pipeline:
+        for cx in ctxs:
+            cx.set_profiling(_lib.PROFILE_THRESHOLD_ONLY); cx.profile(_lib.STAGE_THRESHOLD, reset=True)
+        run_steps(max(8, 2 * n_ctx))
+        tot = [cx.profile(_lib.STAGE_THRESHOLD, reset=True) for cx in ctxs]
+        k1_company = round(sum(a for a, _ in tot) / max(sum(b for _, b in tot), 1), 4)
+        for cx in ctxs:
+            cx.set_profiling(0)
 
-    # The other way to step, measured beside the headline (one rank, both contexts on streams of their OWN, nothing deferred):
-    # consecutive batches overlap wherever the GPU has room -- the threshold kernel of batch i+1 runs beside the contour and decode
-    # stages of batch i.  More frames per second, but no kernel runs alone any more: the threshold kernel's launches then last
-    # ~0.44-0.48 ms, of which only part is its own, and a roofline fraction computed from that duration would describe the
-    # company, not the kernel.  The headline keeps the steps in order (K1 alone, timed alone) and this number is reported as what
-    # it is.
-    free_running = None
-    if not use_dist and not args.no_pipeline and not own_streams and not args.no_other_workloads:   # (a side measurement like those)
+    # A/B in this process: the other way to step (all contexts on ONE stream, two of them, the decode stage of a submitted batch
+    # deferred behind the next batch's k_local_contract -- round 3's headline), same frames, same box, same minute
+    ab_shared = None
+    if not use_dist and own_streams and not args.no_other_workloads:
         try:
-            L = _lib.load()
-            L.a3_debug_set_overlap(0)
-            fctx = [Detector(DetectorConfig.default(), d, device=local_rank)._context() for _ in range(2)]   # (never given a stream: their own)
-            for cx in fctx:
-                cx.set_profiling(_lib.PROFILE_THRESHOLD_SAMPLED)
+            assert L.a3_debug_set_overlap(2) == 0
+            sctx = [Detector(DetectorConfig.default(), d, device=local_rank)._context() for _ in range(2)]
+            for cx in sctx:
+                cx.set_stream(stream.cuda_stream)
                 for _ in range(2):
-                    cx.detect_batch(*batch_args, out_cap=n * 64)
+                    detect_sync(cx)
 
-            def free_steps(k):
+            def shared_steps(k):
                 for i in range(min(2, k)):
-                    fctx[i % 2].submit(*batch_args, out_cap=n * 64)
-                res = None
+                    submit_raw(sctx[i % 2])
+                r = None
                 for i in range(k):
-                    res = fctx[i % 2].collect()
+                    r = collect_raw(sctx[i % 2])
                     if i + 2 < k:
-                        fctx[i % 2].submit(*batch_args, out_cap=n * 64)
-                return res
+                        submit_raw(sctx[i % 2])
+                return r
 
-            free_steps(args.steps)
-            for cx in fctx:
-                cx.profile(_lib.STAGE_THRESHOLD, reset=True)
-            fr_regions = []
+            shared_steps(args.steps)
+            sr = []
             for _ in range(20):
                 torch.cuda.synchronize(); t0 = time.perf_counter()
-                m2, p2 = free_steps(args.steps)
-                torch.cuda.synchronize(); fr_regions.append(time.perf_counter() - t0)
-            fr = sorted(fr_regions)[len(fr_regions) // 2]
-            fk = [cx.profile(_lib.STAGE_THRESHOLD) for cx in fctx]
-            free_running = {"value": round(args.frames * args.steps / fr, 2), "unit": "frames/s", "ms_per_step": round(fr / args.steps * 1e3, 4),
-                            "regions": len(fr_regions), "same_markers": bool(len(m2) == len(markers) and np.array_equal(p2, per)),
-                            "threshold_kernel_ms_in_company": round(sum(a for a, _ in fk) / max(sum(b for _, b in fk), 1), 4),
-                            "stepping": "two contexts, each on a stream of its own, two batches ahead, no deferred decode: steps overlap freely"}
-            for cx in fctx:
+                r2 = shared_steps(args.steps)
+                torch.cuda.synchronize(); sr.append(time.perf_counter() - t0)
+            med = sorted(sr)[len(sr) // 2]
+            ab_shared = {"value": round(args.frames * args.steps / med, 2), "unit": "frames/s", "ms_per_step": round(med / args.steps * 1e3, 4),
+                         "regions": len(sr), "same_markers": bool(len(r2[0]) == len(markers) and np.array_equal(r2[1], per)),
+                         "stepping": "--streams shared: two contexts on ONE stream, two batches ahead, decode stage of a submitted batch deferred "
+                                     "behind the next batch's k_local_contract (round 3's headline stepping)"}
+            for cx in sctx:
                 cx.close()
         except Exception as e:   # a side measurement must not take the line down
-            free_running = {"error": repr(e)}
+            ab_shared = {"error": repr(e)}
         finally:
-            _lib.load().a3_debug_set_overlap(args.overlap if args.overlap >= 0 else 2)
-    if args.warmup == 0:   # no warm-up to take the breakdown from: every stage was timed in the timed steps instead
-        for name, st_id in (("contour", _lib.STAGE_CONTOUR), ("decode", _lib.STAGE_DECODE)):
-            tot = sum(cx.profile(st_id)[0] for cx in ctxs)
-            stage_ms[name] = round(tot / max(k1_n, 1), 3)
+            L.a3_debug_set_overlap(overlap_mode)
     stats = ctx.stats()
 
     gathered = None
@@ -390,31 +433,48 @@ def main():
         torch.cuda.synchronize()
         g = last_gather[0].cpu().numpy()
         if rank == 0:
-            from aruco3_amd import synth
-            spec2, _ = synth.config_spec(2)
-            recs = shard.unpack_detections(g.reshape(-1, g.shape[-1]))
-            seeds_all = [synth.frame_seed(2, i) for i in range(world * args.frames)]
-            truth_all = [sorted(t.id for t in tr) for tr in synth.device_layout(spec2, d.code_list, d.num_bits, seeds_all)[2]]
-            gathered = {"frames": len(recs), "global_frame_indices_in_order": [f for f, _ in recs] == list(range(world * args.frames)),
-                        "all_ranks_ids_correct": int(sum(sorted(int(x) for x in m["id"]) == truth_all[f] for f, m in recs)),
-                        "record_bytes": int(g.shape[-1]), "packed_on": "device (a3_pack_detections)",
-                        "collective": f"all_gather_into_tensor over {args.backend}"}
+            recs = shard.unpack_detections(g.reshape(-1, g.shape[-1]), with_poses=bool(pose_mm))
+            seeds_all = [synth.frame_seed(wl["config"], i) for i in range(world * args.frames)]
+            truth_all = [sorted(t.id for t in tr) for tr in synth.device_layout(spec, d.code_list, d.num_bits, seeds_all)[2]]
+            gathered = {"frames": len(recs), "global_frame_indices_in_order": [r[0] for r in recs] == list(range(world * args.frames)),
+                        "all_ranks_ids_correct": int(sum(sorted(int(x) for x in r[1]["id"]) == truth_all[r[0]] for r in recs)),
+                        "record_bytes": int(g.shape[-1]), "max_markers_per_record": int(maxm),
+                        "max_markers_from": "--max-markers" if args.max_markers > 0 else "calibrated on the first batch (2 x the largest count on any rank, >= 8)",
+                        "packed_on": "device (a3_pack_detections)", "collective": f"all_gather_into_tensor over {args.backend}"}
+            if pose_mm:   # rank 0's own frames came back as it produced them, poses included
+                mine = [r for r in recs if first_frame <= r[0] < first_frame + n]
+                gp = np.concatenate([r[2] for r in mine]) if mine else np.zeros((0, 2, 13), np.float32)
+                gathered["pose_pairs_gathered"] = int(sum(len(r[2]) for r in recs))
+                gathered["rank0_poses_bit_equal_after_gather"] = bool(gp.shape == poses.shape and np.array_equal(gp.view(np.uint32), poses.view(np.uint32)))
 
     if rank == 0:
         total_frames = args.frames * world * args.steps
         value = total_frames / elapsed
         k1_avg_ms = k1_ms / max(k1_n, 1)
-        k1_bytes = int(K1_BYTES_PER_PIXEL * WIDTH * HEIGHT * args.frames)     # algorithmic bytes per launch = the bytes that move
+        k1_bytes = int(K1_BYTES_PER_PIXEL * w * h * args.frames)     # algorithmic bytes per launch = the bytes that move
         achieved = k1_bytes / (k1_avg_ms * 1e-3) / 1e9 if k1_avg_ms > 0 else 0.0
-        survey_gbs = K1_SURVEY_BYTES_PER_PIXEL * WIDTH * HEIGHT * args.frames / (k1_avg_ms * 1e-3) / 1e9 if k1_avg_ms > 0 else 0.0
+        survey_gbs = K1_SURVEY_BYTES_PER_PIXEL * w * h * args.frames / (k1_avg_ms * 1e-3) / 1e9 if k1_avg_ms > 0 else 0.0
+        ms_per_step = elapsed / args.steps * 1e3
+        e2e_bytes = E2E_BYTES_PER_PIXEL * w * h * args.frames
+        if args.no_pipeline:
+            stepping = "one context, synchronous: every kernel runs alone"
+        elif own_streams:
+            stepping = (f"{n_ctx} contexts, each on a stream of its own, {n_ctx} batches ahead of the host (batch i + {n_ctx} is submitted as soon as batch i "
+                        "is collected).  The threshold kernels of consecutive batches serialise by themselves -- one launch is 2048 waves of 256 VGPRs = "
+                        "every register of the chip, so nothing co-runs with it and a second one only starts where the first retires waves -- while "
+                        "the contour / decode chains of the batches in flight (latency-, LDS- and issue-bound, no HBM traffic to speak of) overlap "
+                        "one another and the tail of the threshold queue; nothing is deferred inside the library (DESIGN.md section 4, Stepping)")
+        else:
+            stepping = (f"{n_ctx} contexts on ONE stream, {n_ctx} batches ahead: steps run in order; the decode stage of a submitted batch runs on the "
+                        "device's decode stream, released behind the next batch's k_local_contract")
         out = {
-            "metric": "frames/sec at 1920x1080 ARUCO dict",
+            "metric": wl["metric"],
             "value": round(value, 2),
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step": round(ms_per_step, 4),
             "repeats": len(regions),
             "ms_per_step_all": [round(r / args.steps * 1e3, 3) for r in regions],
             "ms_per_step_min_max": [round(min(regions) / args.steps * 1e3, 4), round(max(regions) / args.steps * 1e3, 4)],
@@ -426,12 +486,10 @@ def main():
             "dtype": "u8",
             "data": "synthetic" + (" (rendered on the device)" if args.device_synth else ""),
             "config": {
-                "workload": f"BASELINE config 2: batch of {args.frames} x 1920x1080 synthetic RGB frames per GPU, ARUCO dict, 4-8 markers per frame, "
-                            "frames resident in HBM; Detector::detect end to end (grey, threshold, contours, quads, warp+decode, lookup) "
-                            "incl. D2H of the marker list",
+                "workload": wl["label"].format(n=args.frames),
                 "frames_per_gpu": args.frames,
-                "resolution": [WIDTH, HEIGHT],
-                "dictionary": "ARUCO",
+                "resolution": [int(w), int(h)],
+                "dictionary": dict_name,
                 "sharding": "frames by rank, no data-path collective; dictionary broadcast once, detections all-gathered per batch" if world > 1 else "single GPU",
             },
             "roofline": {
@@ -441,7 +499,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic_bytes(),
+                "traffic": pmc_traffic_bytes() if args.workload == "c2" and args.frames == 256 else None,
                 # 3.125 B/px: the frame is read once (3 B/px) and only the bit-packed binary image (1/8 B/px) is written; the
                 # grey plane of SURVEY's 5 B/px accounting is never materialised (the decode stage re-derives the grey levels
                 # it samples).  achieved / frac count the bytes that move; the 5 B/px figure is kept under its own name.
@@ -449,29 +507,38 @@ def main():
                 "bytes_per_launch": k1_bytes,
                 "avg_launch_ms": round(k1_avg_ms, 4),
                 "launches_timed": k1_n,
+                "timed_how": "HIP events around the kernel in dedicated synchronous batches of this run, one at a time, nothing else on the GPU "
+                             "(--isolated-launches); in the stepping itself the kernel never runs alone",
+                "avg_launch_ms_in_company": k1_company,
                 "survey_5Bpp_gbs": round(survey_gbs, 1),
                 "survey_5Bpp_frac": round(survey_gbs / HBM_PEAK_GBS, 4),
             },
-            # threshold: the timed steps; contour / decode: the warm-up steps (every stage timed there, see above)
-            "stage_ms_per_step": {"threshold": round(k1_avg_ms, 3), "contour": stage_ms.get("contour"), "decode": stage_ms.get("decode")},
-            "stepping": "one context, synchronous" if args.no_pipeline else "two contexts on one stream, two batches ahead: step i+2 is submitted as soon as step i is collected; "
-                        "the decode stage of a submitted batch runs on the device's decode stream, released behind the next batch's k_local_contract",
+            # bytes one step must move (3.125 B/px through K1 + the 1/8 B/px re-read of the packed image) over the step's time:
+            # how far the PIPELINE is from the HBM bound, beside the kernel's own fraction above
+            "e2e_frac": round(e2e_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "e2e_bytes_per_step": int(e2e_bytes),
+            # every stage alone (the isolated launches); their sum is longer than a step, which overlaps them
+            "stage_ms_per_step": {"threshold": stage_ms.get("threshold"), "contour": stage_ms.get("contour"), "decode": stage_ms.get("decode")},
+            "stepping": stepping,
+            "contexts": n_ctx,
+            "streams": "one per context" if own_streams else "shared",
+            "library": _lib.library_info(),
             "stats": stats,
             "frames_with_all_ids_correct": f"{id_ok}/{n}",
             "frame_synthesis_s": round(t_gen, 1),
         }
-        if free_running is not None:
-            out["free_running_streams"] = free_running
+        if ab_shared is not None:
+            out["ab_shared_stream"] = ab_shared
         if gathered is not None:
             out["gathered"] = gathered
         if use_dist:   # what the ranks themselves saw
             out["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                            "launcher": os.environ.get("A3_BENCH_LAUNCHER", "external (torch.distributed.run)" if "RANK" in os.environ else "none (one process, --force-dist)"),
-                           "pack_and_collective": "side stream, started when collect() returns (beside the next batch's kernels)"}
+                           "pack_and_collective": "side stream, started when collect() returns (beside the next batch's kernels)",
+                           "note": "an N > 1 RCCL number exists only where the driver's multi-GPU node produced one; a 1-GPU box can run world_size 1 (nccl) or rehearse ranks over gloo"}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(frames, d)
-        if not args.no_other_workloads and world == 1:
-            # free the headline batch first: the 4K batch below needs room only in the sense of tidiness (288 GB of HBM)
+            out["cpu_baseline"], out["parity_in_run"] = cpu_baseline(frames, d, by_frame, poses, per, pose_mm, (w, h))
+        if not args.no_other_workloads and world == 1 and args.workload == "c2":
             try:
                 out["other_workloads"] = other_workloads(local_rank, with_cpu=not args.no_cpu_baseline)
             except Exception as e:   # side measurements never take the line down
@@ -556,24 +623,55 @@ def pmc_traffic_bytes():
     return None
 
 
-def cpu_baseline(frames, d):
+def parity_row(agree, total, what="markers (id, code, corners, rotation, hamming distance)"):
+    return {"frames_compared": total, "frames_equal": agree, "summary": f"{agree}/{total} frames", "compared": what,
+            "against": "oracle/a3_oracle.c (CPU restatement of the reference; the reference itself cannot be built here)"}
+
+
+def cpu_baseline(frames, d, gpu_by_frame=None, gpu_poses=None, gpu_per=None, pose_mm=None, image_size=None):
     """The CPU oracle (a restatement of the reference algorithm, NOT the Rust crate, which cannot be built here) on the
-    same frames, one thread -- the reference's own execution model -- for about 10 s of CPU work."""
+    same frames, one thread -- the reference's own execution model -- for about 10 s of CPU work.  Its output is not thrown
+    away: the markers of every distinct frame it processed are compared with the GPU's for the same frame -> parity_in_run."""
     from oracle import a3oracle
 
     a3oracle.build()
     codes = np.ascontiguousarray(d.code_list)
     done, t0 = 0, time.perf_counter()
     budget_s, max_frames = 10.0, 4 * len(frames)
+    oracle_markers = {}
     while done < max_frames:
-        a3oracle.detect_markers_only(frames[done % len(frames)], codes, d.num_bits, d._tau)
+        f = done % len(frames)
+        r = a3oracle.detect(frames[f], codes, d.num_bits, d._tau, keep_debug=False)
+        if f not in oracle_markers:
+            oracle_markers[f] = r
         done += 1
-        if done >= 32 and time.perf_counter() - t0 > budget_s:
+        if done >= min(32, len(frames)) and time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
+    h, w = frames.shape[1:3]
     out = {"value": round(done / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-           "sample": f"{done} of the same 1920x1080 config-2 frames, single thread, oracle/a3_oracle.c (gcc -O2)",
+           "sample": f"{done} detect() calls over {len(oracle_markers)} of the same {w}x{h} frames, single thread, oracle/a3_oracle.c (gcc -O2)",
            "host_cores_available": os.cpu_count()}
+    parity = None
+    if gpu_by_frame is not None:
+        agree, pose_dev, pos = 0, 0.0, np.concatenate([[0], np.cumsum(gpu_per)]).astype(np.int64)
+        for f, r in oracle_markers.items():
+            same = oracle_marker_tuples(r) == hip_marker_tuples(gpu_by_frame[f])
+            if same and pose_mm:   # both IPPE solutions of every marker, against the oracle's solve_with_undistorted_points
+                for k, m in enumerate(r["markers"]):
+                    sols = a3oracle.solve_with_undistorted_points(m["corners"], pose_mm, image_size)
+                    for j in range(2):
+                        err, rot, tr = sols[j].as_tuple() if hasattr(sols[j], "as_tuple") else sols[j]
+                        want = np.concatenate([[err], np.asarray(rot, np.float32).reshape(-1), np.asarray(tr, np.float32).reshape(-1)])
+                        got = gpu_poses[pos[f] + k, j]
+                        dev = float(np.nanmax(np.abs(want - got))) if not np.isnan(want).all() else 0.0
+                        pose_dev = max(pose_dev, dev)
+                same = pose_dev <= 1e-4
+            agree += same
+        parity = parity_row(agree, len(oracle_markers))
+        if pose_mm:
+            parity["pose_max_abs_diff"] = pose_dev
+            parity["compared"] += " + both IPPE poses of every marker within 1e-4"
     # SURVEY 8d (2): the same oracle, frame-parallel over the host's cores (one frame per worker; the C call releases the
     # GIL).  Informational: the reference itself is single-threaded.
     from concurrent.futures import ThreadPoolExecutor
@@ -587,7 +685,7 @@ def cpu_baseline(frames, d):
     dt = time.perf_counter() - t0
     out["all_cores"] = {"value": round(done_mt / dt, 2), "unit": "frames/s", "cores": workers,
                         "sample": f"{done_mt} frames, one frame per worker thread"}
-    return out
+    return out, parity
 
 
 def other_workloads(device, with_cpu=True, budget_s=60.0):
@@ -678,10 +776,11 @@ def other_workloads(device, with_cpu=True, budget_s=60.0):
             host = frames_dev[:cpu_frames].cpu().numpy()
             codes = np.ascontiguousarray(d.code_list)
             t0 = time.perf_counter()
-            for f in range(cpu_frames):
-                a3oracle.detect_markers_only(host[f], codes, d.num_bits, d._tau)
+            ores = [a3oracle.detect(host[f], codes, d.num_bits, d._tau, keep_debug=False) for f in range(cpu_frames)]
             o["cpu_baseline"] = {"value": round(cpu_frames / (time.perf_counter() - t0), 2), "unit": "frames/s", "cores": 1, "kind": "port",
                                  "sample": f"{cpu_frames} of the same frames, single thread, detection only"}
+            gpu_frames = split_by_frame(r[0], r[1])
+            o["parity_in_run"] = parity_row(sum(oracle_marker_tuples(ores[f]) == hip_marker_tuples(gpu_frames[f]) for f in range(cpu_frames)), cpu_frames)
         res[name] = o
         ctx.close()
 
@@ -747,6 +846,7 @@ def caller_latency(device, with_cpu=True, calls=200):
         r, t = timeit(lambda: ctx.detect_batch(*a, out_cap=64))
         t["markers"] = int(len(r[0])); t["ids_correct"] = sorted(int(m["id"]) for m in r[0]) == sorted(x.id for x in truth[0])
         out[f"markers_only_{label}"] = t
+        r_markers_only = r
         ctx.set_debug_taps(True)
 
         def populated():
@@ -762,8 +862,9 @@ def caller_latency(device, with_cpu=True, calls=200):
         from oracle import a3oracle
         a3oracle.build()
         codes = np.ascontiguousarray(d.code_list)
-        _, t = timeit(lambda: a3oracle.detect_markers_only(frames[0], codes, d.num_bits, d._tau), 20)
+        ores, t = timeit(lambda: a3oracle.detect(frames[0], codes, d.num_bits, d._tau, keep_debug=False), 20)
         out["cpu_baseline"] = dict(t, cores=1, kind="port", sample="the same frame, single thread, 20 calls (markers only)")
+        out["parity_in_run"] = parity_row(int(oracle_marker_tuples(ores) == hip_marker_tuples(r_markers_only[0])), 1)
     pinned.close()
     # the reference's own bench, call for call (benches/detect_markers.rs:29-51): ONE 1920x1080 uniform-noise frame per detect()
     rng = np.random.default_rng(29)
@@ -777,11 +878,13 @@ def caller_latency(device, with_cpu=True, calls=200):
         r, t = timeit(lambda: ctx_n.detect_batch(*a, out_cap=64), max(20, calls // 4))
         t["markers"] = int(len(r[0]))
         row[f"markers_only_{label}"] = t
+        r_noise = r
     if with_cpu:
         dn = ARDictionary.new_from_named_dict("ARUCO")
         codes_n = np.ascontiguousarray(dn.code_list)
-        _, t = timeit(lambda: a3oracle.detect_markers_only(noise, codes_n, dn.num_bits, dn._tau), 3)
+        ores_n, t = timeit(lambda: a3oracle.detect(noise, codes_n, dn.num_bits, dn._tau, keep_debug=False), 3)
         row["cpu_baseline"] = dict(t, cores=1, kind="port", sample="the same frame, single thread, 3 calls")
+        row["parity_in_run"] = parity_row(int(oracle_marker_tuples(ores_n) == hip_marker_tuples(r_noise[0])), 1)
     out["reference_bench_one_frame_per_call_1080p_noise"] = row
     pin_n.close(); ctx_n.close(); ctx.close()
     return out

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""A/B of stepping arrangements inside ONE process (boxes of the pool differ by more than the effects): BASELINE config 2,
+contexts in submit / collect.  An arrangement = (streams: shared | own, contexts, K1 waves per SIMD, overlap mode).  Arrangements
+are interleaved ROUNDS times; prints the median ms per step of each, the threshold kernel's duration in company (sampled events)
+and its duration alone in the same geometry.
+  python tools/ab_streams.py [frames] [steps] [rounds] [spec,spec,...]      spec = streams:contexts:k1waves:overlap  e.g. own:2:1:0"""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+DEFAULT = "shared:2:2:2,own:2:2:0,own:2:1:0,own:3:1:0,own:3:2:0,shared:2:1:2"
+
+
+def main():
+    import torch
+
+    from aruco3_amd import _lib, synth
+    from aruco3_amd.aruco import Detector, DetectorConfig
+    from aruco3_amd.dictionaries import ARDictionary
+
+    frames = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+    specs = (sys.argv[4] if len(sys.argv) > 4 else DEFAULT).split(",")
+    d = ARDictionary.new_from_named_dict("ARUCO")
+    spec, _ = synth.config_spec(2)
+    d_frames, _ = synth.render_frames_device(spec, d.code_list, d.num_bits, [synth.frame_seed(2, i) for i in range(frames)])
+    n, h, w, c = d_frames.shape
+    a = (d_frames.data_ptr(), _lib.MEM_DEVICE, _lib.FMT_RGB8, w, h, w * c, h * w * c, n)
+    L = _lib.load()
+    if os.environ.get("A3_PARTITION", "0") != "0":     # "k1_cus[:pattern]": CU partition, set before any context exists
+        pp = os.environ["A3_PARTITION"].split(":")
+        assert L.a3_debug_set_partition(int(pp[0]), int(pp[1]) if len(pp) > 1 else 0) == 0
+    stream = torch.cuda.Stream()
+    max_ctx = max(int(s.split(":")[1]) for s in specs)
+    pools = {"shared": [], "own": []}
+    for kind in pools:
+        if not any(s.startswith(kind) for s in specs):
+            continue
+        for _ in range(max_ctx):
+            cx = Detector(DetectorConfig.default(), d)._context()
+            if kind == "shared":
+                cx.set_stream(stream.cuda_stream)
+            for _ in range(3):
+                ref = cx.detect_batch(*a, out_cap=n * 64)
+            pools[kind].append(cx)
+
+    def run(k, ctxs):
+        nc = len(ctxs)
+        for i in range(min(nc, k)):
+            ctxs[i % nc].submit(*a, out_cap=n * 64)
+        for i in range(k):
+            m, per = ctxs[i % nc].collect()
+            if i + nc < k:
+                ctxs[i % nc].submit(*a, out_cap=n * 64)
+        return m, per
+
+    res = {s: [] for s in specs}
+    k1c = {s: [0.0, 0] for s in specs}
+    k1a = {}
+    for r in range(rounds):
+        for s in specs:
+            kind, nc, kw, ov = s.split(":")
+            ctxs = pools[kind][: int(nc)]
+            assert L.a3_debug_set_overlap(int(ov)) == 0
+            assert L.a3_debug_set_k1_waves(int(kw)) == 0
+            if s not in k1a:   # the threshold kernel alone in this geometry (synchronous calls, nothing else on the GPU)
+                cx = ctxs[0]
+                cx.set_profiling(_lib.PROFILE_THRESHOLD_ONLY)
+                cx.profile(_lib.STAGE_THRESHOLD, reset=True)
+                for _ in range(8):
+                    cx.detect_batch(*a, out_cap=n * 64)
+                ms, cnt = cx.profile(_lib.STAGE_THRESHOLD, reset=True)
+                k1a[s] = ms / max(cnt, 1)
+            for cx in ctxs:
+                cx.set_profiling(_lib.PROFILE_THRESHOLD_SAMPLED)
+                cx.profile(_lib.STAGE_THRESHOLD, reset=True)
+            run(6, ctxs)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            m, per = run(steps, ctxs)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            assert len(m) == len(ref[0]) and np.array_equal(per, ref[1])
+            res[s].append(dt / steps * 1e3)
+            for cx in ctxs:
+                ms, cnt = cx.profile(_lib.STAGE_THRESHOLD, reset=True)
+                k1c[s][0] += ms; k1c[s][1] += cnt
+                cx.set_profiling(0)
+    for s in specs:
+        v = sorted(res[s])
+        med = v[len(v) // 2]
+        print(f"{s:16s} median {med:.4f} ms/step  ({n / med * 1e3:8.0f} frames/s)  K1 in company {k1c[s][0] / max(k1c[s][1], 1):.4f} ms, alone {k1a[s]:.4f} ms  "
+              f"all {[round(x, 4) for x in res[s]]}", flush=True)
+    L.a3_debug_set_overlap(2)
+    L.a3_debug_set_k1_waves(2)
+
+
+if __name__ == "__main__":
+    main()

@@ -174,6 +174,14 @@ int main() {
     printf("K1 shape (occ 2, strips_y 4): reads only %.3f | + 14 halo rows %.3f | + halo + stores in bursts of 128 rows %.3f | no halo, bursts of 128 rows %.3f\n",
            run<0, 3, 0, 0>(d, row_stride, frames, H, 4, 19000, out, 20), run<0, 3, 0, 0, 7>(d, row_stride, frames, H, 4, 19000, out, 20),
            run<0, 3, 0, 228, 7>(d, row_stride, frames, H, 4, 19000, out, 20), run<0, 3, 0, 228>(d, row_stride, frames, H, 4, 19000, out, 20));
+    // more bytes in flight per SIMD: deeper load queues at two waves per SIMD, three waves per SIMD (LDS cap 13000: bursts of 64 rows)
+    printf("K1 shape, halo + bursts of 128 rows, load queue depth 3 / 5 / 6 / 9 rows: %.3f | %.3f | %.3f | %.3f ; reads only, depth 5 / 9: %.3f | %.3f\n",
+           run<0, 3, 0, 228, 7>(d, row_stride, frames, H, 4, 19000, out, 20), run<0, 5, 0, 228, 7>(d, row_stride, frames, H, 4, 19000, out, 20),
+           run<0, 6, 0, 228, 7>(d, row_stride, frames, H, 4, 19000, out, 20), run<0, 9, 0, 228, 7>(d, row_stride, frames, H, 4, 19000, out, 20),
+           run<0, 5, 0, 0>(d, row_stride, frames, H, 4, 19000, out, 20), run<0, 9, 0, 0>(d, row_stride, frames, H, 4, 19000, out, 20));
+    printf("three waves per SIMD (6 strips of 180 rows), halo + bursts of 64 rows, depth 3 / 5: %.3f | %.3f ; reads only: %.3f\n",
+           run<0, 3, 0, 164, 7>(d, row_stride, frames, H, 6, 13000, out, 20), run<0, 5, 0, 164, 7>(d, row_stride, frames, H, 6, 13000, out, 20),
+           run<0, 3, 0, 0>(d, row_stride, frames, H, 6, 13000, out, 20));
     printf("the same with NON-TEMPORAL loads: reads only %.3f | + halo %.3f | + halo + stores in bursts of 128 rows %.3f | no halo, bursts of 128 rows %.3f | row-by-row stores %.3f\n",
            run<3, 3, 0, 0>(d, row_stride, frames, H, 4, 19000, out, 20), run<3, 3, 0, 0, 7>(d, row_stride, frames, H, 4, 19000, out, 20),
            run<3, 3, 0, 228, 7>(d, row_stride, frames, H, 4, 19000, out, 20), run<3, 3, 0, 228>(d, row_stride, frames, H, 4, 19000, out, 20),
