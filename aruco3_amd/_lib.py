@@ -25,7 +25,7 @@ STAGE_THRESHOLD, STAGE_CONTOUR, STAGE_DECODE = 0, 1, 2
 # every symbol include/aruco3_hip.h declares
 SYMBOLS = [
     "a3_abi_version", "a3_default_config", "a3_create", "a3_destroy", "a3_last_error", "a3_set_stream", "a3_get_stream", "a3_set_pool_limits",
-    "a3_get_tau", "a3_set_debug_taps", "a3_detect_batch", "a3_detect_batch_pose", "a3_detect_batch_submit", "a3_detect_batch_collect", "a3_detect_batch_pose_submit", "a3_detect_batch_pose_collect",
+    "a3_get_tau", "a3_order_after", "a3_set_debug_taps", "a3_detect_batch", "a3_detect_batch_pose", "a3_detect_batch_submit", "a3_detect_batch_collect", "a3_detect_batch_pose_submit", "a3_detect_batch_pose_collect",
     "a3_host_alloc", "a3_host_free", "a3_host_register", "a3_host_unregister", "a3_get_stats", "a3_synth_render", "a3_download_grey", "a3_download_thresholded",
     "a3_candidate_count", "a3_download_candidates", "a3_download_homographies", "a3_estimate_pose", "a3_estimate_pose_normalized",
     "a3_find_nearest", "a3_calculate_tau", "a3_set_profiling", "a3_get_profile",
@@ -125,6 +125,8 @@ def load():
                                               C.POINTER(Intrinsics), C.c_size_t]
     L.a3_detect_batch_pose_collect.restype = C.c_int
     L.a3_detect_batch_pose_collect.argtypes = [vp, vp, vp, C.c_size_t, u32p, C.POINTER(C.c_size_t)]
+    L.a3_order_after.restype = C.c_int
+    L.a3_order_after.argtypes = [vp, vp]
     L.a3_host_alloc.restype = C.c_int
     L.a3_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.a3_host_free.restype = C.c_int
@@ -309,6 +311,10 @@ class Context:
         p = C.c_void_p()
         check(load().a3_get_stream(self.handle, C.byref(p)), self.handle)
         return int(p.value or 0)
+
+    def order_after(self, other: "Context"):
+        """a3_order_after: this context's next batch starts only after `other`'s work in flight has finished (burst stepping)"""
+        check(load().a3_order_after(self.handle, other.handle), self.handle)
 
     def set_debug_taps(self, on: bool):
         check(load().a3_set_debug_taps(self.handle, int(on)), self.handle)

@@ -144,7 +144,7 @@ struct a3_ctx {
     // Deferred decode (submit / collect with more than one context, see enqueue_batch): the decode stage of a submitted batch
     // runs on the device's decode stream, released from inside the launch sequence of the NEXT submitted batch, so that it shares
     // the GPU with that batch's contour stage (both are latency-bound and leave the chip mostly idle) instead of standing in line.
-    hipEvent_t ev_contours = nullptr, ev_k1 = nullptr, ev_k1_ready = nullptr, ev_k1_done = nullptr;
+    hipEvent_t ev_contours = nullptr, ev_k1 = nullptr, ev_k1_ready = nullptr, ev_k1_done = nullptr, ev_gate = nullptr;
     bool back_deferred = false;      // guarded by g_defer_mu
     int back_rc = 0;                 // a failed launch of the deferred half, whoever enqueued it (guarded by g_defer_mu): collect reports it
     bool allow_defer = false;        // set by the submit entry points for the batch being enqueued
@@ -907,6 +907,7 @@ int a3_create(int device, const a3_config* cfg, const uint64_t* codes, size_t n_
     hipError_t e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_contours, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_k1, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_gate, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_k1_ready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_k1_done, hipEventDisableTiming);
     if (e != hipSuccess) { a3_destroy(c); ctx = nullptr; return fail(ctx, A3_ERR_HIP, "hipEventCreate", e); }
@@ -964,6 +965,7 @@ void a3_destroy(a3_ctx* ctx) {
     if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
     if (ctx->ev_contours) (void)hipEventDestroy(ctx->ev_contours);
     if (ctx->ev_k1) (void)hipEventDestroy(ctx->ev_k1);
+    if (ctx->ev_gate) (void)hipEventDestroy(ctx->ev_gate);
     if (ctx->ev_k1_ready) (void)hipEventDestroy(ctx->ev_k1_ready);
     if (ctx->ev_k1_done) (void)hipEventDestroy(ctx->ev_k1_done);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -998,6 +1000,25 @@ int a3_host_unregister(void* p) {
     if (!p) return A3_ERR_INVALID;
     const hipError_t e = hipHostUnregister(p);
     return e == hipSuccess ? A3_OK : fail(nullptr, A3_ERR_HIP, "hipHostUnregister", e);
+}
+
+// The next batch submitted on `ctx` starts on the device only after everything enqueued so far on `other` (its batch in flight
+// included) has finished.  A scheduling hint for callers that keep several contexts in flight (include/aruco3_hip.h, "bursts"):
+// results do not depend on it.
+int a3_order_after(a3_ctx* ctx, a3_ctx* other) {
+    if (!ctx || !other) return A3_ERR_INVALID;
+    if (ctx == other || ctx->device != other->device) return A3_OK;   // (a context's own batches are in order anyway; other devices do not share a chip)
+    A3_HIP(hipSetDevice(ctx->device));
+    if (int rc = need_stream(ctx)) return rc;
+    if (!other->stream) return A3_OK;   // never used: nothing in flight
+    {   // a decode stage still held back would not be covered by an event on the owner's stream: it goes out now
+        std::lock_guard<std::mutex> lk(g_defer_mu);
+        if (other->back_deferred) { a3_ctx* o = other; if (int rc = flush_deferred_locked(o, nullptr)) { ctx->err = o->err; return rc; } }
+    }
+    if (other->stream == ctx->stream) return A3_OK;   // one stream: already ordered
+    A3_HIP(hipEventRecord(other->ev_gate, other->stream));
+    A3_HIP(hipStreamWaitEvent(ctx->stream, other->ev_gate, 0));
+    return A3_OK;
 }
 
 int a3_get_stream(const a3_ctx* ctx, void** hip_stream) {

@@ -117,6 +117,10 @@ def main():
                     help="own (default): every context on a stream of its own -- the threshold kernels of consecutive batches serialise (each "
                          "fills the chip's register file), the contour / decode chains of the batches in flight overlap one another; "
                          "shared: all contexts enqueue on ONE stream (steps run in order; only the deferred decode stage overlaps)")
+    ap.add_argument("--gates", choices=("burst", "none"), default="burst",
+                    help="with --streams own: burst (default) = before each submit context k calls a3_order_after for the contexts k+1 .. N-1, so "
+                         "the threshold kernels of one rotation run back to back after the previous rotation's chains have drained; none = "
+                         "free-running rotation")
     ap.add_argument("--overlap", type=int, default=-1, help="measurement aid (a3_internal.h: a3_debug_set_overlap): where the decode stage of a "
                                                             "submitted batch is released, 0 never deferred / 1 / 2; -1 = 0 with --streams own, "
                                                             "the library's default (2) with shared")
@@ -274,10 +278,16 @@ def main():
                 rec = pinned_rec[key]
             last_gather[0] = shard._all_gather(rec, n)
 
+    gated = own_streams and args.gates == "burst" and n_ctx > 1
+    ctx_index = {id(cx): k for k, cx in enumerate(ctxs)}
+
     def submit(cx):
         ev = pack_done.pop(id(cx), None)
         if ev is not None:
             ctx_stream[id(cx)].wait_event(ev)        # the pack of this context's previous batch has read the marker list
+        if gated:   # bursts: this batch's threshold kernel starts once the previous rotation's chains (contexts k+1 ..) have drained
+            for other in ctxs[ctx_index[id(cx)] + 1:]:
+                cx.order_after(other)
         submit_raw(cx)
 
     def run_steps(k):
@@ -459,11 +469,14 @@ def main():
         if args.no_pipeline:
             stepping = "one context, synchronous: every kernel runs alone"
         elif own_streams:
-            stepping = (f"{n_ctx} contexts, each on a stream of its own, {n_ctx} batches ahead of the host (batch i + {n_ctx} is submitted as soon as batch i "
-                        "is collected).  The threshold kernels of consecutive batches serialise by themselves -- one launch is 2048 waves of 256 VGPRs = "
-                        "every register of the chip, so nothing co-runs with it and a second one only starts where the first retires waves -- while "
-                        "the contour / decode chains of the batches in flight (latency-, LDS- and issue-bound, no HBM traffic to speak of) overlap "
-                        "one another and the tail of the threshold queue; nothing is deferred inside the library (DESIGN.md section 4, Stepping)")
+            stepping = (f"{n_ctx} contexts, each on a stream of its own, used in rotation, {n_ctx} batches ahead of the host (batch i + {n_ctx} is submitted as "
+                        "soon as batch i is collected).  One threshold launch is 2048 waves of 256 VGPRs = every register of the chip: nothing co-runs "
+                        "with it, and one that arrives while other batches are in the middle of their contour / decode chains only slows those down.  "
+                        + ("The rotation therefore runs in BURSTS (a3_order_after: before each submit context k waits for the contexts k+1 .. N-1): the "
+                           f"{n_ctx} threshold kernels of a rotation run back to back once the previous rotation's chains have drained, then the {n_ctx} chains "
+                           "(latency-, LDS- and issue-bound, almost no HBM traffic) run together and overlap one another"
+                           if gated else "Free-running rotation: no gates, the hardware interleaves threshold kernels and chains as they come")
+                        + "; nothing is deferred inside the library (DESIGN.md section 4, Stepping)")
         else:
             stepping = (f"{n_ctx} contexts on ONE stream, {n_ctx} batches ahead: steps run in order; the decode stage of a submitted batch runs on the "
                         "device's decode stream, released behind the next batch's k_local_contract")
@@ -522,6 +535,7 @@ def main():
             "stepping": stepping,
             "contexts": n_ctx,
             "streams": "one per context" if own_streams else "shared",
+            "gates": "burst (a3_order_after)" if gated else "none",
             "library": _lib.library_info(),
             "stats": stats,
             "frames_with_all_ids_correct": f"{id_ok}/{n}",

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define A3_ABI_VERSION 3
+#define A3_ABI_VERSION 4
 
 enum {
     A3_OK = 0,
@@ -137,6 +137,18 @@ int  a3_detect_batch_pose_submit(a3_ctx *ctx, const void *pixels, int memory, in
                                  const a3_intrinsics *intr, size_t out_cap);
 int  a3_detect_batch_pose_collect(a3_ctx *ctx, a3_marker *out, a3_pose *poses, size_t out_cap, uint32_t *per_frame_count,
                                   size_t *out_n);
+
+/* Several contexts in flight on one device ("bursts").  A context per batch in flight, each on a stream of its own, lets the
+ * contour / decode chains of consecutive batches overlap one another (they are latency-, LDS- and issue-bound and leave most of
+ * the chip idle); the threshold kernel does not take part in that -- one launch occupies every register of the chip -- and a
+ * threshold kernel that arrives while other batches are in the middle of their chains only slows those down.  The fastest
+ * arrangement measured (Stepping) therefore runs BURSTS: with N contexts used in rotation (batch j on context
+ * j % N, batch j + N submitted as soon as batch j is collected), context k calls
+ *     a3_order_after(ctx[k], ctx[m])   for every m in k+1 .. N-1
+ * before each submit: the batches of one rotation then start their threshold kernels back to back, after the previous
+ * rotation's chains have drained, and their own chains run together.  N = 4 for 256 x 1920x1080 frames per batch.  A scheduling
+ * hint only: results are identical with and without it.  Contexts that share one caller stream are in order already (no-op). */
+int  a3_order_after(a3_ctx *ctx, a3_ctx *other);
 
 /* Host frames (A3_MEM_HOST) cross the link on the device's copy stream, beside the kernels of whatever batch another
  * context has in flight.  From pageable memory the runtime stages the copy and the call returns once the caller's buffer has

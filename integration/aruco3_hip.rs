@@ -42,7 +42,7 @@ use crate::pose::MarkerPose;
 // 1. The C ABI, one declaration per entry point of include/aruco3_hip.h
 // =====================================================================================================
 
-pub const A3_ABI_VERSION: c_int = 3;
+pub const A3_ABI_VERSION: c_int = 4;
 
 pub const A3_OK: c_int = 0;
 pub const A3_ERR_INVALID: c_int = -1;
@@ -172,6 +172,7 @@ extern "C" {
     pub fn a3_set_pool_limits(ctx: *mut A3Ctx, max_darts: u64, max_points: u64) -> c_int;
     pub fn a3_get_tau(ctx: *const A3Ctx, tau: *mut u8) -> c_int;
     pub fn a3_set_debug_taps(ctx: *mut A3Ctx, enabled: c_int) -> c_int;
+    pub fn a3_order_after(ctx: *mut A3Ctx, other: *mut A3Ctx) -> c_int;
     pub fn a3_detect_batch(ctx: *mut A3Ctx, pixels: *const c_void, memory: c_int, fmt: c_int, width: u32, height: u32,
                            row_stride: usize, frame_stride: usize, n_frames: u32, out: *mut A3Marker, out_cap: usize,
                            per_frame_count: *mut u32, out_n: *mut usize) -> c_int;

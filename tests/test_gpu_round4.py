@@ -1,0 +1,142 @@
+"""Round-4 GPU tests: burst stepping (a3_order_after) gives the results of synchronous calls in every arrangement, BASELINE
+config 5 through the bench's front door with two ranks (poses in the gather records), the library reports which build it is.
+Everything goes through the C ABI; the oracle is the checker.  GPU only."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from tests.util import marker_tuples
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _detector(dicts, name="ARUCO", **cfg):
+    from aruco3_amd.aruco import Detector, DetectorConfig
+
+    return Detector(DetectorConfig(**cfg), dicts.new_from_named_dict(name))
+
+
+def _args(frames, mem, ptr=None):
+    from aruco3_amd import _lib
+
+    n, h, w, c = frames.shape
+    fmt = {1: _lib.FMT_L8, 3: _lib.FMT_RGB8, 4: _lib.FMT_RGBA8}[c]
+    return (ptr if ptr is not None else frames.ctypes.data, mem, fmt, w, h, w * c, h * w * c, n)
+
+
+def test_the_test_run_uses_the_product_library():
+    """A leftover A3_HIP_LIB pointing at a tuning build must not pass for the product."""
+    from aruco3_amd import _lib
+
+    info = _lib.library_info()
+    assert info["abi"] == 4
+    if not info["from_A3_HIP_LIB"]:
+        assert info["tuning_build"] is False and info["non_default_kernel_build"] is False
+        assert Path(info["path"]) == ROOT / "aruco3_amd" / "libaruco3_hip.so"
+
+
+def test_burst_stepping_equals_synchronous_calls(dicts):
+    """Four contexts on streams of their own, used in rotation with the burst gates of include/aruco3_hip.h (context k orders itself
+    after the contexts k+1 .. N-1 before each submit): every batch -- they alternate between two different sets of frames -- must
+    equal the synchronous call's result; also with every gate (a stricter order), with gates between contexts that share one
+    stream (no-ops), and with a gate on a context whose decode stage is being held back (it is released first)."""
+    import torch
+
+    from aruco3_amd import _lib, synth
+
+    fa, _ = synth.config_frames(1, 6)
+    fb, _ = synth.config_frames(1, 6, first=6)
+    da, db = torch.from_numpy(fa).cuda(), torch.from_numpy(fb).cuda()
+    aa, ab = _args(fa, _lib.MEM_DEVICE, da.data_ptr()), _args(fb, _lib.MEM_DEVICE, db.data_ptr())
+    L = _lib.load()
+    ctxs = [_detector(dicts, "ARUCO_DEFAULT")._context() for _ in range(4)]
+    assert L.a3_debug_set_overlap(0) == 0
+    want = [ctxs[0].detect_batch(*aa), ctxs[0].detect_batch(*ab)]
+    same = lambda got, w: marker_tuples(got[0]) == marker_tuples(w[0]) and np.array_equal(got[1], w[1])
+    assert len(want[0][0]) > 0 and marker_tuples(want[0][0]) != marker_tuples(want[1][0])
+
+    def rotate(k, nc, gate):
+        cs = ctxs[:nc]
+        which = {}
+
+        def sub(i):
+            for m in gate(i % nc, nc):
+                cs[i % nc].order_after(cs[m])
+            which[i] = i % 2 if i % 3 else 1 - i % 2
+            cs[i % nc].submit(*(aa if which[i] == 0 else ab))
+
+        for i in range(min(nc, k)):
+            sub(i)
+        for i in range(k):
+            assert same(cs[i % nc].collect(), want[which[i]]), (i, nc)
+            if i + nc < k:
+                sub(i + nc)
+
+    try:
+        for mode in (0, 2):     # nothing deferred / decode stage deferred (a gate on such a context releases it first)
+            assert L.a3_debug_set_overlap(mode) == 0
+            for nc in (4, 3, 2):
+                rotate(13, nc, lambda k, n: range(k + 1, n))                       # the documented rule
+                rotate(9, nc, lambda k, n: [m for m in range(n) if m != k])        # every other context
+                rotate(9, nc, lambda k, n: [(k + 1) % n])                          # only the next one
+        # contexts that share the caller's stream: already in order, the call is a no-op and must stay harmless
+        st = torch.cuda.Stream()
+        for cx in ctxs:
+            cx.set_stream(st.cuda_stream)
+        rotate(9, 4, lambda k, n: range(k + 1, n))
+        # a context orders itself after itself / after a context that has never run anything
+        fresh = _detector(dicts, "ARUCO_DEFAULT")._context()
+        ctxs[0].order_after(ctxs[0]); ctxs[0].order_after(fresh); fresh.order_after(ctxs[0])
+        assert same(fresh.detect_batch(*aa), want[0])
+    finally:
+        L.a3_debug_set_overlap(2)
+
+
+def test_bench_config5_two_ranks_gloo_with_poses_in_the_gather():
+    """BASELINE config 5 through the bench's front door: `python bench.py --workload c5 --gpus 2 --backend gloo` (two fresh child
+    ranks on the one leased GPU): detect + pose in submit / collect form on four contexts per rank, pose pairs inside the gather
+    records, rank 0's poses bit-equal after the gather."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--workload", "c5", "--gpus", "2", "--backend", "gloo", "--frames", "4", "--steps", "4", "--warmup", "1",
+           "--device-synth", "--repeats", "2", "--no-other-workloads", "--no-cpu-baseline", "--isolated-launches", "2", "--launch-timeout", "500"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["resolution"] == [3840, 2160] and "detect + estimate_pose" in out["metric"]
+    g = out["gathered"]
+    assert g["frames"] == 8 and g["global_frame_indices_in_order"] is True and g["rank0_poses_bit_equal_after_gather"] is True
+    assert g["pose_pairs_gathered"] >= 8 * 10 and g["max_markers_per_record"] >= 16
+    assert g["record_bytes"] == 8 + g["max_markers_per_record"] * (56 + 104)
+    assert out["gates"].startswith("burst") and out["contexts"] == 4
+
+
+def test_bench_line_carries_parity_and_isolated_roofline():
+    """one small run of the default workload's code path: parity_in_run against the oracle, the roofline from isolated launches,
+    e2e_frac, the A/B against the shared-stream stepping, the library's identity"""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--frames", "8", "--steps", "4", "--warmup", "1", "--repeats", "2", "--isolated-launches", "3",
+           "--synth-workers", "4"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-4000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["parity_in_run"]["summary"] == "8/8 frames"
+    assert out["roofline"]["launches_timed"] == 3 and out["roofline"]["avg_launch_ms"] > 0 and 0 < out["e2e_frac"] < 1
+    assert out["ab_shared_stream"]["same_markers"] is True
+    assert out["library"]["tuning_build"] is False
+    ow = out["other_workloads"]
+    for k in ("C0_reference_bench_noise_1080p", "C4_apriltag36h11_720p_noise", "C5_4k_16_markers_detect_plus_pose"):
+        if "skipped" not in ow[k]:
+            pr = ow[k]["parity_in_run"]
+            assert pr["frames_equal"] == pr["frames_compared"] > 0, (k, pr)

@@ -3,7 +3,7 @@
 contexts in submit / collect.  An arrangement = (streams: shared | own, contexts, K1 waves per SIMD, overlap mode).  Arrangements
 are interleaved ROUNDS times; prints the median ms per step of each, the threshold kernel's duration in company (sampled events)
 and its duration alone in the same geometry.
-  python tools/ab_streams.py [frames] [steps] [rounds] [spec,spec,...]      spec = streams:contexts:k1waves:overlap  e.g. own:2:1:0"""
+  python tools/ab_streams.py [frames] [steps] [rounds] [spec,spec,...]      spec = streams:contexts:k1waves:overlap[:group]  e.g. own:2:1:0, own:8:2:0:4 (two bursts of four)"""
 import sys
 import time
 from pathlib import Path
@@ -52,14 +52,40 @@ def main():
                 ref = cx.detect_batch(*a, out_cap=n * 64)
             pools[kind].append(cx)
 
-    def run(k, ctxs):
+    def run(k, ctxs, group=1):
         nc = len(ctxs)
-        for i in range(min(nc, k)):
-            ctxs[i % nc].submit(*a, out_cap=n * 64)
-        for i in range(k):
-            m, per = ctxs[i % nc].collect()
-            if i + nc < k:
+        if group <= 1:       # rotation: the context just collected submits the batch nc ahead
+            def sub(i):      # group < 0: gated rotation (a3_order_after): context k waits for contexts k+1 .. nc-1
+                if group < 0:   # -1: every later context; -2: all but the last; -3: only the next one
+                    k0 = i % nc
+                    later = list(range(k0 + 1, nc))
+                    if group == -2: later = later[:-1]
+                    if group == -3: later = later[:1]
+                    for mth in later:
+                        ctxs[k0].order_after(ctxs[mth])
                 ctxs[i % nc].submit(*a, out_cap=n * 64)
+            for i in range(min(nc, k)):
+                sub(i)
+            for i in range(k):
+                m, per = ctxs[i % nc].collect()
+                if i + nc < k:
+                    sub(i)
+            return m, per
+        # bursts: the contexts form nc / group groups; a group's batches are submitted together (their threshold kernels back to
+        # back), collected together, and submitted again
+        groups = [ctxs[g * group:(g + 1) * group] for g in range(nc // group)]
+        left = k
+        pending = []
+        for grp in groups:
+            if left >= group:
+                for cx in grp: cx.submit(*a, out_cap=n * 64)
+                pending.append(grp); left -= group
+        while pending:
+            grp = pending.pop(0)
+            for cx in grp: m, per = cx.collect()
+            if left >= group:
+                for cx in grp: cx.submit(*a, out_cap=n * 64)
+                pending.append(grp); left -= group
         return m, per
 
     res = {s: [] for s in specs}
@@ -67,7 +93,8 @@ def main():
     k1a = {}
     for r in range(rounds):
         for s in specs:
-            kind, nc, kw, ov = s.split(":")
+            kind, nc, kw, ov = s.split(":")[:4]
+            group = int(s.split(":")[4]) if len(s.split(":")) > 4 else 1
             ctxs = pools[kind][: int(nc)]
             assert L.a3_debug_set_overlap(int(ov)) == 0
             assert L.a3_debug_set_k1_waves(int(kw)) == 0
@@ -82,12 +109,13 @@ def main():
             for cx in ctxs:
                 cx.set_profiling(_lib.PROFILE_THRESHOLD_SAMPLED)
                 cx.profile(_lib.STAGE_THRESHOLD, reset=True)
-            run(6, ctxs)
+            run(8 * max(group, 1), ctxs, group)
             torch.cuda.synchronize(); t0 = time.perf_counter()
-            m, per = run(steps, ctxs)
+            m, per = run(steps, ctxs, group)
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
             assert len(m) == len(ref[0]) and np.array_equal(per, ref[1])
-            res[s].append(dt / steps * 1e3)
+            done_steps = steps if group <= 1 else (steps // group) * group
+            res[s].append(dt / done_steps * 1e3)
             for cx in ctxs:
                 ms, cnt = cx.profile(_lib.STAGE_THRESHOLD, reset=True)
                 k1c[s][0] += ms; k1c[s][1] += cnt
