@@ -64,6 +64,7 @@ hipError_t launch_find_nearest(hipStream_t, const uint64_t*, uint32_t, const uin
 hipError_t launch_calc_tau(hipStream_t, const uint64_t*, uint32_t, unsigned int*);
 hipError_t launch_synth_render(hipStream_t, const a3_synth_frame*, uint32_t, const a3_synth_marker*, uint32_t, uint32_t, int, float, float, int,
                                uint8_t*, size_t, size_t);
+hipError_t launch_spin(hipStream_t, int, int, int, uint32_t*);
 hipError_t launch_selftest(hipStream_t, const double*, const double*, uint32_t, double*, double*, float*, float*);
 }  // namespace a3
 
@@ -145,6 +146,7 @@ struct a3_ctx {
     // runs on the device's decode stream, released from inside the launch sequence of the NEXT submitted batch, so that it shares
     // the GPU with that batch's contour stage (both are latency-bound and leave the chip mostly idle) instead of standing in line.
     hipEvent_t ev_contours = nullptr, ev_k1 = nullptr, ev_k1_ready = nullptr, ev_k1_done = nullptr, ev_gate = nullptr;
+    bool k1_marked = false;          // ev_k1_done was recorded behind the threshold kernel of the batch in flight
     bool back_deferred = false;      // guarded by g_defer_mu
     int back_rc = 0;                 // a failed launch of the deferred half, whoever enqueued it (guarded by g_defer_mu): collect reports it
     bool allow_defer = false;        // set by the submit entry points for the batch being enqueued
@@ -314,6 +316,7 @@ bool g_decode_low_prio = false;   // (see a3_debug_set_overlap)
 // CU partition (a3_internal.h: a3_debug_set_partition): the threshold kernel of every batch on a device-wide stream restricted to
 // g_part_k1_cus compute units, everything else on streams restricted to the others.  0 = off.
 int g_part_k1_cus = 0, g_part_pattern = 0;
+bool g_mark_threshold = false;   // a3_debug_set_mark_threshold: record an event behind every threshold kernel (costs ~2 % of a step: tools/spin_probe.py)
 enum { kStreamCopy = 0, kStreamDecode = 1, kStreamK1 = 2 };
 
 // CU masks of the partition: 256 bits, bit i = compute unit i as the runtime numbers them
@@ -485,7 +488,8 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     if (k1st != st) {
         A3_HIP(hipEventRecord(ctx->ev_k1_done, k1st));
         A3_HIP(hipStreamWaitEvent(st, ctx->ev_k1_done, 0));
-    }
+    } else if (g_mark_threshold) A3_HIP(hipEventRecord(ctx->ev_k1_done, st));   // a3_debug_stream_wait_threshold
+    ctx->k1_marked = g_mark_threshold || k1st != st;
     // batches of OTHER contexts (same device) that wait with their decode stage are released from inside this batch's launch
     // sequence (see g_overlap_mode): `release_point(true)` records the event they wait for and enqueues them
     bool released = false;
@@ -1021,6 +1025,16 @@ int a3_order_after(a3_ctx* ctx, a3_ctx* other) {
     return A3_OK;
 }
 
+// internal (a3_internal.h, tools/spin_probe.py): work enqueued on `hip_stream` after this call starts only once the threshold kernel
+// of ctx's batch in flight has finished; needs a3_debug_set_mark_threshold(1) before the submit
+int a3_debug_stream_wait_threshold(a3_ctx* ctx, void* hip_stream) {
+    if (!ctx) return A3_ERR_INVALID;
+    if (!ctx->pending.active || !ctx->k1_marked) return A3_OK;   // nothing in flight (or a synchronous call): nothing to wait for
+    A3_HIP(hipSetDevice(ctx->device));
+    A3_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(hip_stream), ctx->ev_k1_done, 0));
+    return A3_OK;
+}
+
 int a3_get_stream(const a3_ctx* ctx, void** hip_stream) {
     if (!ctx || !hip_stream) return A3_ERR_INVALID;
     if (int rc = need_stream(const_cast<a3_ctx*>(ctx))) return rc;
@@ -1258,6 +1272,22 @@ int a3_debug_set_overlap(int mode) {   // bits 0-7: mode; bit 8: a decode stream
     return A3_OK;
 }
 
+// a kernel of `workgroups` x `threads` that stays resident for `usec` microseconds on `hip_stream` (stand-in for a collective's
+// channel kernels while only one GPU is at hand); returns at once
+int a3_debug_spin(void* hip_stream, int workgroups, int threads, int usec) {
+    if (workgroups < 1 || workgroups > 1024 || threads < 64 || threads > 512 || threads % 64 || usec < 1 || usec > 100000) return A3_ERR_INVALID;
+    static uint32_t* sink = nullptr;
+    static std::mutex mu;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!sink) {
+            if (hipMalloc(&sink, 4096 * 4) != hipSuccess) return A3_ERR_HIP;
+            if (hipMemset(sink, 0, 4096 * 4) != hipSuccess) return A3_ERR_HIP;
+        }
+    }
+    return launch_spin(reinterpret_cast<hipStream_t>(hip_stream), workgroups, threads, usec, sink) == hipSuccess ? A3_OK : A3_ERR_HIP;
+}
+
 // bit 0: built with -DA3_TUNING (environment knobs are read), bit 1: any other non-default build flag of the kernels
 int a3_debug_build_flags(void) {
     int f = 0;
@@ -1275,6 +1305,8 @@ int a3_debug_set_partition(int k1_cus, int pattern) {   // before the first cont
     set_k1_cus(k1_cus > 0 ? k1_cus : 256);
     return A3_OK;
 }
+
+int a3_debug_set_mark_threshold(int on) { g_mark_threshold = on != 0; return A3_OK; }
 
 int a3_debug_set_k1_waves(int waves_per_simd) { set_k1_waves(waves_per_simd); return A3_OK; }
 

@@ -27,6 +27,18 @@ int  a3_debug_set_overlap(int mode);
  * SIMD, twice as tall strips).  Process-wide; results are identical. */
 int  a3_debug_set_k1_waves(int waves_per_simd);
 
+/* A stand-in for a collective's channel kernels, for a box with one GPU: `workgroups` workgroups of `threads` threads stay
+ * resident on `hip_stream` for `usec` microseconds (48 live registers per lane, a read and a short sleep per turn).
+ * tools/spin_probe.py measures what such company does to the threshold kernel and to a step. */
+int  a3_debug_spin(void *hip_stream, int workgroups, int threads, int usec);
+
+/* Release point of a caller's side work (a collective's kernels), measured and NOT adopted (tools/spin_probe.py,
+ * profiles/r04_spin_probe.txt): with a3_debug_set_mark_threshold(1) an event is recorded behind the threshold kernel of every
+ * batch -- which alone costs ~2 % of a step -- and a3_debug_stream_wait_threshold makes work enqueued on `hip_stream` afterwards
+ * wait for the threshold kernel of ctx's batch in flight.  Company released there costs a step as much as company released at once. */
+int  a3_debug_set_mark_threshold(int on);
+int  a3_debug_stream_wait_threshold(a3_ctx *ctx, void *hip_stream);
+
 /* which build this is: bit 0 = -DA3_TUNING (the library reads tuning knobs from the environment), bit 1 = a non-default kernel
  * build option (A3_T_LPX, A3_T_WAVES ...).  0 for the product library; bench.py and the GPU tests report it. */
 int  a3_debug_build_flags(void);

@@ -66,5 +66,31 @@ hipError_t launch_synth_render(hipStream_t st, const a3_synth_frame* frames, uin
     return hipGetLastError();
 }
 
+// A stand-in for a collective's channel kernels (a3_internal.h: a3_debug_spin): `workgroups` workgroups that stay resident
+// for `usec` microseconds, each lane holding kSpinRegs registers' worth of state alive and touching a little memory per turn.  The
+// exit condition is the wall clock (constant 100 MHz), which every wave reaches.
+constexpr int kSpinRegs = 48;
+__global__ __launch_bounds__(512) void k_spin(unsigned long long ticks, uint32_t* __restrict__ sink) {
+    const unsigned long long t0 = wall_clock64();
+    uint32_t r[kSpinRegs];
+#pragma unroll
+    for (int i = 0; i < kSpinRegs; i++) r[i] = threadIdx.x * 31u + (uint32_t)i;
+    while (wall_clock64() - t0 < ticks) {
+#pragma unroll
+        for (int i = 0; i < kSpinRegs; i++) r[i] = r[i] * 1664525u + 1013904223u + r[(i + 7) % kSpinRegs];
+        r[0] += sink[(blockIdx.x * 64u + (threadIdx.x & 63u)) & 4095u];   // a read per turn, as a channel kernel polls its flags
+        __builtin_amdgcn_s_sleep(8);
+    }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < kSpinRegs; i++) acc ^= r[i];
+    if (acc == 0x12345678u) sink[threadIdx.x & 4095u] = acc;
+}
+
+hipError_t launch_spin(hipStream_t st, int workgroups, int threads, int usec, uint32_t* sink) {
+    hipLaunchKernelGGL(k_spin, dim3(workgroups), dim3(threads), 0, st, (unsigned long long)usec * 100ull, sink);
+    return hipGetLastError();
+}
+
 }  // namespace a3
 static_assert(sizeof(a3_synth_marker) == 80 && sizeof(a3_synth_frame) == 32, "record layouts mirrored in aruco3_amd/synth.py");
