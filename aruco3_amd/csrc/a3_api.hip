@@ -147,6 +147,15 @@ struct a3_ctx {
     // the GPU with that batch's contour stage (both are latency-bound and leave the chip mostly idle) instead of standing in line.
     hipEvent_t ev_contours = nullptr, ev_k1 = nullptr, ev_k1_ready = nullptr, ev_k1_done = nullptr, ev_gate = nullptr;
     bool k1_marked = false;          // ev_k1_done was recorded behind the threshold kernel of the batch in flight
+    // Bursts (a3_order_after): a context that declared gates since its last submit is a member of a burst that is not the last
+    // one: its submit enqueues the threshold kernel only and HOLDS the rest (contour stage ... read-back) until the burst's last
+    // member -- the first submit without gates on the device -- has enqueued its threshold kernel; the held chains are then
+    // enqueued behind that kernel.  The threshold kernels of a burst so run back to back with nothing in between.
+    bool gates_declared = false;     // a3_order_after was called since the last submit
+    bool rest_held = false;          // guarded by g_defer_mu: the chain of the submitted batch has not been enqueued yet
+    int held_rc = 0;                 // guarded by g_defer_mu: what enqueueing the held chain returned, whoever did it
+    int front_prof = 0;              // profiling level in force for the batch whose front half has been enqueued
+    size_t held_out_cap = 0;
     bool back_deferred = false;      // guarded by g_defer_mu
     int back_rc = 0;                 // a failed launch of the deferred half, whoever enqueued it (guarded by g_defer_mu): collect reports it
     bool allow_defer = false;        // set by the submit entry points for the batch being enqueued
@@ -316,6 +325,7 @@ bool g_decode_low_prio = false;   // (see a3_debug_set_overlap)
 // CU partition (a3_internal.h: a3_debug_set_partition): the threshold kernel of every batch on a device-wide stream restricted to
 // g_part_k1_cus compute units, everything else on streams restricted to the others.  0 = off.
 int g_part_k1_cus = 0, g_part_pattern = 0;
+bool g_hold_rests = true;        // a3_debug_set_hold: bursts hold their chains back (see submit_common); 0 for A/B
 bool g_mark_threshold = false;   // a3_debug_set_mark_threshold: record an event behind every threshold kernel (costs ~2 % of a step: tools/spin_probe.py)
 enum { kStreamCopy = 0, kStreamDecode = 1, kStreamK1 = 2 };
 
@@ -436,12 +446,37 @@ int need_stream(a3_ctx* ctx) {
     return A3_OK;
 }
 
+// ---- bursts: contexts whose submitted batch has its threshold kernel enqueued and the rest held back (see a3_ctx::rest_held) ----
+std::vector<a3_ctx*> g_held;   // guarded by g_defer_mu, in submission order
+int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t H, size_t row_stride, size_t frame_stride, uint32_t n,
+                  size_t out_cap, int phase);
+// Enqueue the held chain of `ctx`'s batch on its stream, behind `after` when given (the threshold kernel of the burst's last
+// member).  g_defer_mu is held; the owner may be another thread's context, so the verdict is kept for its collect.
+int flush_held_locked(a3_ctx* ctx, hipEvent_t after) {
+    if (!ctx->rest_held) return A3_OK;
+    ctx->rest_held = false;
+    for (size_t i = 0; i < g_held.size(); i++)
+        if (g_held[i] == ctx) { g_held.erase(g_held.begin() + (long)i); break; }
+    const Pending pd = ctx->pending;
+    const bool wp = ctx->want_pose;
+    ctx->want_pose = pd.want_pose;
+    int rc = A3_OK;
+    if (after && hipStreamWaitEvent(ctx->stream, after, 0) != hipSuccess) rc = fail(ctx, A3_ERR_HIP, "hipStreamWaitEvent (burst gate)");
+    if (rc == A3_OK) rc = enqueue_batch(ctx, pd.pixels, pd.fmt, pd.W, pd.H, pd.row_stride, pd.frame_stride, pd.n, ctx->held_out_cap, 2);
+    ctx->want_pose = wp;
+    ctx->held_rc = rc;
+    (void)hipStreamQuery(ctx->stream);   // hands what was just queued to the GPU now (the owner may be polling an event)
+    return rc;
+}
+
 // the whole pipeline for one batch; `pixels` is a device pointer here
 // One batch = enqueue_batch (every launch and the read-back copies, then an event) + finish_batch (wait for the event, check
 // the device's verdict, hand out the markers).  a3_detect_batch runs them back to back; a3_detect_batch_submit / _collect
 // let the caller enqueue the next batch (on another context) before collecting this one, so the GPU never waits for the host.
+// phase 0: the whole batch; 1: the front half only (buffers + threshold kernel + an event behind it); 2: everything after the
+// threshold kernel of a batch whose front half phase 1 enqueued (same arguments)
 int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t H, size_t row_stride, size_t frame_stride, uint32_t n,
-                  size_t out_cap) {
+                  size_t out_cap, int phase) {
     hipStream_t st = ctx->stream;
     const size_t npx = (size_t)W * H;
     const uint32_t minwh = W < H ? W : H;
@@ -468,13 +503,16 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     const uint32_t marker_cap = (uint32_t)std::min<size_t>(std::max<size_t>(out_cap, 1), (size_t)n * kMaxCand);
     const uint32_t patch_cap = (uint32_t)std::min<uint64_t>(kPatchCapMax, std::max<uint64_t>(kPatchCapMin, (uint64_t)n * kMaxCand));
     if (ctx->debug_taps) { A3_HIP(ctx->patches.ensure((size_t)patch_cap * S * S)); ctx->patch_cap = patch_cap; }
+    int prof = ctx->front_prof;
+    if (phase != 2) {
     ctx->W = W; ctx->H = H; ctx->frames = n;
     ctx->stats = a3_stats{};
     ctx->contours_valid = false; ctx->markers_valid = false; ctx->poses_valid = false;
 
     // ---- K1 ----
     // (level in force for THIS batch: the sampled threshold-only mode times one batch in profile_every)
-    const int prof = ctx->profiling == 1 && (ctx->batch_seq++ % (uint32_t)ctx->profile_every) != 0 ? 0 : ctx->profiling;
+    prof = ctx->profiling == 1 && (ctx->batch_seq++ % (uint32_t)ctx->profile_every) != 0 ? 0 : ctx->profiling;
+    ctx->front_prof = prof;
     hipStream_t k1st = st;
     if (g_part_k1_cus > 0) {   // CU partition: the threshold kernel runs on the device's K1 stream, between two events
         A3_HIP(device_stream(ctx->device, kStreamK1, &k1st));
@@ -488,8 +526,10 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     if (k1st != st) {
         A3_HIP(hipEventRecord(ctx->ev_k1_done, k1st));
         A3_HIP(hipStreamWaitEvent(st, ctx->ev_k1_done, 0));
-    } else if (g_mark_threshold) A3_HIP(hipEventRecord(ctx->ev_k1_done, st));   // a3_debug_stream_wait_threshold
-    ctx->k1_marked = g_mark_threshold || k1st != st;
+    } else if (g_mark_threshold || phase == 1) A3_HIP(hipEventRecord(ctx->ev_k1_done, st));   // (held chains of a burst wait for the last member's)
+    ctx->k1_marked = g_mark_threshold || phase == 1 || k1st != st;
+    if (phase == 1) return A3_OK;
+    }
     // batches of OTHER contexts (same device) that wait with their decode stage are released from inside this batch's launch
     // sequence (see g_overlap_mode): `release_point(true)` records the event they wait for and enqueues them
     bool released = false;
@@ -724,6 +764,11 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
 int finish_batch(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_frame_count, size_t* out_n) {
     Pending& pd = ctx->pending;
     if (!pd.active) return fail(ctx, A3_ERR_INVALID, "no batch was submitted");
+    {   // a chain still held back (no later member of its burst was submitted): it goes out now
+        std::lock_guard<std::mutex> lk(g_defer_mu);
+        (void)flush_held_locked(ctx, nullptr);
+        if (const int rc = ctx->held_rc) { ctx->held_rc = 0; pd.active = false; return rc; }
+    }
     pd.active = false;
     hipStream_t st = ctx->stream;
     const size_t ctr_bytes = pd.ctr_bytes, head_pad = pd.head_pad, pose_bytes = pd.pose_bytes, n_chunks = pd.n_chunks;
@@ -842,7 +887,7 @@ int finish_batch(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_fram
 
 int run_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t H, size_t row_stride, size_t frame_stride, uint32_t n,
               a3_marker* out, size_t out_cap, uint32_t* per_frame_count, size_t* out_n) {
-    if (int rc = enqueue_batch(ctx, pixels, fmt, W, H, row_stride, frame_stride, n, out_cap)) return rc;
+    if (int rc = enqueue_batch(ctx, pixels, fmt, W, H, row_stride, frame_stride, n, out_cap, 0)) return rc;
     return finish_batch(ctx, out, out_cap, per_frame_count, out_n);
 }
 
@@ -946,6 +991,9 @@ void a3_destroy(a3_ctx* ctx) {
         for (size_t i = 0; i < g_deferred.size(); i++)
             if (g_deferred[i] == ctx) { g_deferred.erase(g_deferred.begin() + (long)i); break; }
         ctx->back_deferred = false;
+        for (size_t i = 0; i < g_held.size(); i++)
+            if (g_held[i] == ctx) { g_held.erase(g_held.begin() + (long)i); break; }
+        ctx->rest_held = false;
     }
     if (ctx->stream && ctx->stream != ctx->own_stream) (void)hipStreamSynchronize(ctx->stream);
     {   // the device's shared streams may still hold work of this context
@@ -1018,10 +1066,12 @@ int a3_order_after(a3_ctx* ctx, a3_ctx* other) {
     {   // a decode stage still held back would not be covered by an event on the owner's stream: it goes out now
         std::lock_guard<std::mutex> lk(g_defer_mu);
         if (other->back_deferred) { a3_ctx* o = other; if (int rc = flush_deferred_locked(o, nullptr)) { ctx->err = o->err; return rc; } }
+        if (other->rest_held) (void)flush_held_locked(other, nullptr);   // (likewise a held chain; its verdict is its owner's)
     }
     if (other->stream == ctx->stream) return A3_OK;   // one stream: already ordered
     A3_HIP(hipEventRecord(other->ev_gate, other->stream));
     A3_HIP(hipStreamWaitEvent(ctx->stream, other->ev_gate, 0));
+    ctx->gates_declared = true;
     return A3_OK;
 }
 
@@ -1135,8 +1185,40 @@ static int submit_common(a3_ctx* ctx, const void* pixels, int memory, int fmt, u
     ctx->want_pose = want_pose;
     Pending& pd = ctx->pending;
     pd.pixels = d_pixels; pd.fmt = fmt; pd.row_stride = row_stride; pd.frame_stride = frame_stride; pd.want_pose = want_pose;
+    // Bursts: a context that declared gates (a3_order_after) since its last submit holds its chain back behind its threshold
+    // kernel; a submit without gates is the last member of its burst and releases every held chain of the device behind ITS
+    // threshold kernel.  Not while every stage is being timed, not with the deferred decode of the shared-stream stepping.
+    const bool gated = ctx->gates_declared;
+    ctx->gates_declared = false;
+    const bool bursts = g_overlap_mode == 0 && g_hold_rests && ctx->profiling < 2;
+    if (bursts && gated) {
+        pd.n = n_frames; pd.W = width; pd.H = height;
+        ctx->held_out_cap = out_cap;
+        if (int erc = enqueue_batch(ctx, d_pixels, fmt, width, height, row_stride, frame_stride, n_frames, out_cap, 1)) return erc;
+        (void)hipStreamQuery(ctx->stream);
+        std::lock_guard<std::mutex> lk(g_defer_mu);
+        pd.active = true;
+        ctx->rest_held = true; ctx->held_rc = 0;
+        g_held.push_back(ctx);
+        return A3_OK;
+    }
+    bool any_held = false;
+    if (bursts) {
+        std::lock_guard<std::mutex> lk(g_defer_mu);
+        for (a3_ctx* o : g_held) any_held |= (o != ctx && o->device == ctx->device);
+    }
+    if (any_held) {   // the last member: threshold kernel, then the held chains of the others behind it, then this batch's own
+        if (int erc = enqueue_batch(ctx, d_pixels, fmt, width, height, row_stride, frame_stride, n_frames, out_cap, 1)) return erc;
+        {
+            std::lock_guard<std::mutex> lk(g_defer_mu);
+            const std::vector<a3_ctx*> list = g_held;   // (flush edits g_held)
+            for (a3_ctx* o : list)
+                if (o != ctx && o->device == ctx->device) (void)flush_held_locked(o, ctx->ev_k1_done);   // (a failure is o's: its collect reports it)
+        }
+        return enqueue_batch(ctx, d_pixels, fmt, width, height, row_stride, frame_stride, n_frames, out_cap, 2);
+    }
     ctx->allow_defer = true;    // (a synchronous call, or a re-run, enqueues both halves at once)
-    const int erc = enqueue_batch(ctx, d_pixels, fmt, width, height, row_stride, frame_stride, n_frames, out_cap);
+    const int erc = enqueue_batch(ctx, d_pixels, fmt, width, height, row_stride, frame_stride, n_frames, out_cap, 0);
     ctx->allow_defer = false;
     return erc;
 }
@@ -1307,6 +1389,7 @@ int a3_debug_set_partition(int k1_cus, int pattern) {   // before the first cont
 }
 
 int a3_debug_set_mark_threshold(int on) { g_mark_threshold = on != 0; return A3_OK; }
+int a3_debug_set_hold(int on) { std::lock_guard<std::mutex> lk(g_defer_mu); g_hold_rests = on != 0; return A3_OK; }
 
 int a3_debug_set_k1_waves(int waves_per_simd) { set_k1_waves(waves_per_simd); return A3_OK; }
 

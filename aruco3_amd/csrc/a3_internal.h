@@ -39,6 +39,11 @@ int  a3_debug_spin(void *hip_stream, int workgroups, int threads, int usec);
 int  a3_debug_set_mark_threshold(int on);
 int  a3_debug_stream_wait_threshold(a3_ctx *ctx, void *hip_stream);
 
+/* 0: contexts that declared burst gates (a3_order_after) enqueue their whole batch at submit, as round 3's library did; 1 (default):
+ * they hold the chain behind their threshold kernel until the burst's last member has enqueued its own (a3_api.hip, submit_common).
+ * Process-wide, for A/B timing; results are identical. */
+int  a3_debug_set_hold(int on);
+
 /* which build this is: bit 0 = -DA3_TUNING (the library reads tuning knobs from the environment), bit 1 = a non-default kernel
  * build option (A3_T_LPX, A3_T_WAVES ...).  0 for the product library; bench.py and the GPU tests report it. */
 int  a3_debug_build_flags(void);

@@ -79,12 +79,30 @@ def test_burst_stepping_equals_synchronous_calls(dicts):
                 sub(i + nc)
 
     try:
-        for mode in (0, 2):     # nothing deferred / decode stage deferred (a gate on such a context releases it first)
-            assert L.a3_debug_set_overlap(mode) == 0
+        for mode, hold in ((0, 1), (0, 0), (2, 1)):     # chains held back (the default) / enqueued at submit / decode stage deferred
+            assert L.a3_debug_set_overlap(mode) == 0 and L.a3_debug_set_hold(hold) == 0
             for nc in (4, 3, 2):
                 rotate(13, nc, lambda k, n: range(k + 1, n))                       # the documented rule
-                rotate(9, nc, lambda k, n: [m for m in range(n) if m != k])        # every other context
+                rotate(9, nc, lambda k, n: [m for m in range(n) if m != k])        # every other context (nobody is "last": collect releases)
                 rotate(9, nc, lambda k, n: [(k + 1) % n])                          # only the next one
+        assert L.a3_debug_set_overlap(0) == 0 and L.a3_debug_set_hold(1) == 0
+        # held chains in awkward orders: collected before the burst's last member ever submits; collected in reverse; a gate on a
+        # context whose chain is held (it is released first); a synchronous call in between; a member destroyed while held
+        c0, c1, c2, c3 = ctxs
+        c0.order_after(c1); c0.submit(*aa)                       # held: nobody releases it ...
+        assert same(c0.collect(), want[0])                       # ... collect does
+        c0.order_after(c1); c0.submit(*aa); c1.order_after(c2); c1.submit(*ab); c2.submit(*aa)    # c2 is the last member: releases c0, c1
+        assert same(c2.collect(), want[0]) and same(c1.collect(), want[1]) and same(c0.collect(), want[0])
+        c0.order_after(c3); c0.submit(*ab)                       # held
+        c1.order_after(c0)                                       # a gate on the holder: its chain goes out first
+        c1.submit(*aa)                                           # (c1 declared a gate: held itself)
+        assert same(c3.detect_batch(*ab), want[1])               # a synchronous call on a third context does not disturb them
+        assert same(c1.collect(), want[0]) and same(c0.collect(), want[1])
+        extra = _detector(dicts, "ARUCO_DEFAULT")._context()
+        extra.order_after(c0); c0.submit(*aa); extra.order_after(c0); extra.submit(*ab)      # extra holds a chain ...
+        extra.close()                                            # ... and is destroyed with it
+        c1.submit(*ab)                                           # the next last member must not trip over it
+        assert same(c0.collect(), want[0]) and same(c1.collect(), want[1])
         # contexts that share the caller's stream: already in order, the call is a no-op and must stay harmless
         st = torch.cuda.Stream()
         for cx in ctxs:
@@ -94,6 +112,71 @@ def test_burst_stepping_equals_synchronous_calls(dicts):
         fresh = _detector(dicts, "ARUCO_DEFAULT")._context()
         ctxs[0].order_after(ctxs[0]); ctxs[0].order_after(fresh); fresh.order_after(ctxs[0])
         assert same(fresh.detect_batch(*aa), want[0])
+    finally:
+        L.a3_debug_set_overlap(2)
+        L.a3_debug_set_hold(1)
+
+
+def test_held_chains_with_poses_and_host_threads(dicts):
+    """bursts with a3_detect_batch_pose_submit (the pose request must survive the hold) and with the members driven from different
+    host threads (the last member's thread enqueues the others' chains): results equal the synchronous calls'"""
+    import threading
+
+    import torch
+
+    from aruco3_amd import _lib, synth
+
+    fa, _ = synth.config_frames(1, 4)
+    da = torch.from_numpy(fa).cuda()
+    aa = _args(fa, _lib.MEM_DEVICE, da.data_ptr())
+    L = _lib.load()
+    ctxs = [_detector(dicts, "ARUCO_DEFAULT")._context() for _ in range(4)]
+    assert L.a3_debug_set_overlap(0) == 0 and L.a3_debug_set_hold(1) == 0
+    try:
+        wm, wp, wposes = ctxs[0].detect_batch_pose(*aa, 40.0, None, 256)
+        plain = ctxs[0].detect_batch(*aa)
+        assert len(wm) > 0
+        for rounds in range(3):
+            for k, cx in enumerate(ctxs):       # members 0, 2 ask for poses, 1, 3 do not
+                for m in range(k + 1, 4):
+                    cx.order_after(ctxs[m])
+                if k % 2 == 0:
+                    cx.submit_pose(*aa, 40.0, None, 256)
+                else:
+                    cx.submit(*aa, out_cap=256)
+            for k, cx in enumerate(ctxs):
+                if k % 2 == 0:
+                    m, p, poses = cx.collect_pose()
+                    assert marker_tuples(m) == marker_tuples(wm) and np.array_equal(poses.view(np.uint32), wposes.view(np.uint32))
+                else:
+                    m, p = cx.collect()
+                    assert marker_tuples(m) == marker_tuples(plain[0])
+        # four threads, one context each, a barrier per rotation so that the submits of a burst come from different threads
+        errs = []
+        bar = threading.Barrier(4)
+
+        def worker(k):
+            try:
+                cx = ctxs[k]
+                for r in range(25):
+                    bar.wait()
+                    for _ in range(k):
+                        pass
+                    for m in range(k + 1, 4):
+                        cx.order_after(ctxs[m])
+                    cx.submit(*aa, out_cap=256)
+                    m_, p_ = cx.collect()
+                    assert marker_tuples(m_) == marker_tuples(plain[0]), (k, r)
+            except Exception as e:   # noqa: BLE001
+                errs.append((k, repr(e)))
+                bar.abort()
+
+        ts = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errs, errs
     finally:
         L.a3_debug_set_overlap(2)
 

@@ -3,7 +3,8 @@
 contexts in submit / collect.  An arrangement = (streams: shared | own, contexts, K1 waves per SIMD, overlap mode).  Arrangements
 are interleaved ROUNDS times; prints the median ms per step of each, the threshold kernel's duration in company (sampled events)
 and its duration alone in the same geometry.
-  python tools/ab_streams.py [frames] [steps] [rounds] [spec,spec,...]      spec = streams:contexts:k1waves:overlap[:group]  e.g. own:2:1:0, own:8:2:0:4 (two bursts of four)"""
+  python tools/ab_streams.py [frames] [steps] [rounds] [spec,spec,...]      spec = streams:contexts:k1waves:overlap[:group[:hold]]  e.g. own:2:1:0, own:8:2:0:4 (two bursts of
+  four, submitted together), own:4:2:0:-1 (rotation with burst gates), own:4:2:0:-1:0 (the same, chains not held back)"""
 import sys
 import time
 from pathlib import Path
@@ -95,6 +96,7 @@ def main():
         for s in specs:
             kind, nc, kw, ov = s.split(":")[:4]
             group = int(s.split(":")[4]) if len(s.split(":")) > 4 else 1
+            assert L.a3_debug_set_hold(int(s.split(":")[5]) if len(s.split(":")) > 5 else 1) == 0
             ctxs = pools[kind][: int(nc)]
             assert L.a3_debug_set_overlap(int(ov)) == 0
             assert L.a3_debug_set_k1_waves(int(kw)) == 0
@@ -127,6 +129,7 @@ def main():
               f"all {[round(x, 4) for x in res[s]]}", flush=True)
     L.a3_debug_set_overlap(2)
     L.a3_debug_set_k1_waves(2)
+    L.a3_debug_set_hold(1)
 
 
 if __name__ == "__main__":

@@ -29,7 +29,7 @@ def main():
 
     frames = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-    rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    rounds = int(sys.argv[3]) if len(sys.argv) > 3 else len(CASES)
     d = ARDictionary.new_from_named_dict("ARUCO")
     spec, _ = synth.config_spec(2)
     d_frames, _ = synth.render_frames_device(spec, d.code_list, d.num_bits, [synth.frame_seed(2, i) for i in range(frames)])
@@ -71,7 +71,9 @@ def main():
     res = {cs: [] for cs in CASES}
     k1 = {cs: [] for cs in CASES}
     for r in range(rounds):
-        for wg, usec, mode in CASES:
+        order = CASES[r % len(CASES):] + CASES[:r % len(CASES)]      # every case takes every position in turn: what runs before a case moves it by 1-2 %
+        run(2 * nc, 0, 0, False, 0)
+        for wg, usec, mode in order:
             run(8, wg, usec, False, mode)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             m, per, _ = run(steps, wg, usec, False, mode)
