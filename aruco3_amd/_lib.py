@@ -16,7 +16,7 @@ _HERE = Path(__file__).resolve().parent
 # everything else loads the product library next to this file.
 LIB_PATH = Path(os.environ["A3_HIP_LIB"]).resolve() if os.environ.get("A3_HIP_LIB") else _HERE / "libaruco3_hip.so"
 
-OK, ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_INTERNAL, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
+OK, ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_INTERNAL, ERR_NO_DEVICE, ERR_LIMIT = 0, -1, -2, -3, -4, -5, -6
 FMT_RGB8, FMT_RGBA8, FMT_L8, FMT_BGRA8 = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
 PROFILE_OFF, PROFILE_STAGES, PROFILE_THRESHOLD_ONLY, PROFILE_THRESHOLD_SAMPLED = 0, 1, 2, 3

@@ -78,8 +78,8 @@ thread_local std::string g_create_error;
 
 // Quad candidates kept per frame.  The reference is unbounded (src/aruco.rs:124-166 pushes into a Vec); here the tables start at
 // kMaxCandDefault per frame and a batch that overflows them is re-run with tables twice the size, up to kMaxCandLimit (the
-// per-frame ordering + discard_too_near kernel keeps a frame's candidates in LDS: 21 bytes each); beyond that: A3_ERR_CAPACITY.
-constexpr uint32_t kMaxCandDefault = 1024, kMaxCandLimit = 6144;
+// per-frame ordering + discard_too_near kernel keeps a frame's candidates in LDS: 21 bytes each); beyond that: A3_ERR_LIMIT.
+constexpr uint32_t kMaxCandDefault = 1024, kMaxCandLimit = A3_MAX_CANDIDATES_PER_FRAME;
 constexpr uint32_t kMaxContoursDefault = 1u << 20;
 constexpr uint64_t kMaxDartsDefault = 48ull << 20;
 constexpr uint64_t kMaxPointsDefault = 64ull << 20;
@@ -610,7 +610,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
         fd.assign((uint64_t*)ctx->pinned, (uint64_t*)ctx->pinned + n);
         uint64_t biggest = 0;
         for (uint64_t v : fd) { biggest = std::max(biggest, v); ctx->stats.darts += v; }
-        if (biggest > kHardMaxDarts) return fail(ctx, A3_ERR_CAPACITY, "a frame needs more contour-graph nodes than 32-bit indices allow");
+        if (biggest > kHardMaxDarts) return fail(ctx, A3_ERR_LIMIT, "a frame needs more contour-graph nodes than 32-bit indices allow");
         if (biggest > ctx->max_darts) ctx->max_darts = biggest;  // one frame must fit; grow the pool
         Chunk c{0, 0, 0, 0};
         for (uint32_t f = 0; f < n; f++) {
@@ -833,7 +833,7 @@ int finish_batch(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_fram
     if (flags & kErrBrokenEvent) return fail(ctx, A3_ERR_INTERNAL, "contour graph: a start event lies on an open chain");
     if (flags & kErrResolve) return fail(ctx, A3_ERR_INTERNAL, "contour start resolution did not converge");
     if (flags & kErrCandTable) {   // a frame has more quad candidates than its table: twice the table and again
-        if (ctx->max_cand >= kMaxCandLimit) return fail(ctx, A3_ERR_CAPACITY, "a frame holds more than 6144 quad candidates");
+        if (ctx->max_cand >= kMaxCandLimit) return fail(ctx, A3_ERR_LIMIT, "a frame holds more than 6144 quad candidates (A3_MAX_CANDIDATES_PER_FRAME)");
         ctx->max_cand = std::min(kMaxCandLimit, ctx->max_cand * 2);
         return 1;
     }
@@ -996,9 +996,9 @@ void a3_destroy(a3_ctx* ctx) {
         ctx->rest_held = false;
     }
     if (ctx->stream && ctx->stream != ctx->own_stream) (void)hipStreamSynchronize(ctx->stream);
-    {   // the device's shared streams may still hold work of this context
-        std::lock_guard<std::mutex> lk(g_streams_mu);
-        const DeviceStreams& ds = g_dev_streams[ctx->device & 63];
+    {   // the device's shared streams may still hold work of this context: handles copied under the mutex, waited for outside it
+        DeviceStreams ds;   // (a destroy must not stall every other thread's first use of a stream for the length of the queued work)
+        { std::lock_guard<std::mutex> lk(g_streams_mu); ds = g_dev_streams[ctx->device & 63]; }
         if (ds.decode) (void)hipStreamSynchronize(ds.decode);
         if (ds.copy) (void)hipStreamSynchronize(ds.copy);
         if (ds.k1) (void)hipStreamSynchronize(ds.k1);

@@ -29,8 +29,14 @@ enum {
     A3_ERR_HIP = -2,        /* a HIP runtime call failed */
     A3_ERR_CAPACITY = -3,   /* caller's output array (or a fixed device pool) is too small */
     A3_ERR_INTERNAL = -4,   /* an invariant of the contour stage did not hold; results withheld */
-    A3_ERR_NO_DEVICE = -5
+    A3_ERR_NO_DEVICE = -5,
+    A3_ERR_LIMIT = -6       /* a fixed limit of this implementation, which no larger buffer of the caller's cures: more than
+                             * A3_MAX_CANDIDATES_PER_FRAME quad candidates in one frame (the reference's lists are unbounded Vecs,
+                             * src/aruco.rs:128; here a frame's candidates are ordered and thinned (discard_too_near) in one
+                             * workgroup's LDS), or a frame whose contour graph needs more than 2^32 nodes.  Growing `out` and
+                             * calling again -- the cure for A3_ERR_CAPACITY -- does not help. */
 };
+#define A3_MAX_CANDIDATES_PER_FRAME 6144
 
 /* pixel layouts accepted where the reference takes an image::DynamicImage (src/aruco.rs:52,60) */
 enum { A3_FMT_RGB8 = 0, A3_FMT_RGBA8 = 1, A3_FMT_L8 = 2,
@@ -123,11 +129,21 @@ int  a3_detect_batch_pose(a3_ctx *ctx, const void *pixels, int memory, int fmt, 
                           size_t row_stride, size_t frame_stride, uint32_t n_frames, float marker_size_mm,
                           const a3_intrinsics *intr, a3_marker *out, a3_pose *poses, size_t out_cap,
                           uint32_t *per_frame_count, size_t *out_n);
-/* The same call in two halves, for callers that keep the GPU fed: submit enqueues the whole batch and returns without
+/* The same call in two halves, for callers that keep the GPU fed: submit enqueues the batch and returns without
  * waiting; collect waits for it and hands out the results (re-running the batch synchronously in the rare cases
- * a3_detect_batch would).  One batch may be in flight per context; with two contexts on one stream, batch i+1 is
- * submitted before batch i is collected.  Device-resident frames and pinned host frames must stay valid until collect;
- * pageable host frames have been read when submit returns.  out_cap of submit bounds the marker list; collect's must not be smaller than what was found. */
+ * a3_detect_batch would).  One batch may be in flight per context; several contexts keep several batches in flight (see
+ * a3_order_after).  out_cap of submit bounds the marker list; collect's must not be smaller than what was found.
+ *
+ * Frames: device-resident frames and pinned host frames must stay valid AND UNMODIFIED from submit until collect returns --
+ * also by work the caller queues on its own stream behind the submit.  Part of a submitted batch runs on streams the library
+ * owns (the device-wide decode and copy streams; a chain held back for a burst is enqueued later), ordered against the caller's
+ * stream only through events recorded at submit; and the decode stage samples the FRAMES themselves (no grey plane is kept), so
+ * a frame overwritten before collect changes what is read.  Pageable host frames have been read when submit returns.
+ *
+ * Hardware queues: the HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and two
+ * streams that share a queue run in order whatever their events say.  A process that keeps four contexts on their own streams
+ * plus the library's decode / copy streams in flight should export GPU_MAX_HW_QUEUES=8 before the runtime starts (bench.py
+ * does); with fewer queues results are the same and the batches merely overlap less. */
 int  a3_detect_batch_submit(a3_ctx *ctx, const void *pixels, int memory, int fmt, uint32_t width, uint32_t height,
                             size_t row_stride, size_t frame_stride, uint32_t n_frames, size_t out_cap);
 int  a3_detect_batch_collect(a3_ctx *ctx, a3_marker *out, size_t out_cap, uint32_t *per_frame_count, size_t *out_n);

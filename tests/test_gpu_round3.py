@@ -266,7 +266,7 @@ def test_more_candidates_than_the_limit_is_an_error_not_a_clip(dicts):
     det = _detector(dicts, "ARUCO")
     with pytest.raises(_lib.A3Error) as e:
         _detect_host(det, np.ascontiguousarray(img[None, :, :, None]), taps=False)
-    assert e.value.code == _lib.ERR_CAPACITY
+    assert e.value.code == _lib.ERR_LIMIT
 
 
 def test_uniform_noise_frame_3840x2160(dicts, oracle):
