@@ -612,6 +612,95 @@ impl Detector {
 }
 
 // =====================================================================================================
+// 3b. BatchQueue: several batches in flight, stepped in bursts (include/aruco3_hip.h, a3_order_after)
+// =====================================================================================================
+
+/// New (additive).  A capture / processing loop that must keep the GPU fed keeps `depth` batches in flight: `submit` hands a
+/// batch over and returns at once, `collect` waits for the OLDEST batch in flight and returns its detections (markers only:
+/// `Detection.grey` / `.candidates` / `.homographies` stay empty).  Inside, `depth` contexts of their own (not the registry's) are
+/// used in rotation, each on a stream of its own, with the burst gates the header describes: before each submit context k calls
+/// `a3_order_after` for the contexts k+1 .. depth-1, so the threshold kernels of one rotation run back to back after the previous
+/// rotation's chains have drained and the contour / decode chains of the rotation run together.  depth = 4 is the fastest
+/// arrangement measured for 256 x 1920x1080 frames per batch (Stepping); results never depend on it.
+/// Export GPU_MAX_HW_QUEUES=8 before the process touches HIP (header, "Hardware queues").
+pub struct BatchQueue {
+    ctxs: Vec<HipCtx>,
+    frames_in: Vec<usize>, // frames of the batch in flight on each context
+    head: usize,           // context of the oldest batch in flight
+    in_flight: usize,
+    submitted: usize,
+}
+
+impl BatchQueue {
+    pub fn new(detector: &Detector, depth: usize) -> BatchQueue {
+        assert!(depth >= 1 && depth <= 8, "aruco3_hip: BatchQueue depth must be in 1..=8");
+        let device = DEVICE.load(Ordering::Relaxed);
+        let cfg = to_a3_config(&detector.config);
+        let ctxs: Vec<HipCtx> = (0..depth).map(|_| HipCtx::create(device, &cfg, &detector.dictionary)).collect();
+        BatchQueue { frames_in: vec![0; depth], ctxs, head: 0, in_flight: 0, submitted: 0 }
+    }
+
+    /// batches in flight
+    pub fn len(&self) -> usize {
+        self.in_flight
+    }
+    pub fn is_full(&self) -> bool {
+        self.in_flight == self.ctxs.len()
+    }
+
+    /// Enqueue one batch (all frames of one size).  Panics if `depth` batches are already in flight: collect first.
+    pub fn submit(&mut self, images: &[DynamicImage]) {
+        assert!(!self.is_full(), "aruco3_hip: BatchQueue is full: collect() the oldest batch first");
+        assert!(!images.is_empty(), "aruco3_hip: empty batch");
+        let depth = self.ctxs.len();
+        let k = self.submitted % depth;
+        for m in k + 1..depth {
+            // burst gate: this batch's threshold kernel starts once the batches in flight on the later contexts (the previous
+            // rotation's) have drained.  A scheduling hint: a3_order_after never changes a result.
+            let (this, other) = (self.ctxs[k].raw, self.ctxs[m].raw);
+            self.ctxs[k].check(unsafe { a3_order_after(this, other) }, "a3_order_after");
+        }
+        let ctx = &mut self.ctxs[k];
+        let p = pack(images, &mut ctx.staging); // pinned staging owned by the context: stays untouched until collect
+        ctx.check(unsafe { a3_set_debug_taps(ctx.raw, 0) }, "a3_set_debug_taps");
+        let n = images.len();
+        let rc = unsafe {
+            a3_detect_batch_submit(ctx.raw, p.bytes as *const c_void, A3_MEM_HOST, p.fmt, p.width, p.height, p.width as usize * p.bpp,
+                                   p.width as usize * p.height as usize * p.bpp, n as u32, MAX_MARKERS_PER_FRAME.min(64) * n)
+        };
+        ctx.check(rc, "a3_detect_batch_submit");
+        self.frames_in[k] = n;
+        self.submitted += 1;
+        self.in_flight += 1;
+    }
+
+    /// Wait for the oldest batch in flight; one `Detection` per frame, in frame order.
+    pub fn collect(&mut self) -> Vec<Detection> {
+        assert!(self.in_flight > 0, "aruco3_hip: BatchQueue::collect with nothing in flight");
+        let k = self.head;
+        let ctx = &self.ctxs[k];
+        let n = self.frames_in[k];
+        let mut markers = vec![A3Marker::default(); 64 * n];
+        let mut per = vec![0u32; n];
+        let mut found = 0usize;
+        // (a list longer than 64 markers per frame: the library reports A3_ERR_CAPACITY and the batch has to be re-run through
+        // detect_batch, which grows its list; marker-dense workloads should size for it here)
+        let rc = unsafe { a3_detect_batch_collect(ctx.raw, markers.as_mut_ptr(), markers.len(), per.as_mut_ptr(), &mut found) };
+        ctx.check(rc, "a3_detect_batch_collect");
+        self.head = (self.head + 1) % self.ctxs.len();
+        self.in_flight -= 1;
+        let mut out = Vec::with_capacity(n);
+        let mut pos = 0usize;
+        for f in 0..n {
+            let cnt = per[f] as usize;
+            out.push(Detection { grey: None, candidates: vec![], homographies: vec![], markers: markers[pos..pos + cnt].iter().map(marker_of).collect() });
+            pos += cnt;
+        }
+        out
+    }
+}
+
+// =====================================================================================================
 // 4. Pose: the bodies of src/pose.rs:52-81 + README.md:34's `estimate_pose`
 // =====================================================================================================
 

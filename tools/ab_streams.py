@@ -55,6 +55,7 @@ def main():
 
     def run(k, ctxs, group=1):
         nc = len(ctxs)
+        host_us.clear(); host_us.extend([] for _ in range(nc))
         if group <= 1:       # rotation: the context just collected submits the batch nc ahead
             def sub(i):      # group < 0: gated rotation (a3_order_after): context k waits for contexts k+1 .. nc-1
                 if group < 0:   # -1: every later context; -2: all but the last; -3: only the next one
@@ -64,7 +65,9 @@ def main():
                     if group == -3: later = later[:1]
                     for mth in later:
                         ctxs[k0].order_after(ctxs[mth])
+                t_s = time.perf_counter()
                 ctxs[i % nc].submit(*a, out_cap=n * 64)
+                host_us[i % nc].append((time.perf_counter() - t_s) * 1e6)
             for i in range(min(nc, k)):
                 sub(i)
             for i in range(k):
@@ -89,7 +92,9 @@ def main():
                 pending.append(grp); left -= group
         return m, per
 
+    host_us = []
     res = {s: [] for s in specs}
+    host = {}
     k1c = {s: [0.0, 0] for s in specs}
     k1a = {}
     for r in range(rounds):
@@ -118,6 +123,7 @@ def main():
             assert len(m) == len(ref[0]) and np.array_equal(per, ref[1])
             done_steps = steps if group <= 1 else (steps // group) * group
             res[s].append(dt / done_steps * 1e3)
+            host[s] = [round(sum(v) / max(len(v), 1)) for v in host_us]
             for cx in ctxs:
                 ms, cnt = cx.profile(_lib.STAGE_THRESHOLD, reset=True)
                 k1c[s][0] += ms; k1c[s][1] += cnt
@@ -126,7 +132,7 @@ def main():
         v = sorted(res[s])
         med = v[len(v) // 2]
         print(f"{s:16s} median {med:.4f} ms/step  ({n / med * 1e3:8.0f} frames/s)  K1 in company {k1c[s][0] / max(k1c[s][1], 1):.4f} ms, alone {k1a[s]:.4f} ms  "
-              f"all {[round(x, 4) for x in res[s]]}", flush=True)
+              f"all {[round(x, 4) for x in res[s]]}  host us per submit by context {host.get(s)}", flush=True)
     L.a3_debug_set_overlap(2)
     L.a3_debug_set_k1_waves(2)
     L.a3_debug_set_hold(1)
