@@ -32,7 +32,7 @@ SYMBOLS = [
     "a3_contour_count", "a3_download_contours", "a3_detection_record_bytes", "a3_pack_detections",
 ]
 # aruco3_amd/csrc/a3_internal.h: probes and single-stage hooks for this repository's tests and tools, not for bindings
-INTERNAL_SYMBOLS = ["a3_debug_set_overlap", "a3_debug_set_k1_waves", "a3_debug_set_partition", "a3_debug_build_flags", "a3_debug_spin", "a3_debug_set_mark_threshold", "a3_debug_set_hold", "a3_debug_stream_wait_threshold", "a3_debug_kernel_time", "a3_selftest_ieee", "a3_debug_clockwise", "a3_debug_rotate_bits", "a3_debug_discard_too_near"]
+INTERNAL_SYMBOLS = ["a3_debug_set_overlap", "a3_debug_set_k1_waves", "a3_debug_set_partition", "a3_debug_build_flags", "a3_debug_spin", "a3_debug_set_mark_threshold", "a3_debug_set_hold", "a3_debug_launch_threshold", "a3_debug_stream_wait_threshold", "a3_debug_kernel_time", "a3_selftest_ieee", "a3_debug_clockwise", "a3_debug_rotate_bits", "a3_debug_discard_too_near"]
 
 
 class A3Error(RuntimeError):
@@ -160,6 +160,9 @@ def load():
     if hasattr(L, "a3_debug_set_k1_waves"):
         L.a3_debug_set_k1_waves.restype = C.c_int
         L.a3_debug_set_k1_waves.argtypes = [C.c_int]
+    if hasattr(L, "a3_debug_launch_threshold"):
+        L.a3_debug_launch_threshold.restype = C.c_int
+        L.a3_debug_launch_threshold.argtypes = [vp, vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32]
     if hasattr(L, "a3_debug_set_hold"):
         L.a3_debug_set_hold.restype = C.c_int
         L.a3_debug_set_hold.argtypes = [C.c_int]

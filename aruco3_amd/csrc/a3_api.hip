@@ -1388,6 +1388,18 @@ int a3_debug_set_partition(int k1_cus, int pattern) {   // before the first cont
     return A3_OK;
 }
 
+// the threshold kernel alone on the context's stream, asynchronously (buffers of a preceding batch of the same shape are re-used)
+int a3_debug_launch_threshold(a3_ctx* ctx, const void* pixels_device, int fmt, uint32_t width, uint32_t height, uint32_t n_frames) {
+    if (!ctx || !pixels_device || n_frames == 0) return A3_ERR_INVALID;
+    A3_HIP(hipSetDevice(ctx->device));
+    if (int rc = need_stream(ctx)) return rc;
+    const size_t bpp = fmt == A3_FMT_RGB8 ? 3 : (fmt == A3_FMT_L8 ? 1 : 4);
+    A3_HIP(ctx->bin.ensure((size_t)words_per_row(width) * 8 * height * n_frames));
+    A3_HIP(launch_grey_threshold(ctx->stream, reinterpret_cast<const uint8_t*>(pixels_device), fmt, (size_t)width * bpp, (size_t)width * bpp * height,
+                                 (int)width, (int)height, n_frames, ctx->cfg.threshold_window, nullptr, ctx->bin.as<uint64_t>()));
+    return A3_OK;
+}
+
 int a3_debug_set_mark_threshold(int on) { g_mark_threshold = on != 0; return A3_OK; }
 int a3_debug_set_hold(int on) { std::lock_guard<std::mutex> lk(g_defer_mu); g_hold_rests = on != 0; return A3_OK; }
 

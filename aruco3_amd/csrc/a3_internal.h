@@ -44,6 +44,10 @@ int  a3_debug_stream_wait_threshold(a3_ctx *ctx, void *hip_stream);
  * Process-wide, for A/B timing; results are identical. */
 int  a3_debug_set_hold(int on);
 
+/* the threshold kernel alone, asynchronously, on the context's stream (tools/k1_concurrency.py: how several launches in flight
+ * at once share the chip) */
+int  a3_debug_launch_threshold(a3_ctx *ctx, const void *pixels_device, int fmt, uint32_t width, uint32_t height, uint32_t n_frames);
+
 /* which build this is: bit 0 = -DA3_TUNING (the library reads tuning knobs from the environment), bit 1 = a non-default kernel
  * build option (A3_T_LPX, A3_T_WAVES ...).  0 for the product library; bench.py and the GPU tests report it. */
 int  a3_debug_build_flags(void);

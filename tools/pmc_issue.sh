@@ -1,7 +1,7 @@
 #!/bin/bash
 # Two PMC passes over the bench (GPU box): per kernel, how busy the VALU is and what the waves wait for (tuning aid).
 ROOT=$(cd "$(dirname "$0")/.." && pwd); OUT=$ROOT/gpurun_out/pmc_issue; rm -rf "$OUT"; mkdir -p "$OUT"; export TMPDIR=/tmp
-ARGS="--device-synth --no-cpu-baseline --no-other-workloads --repeats 1 --steps 3 --warmup 1"
+ARGS="--device-synth --no-cpu-baseline --no-other-workloads --no-pipeline --isolated-launches 2 --repeats 1 --steps 3 --warmup 1"
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS --output-format csv -d "$OUT" -o p1 -- python3 "$ROOT/bench.py" $ARGS > "$OUT/p1.log" 2>&1 || { tail -5 "$OUT/p1.log"; exit 1; }
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$OUT" -o p2 -- python3 "$ROOT/bench.py" $ARGS > "$OUT/p2.log" 2>&1 || { tail -5 "$OUT/p2.log"; exit 2; }
