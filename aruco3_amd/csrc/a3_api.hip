@@ -16,8 +16,9 @@
 
 namespace a3 {
 // k_threshold.hip
-hipError_t launch_grey_threshold(hipStream_t, const uint8_t*, int, size_t, size_t, int, int, uint32_t, uint32_t, uint8_t*, uint64_t*);
+hipError_t launch_grey_threshold(hipStream_t, const uint8_t*, int, size_t, size_t, int, int, uint32_t, uint32_t, uint8_t*, uint64_t*, uint16_t*);
 void set_k1_waves(int);
+bool threshold_writes_grey_plane(uint32_t radius);
 void set_k1_cus(int);
 bool k1_build_is_default();
 // k_contours.hip
@@ -220,6 +221,7 @@ struct a3_ctx {
     unsigned int* scratch_u32 = nullptr; DeviceCounters* counters = nullptr; uint32_t* per_frame = nullptr; uint32_t* frame_cursor = nullptr; uint32_t* cand_count = nullptr;
     uint32_t last_marker_total = 0;   // sizes the speculative marker read-back of the next batch
     DevBuf tmp_a, tmp_b, tmp_c, tmp_d;
+    DevBuf hsum;                // row sums of the grey plane (u16): threshold windows above 7 only
     DevBuf wtab;                // triangle-resize weights of a full patch (sample -> mark_size), written once at a3_create
     DevBuf pose_buf;            // a3_detect_batch_pose: both poses of every marker of the last batch (kept for a3_pack_detections)
     bool poses_valid = false;
@@ -486,10 +488,12 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     const uint32_t kMaxCand = ctx->max_cand;
 
     // the grey plane is materialised only for readers outside the fused path: Detection.grey (debug taps) and the generic
-    // threshold kernels of other window sizes; the decode stage otherwise samples the caller's frames directly
-    const bool need_grey = ctx->debug_taps || ctx->cfg.threshold_window != 7;
+    // threshold kernels of windows above 7; the decode stage otherwise samples the caller's frames directly
+    const bool need_grey = ctx->debug_taps || threshold_writes_grey_plane(ctx->cfg.threshold_window);
     if (need_grey) A3_HIP(ctx->grey.ensure(npx * n));
     ctx->grey_valid = need_grey;
+    const bool big_window = threshold_writes_grey_plane(ctx->cfg.threshold_window);
+    if (big_window) A3_HIP(ctx->hsum.ensure(npx * n * 2));
     const size_t bits_per_frame = (size_t)words_per_row(W) * 8 * H;   // packed thresholded image
     A3_HIP(ctx->bin.ensure(bits_per_frame * n));
     A3_HIP(ctx->frame_darts.ensure((size_t)n * 8));
@@ -521,7 +525,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     }
     if (prof) A3_HIP(hipEventRecord(ctx->ev[0], k1st));
     A3_HIP(launch_grey_threshold(k1st, pixels, fmt, row_stride, frame_stride, (int)W, (int)H, n, ctx->cfg.threshold_window,
-                                 need_grey ? ctx->grey.as<uint8_t>() : nullptr, ctx->bin.as<uint64_t>()));
+                                 need_grey ? ctx->grey.as<uint8_t>() : nullptr, ctx->bin.as<uint64_t>(), big_window ? ctx->hsum.as<uint16_t>() : nullptr));
     if (prof) A3_HIP(hipEventRecord(ctx->ev[1], k1st));
     if (k1st != st) {
         A3_HIP(hipEventRecord(ctx->ev_k1_done, k1st));
@@ -1009,7 +1013,7 @@ void a3_destroy(a3_ctx* ctx) {
                       &ctx->leader_list, &ctx->leader_keep, &ctx->entry_list, &ctx->entry_pos, &ctx->es_a, &ctx->es_b,
                       &ctx->contours, &ctx->cyc_start_off, &ctx->points, &ctx->zero_blk, &ctx->cands,
                       &ctx->pre_xy, &ctx->fin_xy, &ctx->fin_count, &ctx->work, &ctx->outs, &ctx->proj, &ctx->patches,
-                      &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_d, &ctx->pose_buf, &ctx->wtab};
+                      &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_d, &ctx->hsum, &ctx->pose_buf, &ctx->wtab};
     for (DevBuf* b : bufs) b->release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_counts) (void)hipHostFree(ctx->pinned_counts);
@@ -1396,7 +1400,7 @@ int a3_debug_launch_threshold(a3_ctx* ctx, const void* pixels_device, int fmt, u
     const size_t bpp = fmt == A3_FMT_RGB8 ? 3 : (fmt == A3_FMT_L8 ? 1 : 4);
     A3_HIP(ctx->bin.ensure((size_t)words_per_row(width) * 8 * height * n_frames));
     A3_HIP(launch_grey_threshold(ctx->stream, reinterpret_cast<const uint8_t*>(pixels_device), fmt, (size_t)width * bpp, (size_t)width * bpp * height,
-                                 (int)width, (int)height, n_frames, ctx->cfg.threshold_window, nullptr, ctx->bin.as<uint64_t>()));
+                                 (int)width, (int)height, n_frames, ctx->cfg.threshold_window, nullptr, ctx->bin.as<uint64_t>(), nullptr));
     return A3_OK;
 }
 

@@ -207,32 +207,52 @@ __device__ __forceinline__ uint32_t byte_pair(int k, uint32_t hi, uint32_t lo) {
     return __builtin_amdgcn_perm(hi, lo, 0x0C000C00u | (uint32_t)(k & 3) | ((uint32_t)(4 + (k & 3)) << 16));
 }
 
-// 15-wide horizontal sums of one grey row: Hp[j] = (sum over pixels j-7 .. j+7) | (sum over pixels j+T_NP-7 .. j+T_NP+7) << 16,
-// j = 0 .. T_NP-1, for the lane's T_LPX pixels; 7 grey bytes come from each neighbouring lane (wave shifts, no LDS).
+// (2R+1)-wide horizontal sums of one grey row: Hp[j] = (sum over pixels j-R .. j+R) | (sum over pixels j+T_NP-R .. j+T_NP+R) << 16,
+// j = 0 .. T_NP-1, for the lane's T_LPX pixels; up to 8 grey bytes come from each neighbouring lane (wave shifts, no LDS).
+// R <= 7: a window never reaches past the neighbouring lane's nearest 8 pixels, and sums of 2R+1 bytes fit 16 bits with room.
+// sum of the bytes lo .. hi (inclusive) of the byte string D[] (byte k = byte k & 3 of D[k >> 2]) added to acc: whole dwords
+// cost one v_sad_u8, partial ones an AND more; every index is a compile-time constant
+template <int LO, int HI>
+__device__ __forceinline__ uint32_t sum_bytes(const uint32_t* D, uint32_t acc) {
+#pragma unroll
+    for (int i = LO >> 2; i <= HI >> 2; i++) {
+        const int b0 = i * 4 < LO ? LO - i * 4 : 0, b1 = i * 4 + 3 > HI ? HI - i * 4 : 3;   // bytes b0 .. b1 of dword i are inside
+        const uint32_t mask = (b1 == 3 ? 0xFFFFFFFFu : ((1u << (8 * (b1 + 1))) - 1u)) & ~((1u << (8 * b0)) - 1u);
+        acc = __builtin_amdgcn_sad_u8(mask == 0xFFFFFFFFu ? D[i] : (D[i] & mask), 0u, acc);
+    }
+    return acc;
+}
+template <int R = T_R>
 __device__ __forceinline__ void row_sums(const uint32_t g[T_NG], uint32_t Hp[T_NP]) {
-    // D[] = the dwords of pixels -8 .. T_LPX+7; B[k] = byte k & 3 of D[(k + 8) >> 2]
+    static_assert(R >= 1 && R <= 7, "the packed 16-bit sums and the one-lane halo hold for radii 1..7");
+    // D[] = the dwords of pixels -8 .. T_LPX+7; B[k] = byte k & 3 of D[k >> 2] = pixel k - 8
     uint32_t D[T_NG + 4];
     D[0] = wave_from_left(g[T_NG - 2]); D[1] = wave_from_left(g[T_NG - 1]);
 #pragma unroll
     for (int i = 0; i < T_NG; i++) D[2 + i] = g[i];
     D[T_NG + 2] = wave_from_right(g[0]); D[T_NG + 3] = wave_from_right(g[1]);
-    // the two chains start at pixels 0 and T_NP: bytes p-7 .. p+7 = bytes 1..3 of D[(p + 1) >> 2] and the three dwords behind it
     uint32_t ha, hb;
-    if constexpr (T_LPX == 16) {
-        const uint32_t mid = __builtin_amdgcn_sad_u8(D[3], 0u, 0u);                               // pixels 4..7, in both
-        ha = __builtin_amdgcn_sad_u8(D[2], 0u, __builtin_amdgcn_sad_u8(D[1], 0u, __builtin_amdgcn_sad_u8(D[0] & 0xFFFFFF00u, 0u, mid)));
-        hb = __builtin_amdgcn_sad_u8(D[5], 0u, __builtin_amdgcn_sad_u8(D[4], 0u, __builtin_amdgcn_sad_u8(D[2] & 0xFFFFFF00u, 0u, mid)));
-    } else {
-        const uint32_t mid = __builtin_amdgcn_sad_u8(D[3], 0u, __builtin_amdgcn_sad_u8(D[2], 0u, 0u));   // pixels 0..7, in both
-        ha = __builtin_amdgcn_sad_u8(D[1], 0u, __builtin_amdgcn_sad_u8(D[0] & 0xFFFFFF00u, 0u, mid));
-        hb = __builtin_amdgcn_sad_u8(D[4], 0u, __builtin_amdgcn_sad_u8(D[1] & 0xFFFFFF00u, 0u, mid));
+    if constexpr (R == 7) {
+        // the two chains start at pixels 0 and T_NP: bytes p-7 .. p+7 = bytes 1..3 of D[(p + 1) >> 2] and the three dwords behind it
+        if constexpr (T_LPX == 16) {
+            const uint32_t mid = __builtin_amdgcn_sad_u8(D[3], 0u, 0u);                               // pixels 4..7, in both
+            ha = __builtin_amdgcn_sad_u8(D[2], 0u, __builtin_amdgcn_sad_u8(D[1], 0u, __builtin_amdgcn_sad_u8(D[0] & 0xFFFFFF00u, 0u, mid)));
+            hb = __builtin_amdgcn_sad_u8(D[5], 0u, __builtin_amdgcn_sad_u8(D[4], 0u, __builtin_amdgcn_sad_u8(D[2] & 0xFFFFFF00u, 0u, mid)));
+        } else {
+            const uint32_t mid = __builtin_amdgcn_sad_u8(D[3], 0u, __builtin_amdgcn_sad_u8(D[2], 0u, 0u));   // pixels 0..7, in both
+            ha = __builtin_amdgcn_sad_u8(D[1], 0u, __builtin_amdgcn_sad_u8(D[0] & 0xFFFFFF00u, 0u, mid));
+            hb = __builtin_amdgcn_sad_u8(D[4], 0u, __builtin_amdgcn_sad_u8(D[1] & 0xFFFFFF00u, 0u, mid));
+        }
+    } else {   // pixel p is byte p + 8: chain a sums bytes 8-R .. 8+R, chain b bytes 8+T_NP-R .. 8+T_NP+R
+        ha = sum_bytes<8 - R, 8 + R>(D, 0u);
+        hb = sum_bytes<8 + T_NP - R, 8 + T_NP + R>(D, 0u);
     }
     Hp[0] = ha | (hb << 16);
-    // slide both chains one pixel: + (B[J+8], B[J+8+T_NP]) - (B[J-7], B[J-7+T_NP])
+    // slide both chains one pixel: + (B[J+9+R], B[J+9+R+T_NP]) - (B[J+8-R], B[J+8-R+T_NP])
 #pragma unroll
     for (int J = 0; J + 1 < T_NP; J++)
-        Hp[J + 1] = pk_sub(pk_add(Hp[J], byte_pair(J, D[(J + 16 + T_NP) >> 2], D[(J + 16) >> 2])),
-                           byte_pair(J + 1, D[(J + 1 + T_NP) >> 2], D[(J + 1) >> 2]));
+        Hp[J + 1] = pk_sub(pk_add(Hp[J], byte_pair(J + 9 + R, D[(J + 9 + R + T_NP) >> 2], D[(J + 9 + R) >> 2])),
+                           byte_pair(J + 8 - R, D[(J + 8 - R + T_NP) >> 2], D[(J + 8 - R) >> 2]));
 }
 
 // One wave walks down a strip: lane l owns columns xs - T_LPX + T_LPX l .. + T_LPX - 1.  Per image row it converts its pixels
@@ -240,7 +260,11 @@ __device__ __forceinline__ void row_sums(const uint32_t g[T_NG], uint32_t Hp[T_N
 // packed u16 pairs (pixel j with pixel j + T_NP); the row 7 iterations old is then thresholded: sum < (L+1)*area.
 // No barriers; T_PF rows of loads stay in flight per lane; LDS only parks the result bits between bursts of stores.
 // grid: 8 * ceil(frames / 8) * strips_x * strips_y workgroups of one wave.
-template <int FMT, bool FAST, int T_PF = A3_T_PF>
+// R: the window's radius (threshold_window), 1..7; the window is NR = 2R+1 rows tall.  The rings have NRING slots, NR rounded up to
+// a multiple of the load queue's depth, and the row loop is unrolled NRING times: the ring slot (row % NRING) and the queue slot
+// (row % T_PF) of every row are then compile-time constants, and the row that leaves the window -- NR rows old -- sits in slot
+// (row - NR) % NRING (for the default radius NR = NRING = 15: the very slot the new row overwrites).
+template <int FMT, bool FAST, int T_PF = A3_T_PF, int R = T_R>
 __global__ __launch_bounds__(64, T_PF == A3_T_PF ? A3_T_WAVES : 1) void k_grey_threshold7(const uint8_t* __restrict__ pixels, size_t row_stride, size_t frame_stride,
                                                         int W, int H, int rows_per_wave, int strips_y, int n_pairs,
                                                         uint8_t* __restrict__ grey,
@@ -249,6 +273,7 @@ __global__ __launch_bounds__(64, T_PF == A3_T_PF ? A3_T_WAVES : 1) void k_grey_t
     // flush_rows > 0: the result bits per lane and row are parked in LDS (flush_rows + 15 rows of 64 lanes) and leave in bursts
     // of flush_rows rows.  66 MB of small stores dribbling into a saturating read stream cost K1 ~0.07 ms (HBM bus turnarounds:
     // tools/micro/readbench.hip); the same bytes in a few large bursts per wave cost about half of that.
+    constexpr int NR = 2 * R + 1, NRING = ((NR + T_PF - 1) / T_PF) * T_PF, UNROLL = NRING;
     extern __shared__ uint8_t s_out_raw[];
     out_bits_t* s_out = reinterpret_cast<out_bits_t*>(s_out_raw);
     int n_buf = 0, y_buf0 = 0;
@@ -284,22 +309,22 @@ __global__ __launch_bounds__(64, T_PF == A3_T_PF ? A3_T_WAVES : 1) void k_grey_t
     for (int i = 0; i < T_LPX; i++) {
         const int x = x0 + i;
         int a = 0;
-        if (x >= 0 && x < W) a = min(x + T_R, W - 1) - max(x - T_R, 0) + 1;
+        if (x >= 0 && x < W) a = min(x + R, W - 1) - max(x - R, 0) + 1;
         axp[i >> 3] |= (uint32_t)a << (4 * (i & 7));
     }
 
     uint32_t area[T_NP];       // clipped window areas of columns j | j + T_NP << 16 for the current row's window height
     uint32_t ay_cur = 0;
-    uint32_t gring[15][T_NG];  // grey rows; row `it` lives in slot it % 15 (static: the row loop is unrolled 15x); a row is read
-                               // again 7 iterations later, so only 8 of the slots are live at any time
+    uint32_t gring[NRING][T_NG];  // grey rows; row `it` lives in slot it % NRING (static: the row loop is unrolled); a row is read
+                               // again R iterations later, so only R + 1 of the slots are live at any time
 #if !A3_T_RECOMPUTE
-    uint32_t hring[15][T_NP];  // the last 15 rows of horizontal sums (pairs)
+    uint32_t hring[NRING][T_NP];  // the last NRING rows of horizontal sums (pairs); the window's oldest is NR rows back
 #endif
-    uint32_t S[T_NP];          // 15x15 window sums of the row 7 iterations old (pairs)
+    uint32_t S[T_NP];          // NR x NR window sums of the row R iterations old (pairs)
 #pragma unroll
     for (int i = 0; i < T_NP; i++) S[i] = 0u;
 #pragma unroll
-    for (int q = 0; q < 15; q++) {
+    for (int q = 0; q < NRING; q++) {
 #pragma unroll
         for (int i = 0; i < T_NG; i++) gring[q][i] = 0u;
 #if !A3_T_RECOMPUTE
@@ -314,7 +339,7 @@ __global__ __launch_bounds__(64, T_PF == A3_T_PF ? A3_T_WAVES : 1) void k_grey_t
     // the XCD's L2 instead of fetching them again from HBM.  The box filter is symmetric, so direction only changes
     // the order rows enter and leave the window.
     const int dir = (sy & 1) ? -1 : 1;
-    const int r_first = dir > 0 ? y_begin - T_R : y_end - 1 + T_R, n_rows = (y_end - y_begin) + 2 * T_R;
+    const int r_first = dir > 0 ? y_begin - R : y_end - 1 + R, n_rows = (y_end - y_begin) + 2 * R;
     RawRow<FMT> q[T_PF];
     // FAST: every load is unconditional (row and column clamped into the image) so that the loop body has no branch
     // around a load and the compiler can keep T_PF rows in flight with counted waits; what the clamped address
@@ -328,15 +353,16 @@ __global__ __launch_bounds__(64, T_PF == A3_T_PF ? A3_T_WAVES : 1) void k_grey_t
 #pragma unroll
     for (int k = 0; k < T_PF; k++) issue(r_first + dir * k, q[k]);
 
-    static_assert(15 % T_PF == 0, "the load queue index must be static inside the 15x unrolled body");
-    // FAST: whole blocks of 15 rows and no exit test inside the unrolled body (rows past the strip are clamped loads whose
+    // FAST: whole blocks of UNROLL rows and no exit test inside the unrolled body (rows past the strip are clamped loads whose
     // results are never stored), so the body is straight-line code apart from the store predicates
-    const int n_iter = FAST ? ((n_rows + 14) / 15) * 15 : n_rows;
-    for (int base = 0; base < n_iter; base += 15) {
+    const int n_iter = FAST ? ((n_rows + UNROLL - 1) / UNROLL) * UNROLL : n_rows;
+    for (int base = 0; base < n_iter; base += UNROLL) {
 #pragma unroll
-        for (int k15 = 0; k15 < 15; k15++) {
-            const int k = k15 % T_PF;
-            const int it = base + k15;
+        for (int ku = 0; ku < UNROLL; ku++) {
+            const int k15 = ku;            // ring slot of this row (UNROLL == NRING)
+            const int kold = (ku + NRING - NR) % NRING;   // slot of the row that leaves the window
+            const int k = ku % T_PF;       // load-queue slot of this row
+            const int it = base + ku;
             if (!FAST && it >= n_iter) break;
             const int r = r_first + dir * it;
             uint32_t g[T_NG];
@@ -363,26 +389,26 @@ __global__ __launch_bounds__(64, T_PF == A3_T_PF ? A3_T_WAVES : 1) void k_grey_t
             // horizontal sums of the new row, then the vertical window: + the new row's sums, - those of the row that
             // entered 15 iterations ago (they never underflow: the add comes first and the true sum is >= 0)
             uint32_t Hn[T_NP];
-            row_sums(g, Hn);
+            row_sums<R>(g, Hn);
 #if A3_T_RECOMPUTE
             {   // the sums of the row that leaves the window are formed again from its grey bytes (slot k15 still holds that row)
                 uint32_t Ho[T_NP];
-                row_sums(gring[k15], Ho);
+                row_sums<R>(gring[kold], Ho);
 #pragma unroll
                 for (int j = 0; j < T_NP; j++) S[j] = pk_sub(pk_add(S[j], Hn[j]), Ho[j]);
             }
 #else
 #pragma unroll
-            for (int j = 0; j < T_NP; j++) { S[j] = pk_sub(pk_add(S[j], Hn[j]), hring[k15][j]); hring[k15][j] = Hn[j]; }
+            for (int j = 0; j < T_NP; j++) { S[j] = pk_sub(pk_add(S[j], Hn[j]), hring[kold][j]); hring[k15][j] = Hn[j]; }
 #endif
 #pragma unroll
             for (int i = 0; i < T_NG; i++) gring[k15][i] = g[i];
-            const uint32_t* centre = gring[(k15 + 8) % 15];   // the row 7 iterations old: the one being thresholded
+            const uint32_t* centre = gring[(k15 + NRING - R) % NRING];   // the row R iterations old: the one being thresholded
 
-            const int y = r - dir * T_R;   // the row whose window is now complete
+            const int y = r - dir * R;   // the row whose window is now complete
             if (y < y_begin || y >= y_end) continue;   // wave-uniform
-            const uint32_t ay = (uint32_t)(min(y + T_R, H - 1) - max(y - T_R, 0) + 1);
-            if (ay != ay_cur) {   // wave-uniform; only the first and last 7 image rows differ from 15
+            const uint32_t ay = (uint32_t)(min(y + R, H - 1) - max(y - R, 0) + 1);
+            if (ay != ay_cur) {   // wave-uniform; only the first and last R image rows differ from NR
                 ay_cur = ay;
 #pragma unroll
                 for (int j = 0; j < T_NP; j++)
@@ -418,7 +444,7 @@ __global__ __launch_bounds__(64, T_PF == A3_T_PF ? A3_T_WAVES : 1) void k_grey_t
                 n_buf++;
             }
         }
-        // (checked once per block of 15 rows, outside the unrolled body: the buffer holds flush_rows + 15 rows)
+        // (checked once per block of UNROLL rows, outside the unrolled body: the buffer holds flush_rows + UNROLL rows)
         if (flush_rows > 0 && n_buf >= flush_rows) {   // wave-uniform
             if (owner)
                 for (int q = 0; q < n_buf; q++)
@@ -432,16 +458,40 @@ __global__ __launch_bounds__(64, T_PF == A3_T_PF ? A3_T_WAVES : 1) void k_grey_t
 }
 
 // ---- generic radius: plain two-kernel path (correct for any threshold_window, not tuned) ----
+// four consecutive pixels per thread: dword loads and one dword store where the row is 4-byte aligned, bytes otherwise
 template <int FMT>
 __global__ void k_grey_generic(const uint8_t* __restrict__ pixels, size_t row_stride, size_t frame_stride, int W, int H,
                                uint8_t* __restrict__ grey) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x), y = blockIdx.y;
     if (x >= W) return;
     const uint32_t f = blockIdx.z;
     constexpr int BPP = FMT == A3_FMT_RGB8 ? 3 : (FMT == A3_FMT_L8 ? 1 : 4);
     const uint8_t* p = pixels + (size_t)f * frame_stride + (size_t)y * row_stride + (size_t)x * BPP;
-    grey[(size_t)f * W * H + (size_t)y * W + x] =
-        BPP == 1 ? p[0] : (uint8_t)(FMT == A3_FMT_BGRA8 ? luma_of(p[2], p[1], p[0]) : luma_of(p[0], p[1], p[2]));
+    uint8_t* out = grey + (size_t)f * W * H + (size_t)y * W + x;
+    auto luma = [](uint32_t b0, uint32_t b1, uint32_t b2) -> uint32_t { return FMT == A3_FMT_BGRA8 ? luma_of(b2, b1, b0) : luma_of(b0, b1, b2); };
+    if (x + 3 < W && (reinterpret_cast<uintptr_t>(p) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0) {
+        uint32_t d[BPP];
+#pragma unroll
+        for (int i = 0; i < BPP; i++) d[i] = reinterpret_cast<const uint32_t*>(p)[i];
+        uint32_t g = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t v;
+            if (BPP == 1) v = (d[0] >> (8 * i)) & 0xFFu;
+            else {
+                const int b = i * BPP;   // byte offset of pixel i inside d[]
+                auto byte = [&](int k) -> uint32_t { return (d[k >> 2] >> (8 * (k & 3))) & 0xFFu; };
+                v = luma(byte(b), byte(b + 1), byte(b + 2));
+            }
+            g |= v << (8 * i);
+        }
+        *reinterpret_cast<uint32_t*>(out) = g;
+        return;
+    }
+    for (int i = 0; i < 4 && x + i < W; i++) {
+        const uint8_t* q = p + (size_t)i * BPP;
+        out[i] = BPP == 1 ? q[0] : (uint8_t)luma(q[0], q[1], q[2]);
+    }
 }
 
 // one wave per packed word: 64 consecutive pixels, result gathered with a ballot
@@ -464,6 +514,81 @@ __global__ __launch_bounds__(64) void k_threshold_generic(const uint8_t* __restr
     if (threadIdx.x == 0) bits[(size_t)blockIdx.z * wpr * H + (size_t)y * wpr + blockIdx.x] = m;
 }
 
+// Windows above 7, separable: horizontal sums of the grey plane into a u16 plane (2R+1 <= 257 values of at most 255), then a
+// vertical running sum per column with the compare.  Plain kernels (no register ring: (2R+1)^2 * 256 no longer fits 16 bits), but
+// the work per pixel no longer grows with the window's AREA as in k_threshold_generic.
+// k_hsum_generic: a workgroup covers 1024 columns of one row, four consecutive outputs per thread (a sliding sum: 2R + 4 byte reads for
+// four results); the row segment is staged in LDS with dword loads.
+constexpr int kHsumCols = 1024;
+__global__ __launch_bounds__(256) void k_hsum_generic(const uint8_t* __restrict__ grey, int W, int H, int radius, uint16_t* __restrict__ hsum) {
+    extern __shared__ uint8_t s_row[];   // grey bytes of columns x0 - R4 .. of this row, R4 = R rounded up to 4 (zeros outside the image)
+    const int x0 = blockIdx.x * kHsumCols, y = blockIdx.y;
+    const size_t base = ((size_t)blockIdx.z * H + y) * W;
+    const int r4 = (radius + 3) & ~3, span = kHsumCols + 2 * r4;
+    const bool row_aligned = ((base & 3) == 0) && ((W & 3) == 0);
+    for (int i = threadIdx.x * 4; i < span; i += 1024) {
+        const int x = x0 - r4 + i;
+        uint32_t v = 0;
+        if (row_aligned && x >= 0 && x + 3 < W) v = *reinterpret_cast<const uint32_t*>(grey + base + x);
+        else {
+#pragma unroll
+            for (int b = 0; b < 4; b++) if (x + b >= 0 && x + b < W) v |= (uint32_t)grey[base + x + b] << (8 * b);
+        }
+        *reinterpret_cast<uint32_t*>(s_row + i) = v;
+    }
+    __syncthreads();
+    const int x = x0 + 4 * (int)threadIdx.x;
+    if (x >= W) return;
+    const uint8_t* p = s_row + r4 + 4 * threadIdx.x - radius;   // p[k] = grey(x - R + k)
+    uint32_t sum = 0;
+    for (int k = 0; k <= 2 * radius; k++) sum += p[k];
+    uint32_t out[4];
+    out[0] = sum;
+#pragma unroll
+    for (int j = 1; j < 4; j++) { sum += p[2 * radius + j]; sum -= p[j - 1]; out[j] = sum; }
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (x + j < W) hsum[base + x + j] = (uint16_t)out[j];
+}
+
+// one wave per 64 columns and strip of rows: lane = column, V = sum of hsum over the rows y - R .. y + R inside the image; the loads of
+// eight rows are issued together (they do not depend on V), then the eight rows are finished in order
+constexpr int kVsumRows = 128;
+__global__ __launch_bounds__(64) void k_vsum_threshold_generic(const uint8_t* __restrict__ grey, const uint16_t* __restrict__ hsum, int W, int H, int radius,
+                                                               uint64_t* __restrict__ bits) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y0 = blockIdx.y * kVsumRows, y1 = min(H, y0 + kVsumRows);
+    const size_t plane = (size_t)blockIdx.z * W * H;
+    const bool in = x < W;
+    const int xc = in ? x : W - 1;
+    const uint16_t* hs = hsum + plane + xc;
+    const uint8_t* g = grey + plane + xc;
+    const uint32_t ax = in ? (uint32_t)(min(x + radius, W - 1) - max(x - radius, 0) + 1) : 0u;
+    uint32_t V = 0;
+    for (int yy = max(y0 - radius, 0); yy <= min(y0 + radius, H - 1); yy++) V += hs[(size_t)yy * W];
+    const size_t wpr = words_per_row((uint32_t)W);
+    uint64_t* brow = bits + (size_t)blockIdx.z * wpr * H + blockIdx.x;
+    constexpr int B = 8;
+    for (int yb = y0; yb < y1; yb += B) {
+        uint32_t gv[B], add[B], sub[B];
+#pragma unroll
+        for (int u = 0; u < B; u++) {   // unconditional loads from clamped rows, masked afterwards
+            const int y = yb + u, ya = y + radius + 1, ys = y - radius;
+            gv[u] = g[(size_t)min(y, H - 1) * W];
+            add[u] = hs[(size_t)min(ya, H - 1) * W] & (0u - (uint32_t)(ya < H));
+            sub[u] = hs[(size_t)max(ys, 0) * W] & (0u - (uint32_t)(ys >= 0));
+        }
+#pragma unroll
+        for (int u = 0; u < B; u++) {
+            const int y = yb + u;
+            if (y >= y1) break;
+            const uint32_t ay = (uint32_t)(min(y + radius, H - 1) - max(y - radius, 0) + 1);
+            const bool white = in && V < (gv[u] + 1u) * (ax * ay);     // sum < (L + 1) * area  <=>  L >= floor(sum / area)
+            const unsigned long long m = __ballot(white);
+            if (threadIdx.x == 0) brow[(size_t)y * wpr] = m;
+            V += add[u]; V -= sub[u];
+        }
+    }
+}
+
 // ---- host launcher -------------------------------------------------------------------------
 // K1 waves per SIMD the strip model sizes a launch for (a3_internal.h: a3_debug_set_k1_waves).  2 = the whole chip in one
 // round (every register of every SIMD); 1 = one wave per SIMD, strips twice as tall: half of every SIMD's registers and wave
@@ -474,65 +599,95 @@ bool k1_build_is_default() { return A3_T_LPX == 16 && A3_T_PF == 3 && A3_T_WAVES
 static int g_k1_cus = 256;   // compute units the kernel's stream may use (a3_debug_set_partition)
 void set_k1_cus(int c) { g_k1_cus = c < 8 ? 8 : (c > 256 ? 256 : c); }
 
-hipError_t launch_grey_threshold(hipStream_t st, const uint8_t* pixels, int fmt, size_t row_stride, size_t frame_stride, int W, int H,
-                                 uint32_t n, uint32_t radius, uint8_t* grey, uint64_t* bits) {
-    if (radius == (uint32_t)T_R) {
-        const int aligned_in = ((uintptr_t)pixels % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0);
-        const int aligned_out = (W % 16 == 0) && ((uintptr_t)grey % 16 == 0);
-        uint8_t* bin = reinterpret_cast<uint8_t*>(bits);
-        if (W % 64 != 0) {  // packed rows end in padding bits that no tile writes
-            hipError_t e = hipMemsetAsync(bits, 0, (size_t)words_per_row((uint32_t)W) * 8 * H * n, st);
-            if (e != hipSuccess) return e;
-        }
-        // Rows per wave.  Every wave also reads and converts 14 rows outside its strip, so strips should be tall; but the
-        // chip holds 256 CUs x 4 SIMDs x A3_T_WAVES waves at once and a launch runs in whole rounds of that many, so the
-        // number of strips should fill the last round.  Model: time ~ rounds x (rows per strip + 14); take the best
-        // strip count (at least 16 rows per strip).  256 frames of 1920x1080 with 8 pixels per lane: 4 column strips x 3 strips of
-        // 360 rows = 3072 waves = exactly one round of three waves per SIMD.
-        const int strips_x = (W + T_OUT - 1) / T_OUT;
-        const long long slots = (long long)g_k1_cus * 4 * g_k1_waves, cols = (long long)strips_x * n;
-        int best_sy = 1; double best_cost = 1e300;
-        for (int sy = 1; sy <= std::max(1, H / 16); sy++) {
-            const int rows = (H + sy - 1) / sy;
-            const long long waves = cols * ((H + rows - 1) / rows);
-            const double cost = (double)((waves + slots - 1) / slots) * (rows + 2 * T_R);
-            if (cost < best_cost - 1e-9) { best_cost = cost; best_sy = sy; }
-        }
-        int rows_per_wave = (H + best_sy - 1) / best_sy;
-        if (const int rv = tuning_knob("A3_ROWS_PER_WAVE", 0); rv > 0) rows_per_wave = rv;   // (-DA3_TUNING builds only)
-        const int strips_y = (H + rows_per_wave - 1) / rows_per_wave;
-        const int n_pairs = (int)n * strips_x;
-        // every strip of a frame on one XCD (1) or every (frame, column strip) pair on its own XCD (0).  By frame is ~3 % faster:
-        // the two column strips of a frame overlap by 32 columns and write the same lines of the packed image
-        const int map_by_frame = tuning_knob("A3_K1_MAP", 1);
-        // rows of results a wave parks in LDS before it writes them out (0: store row by row): 128 (+15) rows x 64 lanes x 1 or 2
-        // bytes = 9 or 18 KB per wave; twelve resp. eight waves per CU fit the 160 KB
-        // (-1 = "no stores at all" is a timing probe that leaves the binary image stale: it exists in -DA3_TUNING builds only)
-        // (every resident wave's parking area must fit the CU's 160 KB: 4 x A3_T_WAVES waves)
-        constexpr int flush_cap = (160 * 1024 / (4 * A3_T_WAVES)) / (64 * (int)sizeof(out_bits_t)) - 15;
-        const int fv = tuning_knob("A3_K1_FLUSH", flush_cap < 128 ? flush_cap : 128);
-#ifdef A3_TUNING
-        const int flush_rows = fv < 0 ? -1 : std::min(fv, rows_per_wave);
-#else
-        const int flush_rows = std::min(fv < 0 ? 128 : fv, rows_per_wave);
-#endif
-        const size_t lds_bytes = flush_rows > 0 ? (size_t)(flush_rows + 15) * 64 * sizeof(out_bits_t) : 0;
-        dim3 grid(map_by_frame ? 8 * (((int)n + 7) / 8) * strips_x * strips_y : 8 * ((n_pairs + 7) / 8) * strips_y), block(64);
-        const bool fast = aligned_in && aligned_out;   // W % 16 == 0: a lane's 16 pixels are all inside or all outside
-#define A3_LAUNCH_K1(F, B, ...) hipLaunchKernelGGL((k_grey_threshold7<F, B __VA_OPT__(,) __VA_ARGS__>), grid, block, lds_bytes, st, pixels, row_stride, frame_stride, W, H, \
-                                              rows_per_wave, strips_y, n_pairs, grey, bin, aligned_in, aligned_out, map_by_frame, flush_rows)
-        if (fmt == A3_FMT_RGB8) { if (fast && g_k1_waves == 1 && A3_T_WAVES != 1) A3_LAUNCH_K1(A3_FMT_RGB8, true, 5); else if (fast) A3_LAUNCH_K1(A3_FMT_RGB8, true); else A3_LAUNCH_K1(A3_FMT_RGB8, false); }
-        else if (fmt == A3_FMT_RGBA8) { if (fast) A3_LAUNCH_K1(A3_FMT_RGBA8, true); else A3_LAUNCH_K1(A3_FMT_RGBA8, false); }
-        else if (fmt == A3_FMT_BGRA8) { if (fast) A3_LAUNCH_K1(A3_FMT_BGRA8, true); else A3_LAUNCH_K1(A3_FMT_BGRA8, false); }
-        else { if (fast) A3_LAUNCH_K1(A3_FMT_L8, true); else A3_LAUNCH_K1(A3_FMT_L8, false); }
-#undef A3_LAUNCH_K1
-        return hipGetLastError();
+// the register-resident kernel for one radius R in 1..7 (the default, 7, is the one every figure of DESIGN.md is about)
+template <int R>
+static hipError_t launch_k1(hipStream_t st, const uint8_t* pixels, int fmt, size_t row_stride, size_t frame_stride, int W, int H, uint32_t n,
+                            uint8_t* grey, uint64_t* bits) {
+    constexpr int NR = 2 * R + 1, UNROLL = ((NR + A3_T_PF - 1) / A3_T_PF) * A3_T_PF;   // (as in the kernel)
+    const int aligned_in = ((uintptr_t)pixels % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0);
+    const int aligned_out = (W % 16 == 0) && ((uintptr_t)grey % 16 == 0);
+    uint8_t* bin = reinterpret_cast<uint8_t*>(bits);
+    if (W % 64 != 0) {  // packed rows end in padding bits that no tile writes
+        hipError_t e = hipMemsetAsync(bits, 0, (size_t)words_per_row((uint32_t)W) * 8 * H * n, st);
+        if (e != hipSuccess) return e;
     }
-    dim3 block(64), gridg((W + 63) / 64, H, n), grid1(words_per_row((uint32_t)W), H, n);
+    // Rows per wave.  Every wave also reads and converts 2R rows outside its strip, so strips should be tall; but the
+    // chip holds 256 CUs x 4 SIMDs x A3_T_WAVES waves at once and a launch runs in whole rounds of that many, so the
+    // number of strips should fill the last round.  Model: time ~ rounds x (rows per strip + 2R); take the best
+    // strip count (at least 16 rows per strip).  256 frames of 1920x1080, R = 7: 2 column strips x 4 strips of 270 rows = 2048 waves
+    // = exactly one round of two waves per SIMD.
+    const int strips_x = (W + T_OUT - 1) / T_OUT;
+    const long long slots = (long long)g_k1_cus * 4 * g_k1_waves, cols = (long long)strips_x * n;
+    int best_sy = 1; double best_cost = 1e300;
+    for (int sy = 1; sy <= std::max(1, H / 16); sy++) {
+        const int rows = (H + sy - 1) / sy;
+        const long long waves = cols * ((H + rows - 1) / rows);
+        const double cost = (double)((waves + slots - 1) / slots) * (rows + 2 * R);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best_sy = sy; }
+    }
+    int rows_per_wave = (H + best_sy - 1) / best_sy;
+    if (const int rv = tuning_knob("A3_ROWS_PER_WAVE", 0); rv > 0) rows_per_wave = rv;   // (-DA3_TUNING builds only)
+    const int strips_y = (H + rows_per_wave - 1) / rows_per_wave;
+    const int n_pairs = (int)n * strips_x;
+    // every strip of a frame on one XCD (1) or every (frame, column strip) pair on its own XCD (0).  By frame is ~3 % faster:
+    // the two column strips of a frame overlap by 32 columns and write the same lines of the packed image
+    const int map_by_frame = tuning_knob("A3_K1_MAP", 1);
+    // rows of results a wave parks in LDS before it writes them out (0: store row by row): 128 (+ UNROLL) rows x 64 lanes x 1 or 2
+    // bytes = 9 or 18 KB per wave; twelve resp. eight waves per CU fit the 160 KB
+    // (-1 = "no stores at all" is a timing probe that leaves the binary image stale: it exists in -DA3_TUNING builds only)
+    // (every resident wave's parking area must fit the CU's 160 KB: 4 x A3_T_WAVES waves)
+    constexpr int flush_cap = (160 * 1024 / (4 * A3_T_WAVES)) / (64 * (int)sizeof(out_bits_t)) - UNROLL;
+    const int fv = tuning_knob("A3_K1_FLUSH", flush_cap < 128 ? flush_cap : 128);
+#ifdef A3_TUNING
+    const int flush_rows = fv < 0 ? -1 : std::min(fv, rows_per_wave);
+#else
+    const int flush_rows = std::min(fv < 0 ? 128 : fv, rows_per_wave);
+#endif
+    const size_t lds_bytes = flush_rows > 0 ? (size_t)(flush_rows + UNROLL) * 64 * sizeof(out_bits_t) : 0;
+    dim3 grid(map_by_frame ? 8 * (((int)n + 7) / 8) * strips_x * strips_y : 8 * ((n_pairs + 7) / 8) * strips_y), block(64);
+    const bool fast = aligned_in && aligned_out;   // W % 16 == 0: a lane's 16 pixels are all inside or all outside
+#define A3_LAUNCH_K1(F, B, PF) hipLaunchKernelGGL((k_grey_threshold7<F, B, PF, R>), grid, block, lds_bytes, st, pixels, row_stride, frame_stride, W, H, \
+                                              rows_per_wave, strips_y, n_pairs, grey, bin, aligned_in, aligned_out, map_by_frame, flush_rows)
+    if (fmt == A3_FMT_RGB8) {
+        if constexpr (R == T_R && A3_T_WAVES != 1) { if (fast && g_k1_waves == 1) { A3_LAUNCH_K1(A3_FMT_RGB8, true, 5); return hipGetLastError(); } }
+        if (fast) A3_LAUNCH_K1(A3_FMT_RGB8, true, A3_T_PF); else A3_LAUNCH_K1(A3_FMT_RGB8, false, A3_T_PF);
+    }
+    else if (fmt == A3_FMT_RGBA8) { if (fast) A3_LAUNCH_K1(A3_FMT_RGBA8, true, A3_T_PF); else A3_LAUNCH_K1(A3_FMT_RGBA8, false, A3_T_PF); }
+    else if (fmt == A3_FMT_BGRA8) { if (fast) A3_LAUNCH_K1(A3_FMT_BGRA8, true, A3_T_PF); else A3_LAUNCH_K1(A3_FMT_BGRA8, false, A3_T_PF); }
+    else { if (fast) A3_LAUNCH_K1(A3_FMT_L8, true, A3_T_PF); else A3_LAUNCH_K1(A3_FMT_L8, false, A3_T_PF); }
+#undef A3_LAUNCH_K1
+    return hipGetLastError();
+}
+
+// threshold windows the register-resident kernel covers: radii 1..kFusedMaxRadius.  Beyond 7 the packed 16-bit arithmetic ends --
+// (2R+1)^2 * 256 no longer fits a u16 from R = 8 on (289 * 256 = 73 984), so window sums and the compare would need 32-bit lanes and a ring
+// of 2R+1 rows no register file holds: larger windows take the plain two-kernel path below.
+constexpr uint32_t kFusedMaxRadius = 7;
+bool threshold_writes_grey_plane(uint32_t radius) { return radius == 0 || radius > kFusedMaxRadius; }
+
+hipError_t launch_grey_threshold(hipStream_t st, const uint8_t* pixels, int fmt, size_t row_stride, size_t frame_stride, int W, int H,
+                                 uint32_t n, uint32_t radius, uint8_t* grey, uint64_t* bits, uint16_t* hsum_tmp) {
+    switch (radius) {
+        case 1: return launch_k1<1>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
+        case 2: return launch_k1<2>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
+        case 3: return launch_k1<3>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
+        case 4: return launch_k1<4>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
+        case 5: return launch_k1<5>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
+        case 6: return launch_k1<6>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
+        case 7: return launch_k1<7>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
+        default: break;
+    }
+    dim3 block(64), gridg((W + 255) / 256, H, n), grid1(words_per_row((uint32_t)W), H, n);
     if (fmt == A3_FMT_RGB8) hipLaunchKernelGGL(k_grey_generic<A3_FMT_RGB8>, gridg, block, 0, st, pixels, row_stride, frame_stride, W, H, grey);
     else if (fmt == A3_FMT_RGBA8) hipLaunchKernelGGL(k_grey_generic<A3_FMT_RGBA8>, gridg, block, 0, st, pixels, row_stride, frame_stride, W, H, grey);
     else if (fmt == A3_FMT_BGRA8) hipLaunchKernelGGL(k_grey_generic<A3_FMT_BGRA8>, gridg, block, 0, st, pixels, row_stride, frame_stride, W, H, grey);
     else hipLaunchKernelGGL(k_grey_generic<A3_FMT_L8>, gridg, block, 0, st, pixels, row_stride, frame_stride, W, H, grey);
+    if (hsum_tmp && radius <= 128u) {   // separable: row sums (<= 257 * 255 fit a u16), then a running column sum with the compare
+        hipLaunchKernelGGL(k_hsum_generic, dim3((W + kHsumCols - 1) / kHsumCols, H, n), dim3(256), kHsumCols + 2 * ((radius + 3) & ~3u) + 16, st, grey, W, H, (int)radius, hsum_tmp);
+        hipLaunchKernelGGL(k_vsum_threshold_generic, dim3(words_per_row((uint32_t)W), (H + kVsumRows - 1) / kVsumRows, n), dim3(64), 0, st, grey, hsum_tmp,
+                           W, H, (int)radius, bits);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_threshold_generic, grid1, block, 0, st, grey, W, H, (int)radius, bits);
     return hipGetLastError();
 }

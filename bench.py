@@ -333,6 +333,30 @@ def main():
             k1_ms, k1_n = a, b
     ctx.set_profiling(0)
 
+    # The threshold kernel as the stepping runs it: the n_ctx launches of a burst, back to back on the contexts' own streams, nothing
+    # else on the GPU (a3_debug_launch_threshold: the kernel alone).  Launches in flight together refill each other's retiring wave
+    # slots, which a lone launch -- sized to fill the chip in exactly one round -- cannot: the per-launch time here is what the
+    # kernel costs inside a step, the isolated one above what it costs alone.
+    k1_burst_ms = None
+    if own_streams and n_ctx > 1 and args.workload in WORKLOADS:
+        import ctypes as C
+        spans = []
+        for rep in range(12):
+            torch.cuda.synchronize()
+            s0 = torch.cuda.Event(enable_timing=True)
+            ends = [torch.cuda.Event(enable_timing=True) for _ in ctxs]
+            s0.record(ctx_stream[id(ctxs[0])])
+            for cx in ctxs[1:]:
+                ctx_stream[id(cx)].wait_event(s0)
+            for cx in ctxs:
+                assert L.a3_debug_launch_threshold(cx.handle, C.c_void_p(d_frames.data_ptr()), _lib.FMT_RGB8, w, h, n) == 0
+            for cx, e in zip(ctxs, ends):
+                e.record(ctx_stream[id(cx)])
+            torch.cuda.synchronize()
+            spans.append(max(s0.elapsed_time(e) for e in ends) / n_ctx)
+        spans = sorted(spans[2:])
+        k1_burst_ms = spans[len(spans) // 2]
+
     res = run_steps(args.warmup)
 
     # The timed region: EXACTLY --steps steps between barrier + synchronize on both sides, max over ranks.  It is run
@@ -523,6 +547,12 @@ def main():
                 "timed_how": "HIP events around the kernel in dedicated synchronous batches of this run, one at a time, nothing else on the GPU "
                              "(--isolated-launches); in the stepping itself the kernel never runs alone",
                 "avg_launch_ms_in_company": k1_company,
+                # the same kernel as the stepping runs it: a burst's launches back to back on their own streams, nothing else on the GPU
+                "in_burst": None if not k1_burst_ms else {
+                    "launches_in_flight": n_ctx, "ms_per_launch": round(k1_burst_ms, 4),
+                    "achieved": round(k1_bytes / (k1_burst_ms * 1e-3) / 1e9, 1), "frac": round(k1_bytes / (k1_burst_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "timed_how": "HIP events: from the start of the first launch to the end of the last of the burst's launches (one per context, each "
+                                 "on its context's stream, threshold kernel only), divided by their number; median of 10 bursts"},
                 "survey_5Bpp_gbs": round(survey_gbs, 1),
                 "survey_5Bpp_frac": round(survey_gbs / HBM_PEAK_GBS, 4),
             },
@@ -719,12 +749,12 @@ def other_workloads(device, with_cpu=True, budget_s=60.0):
     dev = torch.device("cuda", device)
     res = {}
 
-    def run(name, frames_dev, dname, pose_mm=None, reps=7, cpu_frames=2, truths=None, note=""):
+    def run(name, frames_dev, dname, pose_mm=None, reps=7, cpu_frames=2, truths=None, note="", window=7):
         if time.perf_counter() - t_start > budget_s:
             res[name] = {"skipped": "time budget"}
             return
         d = ARDictionary.new_from_named_dict(dname)
-        ctx = Detector(DetectorConfig.default(), d, device=device)._context()
+        ctx = Detector(DetectorConfig(threshold_window=window), d, device=device)._context()
         n, h, w, c = frames_dev.shape
         a = (frames_dev.data_ptr(), _lib.MEM_DEVICE, _lib.FMT_RGB8, w, h, w * c, h * w * c, n)
 
@@ -749,7 +779,7 @@ def other_workloads(device, with_cpu=True, budget_s=60.0):
         # the same workload stepped like the headline: two contexts, submit / collect two batches ahead (the decode stage of a
         # batch then runs beside the next batch's contour stage)
         try:
-            ctx2 = Detector(DetectorConfig.default(), d, device=device)._context()
+            ctx2 = Detector(DetectorConfig(threshold_window=window), d, device=device)._context()
             pair = [ctx, ctx2]
 
             def sub(cx):
@@ -790,7 +820,9 @@ def other_workloads(device, with_cpu=True, budget_s=60.0):
             host = frames_dev[:cpu_frames].cpu().numpy()
             codes = np.ascontiguousarray(d.code_list)
             t0 = time.perf_counter()
-            ores = [a3oracle.detect(host[f], codes, d.num_bits, d._tau, keep_debug=False) for f in range(cpu_frames)]
+            ocfg = a3oracle.Config.default()
+            ocfg.threshold_window = window
+            ores = [a3oracle.detect(host[f], codes, d.num_bits, d._tau, config=ocfg, keep_debug=False) for f in range(cpu_frames)]
             o["cpu_baseline"] = {"value": round(cpu_frames / (time.perf_counter() - t0), 2), "unit": "frames/s", "cores": 1, "kind": "port",
                                  "sample": f"{cpu_frames} of the same frames, single thread, detection only"}
             gpu_frames = split_by_frame(r[0], r[1])
@@ -806,6 +838,15 @@ def other_workloads(device, with_cpu=True, budget_s=60.0):
             cpu_frames=2 if nw >= 1280 else 4, reps=5,
             note="benches/detect_markers.rs:29-51 recipe: every channel of every pixel uniform random u8; no markers")
         del noise
+    # other threshold windows on config 2's frames (src/aruco.rs:35,61: the reference's cost does not depend on the radius; here radii 1..7
+    # run the register-resident kernel templated on the radius, larger ones a separable three-kernel path)
+    spec2, name2 = synth.config_spec(2)
+    d2 = ARDictionary.new_from_named_dict(name2)
+    f2, t2 = synth.render_frames_device(spec2, d2.code_list, d2.num_bits, [synth.frame_seed(2, i) for i in range(32)], device=device)
+    for wnd in (3, 11):
+        run(f"C2_threshold_window_{wnd}", f2, name2, cpu_frames=2, truths=t2, window=wnd,
+            note=f"BASELINE config 2's frames with DetectorConfig.threshold_window = {wnd} ({2 * wnd + 1} x {2 * wnd + 1})")
+    del f2
     spec4, name4 = synth.config_spec(4)
     d4 = ARDictionary.new_from_named_dict(name4)
     f4, t4 = synth.render_frames_device(spec4, d4.code_list, d4.num_bits, [synth.frame_seed(4, i) for i in range(32)], device=device)
