@@ -776,35 +776,40 @@ def other_workloads(device, with_cpu=True, budget_s=60.0):
              "borders_per_frame": int(st["contours_traced"] // n), "chunks": st["chunks"]}
         if note:
             o["workload"] = note
-        # the same workload stepped like the headline: two contexts, submit / collect two batches ahead (the decode stage of a
-        # batch then runs beside the next batch's contour stage)
+        # the same workload stepped like the headline: four contexts on streams of their own in rotation, burst gates
         try:
-            ctx2 = Detector(DetectorConfig(threshold_window=window), d, device=device)._context()
-            pair = [ctx, ctx2]
+            ring = [ctx] + [Detector(DetectorConfig(threshold_window=window), d, device=device)._context() for _ in range(3)]
+            nr = len(ring)
 
-            def sub(cx):
+            def sub(i):
+                cx = ring[i % nr]
+                for other in ring[i % nr + 1:]:
+                    cx.order_after(other)
                 if pose_mm:
                     cx.submit_pose(*a, pose_mm, None, n * 64)
                 else:
                     cx.submit(*a, out_cap=n * 64)
 
             col = (lambda cx: cx.collect_pose()) if pose_mm else (lambda cx: cx.collect())
-            ctx2.detect_batch(*a, out_cap=n * 64); ctx2.detect_batch(*a, out_cap=n * 64)
-            k = 12
+            for cx in ring[1:]:
+                cx.detect_batch(*a, out_cap=n * 64); cx.detect_batch(*a, out_cap=n * 64)
+            k = 16
             best = None
             for _ in range(3):
                 torch.cuda.synchronize(); t0 = time.perf_counter()
-                sub(pair[0]); sub(pair[1])
+                for i in range(nr):
+                    sub(i)
                 for i in range(k):
-                    rr = col(pair[i % 2])
-                    if i + 2 < k:
-                        sub(pair[i % 2])
+                    rr = col(ring[i % nr])
+                    if i + nr < k:
+                        sub(i + nr)
                 torch.cuda.synchronize(); dtp = (time.perf_counter() - t0) / k
                 best = dtp if best is None else min(best, dtp)
             assert len(rr[0]) == len(r[0])
             o["pipelined"] = {"value": round(n / best, 1), "unit": "frames/s", "ms_per_batch": round(best * 1e3, 3),
-                              "stepping": "two contexts, submit / collect, two batches ahead"}
-            ctx2.close()
+                              "stepping": "four contexts on their own streams in rotation, burst gates (a3_order_after), four batches ahead"}
+            for cx in ring[1:]:
+                cx.close()
         except Exception as e:   # a side measurement must not take the line down
             o["pipelined"] = {"error": repr(e)}
         if truths is not None:
