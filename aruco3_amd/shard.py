@@ -114,10 +114,14 @@ def _pad_rows(rec: torch.Tensor, rows: int) -> torch.Tensor:
     return torch.cat([rec, pad])
 
 
-def _all_gather(rec: torch.Tensor, rows: int) -> torch.Tensor:
+def _all_gather(rec: torch.Tensor, rows: int, out: torch.Tensor = None) -> torch.Tensor:
+    """`out`: a caller-owned uint8 tensor of world * rows * record bytes to gather into (a stepping loop re-uses one instead of
+    allocating per collective)"""
     world = dist.get_world_size()
     rec = _pad_rows(rec, rows)
-    out = torch.empty((world * rows, rec.shape[1]), dtype=torch.uint8, device=rec.device)
+    if out is None:
+        out = torch.empty((world * rows, rec.shape[1]), dtype=torch.uint8, device=rec.device)
+    out = out.view(world * rows, rec.shape[1])
     dist.all_gather_into_tensor(out, rec)  # ranks concatenated along dim 0
     return out.view(world, rows, rec.shape[1])
 
@@ -130,12 +134,14 @@ def gather_detections(markers: np.ndarray, per_frame: np.ndarray, first_frame: i
     return _all_gather(rec, rows if rows is not None else rec.shape[0])
 
 
-def pack_detections_device(ctx: "_lib.Context", n_frames: int, first_frame: int, device, maxm: int = MAXM, with_poses: bool = False) -> torch.Tensor:
+def pack_detections_device(ctx: "_lib.Context", n_frames: int, first_frame: int, device, maxm: int = MAXM, with_poses: bool = False,
+                           out: torch.Tensor = None) -> torch.Tensor:
     """The last batch of `ctx` as gather records, written by a kernel straight from the device-resident marker list
     (a3_pack_detections): no D2H, no numpy, no H2D.  with_poses: the batch was a detect_batch_pose call and every marker's
     pose pair travels with it (BASELINE config 5).  Enqueued on the context's stream -- call under
     `torch.cuda.stream(<that stream>)` so that torch orders the collective after it."""
-    rec = torch.empty((n_frames, record_bytes(maxm, with_poses)), dtype=torch.uint8, device=device)
+    rec = out if out is not None else torch.empty((n_frames, record_bytes(maxm, with_poses)), dtype=torch.uint8, device=device)
+    assert rec.shape == (n_frames, record_bytes(maxm, with_poses)) and rec.dtype == torch.uint8 and rec.is_contiguous()
     try:
         ctx.pack_detections(first_frame, maxm, rec.data_ptr(), rec.numel(), with_poses)
     except _lib.A3Error as e:

@@ -252,22 +252,28 @@ def main():
     side = torch.cuda.Stream(device=dev)   # pack + collective run beside the detection streams, not in them
     pack_done = {}                         # context -> event after its pack: the context's next batch overwrites the marker list
     pinned_rec = {}
+    # Records of one ROTATION (n_ctx batches) are packed into one buffer and gathered by ONE collective: a collective per batch costs
+    # the stepping loop ~0.1 ms of host time and a kernel's company per step; per rotation it is a quarter of that.  Two buffers in
+    # turn: the collective of one rotation may still be reading while the next rotation's packs write.
+    rec_bytes = shard.record_bytes(maxm, bool(pose_mm)) if use_dist else 0
+    rec_bufs = [torch.empty((n_ctx, n, rec_bytes), dtype=torch.uint8, device=dev) for _ in range(2)] if use_dist else None
+    gather_out = [torch.empty((world * n_ctx * n, rec_bytes), dtype=torch.uint8, device=coll_dev) for _ in range(2)] if use_dist else None
+    rot = [0]
 
-    def pack(cx):
+    def pack(cx, slot):
         # Per batch: fixed-capacity records written by a kernel from the device-resident marker list (a3_pack_detections); no host
         # copy in between.  collect() has returned, so batch i is complete: its pack needs no ordering against the detection
-        # stream and goes to the side stream AT ONCE, beside the kernels of the batches already submitted.  Only the enqueue happens
-        # here; the collective follows in all_gather(), after the next batch has been submitted.
+        # stream and goes to the side stream AT ONCE, beside the kernels of the batches already submitted.
         cx.set_stream(side.cuda_stream)
         try:
             with torch.cuda.stream(side):
-                rec = shard.pack_detections_device(cx, n, first_frame, dev, maxm=maxm, with_poses=bool(pose_mm))
+                shard.pack_detections_device(cx, n, first_frame, dev, maxm=maxm, with_poses=bool(pose_mm), out=rec_bufs[rot[0] & 1][slot])
                 pack_done[id(cx)] = side.record_event()
         finally:
             cx.set_stream(ctx_stream_ptr[id(cx)])
-        return rec
 
-    def all_gather(rec):
+    def all_gather(n_batches):
+        rec = rec_bufs[rot[0] & 1][:n_batches].view(n_batches * n, rec_bytes)
         with torch.cuda.stream(side):
             if coll_dev.type == "cpu":     # gloo rehearsal: host tensors, through a pinned buffer (a pageable D2H copy from a side
                 key = tuple(rec.shape)     # stream stalls for tens of milliseconds under a busy detection stream on this runtime)
@@ -276,7 +282,9 @@ def main():
                 pinned_rec[key].copy_(rec, non_blocking=True)
                 side.synchronize()
                 rec = pinned_rec[key]
-            last_gather[0] = shard._all_gather(rec, n)
+            out = gather_out[rot[0] & 1][: world * n_batches * n]
+            last_gather[0] = (shard._all_gather(rec, n_batches * n, out=out), n_batches)
+        rot[0] += 1
 
     gated = own_streams and args.gates == "burst" and n_ctx > 1
     ctx_index = {id(cx): k for k, cx in enumerate(ctxs)}
@@ -291,7 +299,8 @@ def main():
         submit_raw(cx)
 
     def run_steps(k):
-        """k steps; a step = one pass of Detector::detect over the rank's batch, results on the host (and all-gathered)."""
+        """k steps; a step = one pass of Detector::detect over the rank's batch, results on the host (and, N > 1, packed on the device
+        and all-gathered -- one collective per rotation of n_ctx batches)."""
         res = None
         if args.no_pipeline:
             for _ in range(k):
@@ -300,7 +309,8 @@ def main():
                     ctx_stream[id(ctx)].wait_event(ev)
                 res = detect_sync(ctx)
                 if use_dist:
-                    all_gather(pack(ctx))
+                    pack(ctx, 0)
+                    all_gather(1)
             return res
         # n_ctx batches ahead of the host: batch i + n_ctx goes out (on the context batch i has just been collected from) before
         # anything else happens, so the GPU always finds work queued however long the host takes over the results, the pack and
@@ -310,11 +320,12 @@ def main():
         for i in range(k):
             cx = ctxs[i % n_ctx]
             res = collect_raw(cx)
-            rec = pack(cx) if use_dist else None
+            if use_dist:
+                pack(cx, i % n_ctx)
             if i + n_ctx < k:
                 submit(cx)
-            if use_dist:
-                all_gather(rec)
+            if use_dist and (i % n_ctx == n_ctx - 1 or i == k - 1):
+                all_gather(i % n_ctx + 1)
         return res
 
     # ---- isolated launches: one synchronous batch at a time, every stage between events, nothing else on the GPU ----
@@ -465,16 +476,19 @@ def main():
     if use_dist:
         # what the last all-gather delivered, checked on rank 0: every rank's frames, global indices in order, ids as rendered
         torch.cuda.synchronize()
-        g = last_gather[0].cpu().numpy()
+        g_all, g_batches = last_gather[0]
+        g_all = g_all.cpu().numpy()      # [world, batches of the last rotation * n, record]: the last batch of every rank is checked
+        g = g_all[:, (g_batches - 1) * n: g_batches * n, :]
         if rank == 0:
-            recs = shard.unpack_detections(g.reshape(-1, g.shape[-1]), with_poses=bool(pose_mm))
+            recs = shard.unpack_detections(np.ascontiguousarray(g).reshape(-1, g.shape[-1]), with_poses=bool(pose_mm))
             seeds_all = [synth.frame_seed(wl["config"], i) for i in range(world * args.frames)]
             truth_all = [sorted(t.id for t in tr) for tr in synth.device_layout(spec, d.code_list, d.num_bits, seeds_all)[2]]
             gathered = {"frames": len(recs), "global_frame_indices_in_order": [r[0] for r in recs] == list(range(world * args.frames)),
                         "all_ranks_ids_correct": int(sum(sorted(int(x) for x in r[1]["id"]) == truth_all[r[0]] for r in recs)),
                         "record_bytes": int(g.shape[-1]), "max_markers_per_record": int(maxm),
                         "max_markers_from": "--max-markers" if args.max_markers > 0 else "calibrated on the first batch (2 x the largest count on any rank, >= 8)",
-                        "packed_on": "device (a3_pack_detections)", "collective": f"all_gather_into_tensor over {args.backend}"}
+                        "packed_on": "device (a3_pack_detections)", "collective": f"all_gather_into_tensor over {args.backend}, one per rotation of {n_ctx} batches",
+                        "batches_in_last_collective": int(g_batches)}
             if pose_mm:   # rank 0's own frames came back as it produced them, poses included
                 mine = [r for r in recs if first_frame <= r[0] < first_frame + n]
                 gp = np.concatenate([r[2] for r in mine]) if mine else np.zeros((0, 2, 13), np.float32)
