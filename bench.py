@@ -250,7 +250,6 @@ def main():
 
     last_gather = [None]
     side = torch.cuda.Stream(device=dev)   # pack + collective run beside the detection streams, not in them
-    pack_done = {}                         # context -> event after its pack: the context's next batch overwrites the marker list
     pinned_rec = {}
     # Records of one ROTATION (n_ctx batches) are packed into one buffer and gathered by ONE collective: a collective per batch costs
     # the stepping loop ~0.1 ms of host time and a kernel's company per step; per rotation it is a quarter of that.  Two buffers in
@@ -260,20 +259,23 @@ def main():
     gather_out = [torch.empty((world * n_ctx * n, rec_bytes), dtype=torch.uint8, device=coll_dev) for _ in range(2)] if use_dist else None
     rot = [0]
 
+    pack_events = []
+
     def pack(cx, slot):
         # Per batch: fixed-capacity records written by a kernel from the device-resident marker list (a3_pack_detections); no host
-        # copy in between.  collect() has returned, so batch i is complete: its pack needs no ordering against the detection
-        # stream and goes to the side stream AT ONCE, beside the kernels of the batches already submitted.
-        cx.set_stream(side.cuda_stream)
-        try:
-            with torch.cuda.stream(side):
-                shard.pack_detections_device(cx, n, first_frame, dev, maxm=maxm, with_poses=bool(pose_mm), out=rec_bufs[rot[0] & 1][slot])
-                pack_done[id(cx)] = side.record_event()
-        finally:
-            cx.set_stream(ctx_stream_ptr[id(cx)])
+        # copy in between.  The kernel (one wave per frame) goes onto the context's OWN stream, behind the batch just collected and
+        # ahead of the context's next batch (which overwrites the marker list): no stream switching, no event to wait for before
+        # the next submit.  An event behind it tells the side stream when the rotation's records are complete.
+        shard.pack_detections_device(cx, n, first_frame, dev, maxm=maxm, with_poses=bool(pose_mm), out=rec_bufs[rot[0] & 1][slot])
+        ev = torch.cuda.Event()
+        ev.record(ctx_stream[id(cx)])
+        pack_events.append(ev)
 
     def all_gather(n_batches):
         rec = rec_bufs[rot[0] & 1][:n_batches].view(n_batches * n, rec_bytes)
+        for ev in pack_events:
+            side.wait_event(ev)
+        pack_events.clear()
         with torch.cuda.stream(side):
             if coll_dev.type == "cpu":     # gloo rehearsal: host tensors, through a pinned buffer (a pageable D2H copy from a side
                 key = tuple(rec.shape)     # stream stalls for tens of milliseconds under a busy detection stream on this runtime)
@@ -290,9 +292,6 @@ def main():
     ctx_index = {id(cx): k for k, cx in enumerate(ctxs)}
 
     def submit(cx):
-        ev = pack_done.pop(id(cx), None)
-        if ev is not None:
-            ctx_stream[id(cx)].wait_event(ev)        # the pack of this context's previous batch has read the marker list
         if gated:   # bursts: this batch's threshold kernel starts once the previous rotation's chains (contexts k+1 ..) have drained
             for other in ctxs[ctx_index[id(cx)] + 1:]:
                 cx.order_after(other)
@@ -304,9 +303,6 @@ def main():
         res = None
         if args.no_pipeline:
             for _ in range(k):
-                ev = pack_done.pop(id(ctx), None)
-                if ev is not None:
-                    ctx_stream[id(ctx)].wait_event(ev)
                 res = detect_sync(ctx)
                 if use_dist:
                     pack(ctx, 0)
@@ -592,7 +588,7 @@ def main():
         if use_dist:   # what the ranks themselves saw
             out["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                            "launcher": os.environ.get("A3_BENCH_LAUNCHER", "external (torch.distributed.run)" if "RANK" in os.environ else "none (one process, --force-dist)"),
-                           "pack_and_collective": "side stream, started when collect() returns (beside the next batch's kernels)",
+                           "pack_and_collective": "records packed by a kernel on the context's own stream right after collect(); one all-gather per rotation on a side stream, behind the packs' events",
                            "note": "an N > 1 RCCL number exists only where the driver's multi-GPU node produced one; a 1-GPU box can run world_size 1 (nccl) or rehearse ranks over gloo"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], out["parity_in_run"] = cpu_baseline(frames, d, by_frame, poses, per, pose_mm, (w, h))
