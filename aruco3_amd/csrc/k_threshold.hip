@@ -59,8 +59,29 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 as_pk(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
 __device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
 // packed u16 pairs in one dword: v_pk_add_u16 / v_pk_sub_u16 / v_pk_mad_u16 / v_pk_sub_u16 clamp / v_pk_min_u16
+// Sums of pairs: both halves at once with the plain 32-bit add / subtract.  No half ever carries into or borrows from the other --
+// every partial result is a true window sum (0 .. 15 * 15 * 255 + 15 * 255 = 61 200 < 2^16), and the add comes before the subtract
+// -- and v_add_u32 / v_sub_u32 issue at the SIMD's full rate (2 cycles per wave64) where v_pk_add_u16 / v_pk_sub_u16 take 4
+// (tools/micro/valubench.hip).  -DA3_T_ADD32=0 restores the packed forms.
+#ifndef A3_T_ADD32
+#define A3_T_ADD32 1
+#endif
+#ifndef A3_T_LUMA_GROUPS
+#define A3_T_LUMA_GROUPS 1
+#endif
+#ifndef A3_T_COMPARE4
+#define A3_T_COMPARE4 1
+#endif
+#ifndef A3_T_CMP_NOP
+#define A3_T_CMP_NOP "s_nop 0\n\t"
+#endif
+#if A3_T_ADD32
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return a + b; }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return a - b; }
+#else
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return as_u32(as_pk(a) + as_pk(b)); }
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return as_u32(as_pk(a) - as_pk(b)); }
+#endif
 // The compare stage is written with these three as inline assembly: given the vector expressions the optimiser rewrites
 // min(sat(T - S), 1) into two scalar compares, two selects and a re-pack per pair (5x the instructions).
 __device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) {   // a * b + c per half
@@ -143,6 +164,42 @@ __device__ __forceinline__ void grey_row(const RawRow<FMT>& r, uint32_t g[T_NG])
         for (int i = 0; i < T_NG; i++) g[i] = r.d[i];
     } else {
         uint32_t m[T_LPX];   // (l * 13743896) >> 32; grey = m >> 5
+#if A3_T_LUMA_GROUPS
+        // Four pixels at a time, stage by stage: the eight dot products, then the four sums, then the four multiplies.  A v_dot4's
+        // result is not forwarded to the next two instructions (the compiler pads a closer consumer with s_nop, which costs an issue
+        // slot like any instruction: 24 of them per row when every pixel's chain dot -> add -> multiply was emitted on its own);
+        // with the stages of four pixels interleaved every consumer is at least three instructions behind its producer.
+#pragma unroll
+        for (int i0 = 0; i0 < T_LPX; i0 += 4) {
+            uint32_t px[4], lo[4], hi[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int i = i0 + j;
+                if constexpr (FMT == A3_FMT_RGBA8 || FMT == A3_FMT_BGRA8) px[j] = r.d[i];
+                else {
+                    const int byte = 3 * i, k = byte >> 2, off = byte & 3;   // compile-time after unrolling
+                    px[j] = off <= 1 ? r.d[k] : __builtin_amdgcn_alignbit(r.d[k + 1], r.d[k], 8 * off);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                constexpr bool BGR = FMT == A3_FMT_BGRA8;
+                // RGB8: pixel i starts at byte 3 i; pixels at byte offset 1 of their dword keep the data and move the weights
+                const int off = (FMT == A3_FMT_RGB8) ? ((3 * (i0 + j)) & 3) : 0;
+                const uint32_t sh = off == 1 ? 8u : 0u;
+                const uint32_t wlo = (BGR ? 0x004EF0D2u : 0x00D2F04Eu) << sh, whi = (BGR ? 0x00081B02u : 0x00021B08u) << sh;
+                lo[j] = __builtin_amdgcn_udot4(px[j], wlo, 0u, false);
+                hi[j] = __builtin_amdgcn_udot4(px[j], whi, 0u, false);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) { lo[j] = lo[j] + (hi[j] << 8); __builtin_assume(lo[j] < (1u << 22)); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) m[i0 + j] = (uint32_t)(((uint64_t)lo[j] * 13743896ull) >> 32);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
 #pragma unroll
         for (int i = 0; i < T_LPX; i++) {
             if constexpr (FMT == A3_FMT_RGBA8 || FMT == A3_FMT_BGRA8) m[i] = luma_hi<FMT == A3_FMT_BGRA8, 0>(r.d[i]);
@@ -155,6 +212,7 @@ __device__ __forceinline__ void grey_row(const RawRow<FMT>& r, uint32_t g[T_NG])
                 else m[i] = luma_hi<false, 0>(__builtin_amdgcn_alignbit(r.d[k + 1], r.d[k], 8 * off));
             }
         }
+#endif
         // g[q].byte[j] = m[4 q + j] >> 5, the shift writing its byte in place (SDWA dst_sel).  One asm block so that the order
         // is fixed: gfx950 needs one instruction between a dst_sel write of a VGPR and the next read of it (the partial
         // write is not forwarded); consecutive writes of one g[q] are T_NG instructions apart here, and the s_nop covers
@@ -422,12 +480,51 @@ __global__ __launch_bounds__(64, T_PF == A3_T_PF ? A3_T_WAVES : 1) void k_grey_t
 #pragma unroll
             for (int j = 0; j < T_NP; j++) acc ^= S[j] + centre[j & (T_NG - 1)];
 #else
+#if A3_T_COMPARE4
+            // four pairs per asm block, stage by stage (4 x T = L * area + area, 4 x saturating T - S, 4 x min(.., 1), then the four
+            // bits of each half combined by a tree: b1 * 2 + b0, b3 * 2 + b2, then * 4 +): no instruction directly behind the one
+            // whose result it reads, and two asm blocks per row instead of twenty-four (the compiler pads an asm statement it cannot
+            // see into with s_nop, which costs an issue slot each)
+            {
+                uint32_t part[T_NP / 4];
+#pragma unroll
+                for (int q = 0; q < T_NP / 4; q++) {
+                    uint32_t Lp[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) Lp[u] = byte_pair(4 * q + u, centre[(4 * q + u + T_NP) >> 2], centre[(4 * q + u) >> 2]);
+                    uint32_t t0, t1, t2, t3;
+                    asm("v_pk_mad_u16 %0, %5, %9, %9\n\t"
+                        "v_pk_mad_u16 %1, %6, %10, %10\n\t"
+                        "v_pk_mad_u16 %2, %7, %11, %11\n\t"
+                        "v_pk_mad_u16 %3, %8, %12, %12\n\t"
+                        "v_pk_sub_u16 %0, %0, %13 clamp\n\t"
+                        "v_pk_sub_u16 %1, %1, %14 clamp\n\t"
+                        "v_pk_sub_u16 %2, %2, %15 clamp\n\t"
+                        "v_pk_sub_u16 %3, %3, %16 clamp\n\t"
+                        "v_pk_min_u16 %0, %0, 1 op_sel_hi:[1,0]\n\t"
+                        "v_pk_min_u16 %1, %1, 1 op_sel_hi:[1,0]\n\t"
+                        "v_pk_min_u16 %2, %2, 1 op_sel_hi:[1,0]\n\t"
+                        "v_pk_min_u16 %3, %3, 1 op_sel_hi:[1,0]\n\t"
+                        "v_pk_mad_u16 %1, %1, 2, %0 op_sel_hi:[1,0,1]\n\t"
+                        "v_pk_mad_u16 %3, %3, 2, %2 op_sel_hi:[1,0,1]\n\t"
+                        A3_T_CMP_NOP
+                        "v_pk_mad_u16 %4, %3, 4, %1 op_sel_hi:[1,0,1]"
+                        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(part[q])
+                        : "v"(Lp[0]), "v"(Lp[1]), "v"(Lp[2]), "v"(Lp[3]), "v"(area[4 * q]), "v"(area[4 * q + 1]), "v"(area[4 * q + 2]), "v"(area[4 * q + 3]),
+                          "v"(S[4 * q]), "v"(S[4 * q + 1]), "v"(S[4 * q + 2]), "v"(S[4 * q + 3]));
+                }
+                acc = part[0];   // bits of pairs 0..3; every further group of four sits 4 bits higher (no carries: disjoint bits)
+#pragma unroll
+                for (int q = 1; q < T_NP / 4; q++) acc |= part[q] << (4 * q);
+            }
+#else
 #pragma unroll
             for (int j = T_NP - 1; j >= 0; j--) {
                 const uint32_t Lp = byte_pair(j, centre[(j + T_NP) >> 2], centre[j >> 2]);
                 const uint32_t T = pk_mad(Lp, area[j], area[j]);
                 acc = pk_shift_in(acc, pk_nonzero_diff(T, S[j]));
             }
+#endif
 #endif
             // the bits of pixels 0 .. T_NP-1 sit in the low half of acc, those of pixels T_NP .. in the high half
             const uint32_t outb = T_LPX == 16 ? __builtin_amdgcn_perm(0u, acc, 0x0C0C0200u) : ((acc | (acc >> 12)) & 0xFFu);
@@ -595,7 +692,7 @@ __global__ __launch_bounds__(64) void k_vsum_threshold_generic(const uint8_t* __
 // slots stay free for the kernels of another batch's contour / decode stage.
 static int g_k1_waves = A3_T_WAVES;
 void set_k1_waves(int w) { g_k1_waves = w < 1 ? 1 : (w > A3_T_WAVES ? A3_T_WAVES : w); }
-bool k1_build_is_default() { return A3_T_LPX == 16 && A3_T_PF == 3 && A3_T_WAVES == 2 && A3_T_RECOMPUTE == 0; }
+bool k1_build_is_default() { return A3_T_LPX == 16 && A3_T_PF == 3 && A3_T_WAVES == 2 && A3_T_RECOMPUTE == 0 && A3_T_ADD32 == 1 && A3_T_LUMA_GROUPS == 1 && A3_T_COMPARE4 == 1; }
 static int g_k1_cus = 256;   // compute units the kernel's stream may use (a3_debug_set_partition)
 void set_k1_cus(int c) { g_k1_cus = c < 8 ? 8 : (c > 256 ? 256 : c); }
 
