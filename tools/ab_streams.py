@@ -4,7 +4,8 @@ contexts in submit / collect.  An arrangement = (streams: shared | own, contexts
 are interleaved ROUNDS times; prints the median ms per step of each, the threshold kernel's duration in company (sampled events)
 and its duration alone in the same geometry.
   python tools/ab_streams.py [frames] [steps] [rounds] [spec,spec,...]      spec = streams:contexts:k1waves:overlap[:group[:hold]]  e.g. own:2:1:0, own:8:2:0:4 (two bursts of
-  four, submitted together), own:4:2:0:-1 (rotation with burst gates), own:4:2:0:-1:0 (the same, chains not held back)"""
+  four, submitted together), own:4:2:0:-1 (rotation with burst gates), own:4:2:0:-1:0 (the same, chains not held back);
+  further fields KEY=VALUE are environment knobs of a -DA3_TUNING build (A3_HIP_LIB), set for that arrangement only"""
 import sys
 import time
 from pathlib import Path
@@ -93,6 +94,7 @@ def main():
         return m, per
 
     host_us = []
+    knobs_seen = set()
     res = {s: [] for s in specs}
     host = {}
     k1c = {s: [0.0, 0] for s in specs}
@@ -102,6 +104,11 @@ def main():
             kind, nc, kw, ov = s.split(":")[:4]
             group = int(s.split(":")[4]) if len(s.split(":")) > 4 else 1
             assert L.a3_debug_set_hold(int(s.split(":")[5]) if len(s.split(":")) > 5 else 1) == 0
+            for kv in knobs_seen:                      # tuning builds read their knobs from the environment at every launch
+                os.environ.pop(kv, None)
+            for kv in s.split(":")[6:]:
+                kname, kval = kv.split("=")
+                os.environ[kname] = kval; knobs_seen.add(kname)
             ctxs = pools[kind][: int(nc)]
             assert L.a3_debug_set_overlap(int(ov)) == 0
             assert L.a3_debug_set_k1_waves(int(kw)) == 0
