@@ -1030,6 +1030,10 @@ void a3_destroy(a3_ctx* ctx) {
 
 int a3_set_stream(a3_ctx* ctx, void* hip_stream) {
     if (!ctx) return A3_ERR_INVALID;
+    {   // a chain held back for a burst belongs on the stream its threshold kernel went to: it goes out before the stream changes
+        std::lock_guard<std::mutex> lk(g_defer_mu);
+        if (ctx->rest_held) (void)flush_held_locked(ctx, nullptr);
+    }
     ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;   // (may be null until first needed)
     return A3_OK;
 }

@@ -98,6 +98,13 @@ def test_burst_stepping_equals_synchronous_calls(dicts):
         c1.submit(*aa)                                           # (c1 declared a gate: held itself)
         assert same(c3.detect_batch(*ab), want[1])               # a synchronous call on a third context does not disturb them
         assert same(c1.collect(), want[0]) and same(c0.collect(), want[1])
+        # the caller moves a holding context to another stream: the held chain goes out on the old one first
+        st2 = torch.cuda.Stream()
+        c0.order_after(c1); c0.submit(*aa)
+        old_stream = c0.stream_ptr
+        c0.set_stream(st2.cuda_stream)
+        assert same(c0.collect(), want[0])
+        c0.set_stream(old_stream)
         extra = _detector(dicts, "ARUCO_DEFAULT")._context()
         extra.order_after(c0); c0.submit(*aa); extra.order_after(c0); extra.submit(*ab)      # extra holds a chain ...
         extra.close()                                            # ... and is destroyed with it
