@@ -24,6 +24,8 @@ print("stats", ctx.stats())
 # contract first (it needs a linked successor array), then the assign variants, the full one (5, relinks) last
 for m in (0, -1, -2, -3, -4, -5):   # decode first: it only reads what the batch left behind (frames, work list)
     print(f"decode          dbg={m:3d}  {ctx.debug_kernel_time(3, m, 5) * 1e3:8.1f} us", flush=True)
+if len(sys.argv) > 2 and sys.argv[2] == "decode":
+    sys.exit(0)
 for name, k, modes in (("local_contract", 2, (-1, 1, 2, 4, 6, 8, 11)), ("dart_count", 0, (0,)), ("dart_assign", 1, (1, 2, 3, 4, 5))):
     for m in modes:
         print(f"{name:15s} dbg={m:3d}  {ctx.debug_kernel_time(k, m, 5) * 1e3:8.1f} us", flush=True)
