@@ -18,7 +18,7 @@ namespace a3 {
 // k_threshold.hip
 hipError_t launch_grey_threshold(hipStream_t, const uint8_t*, int, size_t, size_t, int, int, uint32_t, uint32_t, uint8_t*, uint64_t*, uint16_t*);
 void set_k1_waves(int);
-bool threshold_writes_grey_plane(uint32_t radius);
+bool threshold_writes_grey_plane(uint32_t radius, const uint8_t* pixels, size_t row_stride, size_t frame_stride, int W);
 void set_k1_cus(int);
 bool k1_build_is_default();
 // k_contours.hip
@@ -489,10 +489,10 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
 
     // the grey plane is materialised only for readers outside the fused path: Detection.grey (debug taps) and the generic
     // threshold kernels of windows above 7; the decode stage otherwise samples the caller's frames directly
-    const bool need_grey = ctx->debug_taps || threshold_writes_grey_plane(ctx->cfg.threshold_window);
+    const bool big_window = threshold_writes_grey_plane(ctx->cfg.threshold_window, pixels, row_stride, frame_stride, (int)W);
+    const bool need_grey = ctx->debug_taps || big_window;
     if (need_grey) A3_HIP(ctx->grey.ensure(npx * n));
     ctx->grey_valid = need_grey;
-    const bool big_window = threshold_writes_grey_plane(ctx->cfg.threshold_window);
     if (big_window) A3_HIP(ctx->hsum.ensure(npx * n * 2));
     const size_t bits_per_frame = (size_t)words_per_row(W) * 8 * H;   // packed thresholded image
     A3_HIP(ctx->bin.ensure(bits_per_frame * n));

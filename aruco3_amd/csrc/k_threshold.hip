@@ -176,8 +176,15 @@ hipError_t launch_k1_r2(uint32_t radius, hipStream_t st, const uint8_t* pixels, 
 // threshold windows the register-resident kernel covers: radii 1..kFusedMaxRadius.  Beyond 7 the packed 16-bit arithmetic ends --
 // (2R+1)^2 * 256 no longer fits a u16 from R = 8 on (289 * 256 = 73 984), so window sums and the compare would need 32-bit lanes and a ring
 // of 2R+1 rows no register file holds: larger windows take the plain two-kernel path below.
+// Radii 8..15 have a fused kernel of their own (k_threshold_big.hip: the ring in LDS, 32-bit sums) for aligned input; what is left for
+// the separable path -- which needs a grey plane and a plane of row sums -- is radius 0, radii above 15 and unaligned frames.
 constexpr uint32_t kFusedMaxRadius = 7;
-bool threshold_writes_grey_plane(uint32_t radius) { return radius == 0 || radius > kFusedMaxRadius; }
+bool ring_kernel_applies(uint32_t radius, const uint8_t* pixels, size_t row_stride, size_t frame_stride, int W);
+hipError_t launch_ring_threshold(uint32_t radius, hipStream_t st, const uint8_t* pixels, int fmt, size_t row_stride, size_t frame_stride, int W, int H,
+                                 uint32_t n, uint8_t* grey, uint64_t* bits);
+bool threshold_writes_grey_plane(uint32_t radius, const uint8_t* pixels, size_t row_stride, size_t frame_stride, int W) {
+    return (radius == 0 || radius > kFusedMaxRadius) && !ring_kernel_applies(radius, pixels, row_stride, frame_stride, W);
+}
 
 hipError_t launch_grey_threshold(hipStream_t st, const uint8_t* pixels, int fmt, size_t row_stride, size_t frame_stride, int W, int H,
                                  uint32_t n, uint32_t radius, uint8_t* grey, uint64_t* bits, uint16_t* hsum_tmp) {
@@ -187,6 +194,7 @@ hipError_t launch_grey_threshold(hipStream_t st, const uint8_t* pixels, int fmt,
         case 7: return launch_k1<7>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
         default: break;
     }
+    if (ring_kernel_applies(radius, pixels, row_stride, frame_stride, W)) return launch_ring_threshold(radius, st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
     dim3 block(64), gridg((W + 255) / 256, H, n), grid1(words_per_row((uint32_t)W), H, n);
     if (fmt == A3_FMT_RGB8) hipLaunchKernelGGL(k_grey_generic<A3_FMT_RGB8>, gridg, block, 0, st, pixels, row_stride, frame_stride, W, H, grey);
     else if (fmt == A3_FMT_RGBA8) hipLaunchKernelGGL(k_grey_generic<A3_FMT_RGBA8>, gridg, block, 0, st, pixels, row_stride, frame_stride, W, H, grey);

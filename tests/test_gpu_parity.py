@@ -142,6 +142,33 @@ def test_other_threshold_window(dicts, oracle):
         assert np.array_equal(ctx.download_grey(0, 640, 480, thresholded=True), oracle.adaptive_threshold(grey, win))
 
 
+@pytest.mark.parametrize("radius", [8, 9, 10, 11, 12, 13, 14, 15])
+def test_threshold_windows_8_to_15(dicts, oracle, radius):
+    """The fused kernel of windows 8..15 (grey ring in LDS, 32-bit sums: k_threshold_big.hip) on widths it takes (W % 16 == 0: one
+    and two column strips, images lower and narrower than the window) and on widths that go through the separable path, every
+    pixel format, noise / ramps / flat: into_luma8 + adaptive_threshold(&grey, radius) bit for bit, with and without a grey plane."""
+    for (h, w), channels in (((480, 640), 3), ((250, 1040), 3), ((37, 2000), 4), ((300, 16), 1), ((9, 48), 3), ((1, 16), 4),
+                             ((70, 1008), 1), ((129, 641), 3), ((40, 30), 4)):
+        rng = np.random.default_rng(radius * 7919 + h * 31 + w + channels)
+        noise = rng.integers(0, 256, (h, w, channels), dtype=np.uint8)
+        yy, xx = np.mgrid[0:h, 0:w]
+        ramp = ((xx * 3 + yy * 5) % 256).astype(np.uint8)[..., None].repeat(channels, axis=2)
+        flat = np.full((h, w, channels), 200, np.uint8)
+        frames = np.stack([noise, ramp, flat, noise[::-1].copy()])
+        batch = frames if channels > 1 else frames[..., 0][..., None]
+        det = _detector(dicts, threshold_window=radius)
+        want = []
+        ctx, _, _ = _run(det, batch, populate=True)
+        for f in range(len(frames)):
+            grey = oracle.to_luma8(frames[f] if channels > 1 else frames[f][..., 0])
+            want.append(oracle.adaptive_threshold(grey, radius))
+            assert np.array_equal(ctx.download_grey(f, w, h), grey), (radius, h, w, channels, f)
+            assert np.array_equal(ctx.download_grey(f, w, h, thresholded=True), want[f]), (radius, h, w, channels, f)
+        ctx, _, _ = _run(det, batch, populate=False)
+        for f in range(len(frames)):
+            assert np.array_equal(ctx.download_grey(f, w, h, thresholded=True), want[f]), (radius, h, w, channels, f, "no taps")
+
+
 @pytest.mark.parametrize("config", [1, 2, 4])
 def test_baseline_configs_full_parity(dicts, oracle, config):
     """BASELINE.json configs 1, 2 (=3 per GPU) and 4 at full resolution, a few frames each: every stage equal."""
