@@ -44,7 +44,7 @@ hipError_t launch_select_scatter(hipStream_t, const JumpState*, uint32_t, const 
 hipError_t launch_debug_clockwise(hipStream_t, const int32_t*, uint32_t, int32_t*);
 hipError_t launch_unpack_bits(hipStream_t, const uint64_t*, int, int, uint8_t*);
 hipError_t launch_contour_quads(hipStream_t, const ContourRec*, const DeviceCounters*, uint32_t, const uint32_t*, double, uint32_t, uint32_t,
-                                uint32_t, CandRec*, uint32_t*, unsigned int*, int);
+                                uint32_t, CandRec*, uint32_t*, unsigned int*, int, uint32_t);
 // k_decode.hip
 size_t decode_out_bytes();
 hipError_t launch_frame_candidates(hipStream_t, const CandRec*, const uint32_t*, uint32_t, uint32_t, float, uint16_t*, uint16_t*, uint32_t*,
@@ -392,7 +392,8 @@ int enqueue_back(a3_ctx* ctx, hipStream_t st, const BackArgs& b) {
                                    ctx->work.as<uint32_t>(), d_work_count, b.S, ctx->proj.p));
     A3_HIP(launch_decode(st, b.src, (int)b.W, (int)b.H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), d_work_count,
                          b.max_cand, b.S, ctx->mark_size, b.S, ctx->dict.as<uint64_t>(), ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors,
-                         ctx->proj.p, ctx->wtab.as<float>(), ctx->outs.p, b.taps ? ctx->patches.as<uint8_t>() : nullptr, b.patch_cap, ctx->per_frame, 4096, 0,
+                         ctx->proj.p, ctx->wtab.as<float>(), ctx->outs.p, b.taps ? ctx->patches.as<uint8_t>() : nullptr, b.patch_cap, ctx->per_frame,
+                         (int)std::min<uint32_t>(4096u, b.n * 128u) /* (grid-stride over the work list; 4096 workgroups that find nothing cost a one-frame call ~4 us) */, 0,
                          b.n <= 64u ? 1 : 0));
     A3_HIP(launch_compact_markers(st, ctx->outs.p, ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(), b.n, 0, b.max_cand,
                                   ctx->markers_ptr, b.marker_cap, ctx->per_frame, d_marker_total, d_err, ctx->cand_count, ctx->scratch_u32 + 2));
@@ -716,7 +717,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
             A3_HIP(launch_contour_quads(s2, ctx->contours.as<ContourRec>(), ctr, max_contours, ctx->points.as<uint32_t>(),
                                         eps_factor, min_edge_length, cc.first, kMaxCand,
                                         ctx->cands.as<CandRec>() + (size_t)cc.first * kMaxCand, ctx->cand_count + cc.first, d_err,
-                                        W <= 16384u && H <= 16384u ? 1 : 0));
+                                        W <= 16384u && H <= 16384u ? 1 : 0, nd));
             return A3_OK;
         };
         if (int rc = chunk_back(st)) return rc;
