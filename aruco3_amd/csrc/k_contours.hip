@@ -449,7 +449,16 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
     __shared__ uint64_t s_t[kTileRows + 2][kTileWords + 2];
     __shared__ uint64_t s_nodes[256];
     __shared__ uint64_t s_c0[256], s_c1[256], s_c2[256];   // darts per pixel (0..4) as three bit planes
-    __shared__ uint32_t s_dbase[256], s_nbase[257];
+    __shared__ uint32_t s_dbase[256];
+    // Locating the n-th border pixel of the tile (phase 2) without a search.  Phase 1 numbers the words that own darts (rank k: its
+    // lane index); behind the scan every such word w leaves its first pixel's index under its rank (s_nbk), a marker bit at that
+    // index - 1 (s_mark: one bit per border pixel of the tile, 64 per segment), and -- if it holds the first pixel of a 64-pixel
+    // segment -- its rank as the segment's first (s_fr).  A wave of phase 2 works on exactly one segment, lane l on its pixel l: the
+    // rank of that pixel's word is s_fr + the markers below bit l (v_mbcnt), where the 8-step binary search over the 256 prefix
+    // sums used to be 64 of the ~ 230 instructions a border pixel costs before its darts.
+    __shared__ uint32_t s_mark[512];
+    __shared__ uint16_t s_nbk[256];
+    __shared__ uint8_t s_wofrank[256], s_rank[256], s_fr[256];
     const int wpr = (int)words_per_row((uint32_t)W);
     const uint32_t f = blockIdx.y;
     if (tile_darts[(size_t)(first_frame + f) * gridDim.x + blockIdx.x] == 0u) return;   // uniform for the workgroup
@@ -465,6 +474,7 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
     const unsigned long long m0 = tm[0], m1 = tm[1], m2 = tm[2], m3 = tm[3];
     tile_stage(bits + (size_t)(first_frame + f) * wpr * H, W, H, s_t);
     s_nodes[threadIdx.x] = 0; s_c0[threadIdx.x] = 0; s_c1[threadIdx.x] = 0; s_c2[threadIdx.x] = 0; s_cnt[threadIdx.x] = 0;
+    s_mark[threadIdx.x] = 0; s_mark[256 + threadIdx.x] = 0;
     __syncthreads();
     const uint32_t a0 = (uint32_t)__popcll(m0), a1 = a0 + (uint32_t)__popcll(m1), a2 = a1 + (uint32_t)__popcll(m2), n_act = a2 + (uint32_t)__popcll(m3);
     for (uint32_t k = threadIdx.x; k < n_act; k += 256) {
@@ -487,6 +497,7 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
         s_nodes[w] = nodes;
         s_c0[w] = s1 ^ s2 ^ s3; s_c1[w] = t ^ k4; s_c2[w] = q1 | (t & k4);
         s_cnt[w] = nd | ((uint32_t)__popcll(nodes) << 17);
+        s_wofrank[k] = (uint8_t)w; s_rank[w] = (uint8_t)k;
     }
     __syncthreads();
     // one block scan for both counts: darts (<= 65536 per tile) in the low 17 bits, border pixels (<= 16384) above
@@ -494,19 +505,28 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
     const uint32_t excl_p = block_excl_scan_256(s_cnt[threadIdx.x], s_wave, &total_p);
     const uint32_t excl_d = excl_p & 0x1FFFFu, excl_n = excl_p >> 17, total_n = total_p >> 17;
     s_dbase[threadIdx.x] = excl_d;
-    s_nbase[threadIdx.x] = excl_n;
+    {   // (thread = word) a word with border pixels: first index under its rank, marker, first-of-segment
+        const uint32_t cw = s_cnt[threadIdx.x] >> 17;
+        if (cw) {
+            const uint32_t k = s_rank[threadIdx.x];
+            s_nbk[k] = (uint16_t)excl_n;
+            if (excl_n) atomicOr(&s_mark[(excl_n - 1u) >> 5], 1u << ((excl_n - 1u) & 31u));
+            const uint32_t seg = (excl_n + 63u) >> 6;               // the first segment boundary at or behind the word's first pixel
+            if ((seg << 6) < excl_n + cw) s_fr[seg] = (uint8_t)k;   // (a word holds at most 64 border pixels: at most one boundary)
+        }
+    }
     if (dbg == 2) return;
-    if (threadIdx.x == 0) s_nbase[256] = total_n;
     __syncthreads();
     if (dbg == 3) return;
     const int tx = blockIdx.x % dart_tiles_x((uint32_t)W), ty = blockIdx.x / dart_tiles_x((uint32_t)W);
     uint32_t* pbf = pix_base + (size_t)f * W * H;
     for (uint32_t n = threadIdx.x; n < total_n; n += 256) {
-        // word holding the n-th border pixel of the tile: largest w with s_nbase[w] <= n
-        uint32_t lo = 0, hi = 256;
-#pragma unroll
-        for (int it = 0; it < 8; it++) { const uint32_t mid = (lo + hi) >> 1; if (s_nbase[mid] <= n) lo = mid; else hi = mid; }
-        const uint32_t w = lo, r = n - s_nbase[w];
+        // word holding the n-th border pixel of the tile: the segment's first word + the words that begin inside the segment at or
+        // before this pixel (n = threadIdx.x + 256 t: a wave's lanes are the 64 pixels of segment n >> 6, lane = n & 63)
+        const uint32_t seg = n >> 6;
+        const uint32_t marks_below = __builtin_amdgcn_mbcnt_hi(s_mark[2u * seg + 1u], __builtin_amdgcn_mbcnt_lo(s_mark[2u * seg], 0u));
+        const uint32_t kr = (uint32_t)s_fr[seg] + marks_below;
+        const uint32_t w = s_wofrank[kr], r = n - (uint32_t)s_nbk[kr];
         const uint64_t m = s_nodes[w];
         const int i = select_bit(m, r);
         const int jl = w & (kTileWords - 1), rl = w >> 2;
