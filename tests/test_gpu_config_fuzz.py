@@ -18,8 +18,10 @@ from tests.util import assert_frame_parity, markers_of_hip, markers_of_oracle  #
 DICTS = ("ARUCO", "ARUCO_MIP_16H3", "APRILTAG_16H5", "APRILTAG_25H9", "ARUCO_MIP_36H12", "APRILTAG_36H11", "ARTOOLKITPLUS", "CHILITAGS")
 
 
-def _case(rng):
-    """one random case -> (config dict, dictionary name, pixel format name, frames [n, h, w, c] in R,G,B(,A) order)"""
+def _case(rng, big_windows=False):
+    """one random case -> (config dict, dictionary name, pixel format name, frames [n, h, w, c] in R,G,B(,A) order).
+    big_windows: threshold windows 8..16 on widths that are multiples of 16 -- what the fused kernel of windows 8..15
+    (k_threshold_big.hip) takes; 16 and the occasional odd width go through the separable path."""
     from aruco3_amd import synth
     from aruco3_amd.dictionaries import ARDictionary
 
@@ -35,6 +37,12 @@ def _case(rng):
     d = ARDictionary.new_from_named_dict(name)
     fmt = ("RGB8", "RGB8", "RGBA8", "BGRA8", "L8")[int(rng.integers(0, 5))]
     w, h = int(rng.integers(200, 900)), int(rng.integers(160, 700))
+    if big_windows:
+        cfg["threshold_window"] = int(rng.integers(8, 17))
+        if rng.integers(0, 8):
+            w = (w + 15) // 16 * 16
+        if not rng.integers(0, 6):
+            w, h = int(rng.choice([1008, 1040, 1280])), int(rng.integers(60, 200))   # one and two column strips of 992
     n = int(rng.integers(1, 4))
     kind = int(rng.integers(0, 4))
     frames = []
@@ -64,7 +72,7 @@ def run_case(oracle, seed):
     from aruco3_amd.dictionaries import ARDictionary
 
     rng = np.random.default_rng(seed)
-    cfg, name, fmt, frames = _case(rng)
+    cfg, name, fmt, frames = _case(rng, big_windows=seed >= 1000000)
     d = ARDictionary.new_from_named_dict(name)
     det = Detector(DetectorConfig(**cfg), d)
     ctx = det._context()
@@ -98,6 +106,13 @@ def run_case(oracle, seed):
 @pytest.mark.parametrize("block", range(4))
 def test_random_config_dictionary_format_combinations(oracle, block):
     found = sum(run_case(oracle, 9000 + 12 * block + i) for i in range(12))
+    assert found >= 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block", range(2))
+def test_random_combinations_with_windows_8_to_16(oracle, block):
+    found = sum(run_case(oracle, 1000000 + 10 * block + i) for i in range(10))
     assert found >= 0
 
 
