@@ -1403,6 +1403,8 @@ int a3_debug_launch_threshold(a3_ctx* ctx, const void* pixels_device, int fmt, u
     A3_HIP(hipSetDevice(ctx->device));
     if (int rc = need_stream(ctx)) return rc;
     const size_t bpp = fmt == A3_FMT_RGB8 ? 3 : (fmt == A3_FMT_L8 ? 1 : 4);
+    if (threshold_writes_grey_plane(ctx->cfg.threshold_window, reinterpret_cast<const uint8_t*>(pixels_device), (size_t)width * bpp, (size_t)width * bpp * height, (int)width))
+        return fail(ctx, A3_ERR_INVALID, "a3_debug_launch_threshold: this threshold_window / frame layout takes the separable path, which needs a grey plane");
     A3_HIP(ctx->bin.ensure((size_t)words_per_row(width) * 8 * height * n_frames));
     A3_HIP(launch_grey_threshold(ctx->stream, reinterpret_cast<const uint8_t*>(pixels_device), fmt, (size_t)width * bpp, (size_t)width * bpp * height,
                                  (int)width, (int)height, n_frames, ctx->cfg.threshold_window, nullptr, ctx->bin.as<uint64_t>(), nullptr));
