@@ -25,7 +25,8 @@
 
 namespace a3 {
 
-// ---- generic radius: plain two-kernel path (correct for any threshold_window, not tuned) ----
+// ---- generic radius: plain kernels (correct for any threshold_window and any alignment, not tuned): what is left for them are
+// windows above 15, radius 0 and frames the fused kernels cannot read in place (k_threshold_big.hip: ring_kernel_applies) ----
 // four consecutive pixels per thread: dword loads and one dword store where the row is 4-byte aligned, bytes otherwise
 template <int FMT>
 __global__ void k_grey_generic(const uint8_t* __restrict__ pixels, size_t row_stride, size_t frame_stride, int W, int H,
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(64) void k_threshold_generic(const uint8_t* __restr
     if (threadIdx.x == 0) bits[(size_t)blockIdx.z * wpr * H + (size_t)y * wpr + blockIdx.x] = m;
 }
 
-// Windows above 7, separable: horizontal sums of the grey plane into a u16 plane (2R+1 <= 257 values of at most 255), then a
+// Windows above 7 on this path, separable: horizontal sums of the grey plane into a u16 plane (2R+1 <= 257 values of at most 255), then a
 // vertical running sum per column with the compare.  Plain kernels (no register ring: (2R+1)^2 * 256 no longer fits 16 bits), but
 // the work per pixel no longer grows with the window's AREA as in k_threshold_generic.
 // k_hsum_generic: a workgroup covers 1024 columns of one row, four consecutive outputs per thread (a sliding sum: 2R + 4 byte reads for
@@ -165,6 +166,13 @@ int g_k1_waves = A3_T_WAVES;
 void set_k1_waves(int w) { g_k1_waves = w < 1 ? 1 : (w > A3_T_WAVES ? A3_T_WAVES : w); }
 bool k1_build_is_default() { return A3_T_LPX == 16 && A3_T_PF == 3 && A3_T_WAVES == 2 && A3_T_RECOMPUTE == 0 && A3_T_ADD32 == 1 && A3_T_LUMA_GROUPS == 1 && A3_T_COMPARE4 == 1; }
 int g_k1_cus = 256;   // compute units the kernel's stream may use (a3_debug_set_partition)
+#ifdef A3_TUNING
+// (tuning builds only) where the radius-7 kernel writes one record per wave: {begin, end (100 MHz), HW_ID, XCC_ID}; nullptr = off
+extern "C" __attribute__((visibility("default"))) int a3_debug_set_k1_stamps(void* device_buffer) {
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(device_buffer);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_k1_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -5;
+}
+#endif
 void set_k1_cus(int c) { g_k1_cus = c < 8 ? 8 : (c > 256 ? 256 : c); }
 
 // radii 1..3 and 4..6: k_threshold_r1.hip, k_threshold_r2.hip
@@ -175,7 +183,7 @@ hipError_t launch_k1_r2(uint32_t radius, hipStream_t st, const uint8_t* pixels, 
 
 // threshold windows the register-resident kernel covers: radii 1..kFusedMaxRadius.  Beyond 7 the packed 16-bit arithmetic ends --
 // (2R+1)^2 * 256 no longer fits a u16 from R = 8 on (289 * 256 = 73 984), so window sums and the compare would need 32-bit lanes and a ring
-// of 2R+1 rows no register file holds: larger windows take the plain two-kernel path below.
+// of 2R+1 rows no register file holds.
 // Radii 8..15 have a fused kernel of their own (k_threshold_big.hip: the ring in LDS, 32-bit sums) for aligned input; what is left for
 // the separable path -- which needs a grey plane and a plane of row sums -- is radius 0, radii above 15 and unaligned frames.
 constexpr uint32_t kFusedMaxRadius = 7;

@@ -12,6 +12,9 @@
 namespace a3 {
 
 constexpr int T_R = 7;               // fast path radius (threshold_window = 7)
+#ifdef A3_TUNING
+static __device__ unsigned long long* g_k1_stamps = nullptr;   // per translation unit; k_threshold.hip's copy (radius 7) is the one a3_debug_set_k1_stamps sets
+#endif
 #ifndef A3_T_LPX
 #define A3_T_LPX 16
 #endif
@@ -330,6 +333,9 @@ __global__ __launch_bounds__(64, T_PF == A3_T_PF ? A3_T_WAVES : 1) void k_grey_t
         sy = idx % strips_y;
     } else { pair = (k / strips_y) * 8 + xcd; sy = k % strips_y; }
     if (pair >= n_pairs) return;
+#ifdef A3_TUNING
+    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();   // (tools/k1_wave_times.py: when a launch's waves start and end)
+#endif
     const int sx = pair % strips_x;
     const uint32_t f = pair / strips_x;
     const uint8_t* frame = pixels + (size_t)f * frame_stride;
@@ -533,6 +539,14 @@ __global__ __launch_bounds__(64, T_PF == A3_T_PF ? A3_T_WAVES : 1) void k_grey_t
     if (flush_rows > 0 && owner)
         for (int q = 0; q < n_buf; q++)
             *reinterpret_cast<out_bits_t*>(bout + (size_t)(y_buf0 + dir * q) * bpr + (x0 >> 3)) = s_out[q * 64 + lane];
+#ifdef A3_TUNING
+    if (g_k1_stamps && lane == 0) {   // 100 MHz timestamps of this wave's life + where it ran (HW_ID, XCC_ID)
+        unsigned long long* o = g_k1_stamps + (size_t)blockIdx.x * 4;
+        o[0] = t_begin; o[1] = __builtin_amdgcn_s_memrealtime();
+        o[2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID, 32 bits
+        o[3] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+    }
+#endif
 }
 
 // launch geometry switches (k_threshold.hip; a3_internal.h: a3_debug_set_k1_waves, a3_debug_set_partition)

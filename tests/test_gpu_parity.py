@@ -347,23 +347,27 @@ def test_detector_config_variants(dicts, oracle, cfg):
         pos += int(per[f])
 
 
-def test_strided_and_offset_input(hip, dicts, oracle):
+@pytest.mark.parametrize("window,row_pad,off", [(7, 20, 3), (11, 32, 16), (11, 20, 3)])
+def test_strided_and_offset_input(hip, dicts, oracle, window, row_pad, off):
     """row_stride / frame_stride larger than the packed size and a base pointer that is not 16-byte aligned
-    (the kernel then takes its per-pixel path); results must not change."""
+    (the kernel then takes its per-pixel path); results must not change.  Window 11: padded but aligned rows (the fused kernel
+    of windows 8..15 reads them in place) and unaligned ones (the separable path does)."""
     import torch
 
     from aruco3_amd import synth
 
     frames, _ = synth.config_frames(1, 2)
     n, h, w, c = frames.shape
-    row_stride, frame_stride, off = w * c + 20, (w * c + 20) * h + 64, 3
+    row_stride, frame_stride = w * c + row_pad, (w * c + row_pad) * h + 64
     buf = np.zeros(off + n * frame_stride, dtype=np.uint8)
     for f in range(n):
         for y in range(h):
             s = off + f * frame_stride + y * row_stride
             buf[s: s + w * c] = frames[f, y].reshape(-1)
     d = dicts.new_from_named_dict("ARUCO_DEFAULT")
-    det = _detector(dicts, "ARUCO_DEFAULT")
+    det = _detector(dicts, "ARUCO_DEFAULT", threshold_window=window)
+    ocfg = oracle.Config.default()
+    ocfg.threshold_window = window
     ctx = det._context()
     ctx.set_debug_taps(True)
     for mem, ptr, keep in ((hip.MEM_HOST, buf.ctypes.data + off, buf), (hip.MEM_DEVICE, None, None)):
@@ -377,7 +381,7 @@ def test_strided_and_offset_input(hip, dicts, oracle):
         assert np.array_equal(per0, per) and np.array_equal(markers0, markers)
         pos = 0
         for f in range(n):
-            res = oracle.detect(frames[f], d.code_list, d.num_bits, d._tau)
+            res = oracle.detect(frames[f], d.code_list, d.num_bits, d._tau, config=ocfg)
             assert_frame_parity(ctx, f, frames[f], res, w, h)
             assert markers_of_hip(markers[pos: pos + int(per[f])]) == markers_of_oracle(res)
             pos += int(per[f])
