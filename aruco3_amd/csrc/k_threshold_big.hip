@@ -65,8 +65,8 @@ __global__ __launch_bounds__(64, 2) void k_grey_threshold_ring(const uint8_t* __
                                                                 uint8_t* __restrict__ bits, int flush_rows) {
     static_assert(R >= 8 && R <= 15, "radii 8..15: the neighbouring lane's 16 columns cover the window's reach");
     constexpr int NB = R + 1, PF = A3_T_PF;   // NB: rows of the ring's second stage (LDS)
-    // LDS admits eight waves per CU; they must sit two on every SIMD.  Below 169 VGPRs a SIMD takes three, the dispatcher then
-    // spreads the eight 3 + 3 + 2 + 0, and a kernel bound by its instruction issue runs at the pace of the fullest SIMD (radii 8..13
+    // LDS admits eight waves per CU; they must sit two on every SIMD.  Below 169 VGPRs a SIMD takes three, the eight are then
+    // spread unevenly (3 + 3 + 2 + 0 at worst), and a kernel bound by its instruction issue runs at the pace of the fullest SIMD (radii 8..13
     // compile to 140 .. 166 VGPRs and took 1.4 x window 7 that way, 14 and 15 -- 170 and 175 -- 1.17 x): the clobber lifts the
     // allocation above the line for every radius.
     asm volatile("" ::: "v176");
