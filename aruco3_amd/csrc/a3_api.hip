@@ -221,7 +221,7 @@ struct a3_ctx {
     unsigned int* scratch_u32 = nullptr; DeviceCounters* counters = nullptr; uint32_t* per_frame = nullptr; uint32_t* frame_cursor = nullptr; uint32_t* cand_count = nullptr;
     uint32_t last_marker_total = 0;   // sizes the speculative marker read-back of the next batch
     DevBuf tmp_a, tmp_b, tmp_c, tmp_d;
-    DevBuf hsum;                // row sums of the grey plane (u16): the separable threshold path only (windows above 15, unaligned frames with a window above 7)
+    DevBuf hsum;                // row sums of the grey plane (u16): the separable threshold path only (windows above 15)
     DevBuf wtab;                // triangle-resize weights of a full patch (sample -> mark_size), written once at a3_create
     DevBuf pose_buf;            // a3_detect_batch_pose: both poses of every marker of the last batch (kept for a3_pack_detections)
     bool poses_valid = false;
@@ -489,8 +489,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     const uint32_t kMaxCand = ctx->max_cand;
 
     // the grey plane is materialised only for readers outside the fused path: Detection.grey (debug taps) and the generic
-    // threshold kernels (windows above 15; windows above 7 on frames the fused kernel cannot read in place); the decode stage otherwise
-    // samples the caller's frames directly
+    // threshold kernels (windows above 15); the decode stage otherwise samples the caller's frames directly
     const bool big_window = threshold_writes_grey_plane(ctx->cfg.threshold_window, pixels, row_stride, frame_stride, (int)W);
     const bool need_grey = ctx->debug_taps || big_window;
     if (need_grey) A3_HIP(ctx->grey.ensure(npx * n));

@@ -14,9 +14,9 @@
 //     (0, 1) one half, v_dot2_i32_i16 with -1 subtracts: two chains (pixels 0 and 8) of R + 1 instructions to start and two per
 //     slide step; the 2R columns beside the lane's 16 come from the neighbouring lanes (wave shifts, as in K1);
 //   * compare per pixel in 32 bits: d = S - (L + 1) * area, the result bit is d's sign, shifted in with one v_alignbit.
-// Lanes, strips (2048 waves of 270 rows for 256 frames of 1920x1080), directions, the load queue and the XCD mapping are K1's.  Only
-// the aligned case (what launch_k1 calls `fast`: 16-byte aligned pointers and strides, W % 16 == 0) is built; anything else takes the
-// separable three-kernel path of k_threshold.hip.
+// Lanes, strips (2048 waves of 270 rows for 256 frames of 1920x1080), directions, the load queue and the XCD mapping are K1's, and so
+// are its two ways of reading a row: FAST (16-byte aligned pointers and strides, W % 16 == 0: unconditional vector loads from clamped
+// addresses) and the per-pixel loads of any other layout (load_raw).
 #include "k_threshold_k1.h"
 
 namespace a3 {
@@ -59,10 +59,10 @@ __device__ __forceinline__ void slide_chain(const uint32_t* E, uint32_t* S) {   
 }
 
 // grid: 8 * ceil(frames / 8) * strips_x * strips_y workgroups of one wave; dynamic LDS: (R + 1) KB of ring + (flush_rows + T_PF) * 128 B
-template <int FMT, int R>
+template <int FMT, int R, bool FAST>
 __global__ __launch_bounds__(64, 2) void k_grey_threshold_ring(const uint8_t* __restrict__ pixels, size_t row_stride, size_t frame_stride, int W, int H,
                                                                 int rows_per_wave, int strips_y, int n_frames, uint8_t* __restrict__ grey,
-                                                                uint8_t* __restrict__ bits, int flush_rows) {
+                                                                uint8_t* __restrict__ bits, int flush_rows, int aligned_in) {
     static_assert(R >= 8 && R <= 15, "radii 8..15: the neighbouring lane's 16 columns cover the window's reach");
     constexpr int NB = R + 1, PF = A3_T_PF;   // NB: rows of the ring's second stage (LDS)
     // LDS admits eight waves per CU; they must sit two on every SIMD.  Below 169 VGPRs a SIMD takes three, the eight are then
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64, 2) void k_grey_threshold_ring(const uint8_t* __
     const int x0 = sx * T_OUT - T_LPX + T_LPX * lane;
     const int y_begin = sy * rows_per_wave, y_end = min(H, y_begin + rows_per_wave);
     const bool owner = lane >= 1 && lane <= 62 && x0 < W;
-    const bool lane_in = x0 >= 0 && x0 + T_LPX <= W;   // (W % 16 == 0: a lane's columns are all inside or all outside)
+    const bool lane_in = x0 >= 0 && x0 + T_LPX <= W;   // (FAST, W % 16 == 0: a lane's columns are all inside or all outside)
 
     // clipped window widths of the lane's columns (0 outside the image: the comparison then fails), 8 bits each
     uint32_t axp[4] = {0u, 0u, 0u, 0u};
@@ -117,7 +117,10 @@ __global__ __launch_bounds__(64, 2) void k_grey_threshold_ring(const uint8_t* __
     const int r_first = dir > 0 ? y_begin - R : y_end - 1 + R, n_rows = (y_end - y_begin) + 2 * R;
     RawRow<FMT> q[PF];
     const uint8_t* lane_ptr = frame + (size_t)(lane_in ? x0 : 0) * RawRow<FMT>::BPP;
-    auto issue = [&](int r, RawRow<FMT>& dst) { load_vec<FMT>(lane_ptr + (size_t)(uint32_t)min(max(r, 0), H - 1) * row_stride, dst); };
+    auto issue = [&](int r, RawRow<FMT>& dst) {
+        if constexpr (FAST) load_vec<FMT>(lane_ptr + (size_t)(uint32_t)min(max(r, 0), H - 1) * row_stride, dst);
+        else load_raw<FMT>(frame, row_stride, x0, r, W, H, aligned_in != 0, dst);   // (zeros where the image is not)
+    };
 #pragma unroll
     for (int k = 0; k < PF; k++) issue(r_first + dir * k, q[k]);
 
@@ -132,11 +135,20 @@ __global__ __launch_bounds__(64, 2) void k_grey_threshold_ring(const uint8_t* __
             uint32_t g[T_NG];
             grey_row<FMT>(q[k], g);
             issue(r + dir * PF, q[k]);
-            if (!(lane_in && r >= 0 && r < H)) {
+            if constexpr (FAST) {   // what the clamped address fetched for a lane or row outside the image is discarded
+                if (!(lane_in && r >= 0 && r < H)) {
 #pragma unroll
-                for (int i = 0; i < T_NG; i++) g[i] = 0u;
+                    for (int i = 0; i < T_NG; i++) g[i] = 0u;
+                }
             }
-            if (write_grey && owner && r >= y_begin && r < y_end) *reinterpret_cast<uint4*>(gout + (size_t)r * W + x0) = make_uint4(g[0], g[1], g[2], g[3]);
+            if (write_grey && owner && r >= y_begin && r < y_end) {
+                uint8_t* dst = gout + (size_t)r * W + x0;
+                if constexpr (FAST) *reinterpret_cast<uint4*>(dst) = make_uint4(g[0], g[1], g[2], g[3]);
+                else {
+#pragma unroll
+                    for (int i = 0; i < T_LPX; i++) if (x0 + i < W) dst[i] = (uint8_t)(g[i >> 2] >> (8 * (i & 3)));
+                }
+            }
             // the ring: the centre row (R iterations old) leaves the registers for the LDS slot of the row that leaves the window
             // (2R + 1 iterations old; zeros at first), the others move up by one
             const uint4 old = s_ring[slot * 64 + lane];
@@ -231,7 +243,15 @@ hipError_t launch_ring(hipStream_t st, const uint8_t* pixels, int fmt, size_t ro
     const int flush_rows = std::min({128, rows_per_wave, (per_wave - NB * 1024) / 128 - A3_T_PF});
     const size_t lds_bytes = (size_t)NB * 1024 + (size_t)(flush_rows + A3_T_PF) * 128;
     dim3 grid(8 * (((int)n + 7) / 8) * strips_x * strips_y), block(64);
-#define A3_LAUNCH_RING(F) hipLaunchKernelGGL((k_grey_threshold_ring<F, R>), grid, block, lds_bytes, st, pixels, row_stride, frame_stride, W, H, rows_per_wave, strips_y, (int)n, grey, bin, flush_rows);
+    const int aligned_in = ((uintptr_t)pixels % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0);
+    const bool fast = aligned_in && W % 16 == 0 && (uintptr_t)grey % 16 == 0;   // (as in launch_k1)
+#define A3_LAUNCH_RING(F)                                                                                                              \
+    {                                                                                                                                  \
+        if (fast) hipLaunchKernelGGL((k_grey_threshold_ring<F, R, true>), grid, block, lds_bytes, st, pixels, row_stride, frame_stride, W, H, rows_per_wave, strips_y, \
+                                     (int)n, grey, bin, flush_rows, aligned_in);                                                       \
+        else hipLaunchKernelGGL((k_grey_threshold_ring<F, R, false>), grid, block, lds_bytes, st, pixels, row_stride, frame_stride, W, H, rows_per_wave, strips_y,    \
+                                (int)n, grey, bin, flush_rows, aligned_in);                                                            \
+    }
     if (fmt == A3_FMT_RGB8) A3_LAUNCH_RING(A3_FMT_RGB8)
     else if (fmt == A3_FMT_RGBA8) A3_LAUNCH_RING(A3_FMT_RGBA8)
     else if (fmt == A3_FMT_BGRA8) A3_LAUNCH_RING(A3_FMT_BGRA8)
@@ -240,14 +260,11 @@ hipError_t launch_ring(hipStream_t st, const uint8_t* pixels, int fmt, size_t ro
     return hipGetLastError();
 }
 
-// what the ring kernel asks of its input (launch_k1's `fast`), and of the grey plane when one is written
-bool ring_kernel_applies(uint32_t radius, const uint8_t* pixels, size_t row_stride, size_t frame_stride, int W) {
-    return radius >= 8 && radius <= 15 && ((uintptr_t)pixels % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0) && (W % 16 == 0);
-}
+// the radii this file covers (any frame layout)
+bool ring_kernel_applies(uint32_t radius, const uint8_t*, size_t, size_t, int) { return radius >= 8 && radius <= 15; }
 
 hipError_t launch_ring_threshold(uint32_t radius, hipStream_t st, const uint8_t* pixels, int fmt, size_t row_stride, size_t frame_stride, int W, int H,
                                  uint32_t n, uint8_t* grey, uint64_t* bits) {
-    if (grey && (uintptr_t)grey % 16 != 0) return hipErrorInvalidValue;
     switch (radius) {
         case 8: return launch_ring<8>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
         case 9: return launch_ring<9>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);

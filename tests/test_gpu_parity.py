@@ -144,9 +144,10 @@ def test_other_threshold_window(dicts, oracle):
 
 @pytest.mark.parametrize("radius", [8, 9, 10, 11, 12, 13, 14, 15])
 def test_threshold_windows_8_to_15(dicts, oracle, radius):
-    """The fused kernel of windows 8..15 (grey ring in LDS, 32-bit sums: k_threshold_big.hip) on widths it takes (W % 16 == 0: one
-    and two column strips, images lower and narrower than the window) and on widths that go through the separable path, every
-    pixel format, noise / ramps / flat: into_luma8 + adaptive_threshold(&grey, radius) bit for bit, with and without a grey plane."""
+    """The fused kernel of windows 8..15 (grey ring in registers + LDS, 32-bit sums: k_threshold_big.hip) with its vector loads
+    (W % 16 == 0: one and two column strips, images lower and narrower than the window) and with its per-pixel loads (any other
+    width), every pixel format, noise / ramps / flat: into_luma8 + adaptive_threshold(&grey, radius) bit for bit, with and
+    without a grey plane."""
     for (h, w), channels in (((480, 640), 3), ((250, 1040), 3), ((37, 2000), 4), ((300, 16), 1), ((9, 48), 3), ((1, 16), 4),
                              ((70, 1008), 1), ((129, 641), 3), ((40, 30), 4)):
         rng = np.random.default_rng(radius * 7919 + h * 31 + w + channels)
@@ -350,8 +351,8 @@ def test_detector_config_variants(dicts, oracle, cfg):
 @pytest.mark.parametrize("window,row_pad,off", [(7, 20, 3), (11, 32, 16), (11, 20, 3)])
 def test_strided_and_offset_input(hip, dicts, oracle, window, row_pad, off):
     """row_stride / frame_stride larger than the packed size and a base pointer that is not 16-byte aligned
-    (the kernel then takes its per-pixel path); results must not change.  Window 11: padded but aligned rows (the fused kernel
-    of windows 8..15 reads them in place) and unaligned ones (the separable path does)."""
+    (the kernel then takes its per-pixel path); results must not change.  Window 11: the fused kernel of windows 8..15 on padded
+    but aligned rows (vector loads) and on unaligned ones (per-pixel loads)."""
     import torch
 
     from aruco3_amd import synth
