@@ -40,7 +40,7 @@ WORKLOADS = {
            "metric": "frames/sec at 1920x1080 ARUCO dict",
            "label": "BASELINE config 2: batch of {n} x 1920x1080 synthetic RGB frames per GPU, ARUCO dict, 4-8 markers per frame, frames resident "
                     "in HBM; Detector::detect end to end (grey, threshold, contours, quads, warp+decode, lookup) incl. D2H of the marker list"},
-    "c5": {"config": 5, "frames": 16, "pose_mm": 40.0,
+    "c5": {"config": 5, "frames": 64, "pose_mm": 40.0,   # (64 x 4K = the pixels of 256 x 1080p: the threshold kernel's strips are then as tall)
            "metric": "frames/sec at 3840x2160 ARUCO dict, detect + estimate_pose",
            "label": "BASELINE config 5: batch of {n} x 3840x2160 synthetic RGB frames per GPU, ARUCO dict, 16 markers per frame, frames resident "
                     "in HBM; Detector::detect + solve_with_undistorted_points of every marker (a3_detect_batch_pose_submit / _collect), "
@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=tuple(WORKLOADS), default="c2", help="c2 (default): BASELINE config 2, the configuration the metric is quoted "
                                                                                 "on; c5: BASELINE config 5 (3840x2160, 16 markers, detect + pose)")
-    ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (0 = the workload's: 256 for c2, 16 for c5)")
+    ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (0 = the workload's: 256 for c2, 64 for c5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--device-synth", action="store_true", help="render the frames on the GPU (a3_synth_render) instead of on the host: no "
                                                                   "host rendering, no H2D copy (same layouts and ids; pixels may differ by "
