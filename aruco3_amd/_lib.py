@@ -21,6 +21,9 @@ FMT_RGB8, FMT_RGBA8, FMT_L8, FMT_BGRA8 = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
 PROFILE_OFF, PROFILE_STAGES, PROFILE_THRESHOLD_ONLY, PROFILE_THRESHOLD_SAMPLED = 0, 1, 2, 3
 STAGE_THRESHOLD, STAGE_CONTOUR, STAGE_DECODE = 0, 1, 2
+# a3_stats.stepping & 0xFF (include/aruco3_hip.h A3_STEP_*)
+STEP_WHOLE, STEP_DECODE_DEFERRED, STEP_HELD_RELEASED_BY_LAST, STEP_HELD_RELEASED_EARLY, STEP_BURST_LAST = 0, 1, 2, 3, 4
+STEP_NAMES = {0: "whole", 1: "decode_deferred", 2: "held_released_by_last", 3: "held_released_early", 4: "burst_last"}
 
 # every symbol include/aruco3_hip.h declares
 SYMBOLS = [
@@ -81,10 +84,13 @@ class Intrinsics(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("darts", C.c_uint64), ("contours_traced", C.c_uint64), ("contours_materialised", C.c_uint64),
                 ("candidates_pre", C.c_uint64), ("candidates", C.c_uint64), ("markers", C.c_uint64),
-                ("resolve_iterations", C.c_uint32), ("jump_rounds", C.c_uint32), ("chunks", C.c_uint32), ("reserved", C.c_uint32)]
+                ("resolve_iterations", C.c_uint32), ("jump_rounds", C.c_uint32), ("chunks", C.c_uint32), ("stepping", C.c_uint32)]
 
     def as_dict(self):
-        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+        d = {k: int(getattr(self, k)) for k, _ in self._fields_}
+        d["released_others"] = d["stepping"] >> 8     # (a3_stats.stepping: bits 8.. = chains of other contexts this batch's submit released)
+        d["stepping"] = STEP_NAMES.get(d["stepping"] & 0xFF, d["stepping"] & 0xFF)
+        return d
 
 
 _lib = None

@@ -2,6 +2,7 @@
 // declared in include/aruco3_hip.h.  No CPU fallback of any stage lives here: without a HIP device
 // a3_create fails with A3_ERR_NO_DEVICE.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <chrono>
 #include <cstddef>
@@ -160,6 +161,9 @@ struct a3_ctx {
     bool back_deferred = false;      // guarded by g_defer_mu
     int back_rc = 0;                 // a failed launch of the deferred half, whoever enqueued it (guarded by g_defer_mu): collect reports it
     bool allow_defer = false;        // set by the submit entry points for the batch being enqueued
+    int batch_mode = 0;              // where the decode stage of the batch being submitted is released (batch_mode_of, fixed at submit)
+    uint32_t stepping = 0;           // A3_STEP_* of the batch in flight / last finished (a3_stats.stepping)
+    uint32_t released_others = 0;    // held chains of other contexts this batch's submit released (the burst's last member)
     BackArgs back;
     a3_config cfg{};
     uint8_t num_bits = 0, tau = 0;
@@ -378,7 +382,31 @@ std::vector<a3_ctx*> g_deferred;
 // for modes 0 / 1 / 2 (0.794 / 0.744 / 0.741 on another box); smaller decode grids (2048 ... 512 workgroups) only lose.  Deferring the second half of the contour stage as well (entry resolution ... quads, released with the
 // decode stage behind the next threshold kernel) was built and measured: 0.777 with two contexts, 0.821 with three -- dropped.
 // (a3_debug_set_overlap in a3_internal.h switches modes for the A/B measurements of tools/.)
-int g_overlap_mode = 2;
+// Since round 5 the mode is decided PER BATCH, by the library, from what the caller did through the public header -- no switch
+// selects the stepping any more (g_overlap_force == -1, the default):
+//   * a context whose stream no other context of the device uses never defers (mode 0): consecutive batches on such contexts
+//     overlap by themselves, and a context that declared burst gates (a3_order_after) holds its chain back (submit_common);
+//   * contexts that SHARE one stream (a3_set_stream with the same caller stream) run in order there, whatever they do: the
+//     deferred decode stage -- mode 2 -- is the only overlap there is, so they get it.
+// a3_debug_set_overlap(0 | 1 | 2) forces one mode on every batch of the process for the A/B measurements of tools/; forced modes
+// 1 and 2 also switch the burst hold off, which is what the library did by default until round 4.
+std::atomic<int> g_overlap_force{-1};
+// the mode of the batch `ctx` is about to submit
+std::vector<a3_ctx*> g_contexts;   // every live context of the process (guarded by g_streams_mu)
+int batch_mode_of(const a3_ctx* ctx) {
+    const int f = g_overlap_force.load(std::memory_order_relaxed);
+    if (f >= 0) return f;
+    if (!ctx->stream || ctx->stream == ctx->own_stream) return 0;
+    std::lock_guard<std::mutex> lk(g_streams_mu);
+    for (const a3_ctx* o : g_contexts)
+        if (o != ctx && o->device == ctx->device && o->stream == ctx->stream) return 2;
+    return 0;
+}
+// where a batch being enqueued releases the decode stages other contexts have deferred
+int release_mode() {
+    const int f = g_overlap_force.load(std::memory_order_relaxed);
+    return f >= 0 ? f : 2;
+}
 // (The decode stream has default priority: the lowest one measured the same, and is the wrong thing to hold when two processes
 // share a GPU.)
 
@@ -452,12 +480,13 @@ int need_stream(a3_ctx* ctx) {
 // ---- bursts: contexts whose submitted batch has its threshold kernel enqueued and the rest held back (see a3_ctx::rest_held) ----
 std::vector<a3_ctx*> g_held;   // guarded by g_defer_mu, in submission order
 int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t H, size_t row_stride, size_t frame_stride, uint32_t n,
-                  size_t out_cap, int phase);
+                  size_t out_cap, int phase, bool defer_locked = false);
 // Enqueue the held chain of `ctx`'s batch on its stream, behind `after` when given (the threshold kernel of the burst's last
 // member).  g_defer_mu is held; the owner may be another thread's context, so the verdict is kept for its collect.
-int flush_held_locked(a3_ctx* ctx, hipEvent_t after) {
+int flush_held_locked(a3_ctx* ctx, hipEvent_t after, bool by_last_member = false) {
     if (!ctx->rest_held) return A3_OK;
     ctx->rest_held = false;
+    ctx->stepping = by_last_member ? A3_STEP_HELD_RELEASED_BY_LAST : A3_STEP_HELD_RELEASED_EARLY;
     for (size_t i = 0; i < g_held.size(); i++)
         if (g_held[i] == ctx) { g_held.erase(g_held.begin() + (long)i); break; }
     const Pending pd = ctx->pending;
@@ -465,11 +494,74 @@ int flush_held_locked(a3_ctx* ctx, hipEvent_t after) {
     ctx->want_pose = pd.want_pose;
     int rc = A3_OK;
     if (after && hipStreamWaitEvent(ctx->stream, after, 0) != hipSuccess) rc = fail(ctx, A3_ERR_HIP, "hipStreamWaitEvent (burst gate)");
-    if (rc == A3_OK) rc = enqueue_batch(ctx, pd.pixels, pd.fmt, pd.W, pd.H, pd.row_stride, pd.frame_stride, pd.n, ctx->held_out_cap, 2);
+    if (rc == A3_OK) rc = enqueue_batch(ctx, pd.pixels, pd.fmt, pd.W, pd.H, pd.row_stride, pd.frame_stride, pd.n, ctx->held_out_cap, 2, /*defer_locked=*/true);
     ctx->want_pose = wp;
     ctx->held_rc = rc;
     (void)hipStreamQuery(ctx->stream);   // hands what was just queued to the GPU now (the owner may be polling an event)
     return rc;
+}
+
+// ---- what a batch's chain needs before it can be enqueued without allocating ----
+// A batch shaped like the previous one, which fitted one chunk, is planned on the device (no read-back of the dart counts before
+// the contour stage).  -> the dart capacity such a batch is launched with; 0: this batch must be planned by the host.
+uint64_t device_plan_capacity(const a3_ctx* ctx, uint32_t n, uint32_t W, uint32_t H) {
+    if (!(ctx->plan_valid && !ctx->force_host_plan && ctx->plan_n == n && ctx->plan_W == W && ctx->plan_H == H && n <= kMaxChunkFrames)) return 0;
+    const uint64_t cap_d = ctx->plan_darts + ctx->plan_darts / 4 + 65536;
+    return cap_d > ctx->max_darts ? 0 : cap_d;
+}
+// One allocation for everything small: [frame_cursor | cand_count | (device plan: frame_darts) | HEAD | markers], HEAD =
+// [scratch 256 B | counters | per_frame]: what the host reads back ahead of the markers.
+struct ZeroLayout { size_t ctr_bytes, head_bytes, head_off, total; };
+ZeroLayout zero_layout(size_t n_chunks, uint32_t chunk_frames, uint32_t n, uint32_t marker_cap) {
+    ZeroLayout z;
+    z.ctr_bytes = sizeof(DeviceCounters) * n_chunks;
+    z.head_bytes = (256 + z.ctr_bytes + (size_t)n * 4 + 7) & ~(size_t)7;
+    const size_t fd_off = ((size_t)chunk_frames * 4 + (size_t)n * 4 + 15) & ~(size_t)15;
+    z.head_off = (fd_off + 255) & ~(size_t)255;
+    z.total = z.head_off + z.head_bytes + (size_t)marker_cap * sizeof(a3_marker);
+    return z;
+}
+uint32_t marker_cap_of(const a3_ctx* ctx, uint32_t n, size_t out_cap) {
+    return (uint32_t)std::min<size_t>(std::max<size_t>(out_cap, 1), (size_t)n * ctx->max_cand);
+}
+uint32_t marker_guess_of(const a3_ctx* ctx, uint32_t marker_cap) {
+    return (uint32_t)std::min<size_t>(marker_cap, (size_t)ctx->last_marker_total + ctx->last_marker_total / 4 + 64);
+}
+// a single-chunk batch is followed by device-planned ones sized darts * 1.25 + 64k: the pool is allocated for that at once
+uint64_t pool_darts_of(const a3_ctx* ctx, uint64_t max_chunk_darts, size_t n_chunks) {
+    uint64_t pool_darts = std::max<uint64_t>(max_chunk_darts, 1);
+    if (n_chunks == 1) pool_darts = std::min<uint64_t>(std::max<uint64_t>(ctx->max_darts, pool_darts), pool_darts + pool_darts / 2 + 131072);
+    return pool_darts;
+}
+// Every buffer the chain (contour stage ... read-back) of a DEVICE-PLANNED batch uses, allocated now: a chain that is held back for
+// a burst is enqueued later -- by whichever thread submits the burst's last member, under the process-wide lock -- and must then
+// find nothing left to allocate (hipMalloc / hipHostMalloc synchronise the device).  The same calls stand in enqueue_batch's chain
+// half, where they are no-ops afterwards (the buffers only grow).
+int ensure_chain_buffers(a3_ctx* ctx, hipStream_t st, uint32_t n, uint32_t W, uint32_t H, uint64_t cap_d, size_t out_cap) {
+    const size_t npx = (size_t)W * H;
+    const uint32_t marker_cap = marker_cap_of(ctx, n, out_cap);
+    const ZeroLayout z = zero_layout(1, n, n, marker_cap);
+    A3_HIP(ctx->tile_darts.ensure(tile_darts_bytes(W, H, n)));
+    A3_HIP(ctx->zero_blk.ensure(z.total));
+    if (ctx->frame_darts_dev.cap < (size_t)n * 8) {
+        A3_HIP(ctx->frame_darts_dev.ensure((size_t)n * 8));
+        A3_HIP(hipMemsetAsync(ctx->frame_darts_dev.p, 0, ctx->frame_darts_dev.cap, st));
+    }
+    A3_HIP(ctx->frame_base.ensure((size_t)(n + 1) * 4));
+    if (int rc = ensure_dart_pool(ctx, pool_darts_of(ctx, cap_d, 1))) return rc;
+    A3_HIP(ctx->pix_base.ensure((size_t)n * npx * 4));
+    A3_HIP(ctx->contours.ensure((size_t)ctx->max_contours * sizeof(ContourRec)));
+    A3_HIP(ctx->cyc_start_off.ensure((size_t)ctx->max_contours * 4));
+    A3_HIP(ctx->points.ensure(ctx->max_points * 4));
+    if (ctx->want_pose) A3_HIP(ctx->pose_buf.ensure((size_t)marker_cap * 2 * sizeof(a3_pose)));
+    if (int rc = ensure_pinned(ctx, z.head_bytes + (size_t)marker_guess_of(ctx, marker_cap) * (sizeof(a3_marker) + 2 * sizeof(a3_pose)) + (1 << 16))) return rc;
+    if (ctx->debug_taps && ctx->pinned_counts_cap < (size_t)n * 8) {
+        if (ctx->pinned_counts) (void)hipHostFree(ctx->pinned_counts);
+        ctx->pinned_counts = nullptr; ctx->pinned_counts_cap = 0;
+        A3_HIP(hipHostMalloc(&ctx->pinned_counts, (size_t)n * 8, hipHostMallocDefault));
+        ctx->pinned_counts_cap = (size_t)n * 8;
+    }
+    return A3_OK;
 }
 
 // the whole pipeline for one batch; `pixels` is a device pointer here
@@ -477,10 +569,14 @@ int flush_held_locked(a3_ctx* ctx, hipEvent_t after) {
 // the device's verdict, hand out the markers).  a3_detect_batch runs them back to back; a3_detect_batch_submit / _collect
 // let the caller enqueue the next batch (on another context) before collecting this one, so the GPU never waits for the host.
 // phase 0: the whole batch; 1: the front half only (buffers + threshold kernel + an event behind it); 2: everything after the
-// threshold kernel of a batch whose front half phase 1 enqueued (same arguments)
+// threshold kernel of a batch whose front half phase 1 enqueued (same arguments).  `defer_locked`: the caller holds g_defer_mu
+// (a held chain released by another context's submit, by a gate, by collect): nothing in here may take that lock again, so such a
+// batch neither releases other contexts' deferred decode stages nor defers its own -- and, planned on the device with every buffer
+// allocated by its phase 1 (ensure_chain_buffers), it neither allocates nor waits for the device.
 int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint32_t H, size_t row_stride, size_t frame_stride, uint32_t n,
-                  size_t out_cap, int phase) {
+                  size_t out_cap, int phase, bool defer_locked) {
     hipStream_t st = ctx->stream;
+    const int rel_mode = defer_locked ? 0 : release_mode();
     const size_t npx = (size_t)W * H;
     const uint32_t minwh = W < H ? W : H;
     const uint32_t min_edge_length = (uint32_t)((float)minwh * ctx->cfg.min_side_length_factor);   // src/aruco.rs:55
@@ -505,7 +601,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     A3_HIP(ctx->work.ensure((size_t)n * kMaxCand * 4));
     A3_HIP(ctx->outs.ensure((size_t)n * kMaxCand * decode_out_bytes()));
     A3_HIP(ctx->proj.ensure((size_t)n * kMaxCand * proj_rec_bytes()));
-    const uint32_t marker_cap = (uint32_t)std::min<size_t>(std::max<size_t>(out_cap, 1), (size_t)n * kMaxCand);
+    const uint32_t marker_cap = marker_cap_of(ctx, n, out_cap);
     const uint32_t patch_cap = (uint32_t)std::min<uint64_t>(kPatchCapMax, std::max<uint64_t>(kPatchCapMin, (uint64_t)n * kMaxCand));
     if (ctx->debug_taps) { A3_HIP(ctx->patches.ensure((size_t)patch_cap * S * S)); ctx->patch_cap = patch_cap; }
     int prof = ctx->front_prof;
@@ -533,10 +629,14 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
         A3_HIP(hipStreamWaitEvent(st, ctx->ev_k1_done, 0));
     } else if (g_mark_threshold || phase == 1) A3_HIP(hipEventRecord(ctx->ev_k1_done, st));   // (held chains of a burst wait for the last member's)
     ctx->k1_marked = g_mark_threshold || phase == 1 || k1st != st;
-    if (phase == 1) return A3_OK;
+    if (phase == 1) {   // the chain is held back: what it will need is allocated now (submit_common holds device-planned batches only)
+        const uint64_t cap1 = device_plan_capacity(ctx, n, W, H);
+        if (cap1 == 0) return fail(ctx, A3_ERR_INTERNAL, "a chain was held back for a batch that needs a host-side plan");
+        return ensure_chain_buffers(ctx, st, n, W, H, cap1, out_cap);
+    }
     }
     // batches of OTHER contexts (same device) that wait with their decode stage are released from inside this batch's launch
-    // sequence (see g_overlap_mode): `release_point(true)` records the event they wait for and enqueues them
+    // sequence (see release_mode()): `release_waiting()` records the event they wait for and enqueues them
     bool released = false;
     auto release_waiting = [&]() -> int {
         if (released) return A3_OK;
@@ -552,28 +652,20 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
                 if (int rc = flush_deferred_locked(o, ctx->ev_k1)) { ctx->err = "deferred decode of another context: " + o->err; return rc; }
         return A3_OK;
     };
-    if (g_overlap_mode == 1) { if (int rc = release_waiting()) return rc; }
+    if (rel_mode == 1) { if (int rc = release_waiting()) return rc; }
 
     // ---- contour graph size per frame -> chunk plan ----
     // A batch shaped like the previous one is planned on the device: no read-back, no idle GPU while the host thinks.
-    uint64_t cap_d = 0;
-    bool device_plan = ctx->plan_valid && !ctx->force_host_plan && ctx->plan_n == n && ctx->plan_W == W && ctx->plan_H == H &&
-                       n <= kMaxChunkFrames;
-    if (device_plan) {
-        cap_d = ctx->plan_darts + ctx->plan_darts / 4 + 65536;
-        if (cap_d > ctx->max_darts) device_plan = false;
-    }
-    // One allocation for everything small: [frame_cursor | cand_count | (device plan: frame_darts) | HEAD | markers].  One
-    // memset zeroes it up to the end of HEAD = [scratch 256 B | counters | per_frame]; HEAD and the marker list that follows it
-    // come back to the host in one copy.
+    const uint64_t cap_d = device_plan_capacity(ctx, n, W, H);
+    const bool device_plan = cap_d != 0;
+    // The zero block (zero_layout): one memset zeroes it up to the end of HEAD; HEAD and the marker list that follows it come back
+    // to the host in one copy.
     size_t ctr_bytes = 0, head_bytes = 0, head_off = 0;
     void* zero_p = nullptr; size_t zero_bytes = 0;
     auto layout_zero_block = [&](size_t n_chunks, uint32_t chunk_frames, bool launch) -> hipError_t {
-        ctr_bytes = sizeof(DeviceCounters) * n_chunks;
-        head_bytes = (256 + ctr_bytes + (size_t)n * 4 + 7) & ~(size_t)7;     // what the host reads back ahead of the markers
-        const size_t fd_off = ((size_t)chunk_frames * 4 + (size_t)n * 4 + 15) & ~(size_t)15;
-        head_off = (fd_off + 255) & ~(size_t)255;
-        const hipError_t e = ctx->zero_blk.ensure(head_off + head_bytes + (size_t)marker_cap * sizeof(a3_marker));
+        const ZeroLayout zl = zero_layout(n_chunks, chunk_frames, n, marker_cap);
+        ctr_bytes = zl.ctr_bytes; head_bytes = zl.head_bytes; head_off = zl.head_off;
+        const hipError_t e = ctx->zero_blk.ensure(zl.total);
         if (e != hipSuccess) return e;
         uint8_t* z = ctx->zero_blk.as<uint8_t>();
         ctx->frame_cursor = reinterpret_cast<uint32_t*>(z);
@@ -627,10 +719,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     uint32_t max_chunk_frames = 0; uint64_t max_chunk_darts = 0;
     for (auto& c : chunks) { max_chunk_frames = std::max(max_chunk_frames, c.count); max_chunk_darts = std::max(max_chunk_darts, c.darts); }
     ctx->stats.chunks = (uint32_t)chunks.size();
-    // a single-chunk batch is followed by device-planned ones sized darts * 1.25 + 64k: allocate that now, not inside batch 2
-    uint64_t pool_darts = std::max<uint64_t>(max_chunk_darts, 1);
-    if (chunks.size() == 1) pool_darts = std::min<uint64_t>(std::max<uint64_t>(ctx->max_darts, pool_darts), pool_darts + pool_darts / 2 + 131072);
-    if (int rc = ensure_dart_pool(ctx, pool_darts)) return rc;
+    if (int rc = ensure_dart_pool(ctx, pool_darts_of(ctx, max_chunk_darts, chunks.size()))) return rc;
     A3_HIP(ctx->pix_base.ensure((size_t)max_chunk_frames * npx * 4));
     A3_HIP(ctx->frame_base.ensure((size_t)(max_chunk_frames + 1) * 4 * chunks.size()));
     if (!device_plan) A3_HIP(layout_zero_block(chunks.size(), max_chunk_frames, true));
@@ -698,7 +787,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
                                   ctx->entry_list.as<uint32_t>(), ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
                                   ctx->stA.as<JumpState>(), ctx->leader_list.as<uint32_t>(), d_leader_count, rounds, ctr, n_live, 0, fb,
                                   frame_entries, cc.count, 1));
-        if (g_overlap_mode == 2) { if (int rc = release_waiting()) return rc; }   // waiting decode stages go out behind this k_local_contract
+        if (rel_mode == 2) { if (int rc = release_waiting()) return rc; }   // waiting decode stages go out behind this k_local_contract
         ctx->dbg_nd = nd; ctx->dbg_frames = c.count; ctx->dbg_chunks = (uint32_t)chunks.size();
         // second half: entry resolution, final states (+ border selection), point scatter, quads -- on `s2`
         auto chunk_back = [=](hipStream_t s2) -> int {
@@ -722,7 +811,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
         };
         if (int rc = chunk_back(st)) return rc;
     }
-    if (g_overlap_mode != 0) { if (int rc = release_waiting()) return rc; }   // (a batch without a contour graph releases here)
+    if (rel_mode != 0) { if (int rc = release_waiting()) return rc; }   // (a batch without a contour graph releases here)
     if (prof >= 2) A3_HIP(hipEventRecord(ctx->ev[2], st));
 
     // ---- candidates -> markers -> read-back: enqueued now, or deferred behind the next submitted batch's threshold kernel ----
@@ -730,7 +819,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
                                    : PixelSrc{pixels, row_stride, frame_stride, fmt};
     ctx->dbg_src = src;
     const size_t pose_bytes = ctx->want_pose ? 2 * sizeof(a3_pose) : 0;
-    const uint32_t guess = (uint32_t)std::min<size_t>(marker_cap, (size_t)ctx->last_marker_total + ctx->last_marker_total / 4 + 64);
+    const uint32_t guess = marker_guess_of(ctx, marker_cap);
     const size_t head_pad = head_bytes;   // the markers follow the head directly, on the device and in the staging buffer
     // every allocation of the second half happens here, at submit time: pose buffer, pinned staging for the head and `guess`
     // markers (+ poses; a longer list is fetched by finish_batch after growing it), pinned staging for the tap counts
@@ -752,11 +841,13 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     // (the stage times are those of stages that run alone).  The decode stage then waits on the context's decode stream until
     // (a) another context submits a batch -- it is released behind that batch's threshold kernel and shares the GPU with its
     // contour stage -- or (b) this batch is collected first.
-    if (ctx->allow_defer && ctx->profiling < 2 && g_overlap_mode != 0) {
+    if (phase == 0) ctx->stepping = A3_STEP_WHOLE;
+    if (ctx->allow_defer && !defer_locked && ctx->profiling < 2 && ctx->batch_mode != 0) {
         A3_HIP(hipEventRecord(ctx->ev_contours, st));
         std::lock_guard<std::mutex> lk(g_defer_mu);
         ctx->back_deferred = true;
         ctx->back_rc = 0;
+        ctx->stepping = A3_STEP_DECODE_DEFERRED;
         g_deferred.push_back(ctx);
     } else if (int rc = enqueue_back(ctx, st, bk)) return rc;
     Pending& pd = ctx->pending;
@@ -984,6 +1075,7 @@ int a3_create(int device, const a3_config* cfg, const uint64_t* codes, size_t n_
         tau = t;
     }
     c->tau = tau;
+    { std::lock_guard<std::mutex> lk(g_streams_mu); g_contexts.push_back(c); }
     *out = c;
     return A3_OK;
 }
@@ -991,6 +1083,11 @@ int a3_create(int device, const a3_config* cfg, const uint64_t* codes, size_t n_
 void a3_destroy(a3_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    {
+        std::lock_guard<std::mutex> lk(g_streams_mu);
+        for (size_t i = 0; i < g_contexts.size(); i++)
+            if (g_contexts[i] == ctx) { g_contexts.erase(g_contexts.begin() + (long)i); break; }
+    }
     {   // a submitted batch that was never collected: its deferred half is dropped
         std::lock_guard<std::mutex> lk(g_defer_mu);
         for (size_t i = 0; i < g_deferred.size(); i++)
@@ -1196,11 +1293,17 @@ static int submit_common(a3_ctx* ctx, const void* pixels, int memory, int fmt, u
     pd.pixels = d_pixels; pd.fmt = fmt; pd.row_stride = row_stride; pd.frame_stride = frame_stride; pd.want_pose = want_pose;
     // Bursts: a context that declared gates (a3_order_after) since its last submit holds its chain back behind its threshold
     // kernel; a submit without gates is the last member of its burst and releases every held chain of the device behind ITS
-    // threshold kernel.  Not while every stage is being timed, not with the deferred decode of the shared-stream stepping.
+    // threshold kernel.  This is the library's behaviour behind the public header -- no switch selects it.  Exceptions, all of
+    // them "enqueue the whole batch now": every stage is being timed (the stage times are those of stages that run alone); the
+    // batch needs a host-side plan (first batch of a shape, or a graph that outgrew the previous plan: the plan waits for the
+    // device, and a chain enqueued later by another thread must not); the context runs on a caller's stream (its batches are
+    // in order there anyway, a3_order_after is a no-op); a forced mode 1 / 2 (a3_debug_set_overlap: round 4's default, for A/B).
     const bool gated = ctx->gates_declared;
     ctx->gates_declared = false;
-    const bool bursts = g_overlap_mode == 0 && g_hold_rests && ctx->profiling < 2;
-    if (bursts && gated) {
+    ctx->batch_mode = batch_mode_of(ctx);
+    ctx->released_others = 0;
+    const bool bursts = ctx->batch_mode == 0 && g_overlap_force.load(std::memory_order_relaxed) <= 0 && g_hold_rests && ctx->profiling < 2;
+    if (bursts && gated && device_plan_capacity(ctx, n_frames, width, height) != 0) {
         pd.n = n_frames; pd.W = width; pd.H = height;
         ctx->held_out_cap = out_cap;
         if (int erc = enqueue_batch(ctx, d_pixels, fmt, width, height, row_stride, frame_stride, n_frames, out_cap, 1)) return erc;
@@ -1217,14 +1320,20 @@ static int submit_common(a3_ctx* ctx, const void* pixels, int memory, int fmt, u
         for (a3_ctx* o : g_held) any_held |= (o != ctx && o->device == ctx->device);
     }
     if (any_held) {   // the last member: threshold kernel, then the held chains of the others behind it, then this batch's own
-        if (int erc = enqueue_batch(ctx, d_pixels, fmt, width, height, row_stride, frame_stride, n_frames, out_cap, 1)) return erc;
+        // A last member that needs a host-side plan cannot be split (phase 1 refuses it): the others are then released ungated,
+        // ahead of its whole batch.
+        const bool planned = device_plan_capacity(ctx, n_frames, width, height) != 0;
+        if (planned) { if (int erc = enqueue_batch(ctx, d_pixels, fmt, width, height, row_stride, frame_stride, n_frames, out_cap, 1)) return erc; }
+        uint32_t released = 0;
         {
             std::lock_guard<std::mutex> lk(g_defer_mu);
             const std::vector<a3_ctx*> list = g_held;   // (flush edits g_held)
             for (a3_ctx* o : list)
-                if (o != ctx && o->device == ctx->device) (void)flush_held_locked(o, ctx->ev_k1_done);   // (a failure is o's: its collect reports it)
+                if (o != ctx && o->device == ctx->device) { (void)flush_held_locked(o, planned ? ctx->ev_k1_done : nullptr, true); released++; }   // (a failure is o's: its collect reports it)
         }
-        return enqueue_batch(ctx, d_pixels, fmt, width, height, row_stride, frame_stride, n_frames, out_cap, 2);
+        const int erc = enqueue_batch(ctx, d_pixels, fmt, width, height, row_stride, frame_stride, n_frames, out_cap, planned ? 2 : 0);
+        ctx->stepping = A3_STEP_BURST_LAST; ctx->released_others = released;
+        return erc;
     }
     ctx->allow_defer = true;    // (a synchronous call, or a re-run, enqueues both halves at once)
     const int erc = enqueue_batch(ctx, d_pixels, fmt, width, height, row_stride, frame_stride, n_frames, out_cap, 0);
@@ -1245,8 +1354,10 @@ static int collect_common(a3_ctx* ctx, a3_marker* out, a3_pose* poses, size_t ou
     ctx->want_pose = pd.want_pose;     // (the other half of the pair may have been a different kind of call on this context)
     ctx->pose_out = pd.want_pose ? poses : nullptr;
     int rc = finish_batch(ctx, out, out_cap, per_frame_count, out_n);
+    const uint32_t stepping = ctx->stepping;   // how the SUBMITTED batch was stepped (a re-run below is a synchronous call of its own)
     // the device asked for a re-run (pool growth, more passes, host-side plan): do it synchronously
     if (rc == 1) rc = run_batch_with_retries(ctx, pd.pixels, pd.fmt, pd.W, pd.H, pd.row_stride, pd.frame_stride, pd.n, out, out_cap, per_frame_count, out_n);
+    ctx->stepping = stepping;
     ctx->want_pose = false;
     ctx->pose_out = nullptr;
     return rc;
@@ -1355,11 +1466,12 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
 
 // internal (a3_internal.h): where a submitted batch's decode stage is released (0 not deferred, 1 behind the next batch's
 // threshold kernel, 2 behind its k_local_contract); process-wide, for A/B measurements
-int a3_debug_set_overlap(int mode) {   // bits 0-7: mode; bit 8: a decode stream created from now on gets the LOWEST priority
-    if (mode < 0 || (mode & 0xFF) > 2) return A3_ERR_INVALID;
+int a3_debug_set_overlap(int mode) {   // -1: the library decides per batch (default); bits 0-7: forced mode; bit 8: a decode stream created from now on gets the LOWEST priority
+    if (mode != -1 && (mode < 0 || (mode & 0xFF) > 2)) return A3_ERR_INVALID;
     std::lock_guard<std::mutex> lk(g_defer_mu);
-    g_overlap_mode = mode & 0xFF;
-    { std::lock_guard<std::mutex> lk2(g_streams_mu); g_decode_low_prio = (mode & 0x100) != 0; }
+    if (!g_held.empty() || !g_deferred.empty()) return A3_ERR_INVALID;   // batches in flight were submitted under the old mode: collect them first
+    g_overlap_force.store(mode == -1 ? -1 : (mode & 0xFF), std::memory_order_relaxed);
+    { std::lock_guard<std::mutex> lk2(g_streams_mu); g_decode_low_prio = mode != -1 && (mode & 0x100) != 0; }
     return A3_OK;
 }
 
@@ -1412,7 +1524,12 @@ int a3_debug_launch_threshold(a3_ctx* ctx, const void* pixels_device, int fmt, u
 }
 
 int a3_debug_set_mark_threshold(int on) { g_mark_threshold = on != 0; return A3_OK; }
-int a3_debug_set_hold(int on) { std::lock_guard<std::mutex> lk(g_defer_mu); g_hold_rests = on != 0; return A3_OK; }
+int a3_debug_set_hold(int on) {
+    std::lock_guard<std::mutex> lk(g_defer_mu);
+    if (!g_held.empty()) return A3_ERR_INVALID;   // (chains held under the old setting: collect them first)
+    g_hold_rests = on != 0;
+    return A3_OK;
+}
 
 int a3_debug_set_k1_waves(int waves_per_simd) { set_k1_waves(waves_per_simd); return A3_OK; }
 
@@ -1447,6 +1564,7 @@ int a3_synth_render(int device, void* hip_stream, const a3_synth_frame* frames, 
 int a3_get_stats(const a3_ctx* ctx, a3_stats* stats) {
     if (!ctx || !stats) return A3_ERR_INVALID;
     *stats = ctx->stats;
+    stats->stepping = ctx->stepping | (ctx->released_others << 8);
     return A3_OK;
 }
 

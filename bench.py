@@ -121,9 +121,15 @@ def main():
                     help="with --streams own: burst (default) = before each submit context k calls a3_order_after for the contexts k+1 .. N-1, so "
                          "the threshold kernels of one rotation run back to back after the previous rotation's chains have drained; none = "
                          "free-running rotation")
-    ap.add_argument("--overlap", type=int, default=-1, help="measurement aid (a3_internal.h: a3_debug_set_overlap): where the decode stage of a "
-                                                            "submitted batch is released, 0 never deferred / 1 / 2; -1 = 0 with --streams own, "
-                                                            "the library's default (2) with shared")
+    ap.add_argument("--overlap", type=int, default=-1, help="measurement aid (a3_internal.h: a3_debug_set_overlap): force where the decode stage of "
+                                                            "a submitted batch is released, 0 never deferred / 1 / 2, for every batch of the process; "
+                                                            "-1 (default) = nothing is switched: the library decides per batch, as it does for any caller")
+    ap.add_argument("--verify-gathers", action="store_true", help="N > 1 / --force-dist test aid: the batches change hands every rotation and EVERY "
+                                                                     "collective's output is kept and checked at the end (global frame indices, ids)")
+    ap.add_argument("--gather-delay-us", type=float, default=0.0, help="test aid: a sleep of this many microseconds on the side stream ahead of every "
+                                                                         "collective (a collective that waits for lagging ranks)")
+    ap.add_argument("--no-gather-backpressure", action="store_true", help="test aid: packs do NOT wait for the collective that last read their record "
+                                                                             "buffer (round 4's behaviour: with --gather-delay-us records are overwritten before they are sent)")
     ap.add_argument("--isolated-launches", type=int, default=24, help="synchronous batches run one at a time, every stage between events, before the "
                                                                       "timed steps: the threshold kernel's launch duration ALONE (roofline) and the stage table")
     ap.add_argument("--max-markers", type=int, default=0, help="N > 1: markers per frame a gather record holds; 0 = calibrated on the first batch "
@@ -148,21 +154,33 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus must agree")
 
+    own_streams = args.streams == "own" and not args.no_pipeline
+    n_ctx = 1 if args.no_pipeline else (args.contexts or (4 if own_streams else 2))
+    # Every context steps a batch of its OWN: n_ctx distinct batches are resident and in flight (a burst is four different batches in
+    # any real use; four contexts re-reading one batch could share it in the 256 MiB Infinity Cache).  Batch j of this rank holds
+    # the frames (rank * n_ctx + j) * frames .. + frames of the workload's seeded generator.
+    n_bufs = n_ctx
+    first_of = lambda j: (rank * n_bufs + j) * args.frames
+
     # host-side frame synthesis first (forks a pool; nothing has touched the GPU yet)
-    workers = args.synth_workers or max(1, min(16, (os.cpu_count() or 8) // max(1, world)))
+    workers = args.synth_workers or max(1, min(32, (os.cpu_count() or 8) // max(1, world)))
     t0 = time.time()
-    cache = Path(f"{args.frames_cache}.{args.workload}.n{args.frames}.r{rank}.npz") if args.frames_cache else None
+    cache = Path(f"{args.frames_cache}.{args.workload}.n{args.frames}x{n_bufs}.r{rank}.npz") if args.frames_cache else None
     if args.device_synth:
-        frames, truth_ids = None, None        # rendered below, once the device is set up
+        frames_h, truth_ids = None, None        # rendered below, once the device is set up
     elif cache is not None and cache.exists():
         z = np.load(cache, allow_pickle=True)
-        frames, truth_ids = z["frames"], [list(t) for t in z["truth"]]
-        assert frames.shape[0] == args.frames
+        frames_all, truth_all_ids = z["frames"], [list(t) for t in z["truth"]]
+        assert frames_all.shape[0] == args.frames * n_bufs
+        frames_h = [frames_all[j * args.frames:(j + 1) * args.frames] for j in range(n_bufs)]
+        truth_ids = [truth_all_ids[j * args.frames:(j + 1) * args.frames] for j in range(n_bufs)]
     else:
-        frames, truth_ids = make_frames(wl["config"], rank * args.frames, args.frames, workers)
+        frames_all, truth_all_ids = make_frames(wl["config"], first_of(0), args.frames * n_bufs, workers)
         if cache is not None:
             cache.parent.mkdir(parents=True, exist_ok=True)
-            np.savez(cache, frames=frames, truth=np.array(truth_ids, dtype=object))
+            np.savez(cache, frames=frames_all, truth=np.array(truth_all_ids, dtype=object))
+        frames_h = [frames_all[j * args.frames:(j + 1) * args.frames] for j in range(n_bufs)]
+        truth_ids = [truth_all_ids[j * args.frames:(j + 1) * args.frames] for j in range(n_bufs)]
     t_gen = time.time() - t0
 
     import torch
@@ -186,11 +204,14 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    own_streams = args.streams == "own" and not args.no_pipeline
-    n_ctx = 1 if args.no_pipeline else (args.contexts or (4 if own_streams else 2))
-    overlap_mode = args.overlap if args.overlap >= 0 else (0 if own_streams else 2)
+    # The stepping below is what the LIBRARY does behind include/aruco3_hip.h: contexts on streams of their own + a3_order_after
+    # gates -> bursts with held chains; contexts on one shared stream -> deferred decode.  No process-wide switch is set for the
+    # headline (`library.internal_switches_used` lists what --overlap, a measurement aid, switched -- nothing by default).
     L = _lib.load()
-    assert L.a3_debug_set_overlap(overlap_mode) == 0
+    internal_switches_used = []
+    if args.overlap >= 0:
+        assert L.a3_debug_set_overlap(args.overlap) == 0
+        internal_switches_used.append(f"a3_debug_set_overlap({args.overlap}) [--overlap]")
     spec, dict_name = synth.config_spec(wl["config"])
     d = ARDictionary.new_from_named_dict(dict_name) if rank == 0 or world == 1 else None
     if use_dist:
@@ -203,35 +224,45 @@ def main():
             ctx.set_stream(stream.cuda_stream)
     # the stream every context enqueues on, as a torch stream (for the waits on the pack of its previous batch)
     ctx_stream = {id(cx): (torch.cuda.ExternalStream(cx.stream_ptr, device=dev) if own_streams else stream) for cx in ctxs}
-    ctx_stream_ptr = {id(cx): cx.stream_ptr for cx in ctxs}
     ctx = ctxs[0]
 
     if args.device_synth:
-        seeds = [synth.frame_seed(wl["config"], rank * args.frames + i) for i in range(args.frames)]
         t0 = time.time()
-        d_frames, truths = synth.render_frames_device(spec, d.code_list, d.num_bits, seeds, device=local_rank)
-        truth_ids = [[t.id for t in tr] for tr in truths]
+        d_bufs, truth_ids = [], []
+        for j in range(n_bufs):
+            seeds = [synth.frame_seed(wl["config"], first_of(j) + i) for i in range(args.frames)]
+            df, truths = synth.render_frames_device(spec, d.code_list, d.num_bits, seeds, device=local_rank)
+            d_bufs.append(df); truth_ids.append([[t.id for t in tr] for tr in truths])
         t_gen = time.time() - t0
-        frames = d_frames.cpu().numpy() if (rank == 0 and not args.no_cpu_baseline and world == 1) else None   # only the CPU baseline reads them
+        want_host = rank == 0 and not args.no_cpu_baseline and world == 1     # only the CPU baseline reads them
+        frames_h = [df.cpu().numpy() for df in d_bufs] if want_host else None
     else:
-        d_frames = torch.from_numpy(frames).to(dev)      # inputs resident in HBM before the timed region
+        d_bufs = [torch.from_numpy(f).to(dev) for f in frames_h]      # inputs resident in HBM before the timed region
     torch.cuda.synchronize()
-    n, h, w, c = d_frames.shape
-    first_frame = rank * args.frames
+    n, h, w, c = d_bufs[0].shape
     out_cap = n * 64
 
-    batch_args = (d_frames.data_ptr(), _lib.MEM_DEVICE, _lib.FMT_RGB8, w, h, w * c, h * w * c, n)
+    buf_args = [(df.data_ptr(), _lib.MEM_DEVICE, _lib.FMT_RGB8, w, h, w * c, h * w * c, n) for df in d_bufs]
+    ctx_index = {id(cx): k for k, cx in enumerate(ctxs)}
+    in_flight_buf = [0] * n_ctx         # the batch (index into d_bufs) context k has in flight / delivered last
+    gstep = [0]                         # steps submitted since the process started
 
-    def detect_sync(cx):
-        if pose_mm:
-            return cx.detect_batch_pose(*batch_args, pose_mm, None, out_cap)
-        return cx.detect_batch(*batch_args, out_cap=out_cap)
+    def buf_for(k, rotation):
+        # --verify-gathers: the batches change hands every rotation, so that the records of consecutive rotations differ and a record
+        # overwritten before its collective has sent it shows (bench default: context k keeps batch k)
+        return (k + rotation) % n_bufs if args.verify_gathers else k % n_bufs
 
-    def submit_raw(cx):
+    def detect_sync(cx, j=None):
+        a = buf_args[ctx_index[id(cx)] % n_bufs if j is None else j]
         if pose_mm:
-            cx.submit_pose(*batch_args, pose_mm, None, out_cap)
+            return cx.detect_batch_pose(*a, pose_mm, None, out_cap)
+        return cx.detect_batch(*a, out_cap=out_cap)
+
+    def submit_raw(cx, j):
+        if pose_mm:
+            cx.submit_pose(*buf_args[j], pose_mm, None, out_cap)
         else:
-            cx.submit(*batch_args, out_cap=out_cap)
+            cx.submit(*buf_args[j], out_cap=out_cap)
 
     def collect_raw(cx):
         return cx.collect_pose() if pose_mm else cx.collect()
@@ -253,11 +284,16 @@ def main():
     pinned_rec = {}
     # Records of one ROTATION (n_ctx batches) are packed into one buffer and gathered by ONE collective: a collective per batch costs
     # the stepping loop ~0.1 ms of host time and a kernel's company per step; per rotation it is a quarter of that.  Two buffers in
-    # turn: the collective of one rotation may still be reading while the next rotation's packs write.
+    # turn: the collective of one rotation may still be reading while the next rotation's packs write -- and before a pack writes
+    # into a buffer, its stream waits for the collective that last READ that buffer (two rotations earlier): `gather_done`.  A rank
+    # whose peers lag therefore stalls on the device, behind its own collective, instead of overwriting records not yet sent.
     rec_bytes = shard.record_bytes(maxm, bool(pose_mm)) if use_dist else 0
     rec_bufs = [torch.empty((n_ctx, n, rec_bytes), dtype=torch.uint8, device=dev) for _ in range(2)] if use_dist else None
     gather_out = [torch.empty((world * n_ctx * n, rec_bytes), dtype=torch.uint8, device=coll_dev) for _ in range(2)] if use_dist else None
+    gather_done = [None, None]            # per record buffer: event behind the last collective that read it (recorded on `side`)
     rot = [0]
+    gather_log = []                       # --verify-gathers: (clone of the collective's output, batches, [first global frame of every slot])
+    slot_first = [0] * n_ctx
 
     pack_events = []
 
@@ -266,17 +302,24 @@ def main():
         # copy in between.  The kernel (one wave per frame) goes onto the context's OWN stream, behind the batch just collected and
         # ahead of the context's next batch (which overwrites the marker list): no stream switching, no event to wait for before
         # the next submit.  An event behind it tells the side stream when the rotation's records are complete.
-        shard.pack_detections_device(cx, n, first_frame, dev, maxm=maxm, with_poses=bool(pose_mm), out=rec_bufs[rot[0] & 1][slot])
+        b = rot[0] & 1
+        if gather_done[b] is not None and not args.no_gather_backpressure:
+            ctx_stream[id(cx)].wait_event(gather_done[b])     # write-after-read: the collective of rotation rot-2 read this buffer
+        slot_first[slot] = first_of(in_flight_buf[ctx_index[id(cx)]])
+        shard.pack_detections_device(cx, n, slot_first[slot], dev, maxm=maxm, with_poses=bool(pose_mm), out=rec_bufs[b][slot])
         ev = torch.cuda.Event()
         ev.record(ctx_stream[id(cx)])
         pack_events.append(ev)
 
     def all_gather(n_batches):
-        rec = rec_bufs[rot[0] & 1][:n_batches].view(n_batches * n, rec_bytes)
+        b = rot[0] & 1
+        rec = rec_bufs[b][:n_batches].view(n_batches * n, rec_bytes)
         for ev in pack_events:
             side.wait_event(ev)
         pack_events.clear()
         with torch.cuda.stream(side):
+            if args.gather_delay_us > 0:   # test aid: a collective that waits (ranks out of step), stood in for by a sleep ahead of it
+                torch.cuda._sleep(int(args.gather_delay_us * 2100))
             if coll_dev.type == "cpu":     # gloo rehearsal: host tensors, through a pinned buffer (a pageable D2H copy from a side
                 key = tuple(rec.shape)     # stream stalls for tens of milliseconds under a busy detection stream on this runtime)
                 if key not in pinned_rec:
@@ -284,26 +327,37 @@ def main():
                 pinned_rec[key].copy_(rec, non_blocking=True)
                 side.synchronize()
                 rec = pinned_rec[key]
-            out = gather_out[rot[0] & 1][: world * n_batches * n]
-            last_gather[0] = (shard._all_gather(rec, n_batches * n, out=out), n_batches)
+            out = gather_out[b][: world * n_batches * n]     # (read only on `side` -- the clone below -- or after a device-wide sync)
+            last_gather[0] = (shard._all_gather(rec, n_batches * n, out=out), n_batches, list(slot_first[:n_batches]))
+            if args.verify_gathers:
+                gather_log.append((last_gather[0][0].clone(), n_batches, list(slot_first[:n_batches])))
+            done = torch.cuda.Event()
+            done.record(side)
+            gather_done[b] = done
         rot[0] += 1
 
     gated = own_streams and args.gates == "burst" and n_ctx > 1
-    ctx_index = {id(cx): k for k, cx in enumerate(ctxs)}
 
     def submit(cx):
+        k = ctx_index[id(cx)]
         if gated:   # bursts: this batch's threshold kernel starts once the previous rotation's chains (contexts k+1 ..) have drained
-            for other in ctxs[ctx_index[id(cx)] + 1:]:
+            for other in ctxs[k + 1:]:
                 cx.order_after(other)
-        submit_raw(cx)
+        j = buf_for(k, gstep[0] // n_ctx)
+        in_flight_buf[k] = j
+        gstep[0] += 1
+        submit_raw(cx, j)
+
+    last_res = {}     # context index -> (result, batch index) of its last collected batch
 
     def run_steps(k):
-        """k steps; a step = one pass of Detector::detect over the rank's batch, results on the host (and, N > 1, packed on the device
-        and all-gathered -- one collective per rotation of n_ctx batches)."""
+        """k steps; a step = one pass of Detector::detect over one batch of the rank's, results on the host (and, N > 1, packed on the
+        device and all-gathered -- one collective per rotation of n_ctx batches)."""
         res = None
         if args.no_pipeline:
             for _ in range(k):
                 res = detect_sync(ctx)
+                last_res[0] = (res, 0)
                 if use_dist:
                     pack(ctx, 0)
                     all_gather(1)
@@ -311,11 +365,14 @@ def main():
         # n_ctx batches ahead of the host: batch i + n_ctx goes out (on the context batch i has just been collected from) before
         # anything else happens, so the GPU always finds work queued however long the host takes over the results, the pack and
         # the collective.
+        if gstep[0] % n_ctx:          # (a region always starts a rotation: the burst's last member is then the last context)
+            gstep[0] += n_ctx - gstep[0] % n_ctx
         for i in range(min(n_ctx, k)):
             submit(ctxs[i % n_ctx])
         for i in range(k):
             cx = ctxs[i % n_ctx]
             res = collect_raw(cx)
+            last_res[i % n_ctx] = (res, in_flight_buf[i % n_ctx])
             if use_dist:
                 pack(cx, i % n_ctx)
             if i + n_ctx < k:
@@ -331,8 +388,8 @@ def main():
     for st_id in (_lib.STAGE_THRESHOLD, _lib.STAGE_CONTOUR, _lib.STAGE_DECODE):
         ctx.profile(st_id, reset=True)
     torch.cuda.synchronize()
-    for _ in range(max(1, args.isolated_launches)):
-        detect_sync(ctx)
+    for it in range(max(1, args.isolated_launches)):
+        detect_sync(ctx, it % n_bufs)
     for name, st_id in (("threshold", _lib.STAGE_THRESHOLD), ("contour", _lib.STAGE_CONTOUR), ("decode", _lib.STAGE_DECODE)):
         a, b = ctx.profile(st_id, reset=True)
         stage_ms[name] = round(a / b, 4) if b else None
@@ -340,31 +397,42 @@ def main():
             k1_ms, k1_n = a, b
     ctx.set_profiling(0)
 
-    # The threshold kernel as the stepping runs it: the n_ctx launches of a burst, back to back on the contexts' own streams, nothing
-    # else on the GPU (a3_debug_launch_threshold: the kernel alone).  Launches in flight together refill each other's retiring wave
-    # slots, which a lone launch -- sized to fill the chip in exactly one round -- cannot: the per-launch time here is what the
-    # kernel costs inside a step, the isolated one above what it costs alone.
+    res = run_steps(args.warmup)
+    stepping_seen = [cx.stats()["stepping"] for cx in ctxs] if not args.no_pipeline and args.warmup >= n_ctx else None
+
+    # The threshold kernel as the stepping runs it: ONE REAL ROTATION of the burst stepping (public calls only: the gates, the
+    # submits, A3_PROFILE_THRESHOLD_ONLY = the library's own events around each threshold kernel on its context's stream), started
+    # from an idle GPU behind a common start event so that the host's enqueue time stays outside.  The four threshold kernels --
+    # each reading its OWN batch -- run back to back, the held chains behind the last of them: the longest of the four event
+    # intervals is the span from the start of the first to the end of the last.  Launches in flight together refill each other's
+    # retiring wave slots, which a lone launch -- sized to fill the chip in exactly one round -- cannot: the per-launch time here
+    # is what the kernel costs inside a step, the isolated one above what it costs alone.
     k1_burst_ms = None
-    if own_streams and n_ctx > 1 and args.workload in WORKLOADS:
-        import ctypes as C
+    if gated and args.workload in WORKLOADS:
         spans = []
+        for cx in ctxs:
+            cx.set_profiling(_lib.PROFILE_THRESHOLD_ONLY)
         for rep in range(12):
             torch.cuda.synchronize()
-            s0 = torch.cuda.Event(enable_timing=True)
-            ends = [torch.cuda.Event(enable_timing=True) for _ in ctxs]
+            for cx in ctxs:
+                cx.profile(_lib.STAGE_THRESHOLD, reset=True)
+            s0 = torch.cuda.Event()
+            with torch.cuda.stream(ctx_stream[id(ctxs[0])]):
+                torch.cuda._sleep(4_000_000)        # ~2 ms: the rotation's submits are enqueued while it runs
             s0.record(ctx_stream[id(ctxs[0])])
             for cx in ctxs[1:]:
                 ctx_stream[id(cx)].wait_event(s0)
             for cx in ctxs:
-                assert L.a3_debug_launch_threshold(cx.handle, C.c_void_p(d_frames.data_ptr()), _lib.FMT_RGB8, w, h, n) == 0
-            for cx, e in zip(ctxs, ends):
-                e.record(ctx_stream[id(cx)])
-            torch.cuda.synchronize()
-            spans.append(max(s0.elapsed_time(e) for e in ends) / n_ctx)
+                submit(cx)
+            for cx in ctxs:
+                collect_raw(cx)
+            per_ctx = [cx.profile(_lib.STAGE_THRESHOLD, reset=True) for cx in ctxs]
+            if all(b == 1 for _, b in per_ctx):
+                spans.append(max(a for a, _ in per_ctx) / n_ctx)
+        for cx in ctxs:
+            cx.set_profiling(0)
         spans = sorted(spans[2:])
-        k1_burst_ms = spans[len(spans) // 2]
-
-    res = run_steps(args.warmup)
+        k1_burst_ms = spans[len(spans) // 2] if spans else None
 
     # The timed region: EXACTLY --steps steps between barrier + synchronize on both sides, max over ranks.  It is run
     # --repeats times back to back and the median region is the one reported (all are listed in ms_per_step_all).  No event is
@@ -408,12 +476,17 @@ def main():
     gc.enable()
     elapsed = sorted(regions)[len(regions) // 2]
     outliers = [{"region": i, "ms_per_step": round(r / args.steps * 1e3, 4)} for i, r in enumerate(regions) if r > 1.5 * elapsed]
-    markers, per = res[0], res[1]
-    poses = res[2] if pose_mm else None
 
-    # sanity: what was rendered is what was read (ids per frame), on this rank's last step
-    by_frame = split_by_frame(markers, per)
-    id_ok = sum(sorted(int(m["id"]) for m in by_frame[f]) == sorted(truth_ids[f]) for f in range(n))
+    # sanity: what was rendered is what was read (ids per frame), on the last batch every context delivered
+    id_ok, id_total = 0, 0
+    by_frame_of, per_of, poses_of = {}, {}, {}
+    for k, (r_k, j) in sorted(last_res.items()):
+        bf = split_by_frame(r_k[0], r_k[1])
+        by_frame_of[j], per_of[j] = bf, r_k[1]
+        poses_of[j] = r_k[2] if pose_mm else None
+        id_ok += sum(sorted(int(m["id"]) for m in bf[f]) == sorted(truth_ids[j][f]) for f in range(n))
+        id_total += n
+    markers, per = res[0], res[1]
 
     # the threshold kernel's launch duration IN COMPANY (a few more steps with its launches between events, outside the timed
     # regions): what the kernel trace of this run shows for it -- it waits for and shares the chip with the other batches
@@ -427,69 +500,124 @@ def main():
         for cx in ctxs:
             cx.set_profiling(0)
 
-    # A/B in this process: the other way to step (all contexts on ONE stream, two of them, the decode stage of a submitted batch
-    # deferred behind the next batch's k_local_contract -- round 3's headline), same frames, same box, same minute
-    ab_shared = None
+    # ==== A/B block: other ways to step, same frames, same box, same minute.  Internal switches (a3_internal.h) may appear from here on;
+    # ==== everything above this line calls the public header only (tests/test_bench_public_abi.py greps for it).
+    ab_shared, ab_r04_default = None, None
+    internal_probes = []
     if not use_dist and own_streams and not args.no_other_workloads:
+        def timed(fn, k=20):
+            fn(args.steps)
+            sr = []
+            for _ in range(k):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                r2 = fn(args.steps)
+                torch.cuda.synchronize(); sr.append(time.perf_counter() - t0)
+            return sorted(sr)[len(sr) // 2], len(sr), r2
+
         try:
-            assert L.a3_debug_set_overlap(2) == 0
+            # (1) all contexts on ONE stream, two of them: the library defers the decode stage of a submitted batch behind the next
+            # batch's k_local_contract by itself (contexts that share a stream) -- round 3's headline; public calls only
             sctx = [Detector(DetectorConfig.default(), d, device=local_rank)._context() for _ in range(2)]
-            for cx in sctx:
+            for q, cx in enumerate(sctx):
                 cx.set_stream(stream.cuda_stream)
                 for _ in range(2):
-                    detect_sync(cx)
+                    detect_sync(cx, q % n_bufs)
 
             def shared_steps(k):
                 for i in range(min(2, k)):
-                    submit_raw(sctx[i % 2])
+                    submit_raw(sctx[i % 2], i % n_bufs)
                 r = None
                 for i in range(k):
                     r = collect_raw(sctx[i % 2])
                     if i + 2 < k:
-                        submit_raw(sctx[i % 2])
+                        submit_raw(sctx[i % 2], (i + 2) % n_bufs)
                 return r
 
-            shared_steps(args.steps)
-            sr = []
-            for _ in range(20):
-                torch.cuda.synchronize(); t0 = time.perf_counter()
-                r2 = shared_steps(args.steps)
-                torch.cuda.synchronize(); sr.append(time.perf_counter() - t0)
-            med = sorted(sr)[len(sr) // 2]
+            med, nr, r2 = timed(shared_steps)
+            jlast = (args.steps - 1) % n_bufs
             ab_shared = {"value": round(args.frames * args.steps / med, 2), "unit": "frames/s", "ms_per_step": round(med / args.steps * 1e3, 4),
-                         "regions": len(sr), "same_markers": bool(len(r2[0]) == len(markers) and np.array_equal(r2[1], per)),
+                         "regions": nr, "same_markers": bool(jlast in per_of and len(r2[0]) == int(per_of[jlast].sum()) and np.array_equal(r2[1], per_of[jlast])),
+                         "library_stepping_seen": sctx[0].stats()["stepping"],
                          "stepping": "--streams shared: two contexts on ONE stream, two batches ahead, decode stage of a submitted batch deferred "
-                                     "behind the next batch's k_local_contract (round 3's headline stepping)"}
+                                     "behind the next batch's k_local_contract (round 3's headline stepping; the library does this by itself for "
+                                     "contexts that share a stream)"}
             for cx in sctx:
                 cx.close()
         except Exception as e:   # a side measurement must not take the line down
             ab_shared = {"error": repr(e)}
+        try:
+            # (2) what a caller of the public header got until round 4: own streams + gates, but the library's process-wide default was
+            # "decode deferred behind the next k_local_contract" and chains were never held (needs the internal switch now)
+            assert L.a3_debug_set_overlap(2) == 0
+            internal_probes.append("a3_debug_set_overlap(2) for ab_r04_library_default, reset to -1 afterwards")
+            med, nr, r2 = timed(run_steps)
+            ab_r04_default = {"value": round(args.frames * args.steps / med, 2), "unit": "frames/s", "ms_per_step": round(med / args.steps * 1e3, 4),
+                              "regions": nr, "library_stepping_seen": [cx.stats()["stepping"] for cx in ctxs],
+                              "stepping": "the headline's calls (four contexts, own streams, a3_order_after gates) on round 4's library default: decode "
+                                          "stage deferred onto the device-wide decode stream, no chain held"}
+        except Exception as e:
+            ab_r04_default = {"error": repr(e)}
         finally:
-            L.a3_debug_set_overlap(overlap_mode)
+            L.a3_debug_set_overlap(args.overlap if args.overlap >= 0 else -1)
     stats = ctx.stats()
 
     gathered = None
     if use_dist:
-        # what the last all-gather delivered, checked on rank 0: every rank's frames, global indices in order, ids as rendered
+        # what the collectives delivered, checked on rank 0: every rank's frames of the rotation, global indices as packed, ids as
+        # rendered.  Default: the last collective; --verify-gathers: every collective of the run (cloned on the side stream).
         torch.cuda.synchronize()
-        g_all, g_batches = last_gather[0]
-        g_all = g_all.cpu().numpy()      # [world, batches of the last rotation * n, record]: the last batch of every rank is checked
-        g = g_all[:, (g_batches - 1) * n: g_batches * n, :]
+        with_p = bool(pose_mm)
+        truth_cache = {}
+
+        def truth_of(gf):   # ids rendered into global frame gf (layout only: no pixels are painted for this)
+            if gf not in truth_cache:
+                truth_cache[gf] = sorted(t.id for t in synth.device_layout(spec, d.code_list, d.num_bits, [synth.frame_seed(wl["config"], gf)])[2][0])
+            return truth_cache[gf]
+
+        def check_gather(g_all, g_batches, firsts):
+            """-> (records, indices as expected, records whose ids are the rendered ones, rank 0's records)"""
+            g_np = g_all.cpu().numpy()      # [world, batches of the rotation * n, record]
+            n_rec = idx_ok = ids_ok = 0
+            mine = []
+            for r in range(world):
+                recs = shard.unpack_detections(np.ascontiguousarray(g_np[r]).reshape(-1, g_np.shape[-1]), with_poses=with_p)
+                # rank r packed slot s with the batch whose first global frame is firsts[s] shifted by the rank's offset
+                want = [f0 - first_of(0) + (r * n_bufs) * args.frames + f for f0 in firsts for f in range(n)]
+                n_rec += len(recs)
+                idx_ok += int([x[0] for x in recs] == want)
+                ids_ok += sum(sorted(int(v) for v in x[1]["id"]) == truth_of(x[0]) for x in recs)
+                if r == rank:
+                    mine = recs
+            return n_rec, idx_ok, ids_ok, mine
+
         if rank == 0:
-            recs = shard.unpack_detections(np.ascontiguousarray(g).reshape(-1, g.shape[-1]), with_poses=bool(pose_mm))
-            seeds_all = [synth.frame_seed(wl["config"], i) for i in range(world * args.frames)]
-            truth_all = [sorted(t.id for t in tr) for tr in synth.device_layout(spec, d.code_list, d.num_bits, seeds_all)[2]]
-            gathered = {"frames": len(recs), "global_frame_indices_in_order": [r[0] for r in recs] == list(range(world * args.frames)),
-                        "all_ranks_ids_correct": int(sum(sorted(int(x) for x in r[1]["id"]) == truth_all[r[0]] for r in recs)),
-                        "record_bytes": int(g.shape[-1]), "max_markers_per_record": int(maxm),
+            g_all, g_batches, g_firsts = last_gather[0]
+            n_rec, idx_ok, ids_ok, mine = check_gather(g_all, g_batches, g_firsts)
+            gathered = {"frames": n_rec, "global_frame_indices_in_order": idx_ok == world, "all_ranks_ids_correct": int(ids_ok),
+                        "record_bytes": int(g_all.shape[-1]), "max_markers_per_record": int(maxm),
                         "max_markers_from": "--max-markers" if args.max_markers > 0 else "calibrated on the first batch (2 x the largest count on any rank, >= 8)",
                         "packed_on": "device (a3_pack_detections)", "collective": f"all_gather_into_tensor over {args.backend}, one per rotation of {n_ctx} batches",
-                        "batches_in_last_collective": int(g_batches)}
-            if pose_mm:   # rank 0's own frames came back as it produced them, poses included
-                mine = [r for r in recs if first_frame <= r[0] < first_frame + n]
-                gp = np.concatenate([r[2] for r in mine]) if mine else np.zeros((0, 2, 13), np.float32)
-                gathered["pose_pairs_gathered"] = int(sum(len(r[2]) for r in recs))
-                gathered["rank0_poses_bit_equal_after_gather"] = bool(gp.shape == poses.shape and np.array_equal(gp.view(np.uint32), poses.view(np.uint32)))
+                        "batches_in_last_collective": int(g_batches), "collectives": int(rot[0]),
+                        "write_after_read_guard": "off (--no-gather-backpressure)" if args.no_gather_backpressure else
+                                                  "a pack waits, on its context's stream, for the collective that last read its record buffer"}
+            if args.verify_gathers:
+                bad = []
+                for gi, (g_c, g_b, g_f) in enumerate(gather_log):
+                    nr, io, ido, _ = check_gather(g_c, g_b, g_f)
+                    if io != world or ido != nr:
+                        bad.append({"collective": gi, "indices_ok_ranks": io, "ids_ok": ido, "records": nr})
+                gathered["verified_collectives"] = len(gather_log)
+                gathered["collectives_with_wrong_records"] = len(bad)
+                gathered["first_wrong"] = bad[:3]
+                gathered["gather_delay_us"] = args.gather_delay_us
+            if pose_mm:   # rank 0's own frames of the last batch came back as it produced them, poses included
+                j_last = in_flight_buf[(g_batches - 1) % n_ctx]
+                lo = first_of(j_last)
+                sel = [x for x in mine if lo <= x[0] < lo + n]
+                gp = np.concatenate([x[2] for x in sel]) if sel else np.zeros((0, 2, 13), np.float32)
+                pz = poses_of.get(j_last)
+                gathered["pose_pairs_gathered"] = int(sum(len(x[2]) for x in mine))
+                gathered["rank0_poses_bit_equal_after_gather"] = bool(pz is not None and gp.shape == pz.shape and np.array_equal(gp.view(np.uint32), pz.view(np.uint32)))
 
     if rank == 0:
         total_frames = args.frames * world * args.steps
@@ -510,7 +638,9 @@ def main():
                            f"{n_ctx} threshold kernels of a rotation run back to back once the previous rotation's chains have drained, then the {n_ctx} chains "
                            "(latency-, LDS- and issue-bound, almost no HBM traffic) run together and overlap one another"
                            if gated else "Free-running rotation: no gates, the hardware interleaves threshold kernels and chains as they come")
-                        + "; nothing is deferred inside the library (DESIGN.md section 4, Stepping)")
+                        + ".  The library holds the chain of every burst member but the last behind its threshold kernel and the last member's "
+                          "submit enqueues them all (a3_order_after in include/aruco3_hip.h: the library's behaviour, no switch; "
+                          "`library_stepping_seen` is a3_stats.stepping of the warm-up's last rotation)")
         else:
             stepping = (f"{n_ctx} contexts on ONE stream, {n_ctx} batches ahead: steps run in order; the decode stage of a submitted batch runs on the "
                         "device's decode stream, released behind the next batch's k_local_contract")
@@ -535,6 +665,7 @@ def main():
             "config": {
                 "workload": wl["label"].format(n=args.frames),
                 "frames_per_gpu": args.frames,
+                "distinct_batches_in_flight": n_bufs if not args.no_pipeline else 1,
                 "resolution": [int(w), int(h)],
                 "dictionary": dict_name,
                 "sharding": "frames by rank, no data-path collective; dictionary broadcast once, detections all-gathered per batch" if world > 1 else "single GPU",
@@ -561,8 +692,10 @@ def main():
                 "in_burst": None if not k1_burst_ms else {
                     "launches_in_flight": n_ctx, "ms_per_launch": round(k1_burst_ms, 4),
                     "achieved": round(k1_bytes / (k1_burst_ms * 1e-3) / 1e9, 1), "frac": round(k1_bytes / (k1_burst_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    "timed_how": "HIP events: from the start of the first launch to the end of the last of the burst's launches (one per context, each "
-                                 "on its context's stream, threshold kernel only), divided by their number; median of 10 bursts"},
+                    "distinct_batches_read": n_bufs,
+                    "timed_how": "one real rotation of the burst stepping from an idle GPU (public calls only: a3_order_after gates, submits, "
+                                 "A3_PROFILE_THRESHOLD_ONLY), all streams released by one start event; the longest of the library's event intervals "
+                                 "around the rotation's threshold kernels = start of the first to end of the last, divided by their number; median of 10 rotations"},
                 "survey_5Bpp_gbs": round(survey_gbs, 1),
                 "survey_5Bpp_frac": round(survey_gbs / HBM_PEAK_GBS, 4),
             },
@@ -576,13 +709,17 @@ def main():
             "contexts": n_ctx,
             "streams": "one per context" if own_streams else "shared",
             "gates": "burst (a3_order_after)" if gated else "none",
-            "library": _lib.library_info(),
+            "library": dict(_lib.library_info(), internal_switches_used=internal_switches_used,
+                            internal_probes_after_the_headline=internal_probes),
             "stats": stats,
-            "frames_with_all_ids_correct": f"{id_ok}/{n}",
+            "frames_with_all_ids_correct": f"{id_ok}/{id_total}",
+            "library_stepping_seen": stepping_seen,
             "frame_synthesis_s": round(t_gen, 1),
         }
         if ab_shared is not None:
             out["ab_shared_stream"] = ab_shared
+        if ab_r04_default is not None:
+            out["ab_r04_library_default"] = ab_r04_default
         if gathered is not None:
             out["gathered"] = gathered
         if use_dist:   # what the ranks themselves saw
@@ -591,7 +728,7 @@ def main():
                            "pack_and_collective": "records packed by a kernel on the context's own stream right after collect(); one all-gather per rotation on a side stream, behind the packs' events",
                            "note": "an N > 1 RCCL number exists only where the driver's multi-GPU node produced one; a 1-GPU box can run world_size 1 (nccl) or rehearse ranks over gloo"}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"], out["parity_in_run"] = cpu_baseline(frames, d, by_frame, poses, per, pose_mm, (w, h))
+            out["cpu_baseline"], out["parity_in_run"] = cpu_baseline(frames_h, d, by_frame_of, poses_of, per_of, pose_mm, (w, h))
         if not args.no_other_workloads and world == 1 and args.workload == "c2":
             try:
                 out["other_workloads"] = other_workloads(local_rank, with_cpu=not args.no_cpu_baseline)
@@ -682,47 +819,53 @@ def parity_row(agree, total, what="markers (id, code, corners, rotation, hamming
             "against": "oracle/a3_oracle.c (CPU restatement of the reference; the reference itself cannot be built here)"}
 
 
-def cpu_baseline(frames, d, gpu_by_frame=None, gpu_poses=None, gpu_per=None, pose_mm=None, image_size=None):
+def cpu_baseline(frames_by_batch, d, gpu_by_frame=None, gpu_poses=None, gpu_per=None, pose_mm=None, image_size=None):
     """The CPU oracle (a restatement of the reference algorithm, NOT the Rust crate, which cannot be built here) on the
     same frames, one thread -- the reference's own execution model -- for about 10 s of CPU work.  Its output is not thrown
-    away: the markers of every distinct frame it processed are compared with the GPU's for the same frame -> parity_in_run."""
+    away: the markers of every distinct frame it processed are compared with the GPU's for the same frame -> parity_in_run.
+    `frames_by_batch`: the host copies of the batches the contexts step (one per context); gpu_by_frame / gpu_poses / gpu_per:
+    dicts batch index -> the GPU's last result for that batch."""
     from oracle import a3oracle
 
     a3oracle.build()
     codes = np.ascontiguousarray(d.code_list)
+    order = [(j, f) for f in range(len(frames_by_batch[0])) for j in range(len(frames_by_batch))     # (batches interleaved: a short budget samples them all)
+             if gpu_by_frame is None or j in gpu_by_frame]
     done, t0 = 0, time.perf_counter()
-    budget_s, max_frames = 10.0, 4 * len(frames)
+    budget_s, max_calls = 10.0, 2 * len(order)
     oracle_markers = {}
-    while done < max_frames:
-        f = done % len(frames)
-        r = a3oracle.detect(frames[f], codes, d.num_bits, d._tau, keep_debug=False)
-        if f not in oracle_markers:
-            oracle_markers[f] = r
+    while done < max_calls:
+        j, f = order[done % len(order)]
+        r = a3oracle.detect(frames_by_batch[j][f], codes, d.num_bits, d._tau, keep_debug=False)
+        oracle_markers.setdefault((j, f), r)
         done += 1
-        if done >= min(32, len(frames)) and time.perf_counter() - t0 > budget_s:
+        if done >= min(32, len(order)) and time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    h, w = frames.shape[1:3]
+    h, w = frames_by_batch[0].shape[1:3]
     out = {"value": round(done / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-           "sample": f"{done} detect() calls over {len(oracle_markers)} of the same {w}x{h} frames, single thread, oracle/a3_oracle.c (gcc -O2)",
+           "sample": f"{done} detect() calls over {len(oracle_markers)} distinct {w}x{h} frames of the {len(frames_by_batch)} batches in flight, single thread, "
+                     "oracle/a3_oracle.c (gcc -O2)",
            "host_cores_available": os.cpu_count()}
     parity = None
     if gpu_by_frame is not None:
-        agree, pose_dev, pos = 0, 0.0, np.concatenate([[0], np.cumsum(gpu_per)]).astype(np.int64)
-        for f, r in oracle_markers.items():
-            same = oracle_marker_tuples(r) == hip_marker_tuples(gpu_by_frame[f])
+        agree, pose_dev = 0, 0.0
+        pos = {j: np.concatenate([[0], np.cumsum(gpu_per[j])]).astype(np.int64) for j in gpu_per}
+        for (j, f), r in oracle_markers.items():
+            same = oracle_marker_tuples(r) == hip_marker_tuples(gpu_by_frame[j][f])
             if same and pose_mm:   # both IPPE solutions of every marker, against the oracle's solve_with_undistorted_points
                 for k, m in enumerate(r["markers"]):
                     sols = a3oracle.solve_with_undistorted_points(m["corners"], pose_mm, image_size)
-                    for j in range(2):
-                        err, rot, tr = sols[j].as_tuple() if hasattr(sols[j], "as_tuple") else sols[j]
+                    for q in range(2):
+                        err, rot, tr = sols[q].as_tuple() if hasattr(sols[q], "as_tuple") else sols[q]
                         want = np.concatenate([[err], np.asarray(rot, np.float32).reshape(-1), np.asarray(tr, np.float32).reshape(-1)])
-                        got = gpu_poses[pos[f] + k, j]
+                        got = gpu_poses[j][pos[j][f] + k, q]
                         dev = float(np.nanmax(np.abs(want - got))) if not np.isnan(want).all() else 0.0
                         pose_dev = max(pose_dev, dev)
                 same = pose_dev <= 1e-4
             agree += same
         parity = parity_row(agree, len(oracle_markers))
+        parity["batches_covered"] = len({j for j, _ in oracle_markers})
         if pose_mm:
             parity["pose_max_abs_diff"] = pose_dev
             parity["compared"] += " + both IPPE poses of every marker within 1e-4"
@@ -730,7 +873,8 @@ def cpu_baseline(frames, d, gpu_by_frame=None, gpu_poses=None, gpu_per=None, pos
     # GIL).  Informational: the reference itself is single-threaded.
     from concurrent.futures import ThreadPoolExecutor
     workers = max(1, min(os.cpu_count() or 1, 64))
-    one = lambda f: a3oracle.detect_markers_only(frames[f % len(frames)], codes, d.num_bits, d._tau)
+    flat = frames_by_batch[0]
+    one = lambda f: a3oracle.detect_markers_only(flat[f % len(flat)], codes, d.num_bits, d._tau)
     done_mt, t0 = 0, time.perf_counter()
     with ThreadPoolExecutor(max_workers=workers) as pool:
         while time.perf_counter() - t0 < 6.0:

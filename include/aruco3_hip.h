@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define A3_ABI_VERSION 4
+#define A3_ABI_VERSION 5
 
 enum {
     A3_OK = 0,
@@ -91,8 +91,18 @@ typedef struct a3_stats {
     uint32_t resolve_iterations;    /* start-resolution passes over all darts (0 = none needed) */
     uint32_t jump_rounds;           /* pointer-doubling rounds that did work */
     uint32_t chunks;                /* sub-batches the frames were split into */
-    uint32_t reserved;
+    uint32_t stepping;              /* bits 0-7: A3_STEP_* -- how the library scheduled the batch (see a3_order_after);
+                                     * bits 8-31: chains of OTHER contexts this batch's submit released (A3_STEP_BURST_LAST) */
 } a3_stats;
+/* a3_stats.stepping & 0xFF */
+enum {
+    A3_STEP_WHOLE = 0,                  /* the whole batch was enqueued by its own call (a3_detect_batch always; a submit outside a burst) */
+    A3_STEP_DECODE_DEFERRED = 1,        /* contexts sharing one stream: decode stage released from inside the next batch's launch sequence */
+    A3_STEP_HELD_RELEASED_BY_LAST = 2,  /* burst member: chain held at submit, enqueued by the submit of the burst's last member */
+    A3_STEP_HELD_RELEASED_EARLY = 3,    /* burst member whose chain went out before a last member came: at collect, at a gate on it,
+                                         * at a3_set_stream */
+    A3_STEP_BURST_LAST = 4              /* the burst's last member: released the others' chains behind its threshold kernel */
+};
 
 typedef struct a3_ctx a3_ctx;
 
@@ -137,9 +147,9 @@ int  a3_detect_batch_pose(a3_ctx *ctx, const void *pixels, int memory, int fmt, 
  * a3_order_after).  out_cap of submit bounds the marker list; collect's must not be smaller than what was found.
  *
  * Frames: device-resident frames and pinned host frames must stay valid AND UNMODIFIED from submit until collect returns --
- * also by work the caller queues on its own stream behind the submit.  Part of a submitted batch runs on streams the library
- * owns (the device-wide decode and copy streams; a chain held back for a burst is enqueued later), ordered against the caller's
- * stream only through events recorded at submit; and the decode stage samples the FRAMES themselves (no grey plane is kept), so
+ * also by work the caller queues on its own stream behind the submit.  Part of a submitted batch may run on streams the library
+ * owns (the device-wide decode and copy streams) and a chain held back for a burst is enqueued later (a3_order_after), ordered
+ * against the caller's stream only through events recorded at submit; and the decode stage samples the FRAMES themselves (no grey plane is kept), so
  * a frame overwritten before collect changes what is read.  Pageable host frames have been read when submit returns.
  *
  * Hardware queues: the HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and two
@@ -163,9 +173,31 @@ int  a3_detect_batch_pose_collect(a3_ctx *ctx, a3_marker *out, a3_pose *poses, s
  * arrangement measured (Stepping) therefore runs BURSTS: with N contexts used in rotation (batch j on context
  * j % N, batch j + N submitted as soon as batch j is collected), context k calls
  *     a3_order_after(ctx[k], ctx[m])   for every m in k+1 .. N-1
- * before each submit: the batches of one rotation then start their threshold kernels back to back, after the previous
- * rotation's chains have drained, and their own chains run together.  N = 4 for 256 x 1920x1080 frames per batch.  A scheduling
- * hint only: results are identical with and without it.  Contexts that share one caller stream are in order already (no-op). */
+ * before each submit.  What the library does with that, always (there is no mode to select; since ABI 5):
+ *   - the call itself: the next batch submitted on `ctx` starts on the device only after everything enqueued so far on `other`
+ *     (its batch in flight included) has finished -- the batches of one rotation start once the previous rotation has drained;
+ *   - a submit on a context that declared such gates since its previous submit enqueues the batch's THRESHOLD KERNEL ONLY and
+ *     holds the rest of the batch (contour stage ... read-back: its "chain") back;
+ *   - the first submit on the device WITHOUT gates is the burst's last member (context N-1 above): it enqueues its threshold
+ *     kernel, then the held chains of the other members behind that kernel, then its own chain.  On the GPU a rotation is then N
+ *     threshold kernels back to back followed by N chains side by side, with no host in between;
+ *   - a held chain nobody released goes out when its batch is collected, when another context declares a gate on it, or when
+ *     a3_set_stream moves its context.  a3_stats.stepping of the collected batch says which of these happened.
+ * The hold does not apply -- the whole batch is enqueued at submit, gates still ordering it -- to the first batch of a shape
+ * (frame count / size) on a context and to batches whose contour graph must be planned on the host (graphs that outgrow the
+ * pools: uniform-noise frames), while a3_set_profiling(A3_PROFILE_STAGES) is on, and to contexts that share one stream: those
+ * are in order already, a3_order_after between them is a no-op, and their decode stage is deferred behind the next batch's
+ * contour stage instead (A3_STEP_DECODE_DEFERRED).  N = 4 for 256 x 1920x1080 frames per batch.  Scheduling only: results are
+ * identical in every arrangement.
+ *
+ * Threading.  One context is never used from two threads at once.  DIFFERENT contexts may be driven from different threads, with
+ * one addition for bursts: the contexts of a device whose chains are held form one scheduling domain -- the submit of the last
+ * member (and a3_order_after / a3_detect_batch_collect / a3_set_stream / a3_destroy naming a holder) enqueues the held chains of
+ * sibling contexts, under a process-wide lock, from the calling thread.  That touches the siblings' internal state only between
+ * their submit and their collect, when the only calls a caller may make on them are collect, a3_set_stream and a3_destroy (all of
+ * which take the same lock); nothing is allocated and the device is never waited for under that lock (held batches are planned
+ * on the device and their buffers allocated by their own submit).  An error met while enqueueing a sibling's chain is reported
+ * by that sibling's collect, not by the call that met it. */
 int  a3_order_after(a3_ctx *ctx, a3_ctx *other);
 
 /* Host frames (A3_MEM_HOST) cross the link on the device's copy stream, beside the kernels of whatever batch another

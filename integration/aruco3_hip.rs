@@ -42,7 +42,7 @@ use crate::pose::MarkerPose;
 // 1. The C ABI, one declaration per entry point of include/aruco3_hip.h
 // =====================================================================================================
 
-pub const A3_ABI_VERSION: c_int = 4;
+pub const A3_ABI_VERSION: c_int = 5;
 
 pub const A3_OK: c_int = 0;
 pub const A3_ERR_INVALID: c_int = -1;
@@ -127,7 +127,9 @@ pub struct A3Stats {
     pub resolve_iterations: u32,
     pub jump_rounds: u32,
     pub chunks: u32,
-    pub reserved: u32,
+    /// bits 0-7: A3_STEP_* (how the library scheduled the batch: 0 whole, 1 decode deferred, 2 chain held and released by the burst's
+    /// last member, 3 chain held and released early, 4 the burst's last member); bits 8-31: other contexts' chains this submit released
+    pub stepping: u32,
 }
 
 /// a3_synth_marker / a3_synth_frame: layouts for the device-side synthetic frame generator
@@ -622,10 +624,15 @@ impl Detector {
 /// `a3_order_after` for the contexts k+1 .. depth-1, so the threshold kernels of one rotation run back to back after the previous
 /// rotation's chains have drained and the contour / decode chains of the rotation run together.  depth = 4 is the fastest
 /// arrangement measured for 256 x 1920x1080 frames per batch (Stepping); results never depend on it.
+/// The burst stepping is what the library does with these calls by itself (include/aruco3_hip.h, a3_order_after: a context that
+/// declared gates holds its chain back behind its threshold kernel, the rotation's last context releases them) -- this type calls
+/// nothing outside the public header, and `last_stepping()` reports what the library did with the batch just collected.
 /// Export GPU_MAX_HW_QUEUES=8 before the process touches HIP (header, "Hardware queues").
 pub struct BatchQueue {
     ctxs: Vec<HipCtx>,
     frames_in: Vec<usize>, // frames of the batch in flight on each context
+    shape_in: Vec<(c_int, u32, u32, usize)>, // (fmt, width, height, bytes per pixel) of that batch, for the re-run of a marker-dense one
+    last_stepping: u32,
     head: usize,           // context of the oldest batch in flight
     in_flight: usize,
     submitted: usize,
@@ -637,7 +644,7 @@ impl BatchQueue {
         let device = DEVICE.load(Ordering::Relaxed);
         let cfg = to_a3_config(&detector.config);
         let ctxs: Vec<HipCtx> = (0..depth).map(|_| HipCtx::create(device, &cfg, &detector.dictionary)).collect();
-        BatchQueue { frames_in: vec![0; depth], ctxs, head: 0, in_flight: 0, submitted: 0 }
+        BatchQueue { frames_in: vec![0; depth], shape_in: vec![(0, 0, 0, 0); depth], last_stepping: 0, ctxs, head: 0, in_flight: 0, submitted: 0 }
     }
 
     /// batches in flight
@@ -646,6 +653,10 @@ impl BatchQueue {
     }
     pub fn is_full(&self) -> bool {
         self.in_flight == self.ctxs.len()
+    }
+    /// a3_stats.stepping of the batch `collect` returned last (A3_STEP_* in bits 0-7)
+    pub fn last_stepping(&self) -> u32 {
+        self.last_stepping
     }
 
     /// Enqueue one batch (all frames of one size).  Panics if `depth` batches are already in flight: collect first.
@@ -670,6 +681,7 @@ impl BatchQueue {
         };
         ctx.check(rc, "a3_detect_batch_submit");
         self.frames_in[k] = n;
+        self.shape_in[k] = (p.fmt, p.width, p.height, p.bpp);
         self.submitted += 1;
         self.in_flight += 1;
     }
@@ -683,12 +695,26 @@ impl BatchQueue {
         let mut markers = vec![A3Marker::default(); 64 * n];
         let mut per = vec![0u32; n];
         let mut found = 0usize;
-        // (a list longer than 64 markers per frame: the library reports A3_ERR_CAPACITY and the batch has to be re-run through
-        // detect_batch, which grows its list; marker-dense workloads should size for it here)
-        let rc = unsafe { a3_detect_batch_collect(ctx.raw, markers.as_mut_ptr(), markers.len(), per.as_mut_ptr(), &mut found) };
-        ctx.check(rc, "a3_detect_batch_collect");
+        let mut rc = unsafe { a3_detect_batch_collect(ctx.raw, markers.as_mut_ptr(), markers.len(), per.as_mut_ptr(), &mut found) };
+        // the batch has left the queue whatever collect said (the library keeps no batch in flight after a failed collect)
         self.head = (self.head + 1) % self.ctxs.len();
         self.in_flight -= 1;
+        let mut stats = A3Stats::default();
+        if unsafe { a3_get_stats(ctx.raw, &mut stats) } == A3_OK {
+            self.last_stepping = stats.stepping;
+        }
+        // The reference's marker Vec is unbounded (src/aruco.rs:75-113).  A frame with more markers than the list submitted for is
+        // A3_ERR_CAPACITY: the frames are still in the context's pinned staging, so the batch is run again synchronously with a
+        // list that grows, exactly as Detector::detect_batch does.
+        while rc == A3_ERR_CAPACITY && markers.len() < MAX_MARKERS_PER_FRAME * n {
+            markers.resize(markers.len() * 4, A3Marker::default());
+            let (fmt, width, height, bpp) = self.shape_in[k];
+            rc = unsafe {
+                a3_detect_batch(ctx.raw, ctx.staging.as_ptr() as *const c_void, A3_MEM_HOST, fmt, width, height, width as usize * bpp,
+                                width as usize * height as usize * bpp, n as u32, markers.as_mut_ptr(), markers.len(), per.as_mut_ptr(), &mut found)
+            };
+        }
+        ctx.check(rc, "a3_detect_batch_collect");
         let mut out = Vec::with_capacity(n);
         let mut pos = 0usize;
         for f in 0..n {

@@ -363,7 +363,7 @@ def test_deferred_decode_in_every_order_of_calls(dicts):
         ctxs[0].submit(*aa)
         assert same(ctxs[0].collect(), want["a"])
     finally:
-        L.a3_debug_set_overlap(2)
+        L.a3_debug_set_overlap(-1)
 
 
 def test_sampled_threshold_profiling_counts_every_fourth_batch(dicts):

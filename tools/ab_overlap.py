@@ -68,7 +68,7 @@ def main():
     for mode in modes:
         v = sorted(res[mode])
         print(f"overlap mode {mode[0]}, {mode[1]}: median {v[len(v) // 2]:.4f} ms/step  ({n / v[len(v) // 2] * 1e3:.0f} frames/s)  all {[round(x, 4) for x in res[mode]]}")
-    L.a3_debug_set_overlap(2)
+    L.a3_debug_set_overlap(-1)
 
 
 if __name__ == "__main__":

@@ -140,7 +140,7 @@ def main():
         med = v[len(v) // 2]
         print(f"{s:16s} median {med:.4f} ms/step  ({n / med * 1e3:8.0f} frames/s)  K1 in company {k1c[s][0] / max(k1c[s][1], 1):.4f} ms, alone {k1a[s]:.4f} ms  "
               f"all {[round(x, 4) for x in res[s]]}  host us per submit by context {host.get(s)}", flush=True)
-    L.a3_debug_set_overlap(2)
+    L.a3_debug_set_overlap(-1)
     L.a3_debug_set_k1_waves(2)
     L.a3_debug_set_hold(1)
 
