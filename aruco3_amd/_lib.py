@@ -88,7 +88,8 @@ class Stats(C.Structure):
 
     def as_dict(self):
         d = {k: int(getattr(self, k)) for k, _ in self._fields_}
-        d["released_others"] = d["stepping"] >> 8     # (a3_stats.stepping: bits 8.. = chains of other contexts this batch's submit released)
+        d["released_others"] = (d["stepping"] >> 8) & 0xFF     # (a3_stats.stepping: bits 8-15 = chains of other contexts this batch's submit released)
+        d["reruns"] = (d["stepping"] >> 16) & 0xFF              # (bits 16-23: synchronous re-runs the device asked for)
         d["stepping"] = STEP_NAMES.get(d["stepping"] & 0xFF, d["stepping"] & 0xFF)
         return d
 

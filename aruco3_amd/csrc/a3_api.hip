@@ -164,6 +164,7 @@ struct a3_ctx {
     int batch_mode = 0;              // where the decode stage of the batch being submitted is released (batch_mode_of, fixed at submit)
     uint32_t stepping = 0;           // A3_STEP_* of the batch in flight / last finished (a3_stats.stepping)
     uint32_t released_others = 0;    // held chains of other contexts this batch's submit released (the burst's last member)
+    uint32_t reruns = 0;             // synchronous re-runs the device asked for while the last call's batch was produced (pool growth, more passes, host plan)
     BackArgs back;
     a3_config cfg{};
     uint8_t num_bits = 0, tau = 0;
@@ -1259,6 +1260,7 @@ static int run_batch_with_retries(a3_ctx* ctx, const uint8_t* d_pixels, int fmt,
     for (int attempt = 0; attempt < 8; attempt++) {
         const int rc = run_batch(ctx, d_pixels, fmt, width, height, row_stride, frame_stride, n_frames, out, out_cap, per_frame_count, out_n);
         if (rc != 1) return rc;
+        ctx->reruns++;
     }
     return fail(ctx, A3_ERR_CAPACITY, "contour pools kept overflowing");
 }
@@ -1277,6 +1279,7 @@ int a3_detect_batch(a3_ctx* ctx, const void* pixels, int memory, int fmt, uint32
     }
     if (rc != A3_OK) return rc;
     ctx->force_host_plan = false;
+    ctx->reruns = 0; ctx->released_others = 0;
     return run_batch_with_retries(ctx, d_pixels, fmt, width, height, row_stride, frame_stride, n_frames, out, out_cap, per_frame_count, out_n);
 }
 
@@ -1301,7 +1304,7 @@ static int submit_common(a3_ctx* ctx, const void* pixels, int memory, int fmt, u
     const bool gated = ctx->gates_declared;
     ctx->gates_declared = false;
     ctx->batch_mode = batch_mode_of(ctx);
-    ctx->released_others = 0;
+    ctx->released_others = 0; ctx->reruns = 0;
     const bool bursts = ctx->batch_mode == 0 && g_overlap_force.load(std::memory_order_relaxed) <= 0 && g_hold_rests && ctx->profiling < 2;
     if (bursts && gated && device_plan_capacity(ctx, n_frames, width, height) != 0) {
         pd.n = n_frames; pd.W = width; pd.H = height;
@@ -1356,7 +1359,7 @@ static int collect_common(a3_ctx* ctx, a3_marker* out, a3_pose* poses, size_t ou
     int rc = finish_batch(ctx, out, out_cap, per_frame_count, out_n);
     const uint32_t stepping = ctx->stepping;   // how the SUBMITTED batch was stepped (a re-run below is a synchronous call of its own)
     // the device asked for a re-run (pool growth, more passes, host-side plan): do it synchronously
-    if (rc == 1) rc = run_batch_with_retries(ctx, pd.pixels, pd.fmt, pd.W, pd.H, pd.row_stride, pd.frame_stride, pd.n, out, out_cap, per_frame_count, out_n);
+    if (rc == 1) { ctx->reruns++; rc = run_batch_with_retries(ctx, pd.pixels, pd.fmt, pd.W, pd.H, pd.row_stride, pd.frame_stride, pd.n, out, out_cap, per_frame_count, out_n); }
     ctx->stepping = stepping;
     ctx->want_pose = false;
     ctx->pose_out = nullptr;
@@ -1564,7 +1567,7 @@ int a3_synth_render(int device, void* hip_stream, const a3_synth_frame* frames, 
 int a3_get_stats(const a3_ctx* ctx, a3_stats* stats) {
     if (!ctx || !stats) return A3_ERR_INVALID;
     *stats = ctx->stats;
-    stats->stepping = ctx->stepping | (ctx->released_others << 8);
+    stats->stepping = ctx->stepping | (std::min(ctx->released_others, 255u) << 8) | (std::min(ctx->reruns, 255u) << 16);
     return A3_OK;
 }
 

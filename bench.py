@@ -21,11 +21,13 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
-# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default), and two streams that
-# share a queue run in order whatever their events say.  This process has the detection stream, the library's decode and copy
-# streams, a side stream for the collective and -- for the free-running side measurement -- two more: with 4 queues some of them
-# collide (measured: the two free-running contexts then run in lock-step).  Must be set before the runtime starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default), handed out in the order the
+# streams are first used, and two streams that share a queue run in order whatever their events say -- a stream that merely waits
+# holds up the others of its queue.  This process has four detection streams, the library's decode and copy streams, a side stream for
+# the collective, the backend's internal stream and torch's explicit one: with 8 queues the side stream landed on a context's queue
+# (tools/queue_probe.py, profiles/r05_queue_collisions.txt: every collective then stalled that context); with 16 none collide, and the
+# one-GPU headline is the same with 8 and 16.  Must be set before the runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 K1_BYTES_PER_PIXEL = 3.125         # what K1 has to move: 3 B RGB read + 1/8 B bit-packed binary written; NO grey plane is written
@@ -128,6 +130,8 @@ def main():
                                                                      "collective's output is kept and checked at the end (global frame indices, ids)")
     ap.add_argument("--gather-delay-us", type=float, default=0.0, help="test aid: a sleep of this many microseconds on the side stream ahead of every "
                                                                          "collective (a collective that waits for lagging ranks)")
+    ap.add_argument("--no-stream-probe", action="store_true", help="N > 1: skip the hardware-queue probe that keeps the contexts' streams off the "
+                                                                     "collective's queues (aruco3_amd/streams.py)")
     ap.add_argument("--no-gather-backpressure", action="store_true", help="test aid: packs do NOT wait for the collective that last read their record "
                                                                              "buffer (round 4's behaviour: with --gather-delay-us records are overwritten before they are sent)")
     ap.add_argument("--isolated-launches", type=int, default=24, help="synchronous batches run one at a time, every stage between events, before the "
@@ -225,6 +229,39 @@ def main():
     # the stream every context enqueues on, as a torch stream (for the waits on the pack of its previous batch)
     ctx_stream = {id(cx): (torch.cuda.ExternalStream(cx.stream_ptr, device=dev) if own_streams else stream) for cx in ctxs}
     ctx = ctxs[0]
+    side = torch.cuda.Stream(device=dev)   # pack events + collective run beside the detection streams, not in them
+    # N > 1: the collective's streams (the side stream it is issued from, the backend's internal one) must not share a HARDWARE queue
+    # with a context's stream -- streams of one queue run in order, so a collective that waits for its peers would hold that context
+    # up for as long as it waits (measured: aruco3_amd/streams.py, profiles/r05_queue_collisions.txt).  Probe, and move the contexts
+    # onto streams that are held up neither by the collective nor by one another (public a3_set_stream; contexts on distinct
+    # streams are stepped exactly like contexts on streams of their own).
+    hw_queues = None
+    if use_dist and own_streams and not args.no_stream_probe:
+        from aruco3_amd import streams as a3streams
+
+        tiny_in = torch.zeros(64, dtype=torch.uint8, device=coll_dev)
+        tiny_out = torch.zeros(64 * world, dtype=torch.uint8, device=coll_dev)
+
+        def collective_behind_a_sleep():
+            with torch.cuda.stream(side):
+                torch.cuda._sleep(int(1.5 * 2.4e6))
+                if coll_dev.type == "cuda":
+                    dist.all_gather_into_tensor(tiny_out, tiny_in)
+
+        cands = [ctx_stream[id(cx)] for cx in ctxs] + [torch.cuda.Stream(device=dev) for _ in range(12)]
+        chosen, hw_queues = a3streams.pick_streams(n_ctx, cands, [collective_behind_a_sleep], dev)
+        hw_queues["own_streams_kept"] = sum(1 for c in chosen if any(c is ctx_stream[id(cx)] for cx in ctxs))
+        taken = set()
+        for cx in ctxs:            # a context whose own stream was chosen keeps it; the others take the remaining chosen streams
+            if any(c is ctx_stream[id(cx)] for c in chosen):
+                taken.add(id(ctx_stream[id(cx)]))
+        spare = [c for c in chosen if id(c) not in taken]
+        for cx in ctxs:
+            if id(ctx_stream[id(cx)]) not in taken:
+                st_new = spare.pop(0)
+                cx.set_stream(st_new.cuda_stream)
+                ctx_stream[id(cx)] = st_new
+        torch.cuda.synchronize()
 
     if args.device_synth:
         t0 = time.time()
@@ -280,7 +317,6 @@ def main():
         maxm = max(8, 2 * int(t[0]))
 
     last_gather = [None]
-    side = torch.cuda.Stream(device=dev)   # pack + collective run beside the detection streams, not in them
     pinned_rec = {}
     # Records of one ROTATION (n_ctx batches) are packed into one buffer and gathered by ONE collective: a collective per batch costs
     # the stepping loop ~0.1 ms of host time and a kernel's company per step; per rotation it is a quarter of that.  Two buffers in
@@ -294,8 +330,10 @@ def main():
     rot = [0]
     gather_log = []                       # --verify-gathers: (clone of the collective's output, batches, [first global frame of every slot])
     slot_first = [0] * n_ctx
+    slot_res = [None] * n_ctx             # --verify-gathers: what collect() handed the host for the batch packed into each slot
 
     pack_events = []
+    timeline = []        # --verify-gathers: (kind, rotation, slot, event) in enqueue order
 
     def pack(cx, slot):
         # Per batch: fixed-capacity records written by a kernel from the device-resident marker list (a3_pack_detections); no host
@@ -306,10 +344,14 @@ def main():
         if gather_done[b] is not None and not args.no_gather_backpressure:
             ctx_stream[id(cx)].wait_event(gather_done[b])     # write-after-read: the collective of rotation rot-2 read this buffer
         slot_first[slot] = first_of(in_flight_buf[ctx_index[id(cx)]])
+        if args.verify_gathers:
+            slot_res[slot] = last_res[ctx_index[id(cx)]][0]
         shard.pack_detections_device(cx, n, slot_first[slot], dev, maxm=maxm, with_poses=bool(pose_mm), out=rec_bufs[b][slot])
-        ev = torch.cuda.Event()
+        ev = torch.cuda.Event(enable_timing=args.verify_gathers)
         ev.record(ctx_stream[id(cx)])
         pack_events.append(ev)
+        if args.verify_gathers:
+            timeline.append(("pack", rot[0], slot, ev))
 
     def all_gather(n_batches):
         b = rot[0] & 1
@@ -330,10 +372,12 @@ def main():
             out = gather_out[b][: world * n_batches * n]     # (read only on `side` -- the clone below -- or after a device-wide sync)
             last_gather[0] = (shard._all_gather(rec, n_batches * n, out=out), n_batches, list(slot_first[:n_batches]))
             if args.verify_gathers:
-                gather_log.append((last_gather[0][0].clone(), n_batches, list(slot_first[:n_batches])))
-            done = torch.cuda.Event()
+                gather_log.append((last_gather[0][0].clone(), n_batches, list(slot_first[:n_batches]), list(slot_res[:n_batches])))
+            done = torch.cuda.Event(enable_timing=args.verify_gathers)
             done.record(side)
             gather_done[b] = done
+            if args.verify_gathers:
+                timeline.append(("gather", rot[0], n_batches, done))
         rot[0] += 1
 
     gated = own_streams and args.gates == "burst" and n_ctx > 1
@@ -397,8 +441,13 @@ def main():
             k1_ms, k1_n = a, b
     ctx.set_profiling(0)
 
-    res = run_steps(args.warmup)
-    stepping_seen = [cx.stats()["stepping"] for cx in ctxs] if not args.no_pipeline and args.warmup >= n_ctx else None
+    res = run_steps(max(args.warmup, 0))
+    # what the library did with the last batch of every context (a3_stats.stepping): one more rotation if the warm-up was shorter
+    stepping_seen = None
+    if not args.no_pipeline:
+        if args.warmup < n_ctx:
+            run_steps(n_ctx)
+        stepping_seen = [cx.stats()["stepping"] for cx in ctxs]
 
     # The threshold kernel as the stepping runs it: ONE REAL ROTATION of the burst stepping (public calls only: the gates, the
     # submits, A3_PROFILE_THRESHOLD_ONLY = the library's own events around each threshold kernel on its context's stream), started
@@ -601,14 +650,28 @@ def main():
                         "write_after_read_guard": "off (--no-gather-backpressure)" if args.no_gather_backpressure else
                                                   "a pack waits, on its context's stream, for the collective that last read its record buffer"}
             if args.verify_gathers:
-                bad = []
-                for gi, (g_c, g_b, g_f) in enumerate(gather_log):
-                    nr, io, ido, _ = check_gather(g_c, g_b, g_f)
-                    if io != world or ido != nr:
-                        bad.append({"collective": gi, "indices_ok_ranks": io, "ids_ok": ido, "records": nr})
+                bad, trace = [], []
+                for gi, (g_c, g_b, g_f, g_res) in enumerate(gather_log):
+                    nr, io, ido, mine_c = check_gather(g_c, g_b, g_f)
+                    # this rank's records against what collect() returned for the very batches packed into the rotation's slots
+                    content_ok = len(mine_c) == g_b * n
+                    for sl in range(g_b):
+                        bf = split_by_frame(g_res[sl][0], g_res[sl][1])
+                        for f in range(n):
+                            x = mine_c[sl * n + f] if content_ok else None
+                            content_ok = content_ok and [int(v) for v in x[1]["id"]] == [int(m["id"]) for m in bf[f]] \
+                                and [tuple(int(v) for v in q) for q in x[1]["corners"]] == [tuple(int(v) for v in m["corners"]) for m in bf[f]]
+                    trace.append({"expected_first_frames": [int(v) for v in g_f], "got_first_frames": [int(mine_c[sl * n][0]) for sl in range(g_b)] if len(mine_c) == g_b * n else None})
+                    if io != world or not content_ok:
+                        bad.append({"collective": gi, "indices_ok_ranks": io, "records_equal_collected_results": bool(content_ok), "records": nr})
                 gathered["verified_collectives"] = len(gather_log)
                 gathered["collectives_with_wrong_records"] = len(bad)
                 gathered["first_wrong"] = bad[:3]
+                gathered["trace"] = trace[:10]
+                # when things finished on the device (ms after the first pack of the run's last 40 entries): a pack of rotation r+2 that
+                # completes BEFORE the collective of rotation r is the write-after-read the guard forbids
+                tl = timeline[-40:]
+                gathered["timeline_ms"] = [(kind, int(r), int(sl), round(tl[0][3].elapsed_time(ev), 3)) for kind, r, sl, ev in tl]
                 gathered["gather_delay_us"] = args.gather_delay_us
             if pose_mm:   # rank 0's own frames of the last batch came back as it produced them, poses included
                 j_last = in_flight_buf[(g_batches - 1) % n_ctx]
@@ -725,6 +788,7 @@ def main():
         if use_dist:   # what the ranks themselves saw
             out["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                            "launcher": os.environ.get("A3_BENCH_LAUNCHER", "external (torch.distributed.run)" if "RANK" in os.environ else "none (one process, --force-dist)"),
+                           "hw_queues": hw_queues,
                            "pack_and_collective": "records packed by a kernel on the context's own stream right after collect(); one all-gather per rotation on a side stream, behind the packs' events",
                            "note": "an N > 1 RCCL number exists only where the driver's multi-GPU node produced one; a 1-GPU box can run world_size 1 (nccl) or rehearse ranks over gloo"}
         if not args.no_cpu_baseline and world == 1:

@@ -92,7 +92,9 @@ typedef struct a3_stats {
     uint32_t jump_rounds;           /* pointer-doubling rounds that did work */
     uint32_t chunks;                /* sub-batches the frames were split into */
     uint32_t stepping;              /* bits 0-7: A3_STEP_* -- how the library scheduled the batch (see a3_order_after);
-                                     * bits 8-31: chains of OTHER contexts this batch's submit released (A3_STEP_BURST_LAST) */
+                                     * bits 8-15: chains of OTHER contexts this batch's submit released (A3_STEP_BURST_LAST);
+                                     * bits 16-23: synchronous re-runs of the batch the device asked for (a pool or table that
+                                     * had to grow, more passes, a host-side plan) -- each costs a whole batch */
 } a3_stats;
 /* a3_stats.stepping & 0xFF */
 enum {

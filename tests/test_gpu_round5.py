@@ -64,7 +64,6 @@ def _fresh_env():
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "A3_HIP_LIB"):
         env.pop(k, None)
-    env["GPU_MAX_HW_QUEUES"] = "8"
     return env
 
 
@@ -72,7 +71,8 @@ def test_default_library_holds_chains_in_the_documented_rotation():
     """fresh process, no a3_debug_* call anywhere in it: contexts 0..2 of every rotation report 'held_released_by_last', context 3
     'burst_last' with three chains released; results equal the synchronous calls'"""
     assert "a3_debug" not in _FRESH and "debug_" not in _FRESH
-    p = subprocess.run([sys.executable, "-c", _FRESH % {"root": str(ROOT)}], cwd=ROOT, env=_fresh_env(), capture_output=True, text=True, timeout=600)
+    p = subprocess.run([sys.executable, "-c", _FRESH % {"root": str(ROOT)}], cwd=ROOT, env=dict(_fresh_env(), GPU_MAX_HW_QUEUES="8"), capture_output=True, text=True,
+                       timeout=600)
     assert p.returncode == 0, p.stderr[-4000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["equal"] is True and min(out["markers"]) > 0
