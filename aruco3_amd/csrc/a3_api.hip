@@ -531,7 +531,14 @@ uint32_t marker_guess_of(const a3_ctx* ctx, uint32_t marker_cap) {
 // a single-chunk batch is followed by device-planned ones sized darts * 1.25 + 64k: the pool is allocated for that at once
 uint64_t pool_darts_of(const a3_ctx* ctx, uint64_t max_chunk_darts, size_t n_chunks) {
     uint64_t pool_darts = std::max<uint64_t>(max_chunk_darts, 1);
-    if (n_chunks == 1) pool_darts = std::min<uint64_t>(std::max<uint64_t>(ctx->max_darts, pool_darts), pool_darts + pool_darts / 2 + 131072);
+    if (n_chunks == 1) {
+        pool_darts = std::min<uint64_t>(std::max<uint64_t>(ctx->max_darts, pool_darts), pool_darts + pool_darts / 2 + 131072);
+        // in steps of an eighth of an octave: a stream of batches whose graphs differ by a percent or two (consecutive batches of one
+        // camera) must not re-allocate the pool -- a dozen hipFree + hipMalloc in the middle of a batch, ~2 ms -- at every new maximum
+        uint64_t step = 1ull << 17;
+        while (step * 16 < pool_darts) step <<= 1;
+        pool_darts = std::min<uint64_t>((pool_darts + step - 1) / step * step, std::max<uint64_t>(kHardMaxDarts, pool_darts));
+    }
     return pool_darts;
 }
 // Every buffer the chain (contour stage ... read-back) of a DEVICE-PLANNED batch uses, allocated now: a chain that is held back for

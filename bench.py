@@ -428,6 +428,8 @@ def main():
     # ---- isolated launches: one synchronous batch at a time, every stage between events, nothing else on the GPU ----
     # The roofline figure of the threshold kernel is its launch duration ALONE; in the stepping below no kernel runs alone.
     stage_ms, k1_ms, k1_n = {}, 0.0, 0
+    for j in range(n_bufs):      # (the context meets every batch once before anything is timed: its pools grow to the largest)
+        detect_sync(ctx, j)
     ctx.set_profiling(True)
     for st_id in (_lib.STAGE_THRESHOLD, _lib.STAGE_CONTOUR, _lib.STAGE_DECODE):
         ctx.profile(st_id, reset=True)

@@ -50,8 +50,10 @@ def test_bench_front_door_starts_its_own_ranks():
     assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]      # ONE JSON line on stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 3
-    assert out["gathered"]["frames"] == 32 and out["gathered"]["global_frame_indices_in_order"] is True
-    assert out["gathered"]["all_ranks_ids_correct"] >= 26
+    g = out["gathered"]       # the last collective: one rotation of four batches of 16 frames from each of the two ranks
+    assert g["frames"] == 2 * 16 * g["batches_in_last_collective"] and g["global_frame_indices_in_order"] is True
+    assert g["all_ranks_ids_correct"] >= 0.8 * g["frames"]
+    assert out["config"]["distinct_batches_in_flight"] == 4
     assert out["dist"]["world_size"] == 2 and out["dist"]["backend"] == "gloo" and "self-launched" in out["dist"]["launcher"]
 
 
