@@ -35,7 +35,7 @@ size_t entry_slots(uint32_t);
 size_t leader_list_bytes(uint32_t);
 hipError_t launch_rank_cycles(hipStream_t, uint32_t, int, const uint64_t*, const uint32_t*, JumpState*,
                               uint32_t*, uint32_t*, unsigned int*, void*, void*, JumpState*, uint32_t*, unsigned int*, int, DeviceCounters*, const uint32_t*, int,
-                              const uint32_t*, uint32_t*, uint32_t, int);
+                              const uint32_t*, uint32_t*, uint32_t, int, uint32_t, unsigned int*);
 hipError_t launch_resolve(hipStream_t, const JumpState*, uint32_t, int, const uint64_t*, const uint32_t*, const unsigned int*, uint64_t*, uint64_t*,
                           DeviceCounters*, int, const uint32_t*);
 hipError_t launch_select_scatter(hipStream_t, const JumpState*, uint32_t, const uint32_t*, const unsigned int*, const uint32_t*, const uint64_t*,
@@ -738,6 +738,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     unsigned int* d_err = ctx->scratch_u32 + 4;             // ([0] work count, [1] marker total: enqueue_back)
     unsigned int* d_entry_count = ctx->scratch_u32 + 32;    // [32..47]
     unsigned int* d_leader_count = ctx->scratch_u32 + 16;   // [16..31]
+    unsigned int* d_dead_count = ctx->scratch_u32 + 48;     // [48..63]: borders k_local_contract finished with (traced, never listed), 16 shards, all chunks
 
     const uint32_t* n_live = nullptr;
     if (device_plan) {
@@ -794,7 +795,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
         A3_HIP(launch_rank_cycles(st, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), ctx->stA.as<JumpState>(),
                                   ctx->entry_list.as<uint32_t>(), ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
                                   ctx->stA.as<JumpState>(), ctx->leader_list.as<uint32_t>(), d_leader_count, rounds, ctr, n_live, 0, fb,
-                                  frame_entries, cc.count, 1));
+                                  frame_entries, cc.count, 1, min_edge_length, keep_all ? nullptr : d_dead_count));
         if (rel_mode == 2) { if (int rc = release_waiting()) return rc; }   // waiting decode stages go out behind this k_local_contract
         ctx->dbg_nd = nd; ctx->dbg_frames = c.count; ctx->dbg_chunks = (uint32_t)chunks.size();
         // second half: entry resolution, final states (+ border selection), point scatter, quads -- on `s2`
@@ -802,7 +803,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
             A3_HIP(launch_rank_cycles(s2, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), ctx->stA.as<JumpState>(),
                                       ctx->entry_list.as<uint32_t>(), ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
                                       ctx->stA.as<JumpState>() /* final states in place */, ctx->leader_list.as<uint32_t>(), d_leader_count, rounds, ctr,
-                                      n_live, 0, fb, frame_entries, cc.count, 2));
+                                      n_live, 0, fb, frame_entries, cc.count, 2, min_edge_length, keep_all ? nullptr : d_dead_count));
             const JumpState* fin = ctx->stA.as<JumpState>();
             A3_HIP(launch_resolve(s2, fin, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->leader_list.as<uint32_t>(), d_leader_count,
                                   ctx->t_cur.as<uint64_t>(), ctx->t_next.as<uint64_t>(), ctr, resolve_iters, n_live));
@@ -902,6 +903,7 @@ int finish_batch(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_fram
         ctx->plan_darts = n_chunks == 1 ? pd.chunk0_darts : 0;
     }
     unsigned int flags = hs[4];
+    for (int sh = 0; sh < 16; sh++) ctx->stats.contours_traced += hs[48 + sh];   // borders finished inside k_local_contract (kDead)
     uint64_t need_points = 0; uint32_t need_contours = 0;
     bool jump_short = false, resolve_needed = false, entry_overflow = false;
     for (size_t ci = 0; ci < n_chunks; ci++) {
@@ -1457,7 +1459,8 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
             A3_HIP(launch_rank_cycles(st, ctx->dbg_nd, (int)ctx->W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), ctx->stA.as<JumpState>(),
                                       ctx->entry_list.as<uint32_t>(),
                                       ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p, ctx->stB.as<JumpState>(),
-                                      ctx->leader_list.as<uint32_t>(), d_leader_count, 0, ctx->counters, nullptr, dbg ? dbg : 11, ctx->frame_base.as<uint32_t>(), nullptr, ctx->dbg_frames, 0));
+                                      ctx->leader_list.as<uint32_t>(), d_leader_count, 0, ctx->counters, nullptr, dbg ? dbg : 11, ctx->frame_base.as<uint32_t>(), nullptr, ctx->dbg_frames, 0,
+                                      0u, nullptr));
         } else if (kernel == 3) {   // dbg < 0: k_decode alone (variant -dbg), dbg >= 0: k_projection + k_decode
             A3_HIP(launch_decode(st, ctx->dbg_src, (int)ctx->W, (int)ctx->H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), ctx->scratch_u32,
                                  ctx->max_cand, ctx->cfg.homography_sample_size, ctx->mark_size, ctx->cfg.homography_sample_size, ctx->dict.as<uint64_t>(),

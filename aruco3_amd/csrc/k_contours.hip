@@ -702,6 +702,12 @@ __device__ __forceinline__ uint32_t loc_off(uint32_t w) { return w & 0xFFFu; }
 // After k_jump_finalize the `off` word of a dart is either still the packed local one (the local window was final: its low 12
 // bits are the hop count) or kFinal | hops to the leader (< 2^30)
 constexpr uint32_t kFinal = 0x40000000u;
+// k_local_contract: the dart lies on a DEAD cycle -- one that closed inside its tile, carries a start event, is too short ever to be
+// materialised (k_cycle_select's parity-safe length test) and whose smallest event fires whatever the other borders do (see
+// static_fire).  Nothing downstream lists, evaluates or scatters it; its key stays in place: the start resolution of OTHER
+// borders through shared pixels reads it (a traced border labels its pixels however short it is).  Only in states whose window
+// did not freeze (kFinal and kDead never meet: k_jump_finalize rewrites frozen windows only).
+constexpr uint32_t kDead = 0x20000000u;
 __device__ __forceinline__ uint32_t fin_off(uint32_t w) { return (w & kFinal) ? (w & 0x3FFFFFFFu) : (w & 0xFFFu); }
 __device__ __forceinline__ uint32_t loc_dist(uint32_t w) { return (w >> 12) & 0x1FFFu; }
 
@@ -714,6 +720,17 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// Does the start event of this dart fire under EVERY assignment of starts to the other borders?  (k_resolve_eval's rule: a W-event
+// fires iff every cycle through its pixel starts at or after it -- certain when the pixel owns this one dart only; an E-event
+// fires iff not (the pixel has a W side and that W-event fires) -- certain when it has no W side.)  A border whose SMALLEST event
+// passes this test starts there, whatever else happens: it needs no look at its neighbours' states.
+__device__ __forceinline__ bool static_fire(uint64_t rec) {
+    const uint32_t info = rec_info(rec), F = rec_F(rec);
+    if (info & kInfoW) return __popc(pdart_mask(F)) == 1;
+    if (info & kInfoE) return (rec_xy(rec) & 0xFFFFu) == 0u || (F & 1u) != 0u;   // no W side: column 0, or the west neighbour is foreground
+    return false;
+}
+
 // Phase 1: 11 doubling rounds inside one tile, entirely in LDS.  A window stops growing ("freezes") when its end leaves
 // the tile; cycles that close inside the tile finish here.  Darts that some frozen window ends on become "entries".
 template <int LT>
@@ -723,7 +740,8 @@ __global__ __launch_bounds__(256, LT >= 2048 ? 4 : 8) void k_local_contract(uint
                                                         uint32_t* __restrict__ entry_list,
                                                         uint32_t* __restrict__ entry_pos, unsigned int* __restrict__ entry_count, uint32_t ecap,
                                                         const uint32_t* __restrict__ frame_base, uint32_t* __restrict__ frame_entries,
-                                                        const uint32_t* __restrict__ n_live, int dbg) {
+                                                        const uint32_t* __restrict__ n_live, int dbg,
+                                                        uint32_t min_edge_length, unsigned int* __restrict__ dead_count /*[16]; nullptr: mark nothing dead*/) {
     // frame_entries != nullptr: entries get slots grouped by frame (slot = frame_base[f] + running count of the frame: a
     // frame has at most as many entries as darts), for k_entry_frame; else the 16-shard allocation of the global rounds
     // dbg (a3_debug_kernel_time only; 0 in the product path): n > 0 runs n doubling rounds instead of 11; -1 = none
@@ -732,7 +750,8 @@ __global__ __launch_bounds__(256, LT >= 2048 ? 4 : 8) void k_local_contract(uint
     __shared__ Win s_win[LT];
     constexpr uint32_t kFrameWin = 64;               // frames a tile may span with block-aggregated counting (beyond: direct atomics)
     __shared__ uint32_t s_fcnt[kFrameWin], s_fbase[kFrameWin];
-    __shared__ uint32_t s_new_count, s_new_base, s_f0;
+    __shared__ uint32_t s_new_count, s_new_base, s_f0, s_dead_n;
+    __shared__ uint8_t s_dead[LT];                   // per dart of the tile: it LEADS a dead cycle
     if (n_live) n_darts = min(n_darts, *n_live);
     const uint32_t lo = blockIdx.x * LT;
     if (lo >= n_darts) return;   // the grid covers the pool's capacity, the graph may be smaller
@@ -741,8 +760,9 @@ __global__ __launch_bounds__(256, LT >= 2048 ? 4 : 8) void k_local_contract(uint
     // copy the other lanes read (per dart and round: one 16-byte read of the next window, one 16-byte write)
     constexpr int PER = LT / 256;
     uint64_t nk[PER]; uint32_t np[PER], no[PER], nd[PER], succ0[PER], frm[PER];
-    if (threadIdx.x == 0) s_new_count = 0;
+    if (threadIdx.x == 0) { s_new_count = 0; s_dead_n = 0; }
     if (threadIdx.x < kFrameWin) s_fcnt[threadIdx.x] = 0;
+    uint32_t sfire = 0;                              // bit u: the start event of my dart u fires unconditionally (static_fire)
     // all 16 loads of a lane are issued before the first is used: unconditional, from a clamped index (behind an `if (i < cnt)`
     // the compiler issues them one at a time, each with its own wait: 16 round trips to memory instead of one)
     uint64_t recs[PER];
@@ -761,7 +781,8 @@ __global__ __launch_bounds__(256, LT >= 2048 ? 4 : 8) void k_local_contract(uint
         const uint32_t ek = (info & kInfoW) ? 2u * q : ((info & kInfoE) ? 2u * q + 1u : kNoKey);
         frm[u] = rec_frame(rec);   // kept, like succ0, for the entry registration (no second read)
         nk[u] = ((uint64_t)ek << 32) | (lo + i); np[u] = succ0[u]; no[u] = 0; nd[u] = 1;
-        if (i < cnt) s_win[i] = Win{nk[u], np[u], 1u << 16};
+        if (i < cnt) { s_win[i] = Win{nk[u], np[u], 1u << 16}; s_dead[i] = 0; }
+        if (ek != kNoKey && static_fire(rec)) sfire |= 1u << u;
     }
     if (threadIdx.x == 0) s_f0 = frm[0];   // darts are frame-major: the tile's frames are f0, f0+1, ...
     lds_barrier();
@@ -837,14 +858,38 @@ __global__ __launch_bounds__(256, LT >= 2048 ? 4 : 8) void k_local_contract(uint
     // results
     if (frame_entries) { if (threadIdx.x < kFrameWin) s_fbase[threadIdx.x] = slot_a + slot_b; }
     else if (threadIdx.x == 0) s_new_base = slot_a + slot_b;
+    // Dead cycles (kDead): a leader whose window wrapped inside the tile knows its border's length from its successor's window
+    // (hops back to the leader + 1), here in LDS; too short for k_cycle_select's test and starting unconditionally, the border is
+    // finished with: counted as traced, listed nowhere.  Noise-like frames: most of the millions of borders.
+    if (dead_count) {
+        uint32_t my_dead = 0;
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const uint32_t i = threadIdx.x + u * 256;
+            if (i >= cnt || !(sfire & (1u << u))) continue;
+            if ((uint32_t)nk[u] != lo + i || (np[u] - lo) >= cnt) continue;            // not the leader, or the window left the tile
+            const uint32_t sl = succ0[u] - lo;
+            if (sl >= cnt || sl == i) continue;                                        // (a chain end: the normal path reports it)
+            const Win ws = s_win[sl];
+            if ((uint32_t)ws.key != lo + i) continue;                                  // the successor's window did not wrap to this leader
+            const uint32_t n = (ws.offdist & 0xFFFFu) + 1u;                            // border length in points
+            if (n >= 5u && (uint64_t)n * n >= 2ull * min_edge_length) continue;        // k_cycle_select's parity-safe test (the diagonal bound cannot bind in a tile)
+            s_dead[i] = 1; my_dead++;
+        }
+        if (my_dead) atomicAdd(&s_dead_n, my_dead);
+        lds_barrier();
+        if (threadIdx.x == 0 && s_dead_n) atomicAdd(&dead_count[blockIdx.x & 15u], s_dead_n);
+    }
 #pragma unroll
     for (int u = 0; u < PER; u++) {
         const uint32_t i = threadIdx.x + u * 256;
         if (i >= cnt) continue;
         const uint32_t e = np[u];
         const bool frozen = (e - lo) >= cnt;
+        const uint32_t li = (uint32_t)nk[u] - lo;                                      // my window's minimum: in the tile when it did not freeze
+        const bool dead = dead_count != nullptr && !frozen && li < cnt && s_dead[li] != 0;
         JumpState r;
-        r.key = nk[u]; r.ptr = e; r.off = loc_pack(no[u], nd[u], frozen);
+        r.key = nk[u]; r.ptr = e; r.off = loc_pack(no[u], nd[u], frozen) | (dead ? kDead : 0u);
         loc[lo + i] = r;
     }
     lds_barrier();
@@ -1030,7 +1075,7 @@ __global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const J
             const bool better = (od[u] & kFrozen) && g[u].key < s[u].key;
             if (better) { s[u].key = g[u].key; s[u].off = (loc_dist(od[u]) + g[u].off) | kFinal; }
             if (better || fin != loc) fin[d] = s[u];
-            if ((uint32_t)s[u].key == d && (uint32_t)(s[u].key >> 32) != kNoKey) mask |= 1u << (it + u);
+            if ((uint32_t)s[u].key == d && (uint32_t)(s[u].key >> 32) != kNoKey && !(s[u].off & kDead)) mask |= 1u << (it + u);
         }
     }
     // one global atomic per workgroup: leaders are counted in a block scan first
@@ -1060,6 +1105,7 @@ constexpr uint64_t kInf64 = ~0ull;
 __device__ __forceinline__ bool natural_start_fires(uint32_t d, uint64_t key0, const JumpState* __restrict__ st, const uint64_t* __restrict__ d_rec,
                                                     int W) {
     const uint64_t rec = d_rec[d];
+    if (static_fire(rec)) return true;   // (the leader's key is its own event's: no look at the neighbours' states needed)
     const uint32_t info = rec_info(rec);
     const uint32_t xy = rec_xy(rec);
     const uint32_t x = xy & 0xFFFF, y = xy >> 16;
@@ -1348,7 +1394,8 @@ __global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restr
         }
 #pragma unroll
         for (int u = 0; u < B; u++) {
-            live[u] = d0 + (uint32_t)u * stride < n_darts && (uint32_t)(s[u].key >> 32) != kNoKey;   // else: no start event on this cycle
+            live[u] = d0 + (uint32_t)u * stride < n_darts && (uint32_t)(s[u].key >> 32) != kNoKey &&   // else: no start event on this cycle
+                      !(s[u].off & kDead);                                                               // ... or a dead one (k_local_contract)
             const uint32_t leader = live[u] ? (uint32_t)s[u].key : 0u;
             ls[u] = st[leader];    // key: is the leader's window intact; ptr: its border slot (k_cycle_select)
             c[u] = ls[u].ptr;
@@ -1663,16 +1710,17 @@ hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uin
                               unsigned int* entry_count, void* es_a, void* es_b, JumpState* fin, uint32_t* leader_list,
                               unsigned int* leader_count, int max_rounds, DeviceCounters* ctr, const uint32_t* n_live, int dbg,
                               const uint32_t* frame_base, uint32_t* frame_entries /*nullptr: global rounds*/, uint32_t n_frames,
-                              int phase /* 0: everything, 1: k_local_contract only, 2: what follows it */) {
+                              int phase /* 0: everything, 1: k_local_contract only, 2: what follows it */,
+                              uint32_t min_edge_length, unsigned int* dead_count /* [16], nullptr: no border is dropped early (debug taps) */) {
     // entry_count[16] and leader_count[16] arrive zeroed (the caller's per-batch / per-chunk memset)
     const uint32_t ecap = entry_shard_cap(n_darts);
     if (phase != 2) {
         if (frame_entries)
             hipLaunchKernelGGL(k_local_contract<kLTFrame>, dim3((n_darts + kLTFrame - 1) / kLTFrame), dim3(256), 0, st, n_darts, W, d_rec, d_succ, loc,
-                               entry_list, entry_pos, entry_count, ecap, frame_base, frame_entries, n_live, dbg);
+                               entry_list, entry_pos, entry_count, ecap, frame_base, frame_entries, n_live, dbg, min_edge_length, dead_count);
         else
             hipLaunchKernelGGL(k_local_contract<kLT>, dim3((n_darts + kLT - 1) / kLT), dim3(256), 0, st, n_darts, W, d_rec, d_succ, loc,
-                               entry_list, entry_pos, entry_count, ecap, frame_base, frame_entries, n_live, dbg);
+                               entry_list, entry_pos, entry_count, ecap, frame_base, frame_entries, n_live, dbg, min_edge_length, dead_count);
     }
     if (dbg || phase == 1) return hipGetLastError();
     EntryState* a = reinterpret_cast<EntryState*>(es_a);

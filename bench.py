@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 K1_BYTES_PER_PIXEL = 3.125         # what K1 has to move: 3 B RGB read + 1/8 B bit-packed binary written; NO grey plane is written
 K1_SURVEY_BYTES_PER_PIXEL = 5      # SURVEY.md section 8d's figure (3 B read + 1 B grey + 1 B byte-wide binary): reported separately
 E2E_BYTES_PER_PIXEL = 3.25         # what one step must move end to end: K1's 3.125 B/px + the 1/8 B/px re-read of the packed image
-PROFILE_TAGS = ("r04", "r03", "r02")   # profiles/<tag>_pmc_bench_c2.json holds the PMC passes of this same command (newest first)
+PROFILE_TAGS = ("r05", "r04", "r03", "r02")   # profiles/<tag>_pmc_bench_c2.json holds the PMC passes of this same command (newest first)
 
 # the workloads this file can step (BASELINE.json configs): c2 is the one the metric is quoted on and the default; c5 is the
 # 3840x2160 detect + estimate_pose configuration (BASELINE config 5: `--workload c5 --gpus 4`)
@@ -612,6 +612,44 @@ def main():
             L.a3_debug_set_overlap(args.overlap if args.overlap >= 0 else -1)
     stats = ctx.stats()
 
+    # ---- the second kernel north_star names: k_decode (homography warp + Otsu + bit grid + dictionary lookup), timed ALONE like K1 ----
+    # Its launch duration comes from the library's kernel probe (a3_debug_kernel_time re-runs the kernel on the work list the last
+    # synchronous batch left behind: nothing else on the GPU); beside SURVEY 8(d)'s BYTES fraction it gets the fraction of what
+    # bounds it -- the L2's REQUEST rate for its scattered taps: tools/micro/scatterbench issues the same tap pattern with
+    # everything else taken away, in this run, on this box.
+    roofline_warp = None
+    if rank == 0 and not use_dist and not args.no_other_workloads and args.workload == "c2":
+        try:
+            detect_sync(ctx, 0)
+            n_cand = int(ctx.stats()["candidates"])
+            dec_ms = ctx.debug_kernel_time(3, -1, 10)          # k_decode alone (no k_projection: the product solves those in k_frame_candidates)
+            samp_ms = ctx.debug_kernel_time(3, -2, 10)         # the same launch stopped after the sampling loop
+            internal_probes.append("a3_debug_kernel_time(decode) for roofline_warp")
+            S = 49
+            warp_bytes = (S * S * 4 + 32) * n_cand             # 9 604 B read upper bound + 32 B written per candidate
+            ceil_us = scatter_ceiling_us(n_cand)
+            roofline_warp = {
+                "kernel": "k_decode<256,64> (49x49 bilinear warp of every candidate straight from the RGB frames, Otsu, triangle resize, bit grid, "
+                          "four rotations, dictionary lookup)",
+                "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                "achieved": round(warp_bytes / (dec_ms * 1e-3) / 1e9, 1), "frac": round(warp_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "bytes_per_candidate": S * S * 4 + 32, "candidates_per_launch": n_cand, "avg_launch_ms": round(dec_ms, 4),
+                "sampling_only_ms": round(samp_ms, 4), "dependent_tail_ms": round(dec_ms - samp_ms, 4),
+                "timed_how": "a3_debug_kernel_time: the kernel re-run alone, 10 times, on the work list of a synchronous batch of this run, HIP events around it",
+                "traffic": pmc_decode_traffic_bytes(),
+                # what the kernel is actually bound by: 64-byte sector requests of scattered 12-byte taps
+                "request_rate": None if ceil_us is None else {
+                    "what": "the tap pattern's sector-request ceiling: tools/micro/scatterbench (same candidates per launch, same 8x8 sample "
+                            "blocks, 4-byte reads at the tap addresses, nothing else), run by this process on this box",
+                    "ceiling_us_per_launch": round(ceil_us, 1), "frac_of_ceiling_whole_kernel": round(ceil_us / (dec_ms * 1e3), 4),
+                    "frac_of_ceiling_sampling_loop": round(ceil_us / (samp_ms * 1e3), 4),
+                    "requests_per_candidate_pmc": 1225,
+                    "note": "1225 sector requests per candidate = 3.15 M per launch / 2571 candidates (profiles/r04_pmc_decode.txt: L2 -> fabric read "
+                            "requests of k_decode); the same pattern in the microbenchmark, so the ratio of times is the ratio of request rates"},
+            }
+        except Exception as e:   # a side measurement must not take the line down
+            roofline_warp = {"error": repr(e)}
+
     gathered = None
     if use_dist:
         # what the collectives delivered, checked on rank 0: every rank's frames of the rotation, global indices as packed, ids as
@@ -781,6 +819,8 @@ def main():
             "library_stepping_seen": stepping_seen,
             "frame_synthesis_s": round(t_gen, 1),
         }
+        if roofline_warp is not None:
+            out["roofline_warp"] = roofline_warp
         if ab_shared is not None:
             out["ab_shared_stream"] = ab_shared
         if ab_r04_default is not None:
@@ -880,6 +920,36 @@ def pmc_traffic_bytes():
     return None
 
 
+def pmc_decode_traffic_bytes():
+    """HBM-side bytes per k_decode launch from the committed PMC passes (tools/pmc_chain.sh -> profiles/<tag>_pmc_chain.json: the
+    byte-accurate TCC_EA0_RDREQ_DRAM_32B / WRREQ_*_DRAM_32B counters), or None"""
+    for tag in PROFILE_TAGS:
+        try:
+            pmc = json.loads((ROOT / "profiles" / f"{tag}_pmc_chain.json").read_text())
+            k = next(v for name, v in pmc.items() if "k_decode" in name)
+            return int((k["read_MB_exact"] + k["write_MB_exact"]) * 1e6)
+        except Exception:
+            continue
+    return None
+
+
+def scatter_ceiling_us(n_cand):
+    """tools/micro/scatterbench (built by __graft_entry__.build()) as a child process: microseconds per launch of the decode stage's tap
+    pattern with 4-byte reads (the request-rate probe), best of its two depths; None when the binary is missing"""
+    import re
+    import subprocess
+
+    exe = ROOT / "tools" / "micro" / "scatterbench"
+    if not exe.exists():
+        return None
+    try:
+        p = subprocess.run([str(exe), str(int(n_cand))], capture_output=True, text=True, timeout=120)
+        m = re.search(r"4-byte reads at the same addresses, KU 2 / 4: ([0-9.]+) / ([0-9.]+) us", p.stdout)
+        return min(float(m.group(1)), float(m.group(2))) if m else None
+    except Exception:
+        return None
+
+
 def parity_row(agree, total, what="markers (id, code, corners, rotation, hamming distance)"):
     return {"frames_compared": total, "frames_equal": agree, "summary": f"{agree}/{total} frames", "compared": what,
             "against": "oracle/a3_oracle.c (CPU restatement of the reference; the reference itself cannot be built here)"}
@@ -952,7 +1022,7 @@ def cpu_baseline(frames_by_batch, d, gpu_by_frame=None, gpu_poses=None, gpu_per=
     return out, parity
 
 
-def other_workloads(device, with_cpu=True, budget_s=60.0):
+def other_workloads(device, with_cpu=True, budget_s=100.0):
     """The rest of BASELINE.json's configurations as driver-visible numbers, each on frames resident in HBM and with the
     single-thread oracle ("port") timed on a few of the same frames:
       C0  the reference's own bench recipe (benches/detect_markers.rs:29-51): uniform-noise RGB at 1920x1080, ARUCO
@@ -969,7 +1039,8 @@ def other_workloads(device, with_cpu=True, budget_s=60.0):
     dev = torch.device("cuda", device)
     res = {}
 
-    def run(name, frames_dev, dname, pose_mm=None, reps=7, cpu_frames=2, truths=None, note="", window=7):
+    def run(name, frames_dev, dname, pose_mm=None, reps=7, cpu_frames=None, truths=None, note="", window=7):
+        # cpu_frames None: the oracle processes EVERY frame the row times (parity_in_run then covers what `value` covers)
         if time.perf_counter() - t_start > budget_s:
             res[name] = {"skipped": "time budget"}
             return
@@ -1039,17 +1110,38 @@ def other_workloads(device, with_cpu=True, budget_s=60.0):
                 ok += got == sorted(t.id for t in truths[f])
             # recall of the reference ALGORITHM on this workload (the oracle finds the same: parity is what tests/ check)
             o["frames_with_all_drawn_ids_found"] = f"{ok}/{n}"
+        # every stage alone on this workload (one more synchronous batch with events between the stages)
+        try:
+            ctx.set_profiling(True)
+            for st_id in (0, 1, 2):
+                ctx.profile(st_id, reset=True)
+            call(); call()
+            o["stage_ms_per_batch"] = {k2: round(ctx.profile(i2)[0] / max(ctx.profile(i2)[1], 1), 4) for i2, k2 in enumerate(("threshold", "contour", "decode"))}
+            ctx.set_profiling(0)
+        except Exception as e:
+            o["stage_ms_per_batch"] = {"error": repr(e)}
         if with_cpu:
             from oracle import a3oracle
             a3oracle.build()
+            if cpu_frames is None:
+                cpu_frames = n
             host = frames_dev[:cpu_frames].cpu().numpy()
             codes = np.ascontiguousarray(d.code_list)
-            t0 = time.perf_counter()
             ocfg = a3oracle.Config.default()
             ocfg.threshold_window = window
-            ores = [a3oracle.detect(host[f], codes, d.num_bits, d._tau, config=ocfg, keep_debug=False) for f in range(cpu_frames)]
-            o["cpu_baseline"] = {"value": round(cpu_frames / (time.perf_counter() - t0), 2), "unit": "frames/s", "cores": 1, "kind": "port",
-                                 "sample": f"{cpu_frames} of the same frames, single thread, detection only"}
+            # the first frames one at a time on one thread (the timed CPU baseline), the rest frame-parallel: the checker's verdict is
+            # what matters for them, not its speed
+            n_timed = min(cpu_frames, 2 if w * h > 1000000 else 4)
+            t0 = time.perf_counter()
+            ores = [a3oracle.detect(host[f], codes, d.num_bits, d._tau, config=ocfg, keep_debug=False) for f in range(n_timed)]
+            dt_cpu = time.perf_counter() - t0
+            if cpu_frames > n_timed:
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=max(1, min(os.cpu_count() or 1, 32))) as pool:
+                    ores += list(pool.map(lambda f: a3oracle.detect(host[f], codes, d.num_bits, d._tau, config=ocfg, keep_debug=False), range(n_timed, cpu_frames)))
+            o["cpu_baseline"] = {"value": round(n_timed / dt_cpu, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+                                 "sample": f"{n_timed} of the same frames, single thread, detection only (all {cpu_frames} frames of the batch go through the "
+                                           "oracle for parity_in_run, the rest frame-parallel)"}
             gpu_frames = split_by_frame(r[0], r[1])
             o["parity_in_run"] = parity_row(sum(oracle_marker_tuples(ores[f]) == hip_marker_tuples(gpu_frames[f]) for f in range(cpu_frames)), cpu_frames)
         res[name] = o
@@ -1060,7 +1152,7 @@ def other_workloads(device, with_cpu=True, budget_s=60.0):
     for (nw, nh), nb in (((1920, 1080), 32), ((1280, 720), 32), ((960, 540), 32), ((512, 512), 32)):
         noise = torch.randint(0, 256, (nb, nh, nw, 3), dtype=torch.uint8, device=dev, generator=g)
         run(f"C0_reference_bench_noise_{nw}x{nh}" if (nw, nh) != (1920, 1080) else "C0_reference_bench_noise_1080p", noise, "ARUCO",
-            cpu_frames=2 if nw >= 1280 else 4, reps=5,
+            reps=5,
             note="benches/detect_markers.rs:29-51 recipe: every channel of every pixel uniform random u8; no markers")
         del noise
     # other threshold windows on config 2's batch (src/aruco.rs:35,61: the reference's cost does not depend on the radius; here radii 1..7
@@ -1070,18 +1162,18 @@ def other_workloads(device, with_cpu=True, budget_s=60.0):
     d2 = ARDictionary.new_from_named_dict(name2)
     f2, t2 = synth.render_frames_device(spec2, d2.code_list, d2.num_bits, [synth.frame_seed(2, i) for i in range(256)], device=device)
     for wnd in (3, 11):
-        run(f"C2_threshold_window_{wnd}", f2, name2, cpu_frames=2, truths=t2, window=wnd,
+        run(f"C2_threshold_window_{wnd}", f2, name2, truths=t2, window=wnd,
             note=f"BASELINE config 2's frames with DetectorConfig.threshold_window = {wnd} ({2 * wnd + 1} x {2 * wnd + 1})")
     del f2
     spec4, name4 = synth.config_spec(4)
     d4 = ARDictionary.new_from_named_dict(name4)
     f4, t4 = synth.render_frames_device(spec4, d4.code_list, d4.num_bits, [synth.frame_seed(4, i) for i in range(32)], device=device)
-    run("C4_apriltag36h11_720p_noise", f4, name4, cpu_frames=4, truths=t4, note="BASELINE config 4")
+    run("C4_apriltag36h11_720p_noise", f4, name4, truths=t4, note="BASELINE config 4")
     del f4
     spec5, name5 = synth.config_spec(5)
     d5 = ARDictionary.new_from_named_dict(name5)
     f5, t5 = synth.render_frames_device(spec5, d5.code_list, d5.num_bits, [synth.frame_seed(5, i) for i in range(16)], device=device)
-    run("C5_4k_16_markers_detect_plus_pose", f5, name5, pose_mm=40.0, cpu_frames=2, truths=t5,
+    run("C5_4k_16_markers_detect_plus_pose", f5, name5, pose_mm=40.0, truths=t5,
         note="BASELINE config 5 on one GPU: detect + solve_with_undistorted_points of every marker in one call")
     del f5
     try:
