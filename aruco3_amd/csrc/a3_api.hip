@@ -54,7 +54,8 @@ size_t proj_rec_bytes();
 size_t weight_table_bytes();
 hipError_t launch_weight_table(hipStream_t, uint32_t, uint32_t, uint32_t, float*);
 hipError_t launch_decode(hipStream_t, PixelSrc, int, int, uint32_t, const uint16_t*, const uint32_t*, const unsigned int*, uint32_t,
-                         uint32_t, uint32_t, uint32_t, const uint64_t*, uint32_t, uint32_t, int, void*, const float*, void*, uint8_t*, uint32_t, uint32_t*, int, int, int);
+                         uint32_t, uint32_t, uint32_t, const uint64_t*, uint32_t, uint32_t, int, void*, const float*, void*, uint8_t*, uint32_t, uint32_t*, int, int, int,
+                         const uint32_t*, uint32_t, a3_marker*, uint32_t, unsigned int*, unsigned int*, const uint32_t*, unsigned int*, unsigned int*);
 hipError_t launch_compact_markers(hipStream_t, const void*, const uint16_t*, const uint32_t*, uint32_t, uint32_t, uint32_t, a3_marker*,
                                   uint32_t, uint32_t*, unsigned int*, unsigned int*, const uint32_t*, unsigned int*);
 hipError_t launch_pack_detections(hipStream_t, const a3_marker*, const a3_pose*, const uint32_t*, uint32_t, uint32_t, uint32_t, void*, unsigned int*);
@@ -419,13 +420,18 @@ int enqueue_back(a3_ctx* ctx, hipStream_t st, const BackArgs& b) {
     A3_HIP(launch_frame_candidates(st, ctx->cands.as<CandRec>(), ctx->cand_count, b.n, b.max_cand, b.min_corner_separation,
                                    ctx->pre_xy.as<uint16_t>(), ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(),
                                    ctx->work.as<uint32_t>(), d_work_count, b.S, ctx->proj.p));
+    // few frames (the one-frame call of the reference's callers, small batches): all four waves of a workgroup run the stages behind
+    // the sampling, and the launch's last workgroup gathers the markers itself (scratch word 5 is its ticket) -- a launch less
+    const int few = b.n <= 64u ? 1 : 0;
     A3_HIP(launch_decode(st, b.src, (int)b.W, (int)b.H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), d_work_count,
                          b.max_cand, b.S, ctx->mark_size, b.S, ctx->dict.as<uint64_t>(), ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors,
                          ctx->proj.p, ctx->wtab.as<float>(), ctx->outs.p, b.taps ? ctx->patches.as<uint8_t>() : nullptr, b.patch_cap, ctx->per_frame,
                          (int)std::min<uint32_t>(4096u, b.n * 128u) /* (grid-stride over the work list; 4096 workgroups that find nothing cost a one-frame call ~4 us) */, 0,
-                         b.n <= 64u ? 1 : 0));
-    A3_HIP(launch_compact_markers(st, ctx->outs.p, ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(), b.n, 0, b.max_cand,
-                                  ctx->markers_ptr, b.marker_cap, ctx->per_frame, d_marker_total, d_err, ctx->cand_count, ctx->scratch_u32 + 2));
+                         few, ctx->fin_count.as<uint32_t>(), b.n, ctx->markers_ptr, b.marker_cap, d_marker_total, d_err, ctx->cand_count, ctx->scratch_u32 + 2,
+                         ctx->scratch_u32 + 5));
+    if (!few)
+        A3_HIP(launch_compact_markers(st, ctx->outs.p, ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(), b.n, 0, b.max_cand,
+                                      ctx->markers_ptr, b.marker_cap, ctx->per_frame, d_marker_total, d_err, ctx->cand_count, ctx->scratch_u32 + 2));
     if (b.want_pose) {   // IPPE on the device-resident marker list (src/pose.rs:52-81), no extra round trip
         const a3_intrinsics& in = b.pose_intr;
         A3_HIP(launch_pose(st, reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(ctx->markers_ptr) + offsetof(a3_marker, corners)),
@@ -790,12 +796,17 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
         const int resolve_iters = ctx->resolve_full_ttl > 0 ? ctx->resolve_iters_hint : 0;
         const int inline_resolve_W = ctx->resolve_full_ttl > 0 ? 0 : (int)W;
         const int keep_all = ctx->debug_taps ? 1 : 0;
+        // Short borders are finished with inside k_local_contract (kDead) on DENSE graphs only -- noise-like frames, where nine borders
+        // in ten die of their length: there it saves a sixth of the contour stage; on clean frames (a dart per hundred pixels, a few
+        // dozen borders per frame) it would only cost its bookkeeping.  Results are the same either way.
+        const bool dense_graph = (uint64_t)nd * 10u >= (uint64_t)c.count * npx;
+        unsigned int* const dead_ctr = (keep_all || !dense_graph) ? nullptr : d_dead_count;
         const Chunk cc = c;
         // first half: the doubling rounds inside LDS tiles
         A3_HIP(launch_rank_cycles(st, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), ctx->stA.as<JumpState>(),
                                   ctx->entry_list.as<uint32_t>(), ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
                                   ctx->stA.as<JumpState>(), ctx->leader_list.as<uint32_t>(), d_leader_count, rounds, ctr, n_live, 0, fb,
-                                  frame_entries, cc.count, 1, min_edge_length, keep_all ? nullptr : d_dead_count));
+                                  frame_entries, cc.count, 1, min_edge_length, dead_ctr));
         if (rel_mode == 2) { if (int rc = release_waiting()) return rc; }   // waiting decode stages go out behind this k_local_contract
         ctx->dbg_nd = nd; ctx->dbg_frames = c.count; ctx->dbg_chunks = (uint32_t)chunks.size();
         // second half: entry resolution, final states (+ border selection), point scatter, quads -- on `s2`
@@ -803,7 +814,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
             A3_HIP(launch_rank_cycles(s2, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), ctx->stA.as<JumpState>(),
                                       ctx->entry_list.as<uint32_t>(), ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
                                       ctx->stA.as<JumpState>() /* final states in place */, ctx->leader_list.as<uint32_t>(), d_leader_count, rounds, ctr,
-                                      n_live, 0, fb, frame_entries, cc.count, 2, min_edge_length, keep_all ? nullptr : d_dead_count));
+                                      n_live, 0, fb, frame_entries, cc.count, 2, min_edge_length, dead_ctr));
             const JumpState* fin = ctx->stA.as<JumpState>();
             A3_HIP(launch_resolve(s2, fin, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->leader_list.as<uint32_t>(), d_leader_count,
                                   ctx->t_cur.as<uint64_t>(), ctx->t_next.as<uint64_t>(), ctr, resolve_iters, n_live));
@@ -1465,7 +1476,7 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
             A3_HIP(launch_decode(st, ctx->dbg_src, (int)ctx->W, (int)ctx->H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), ctx->scratch_u32,
                                  ctx->max_cand, ctx->cfg.homography_sample_size, ctx->mark_size, ctx->cfg.homography_sample_size, ctx->dict.as<uint64_t>(),
                                  ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors, ctx->proj.p, ctx->wtab.as<float>(), ctx->outs.p, nullptr, 0u, nullptr, 4096,
-                                 dbg == 0 ? -1000 : dbg, ctx->frames <= 64u ? 1 : 0));   // 0: k_projection + k_decode, < 0: k_decode alone (variant -dbg)
+                                 dbg == 0 ? -1000 : dbg, ctx->frames <= 64u ? 1 : 0, nullptr, 0u, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr));   // 0: k_projection + k_decode, < 0: k_decode alone (variant -dbg)
         } else return fail(ctx, A3_ERR_INVALID, "kernel: 0 dart_count, 1 dart_assign, 2 local_contract, 3 decode");
         A3_HIP(hipEventRecord(e1, st));
         A3_HIP(hipStreamSynchronize(st));

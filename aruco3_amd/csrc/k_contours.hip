@@ -470,8 +470,25 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
     // in the per-word arrays starts at zero.
     __shared__ uint32_t s_cnt[256];   // per word: darts (low 17 bits) | border pixels << 17
     const unsigned long long* tm = tile_mask + ((size_t)(first_frame + f) * gridDim.x + blockIdx.x) * kCountHalves;
-    static_assert(kCountHalves == 4, "four 64-bit word masks per tile");
-    const unsigned long long m0 = tm[0], m1 = tm[1], m2 = tm[2], m3 = tm[3];
+    static_assert(kCountHalves == 4 && kTileWords == 4 && kTileRows == 64, "four 64-bit word masks per tile, four word columns of 64 rows");
+    // Words are NUMBERED -- and with them the tile's darts -- column by column: w = jl * 64 + rl (word column jl = 64 pixels wide, row
+    // rl).  Consecutive darts then fill blocks about as tall as wide instead of strips 256 pixels wide and a few rows high, and
+    // k_local_contract's tiles of consecutive darts have less than half the rim: fewer windows that freeze, fewer entries for the
+    // global rounds, more short borders that close (and are finished with) inside a tile.  Matters on dense graphs only (noise-like
+    // frames: 16 k darts per tile); a clean frame's tile holds a few hundred darts.  k_dart_count's masks are row-major (bit
+    // r * 4 + jl of part p = word jl of row 16 p + r): every fourth bit of the four parts, compressed, is a column's 64 rows.
+    auto every_fourth = [](unsigned long long x) -> unsigned long long {   // bits 0, 4, 8 ... 60 -> bits 0 .. 15
+        x &= 0x1111111111111111ull;
+        x = (x | (x >> 3)) & 0x0303030303030303ull;
+        x = (x | (x >> 6)) & 0x000F000F000F000Full;
+        x = (x | (x >> 12)) & 0x000000FF000000FFull;
+        return (x | (x >> 24)) & 0xFFFFull;
+    };
+    unsigned long long cm[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        cm[c] = every_fourth(tm[0] >> c) | (every_fourth(tm[1] >> c) << 16) | (every_fourth(tm[2] >> c) << 32) | (every_fourth(tm[3] >> c) << 48);
+    const unsigned long long m0 = cm[0], m1 = cm[1], m2 = cm[2], m3 = cm[3];
     tile_stage(bits + (size_t)(first_frame + f) * wpr * H, W, H, s_t);
     s_nodes[threadIdx.x] = 0; s_c0[threadIdx.x] = 0; s_c1[threadIdx.x] = 0; s_c2[threadIdx.x] = 0; s_cnt[threadIdx.x] = 0;
     s_mark[threadIdx.x] = 0; s_mark[256 + threadIdx.x] = 0;
@@ -480,8 +497,8 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
     for (uint32_t k = threadIdx.x; k < n_act; k += 256) {
         const uint32_t part = (k >= a0) + (k >= a1) + (k >= a2);
         const unsigned long long mm = part == 0 ? m0 : (part == 1 ? m1 : (part == 2 ? m2 : m3));
-        const uint32_t w = part * 64u + (uint32_t)select_bit(mm, k - (part == 0 ? 0u : (part == 1 ? a0 : (part == 2 ? a1 : a2))));
-        const Nb8 nb = tile_nb8(s_t, (int)(w >> 2), (int)(w & (kTileWords - 1)));
+        const uint32_t w = part * 64u + (uint32_t)select_bit(mm, k - (part == 0 ? 0u : (part == 1 ? a0 : (part == 2 ? a1 : a2))));   // (part = word column)
+        const Nb8 nb = tile_nb8(s_t, (int)(w & 63u), (int)(w >> 6));
         uint64_t p[8];
         pdart_words(nb, p);
         uint64_t nodes = 0;
@@ -529,7 +546,7 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
         const uint32_t w = s_wofrank[kr], r = n - (uint32_t)s_nbk[kr];
         const uint64_t m = s_nodes[w];
         const int i = select_bit(m, r);
-        const int jl = w & (kTileWords - 1), rl = w >> 2;
+        const int jl = w >> 6, rl = w & 63;
         const int wj = tx * kTileWords + jl, wy = ty * kTileRows + rl;
         const uint32_t F = tile_F(s_t, rl, jl, i);
         uint32_t P = pdart_mask(F);
@@ -560,7 +577,7 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
             const int lx = jl * 64 + i + dir_dx(ko), ly = rl + dir_dy(ko);
             uint32_t succ;
             if (lx >= 0 && lx < kTileWords * 64 && ly >= 0 && ly < kTileRows) {
-                const int j2 = lx >> 6, i2 = lx & 63, w2 = ly * kTileWords + j2;
+                const int j2 = lx >> 6, i2 = lx & 63, w2 = j2 * kTileRows + ly;
                 const uint32_t P2 = pdart_mask(tile_F(s_t, ly, j2, i2));
                 succ = cur;   // chain end unless the target dart exists
                 if ((P2 >> kin) & 1u) {
@@ -665,7 +682,10 @@ __global__ __launch_bounds__(256) void k_dart_link(int W, int H, uint32_t first_
 // costs the reference's noise recipe 19 %), 1024 with the per-frame entry resolution of clean frames, where the entries are
 // cheap and the smaller tile saves a doubling round and half of the LDS per workgroup (72 -> 60 us on BASELINE config 2;
 // 512: 68 us, 4096: 103 us).
-constexpr int kLT = 2048;                     // the larger of the two: sizes the entry slot space of the global rounds
+#ifndef A3_KLT
+#define A3_KLT 2048
+#endif
+constexpr int kLT = A3_KLT;                   // the larger of the two: sizes the entry slot space of the global rounds
 constexpr int kLTFrame = 1024;
 // Entry slots are handed out from 16 counters (one same-address atomic costs ~11 ns and they serialise): tile t uses
 // shard t & 15, whose slots are [shard * cap, shard * cap + count[shard]); a tile holds at most kLT entries, so
@@ -751,7 +771,7 @@ __global__ __launch_bounds__(256, LT >= 2048 ? 4 : 8) void k_local_contract(uint
     constexpr uint32_t kFrameWin = 64;               // frames a tile may span with block-aggregated counting (beyond: direct atomics)
     __shared__ uint32_t s_fcnt[kFrameWin], s_fbase[kFrameWin];
     __shared__ uint32_t s_new_count, s_new_base, s_f0, s_dead_n;
-    __shared__ uint8_t s_dead[LT];                   // per dart of the tile: it LEADS a dead cycle
+    __shared__ __attribute__((aligned(4))) uint8_t s_dead[LT];   // per dart of the tile: it LEADS a dead cycle
     if (n_live) n_darts = min(n_darts, *n_live);
     const uint32_t lo = blockIdx.x * LT;
     if (lo >= n_darts) return;   // the grid covers the pool's capacity, the graph may be smaller
@@ -762,6 +782,7 @@ __global__ __launch_bounds__(256, LT >= 2048 ? 4 : 8) void k_local_contract(uint
     uint64_t nk[PER]; uint32_t np[PER], no[PER], nd[PER], succ0[PER], frm[PER];
     if (threadIdx.x == 0) { s_new_count = 0; s_dead_n = 0; }
     if (threadIdx.x < kFrameWin) s_fcnt[threadIdx.x] = 0;
+    if (dead_count) { for (uint32_t i4 = threadIdx.x; i4 < LT / 4; i4 += 256) reinterpret_cast<uint32_t*>(s_dead)[i4] = 0u; }
     uint32_t sfire = 0;                              // bit u: the start event of my dart u fires unconditionally (static_fire)
     // all 16 loads of a lane are issued before the first is used: unconditional, from a clamped index (behind an `if (i < cnt)`
     // the compiler issues them one at a time, each with its own wait: 16 round trips to memory instead of one)
@@ -781,8 +802,8 @@ __global__ __launch_bounds__(256, LT >= 2048 ? 4 : 8) void k_local_contract(uint
         const uint32_t ek = (info & kInfoW) ? 2u * q : ((info & kInfoE) ? 2u * q + 1u : kNoKey);
         frm[u] = rec_frame(rec);   // kept, like succ0, for the entry registration (no second read)
         nk[u] = ((uint64_t)ek << 32) | (lo + i); np[u] = succ0[u]; no[u] = 0; nd[u] = 1;
-        if (i < cnt) { s_win[i] = Win{nk[u], np[u], 1u << 16}; s_dead[i] = 0; }
-        if (ek != kNoKey && static_fire(rec)) sfire |= 1u << u;
+        if (i < cnt) s_win[i] = Win{nk[u], np[u], 1u << 16};
+        if (dead_count && ek != kNoKey && static_fire(rec)) sfire |= 1u << u;
     }
     if (threadIdx.x == 0) s_f0 = frm[0];   // darts are frame-major: the tile's frames are f0, f0+1, ...
     lds_barrier();
@@ -873,7 +894,7 @@ __global__ __launch_bounds__(256, LT >= 2048 ? 4 : 8) void k_local_contract(uint
             const Win ws = s_win[sl];
             if ((uint32_t)ws.key != lo + i) continue;                                  // the successor's window did not wrap to this leader
             const uint32_t n = (ws.offdist & 0xFFFFu) + 1u;                            // border length in points
-            if (n >= 5u && (uint64_t)n * n >= 2ull * min_edge_length) continue;        // k_cycle_select's parity-safe test (the diagonal bound cannot bind in a tile)
+            if (n >= 5u && (uint64_t)n * n >= 8ull * min_edge_length) continue;        // k_cycle_select's parity-safe test (the diagonal bound cannot bind in a tile)
             s_dead[i] = 1; my_dead++;
         }
         if (my_dead) atomicAdd(&s_dead_n, my_dead);
@@ -1276,13 +1297,16 @@ __global__ __launch_bounds__(256) void k_cycle_select(JumpState* st, const uint3
         if (sl == e.d || (uint32_t)st[sl].key != e.d) { e.broken = true; return e; }
         e.n = fin_off(st[sl].off) + 1u;
         // Parity-safe pruning (src/aruco.rs:133-158):
-        //  (1) a candidate keeps 4 points whose hull-adjacent pairs are >= sqrt(min_edge_length) apart; two
-        //      border points i < j are at most min(j-i, n-(j-i)) 8-connected steps apart, i.e.
-        //      dist^2 <= 2*(n/2)^2, so n^2 >= 2*min_edge_length is necessary;
+        //  (1) a candidate keeps 4 border points in convex position whose hull edges are all >= sqrt(min_edge_length) long
+        //      (src/aruco.rs:149-159).  The closed border visits the four in some order; between two of them it needs at least
+        //      their Chebyshev distance >= Euclidean distance / sqrt(2) steps (consecutive border points are 8-neighbours), and no
+        //      closed tour through four points in convex position is shorter than their hull's perimeter.  So
+        //      n >= 4 sqrt(min_edge_length) / sqrt(2), i.e. n^2 >= 8 min_edge_length is necessary (round 4 used the bound of ONE
+        //      edge, n^2 >= 2 min_edge_length: on noise-like frames the tighter one materialises a third as many borders);
         //  (2) Douglas-Peucker splits only when a point is further than eps = eps_factor*n from a chord,
         //      and no two pixels are further apart than the image diagonal (+1 slack for rounding).
         const double eps = (double)e.n * eps_factor;
-        e.keep = keep_all || (e.n >= 5u && (uint64_t)e.n * e.n >= 2ull * min_edge_length && eps < image_diag + 1.0);
+        e.keep = keep_all || (e.n >= 5u && (uint64_t)e.n * e.n >= 8ull * min_edge_length && eps < image_diag + 1.0);
         return e;
     };
 
@@ -1390,7 +1414,7 @@ __global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restr
 #pragma unroll
         for (int u = 0; u < B; u++) {
             const uint32_t d = min(d0 + (uint32_t)u * stride, n_darts - 1u);
-            s[u] = st[d]; rec[u] = d_rec[d];
+            s[u] = st[d];
         }
 #pragma unroll
         for (int u = 0; u < B; u++) {
@@ -1399,6 +1423,9 @@ __global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restr
             const uint32_t leader = live[u] ? (uint32_t)s[u].key : 0u;
             ls[u] = st[leader];    // key: is the leader's window intact; ptr: its border slot (k_cycle_select)
             c[u] = ls[u].ptr;
+            // the dart's record travels with the second round of loads, and only for darts that may be written out (on noise-like
+            // frames nine darts in ten are not: a third of the kernel's bytes)
+            rec[u] = live[u] ? d_rec[min(d0 + (uint32_t)u * stride, n_darts - 1u)] : 0ull;
         }
 #pragma unroll
         for (int u = 0; u < B; u++) {

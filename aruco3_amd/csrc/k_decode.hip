@@ -494,6 +494,59 @@ __device__ __forceinline__ void wave_best_var_to63(double& var, int& best_t) {
 #undef A3_S
 }
 
+// gather the accepted markers of frame f, candidate order preserved, by ONE WAVE (per_frame[] holds the number of accepted candidates
+// of every frame: k_decode counted them; a frame's first output slot is the sum over the frames before it)
+struct CompactArgs {
+    const uint32_t* fin_count; uint32_t n_frames; a3_marker* markers; uint32_t marker_cap; unsigned int* marker_total;
+    unsigned int* err_flags; const uint32_t* cand_count; unsigned int* cand_pre_total;
+    unsigned int* ticket;   // != nullptr: the last workgroup of k_decode's launch does the compaction (small batches: a launch less)
+};
+__device__ __forceinline__ void compact_frame_wave(uint32_t f, int lane, const DecodeOut* __restrict__ outs, const uint16_t* __restrict__ fin_xy,
+                                                   const uint32_t* __restrict__ fin_count, uint32_t n_frames, uint32_t max_cand,
+                                                   a3_marker* __restrict__ markers, uint32_t marker_cap, const uint32_t* __restrict__ per_frame,
+                                                   unsigned int* __restrict__ marker_total, unsigned int* __restrict__ err_flags,
+                                                   const uint32_t* __restrict__ cand_count, unsigned int* __restrict__ cand_pre_total) {
+    uint32_t base = 0;
+    for (uint32_t g = lane; g < f; g += 64) base += per_frame[g];
+    for (int o = 32; o > 0; o >>= 1) base += __shfl_xor(base, o);
+    if (f + 1 == n_frames && lane == 0) *marker_total = base + per_frame[f];
+    if (f + 1 == n_frames) {   // a3_stats.candidates_pre: quads after contours_to_candidates, summed over the batch
+        uint32_t pre = 0;
+        for (uint32_t g = lane; g < n_frames; g += 64) pre += min(cand_count[g], max_cand);
+        for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o);
+        if (lane == 0) *cand_pre_total = pre;
+    }
+    const uint32_t c = fin_count[f];
+    uint32_t pos = base;
+    for (uint32_t k0 = 0; k0 < c; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        DecodeOut o;
+        o.valid = 0;
+        if (k < c) o = outs[(size_t)f * max_cand + k];
+        const unsigned long long m = __ballot(o.valid != 0);
+        if (o.valid) {
+            const uint32_t p = pos + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (p < marker_cap) {
+                a3_marker mk;
+                mk.frame = f;
+                mk.id = o.id;
+                mk.code = o.code;
+                const uint16_t* q = fin_xy + ((size_t)f * max_cand + k) * 8;
+                for (int i = 0; i < 4; i++) {  // corners.rotate_left(min_rotation), src/aruco.rs:103
+                    const int s2 = (i + o.rotation) & 3;
+                    mk.corners[2 * i] = q[2 * s2];
+                    mk.corners[2 * i + 1] = q[2 * s2 + 1];
+                }
+                mk.hamming_distance = o.hamming;
+                mk.rotation = o.rotation;
+                mk.candidate_index = (uint16_t)k;
+                markers[p] = mk;
+            } else atomicOr(err_flags, kErrMarkerCap);
+        }
+        pos += (uint32_t)__popcll(m);
+    }
+}
+
 // NT threads sample one candidate, PT of them (64, or all) run the stages after the sampling.  History of the shape, on the
 // 2.5 k candidates of BASELINE config 2 (tools/tune_decode.sh): 256 threads throughout, 4 samples "in flight" per lane, row-major
 // sample order (round 1): 116 us; 64 threads, 8 x 8 blocked order: 98 us; 256 threads sampling, the first wave doing the rest:
@@ -504,7 +557,8 @@ __global__ __launch_bounds__(NT, NT == 64 ? A3_D_WAVES : A3_D_WAVES256) void k_d
                                                 const unsigned int* __restrict__ work_count, uint32_t max_cand, uint32_t S, uint32_t n,
                                                 uint32_t max_taps, const uint64_t* __restrict__ dict, uint32_t n_codes, uint32_t tau,
                                                 int filter, const ProjRec* __restrict__ proj, const float* __restrict__ wtab, DecodeOut* __restrict__ outs,
-                                                uint8_t* __restrict__ patches /*nullable*/, uint32_t patch_cap, uint32_t* __restrict__ per_frame /*nullable*/, int dbg) {
+                                                uint8_t* __restrict__ patches /*nullable*/, uint32_t patch_cap, uint32_t* __restrict__ per_frame /*nullable*/, int dbg,
+                                                CompactArgs ca) {
     // dbg (a3_debug_kernel_time only, 0 in the product path): 1 = no sampling, 2 / 3 / 4 = stop after sampling / Otsu / bits
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* s_patch = smem;
@@ -807,6 +861,22 @@ __global__ __launch_bounds__(NT, NT == 64 ? A3_D_WAVES : A3_D_WAVES256) void k_d
         }
 #undef POST_SYNC
     }
+    // Small batches (the one-frame call of the reference's own callers): the LAST workgroup of the launch to get here gathers the
+    // markers, one wave per frame in turn -- what k_compact_markers_par's launch would do ~5 us later.  Every workgroup's results
+    // are published (fence) before it takes its ticket; the last one sees them all.
+    if (ca.ticket) {
+        __shared__ uint32_t s_last;
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) s_last = atomicAdd(ca.ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+        __syncthreads();
+        if (s_last) {
+            __threadfence();
+            for (uint32_t f = (uint32_t)tid >> 6; f < ca.n_frames; f += NT / 64)
+                compact_frame_wave(f, tid & 63, outs, fin_xy, ca.fin_count, ca.n_frames, max_cand, ca.markers, ca.marker_cap, per_frame, ca.marker_total,
+                                   ca.err_flags, ca.cand_count, ca.cand_pre_total);
+        }
+    }
 }
 
 // gather the accepted markers, frame by frame, candidate order preserved: one wave per frame.  per_frame[] already holds
@@ -820,48 +890,10 @@ __global__ __launch_bounds__(256) void k_compact_markers_par(const DecodeOut* __
                                                              const uint32_t* __restrict__ per_frame, unsigned int* __restrict__ marker_total,
                                                              unsigned int* __restrict__ err_flags, const uint32_t* __restrict__ cand_count,
                                                              unsigned int* __restrict__ cand_pre_total) {
-    const int lane = threadIdx.x & 63;
     const uint32_t f = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (f >= n_frames) return;
-    uint32_t base = 0;
-    for (uint32_t g = lane; g < f; g += 64) base += per_frame[g];
-    for (int o = 32; o > 0; o >>= 1) base += __shfl_xor(base, o);
-    if (f + 1 == n_frames && lane == 0) *marker_total = base + per_frame[f];
-    if (f + 1 == n_frames) {   // a3_stats.candidates_pre: quads after contours_to_candidates, summed over the batch
-        uint32_t pre = 0;
-        for (uint32_t g = lane; g < n_frames; g += 64) pre += min(cand_count[g], max_cand);
-        for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o);
-        if (lane == 0) *cand_pre_total = pre;
-    }
-    const uint32_t c = fin_count[f];
-    uint32_t pos = base;
-    for (uint32_t k0 = 0; k0 < c; k0 += 64) {
-        const uint32_t k = k0 + lane;
-        DecodeOut o;
-        o.valid = 0;
-        if (k < c) o = outs[(size_t)f * max_cand + k];
-        const unsigned long long m = __ballot(o.valid != 0);
-        if (o.valid) {
-            const uint32_t p = pos + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (p < marker_cap) {
-                a3_marker mk;
-                mk.frame = f;
-                mk.id = o.id;
-                mk.code = o.code;
-                const uint16_t* q = fin_xy + ((size_t)f * max_cand + k) * 8;
-                for (int i = 0; i < 4; i++) {  // corners.rotate_left(min_rotation), src/aruco.rs:103
-                    const int s2 = (i + o.rotation) & 3;
-                    mk.corners[2 * i] = q[2 * s2];
-                    mk.corners[2 * i + 1] = q[2 * s2 + 1];
-                }
-                mk.hamming_distance = o.hamming;
-                mk.rotation = o.rotation;
-                mk.candidate_index = (uint16_t)k;
-                markers[p] = mk;
-            } else atomicOr(err_flags, kErrMarkerCap);
-        }
-        pos += (uint32_t)__popcll(m);
-    }
+    compact_frame_wave(f, threadIdx.x & 63, outs, fin_xy, fin_count, n_frames, max_cand, markers, marker_cap, per_frame, marker_total, err_flags, cand_count,
+                       cand_pre_total);
 }
 
 // The same with one workgroup and no pre-computed counts (any number of frames).
@@ -1222,8 +1254,12 @@ hipError_t launch_weight_table(hipStream_t st, uint32_t S, uint32_t n, uint32_t 
 
 hipError_t launch_decode(hipStream_t st, PixelSrc src, int W, int H, uint32_t first_frame, const uint16_t* fin_xy, const uint32_t* work,
                          const unsigned int* work_count, uint32_t max_cand, uint32_t S, uint32_t n, uint32_t max_taps, const uint64_t* dict,
-                         uint32_t n_codes, uint32_t tau, int filter, void* proj, const float* wtab, void* outs, uint8_t* patches, uint32_t patch_cap, uint32_t* per_frame, int grid_blocks, int dbg, int few) {
+                         uint32_t n_codes, uint32_t tau, int filter, void* proj, const float* wtab, void* outs, uint8_t* patches, uint32_t patch_cap, uint32_t* per_frame, int grid_blocks, int dbg, int few,
+                         const uint32_t* fin_count, uint32_t n_frames, a3_marker* markers, uint32_t marker_cap, unsigned int* marker_total, unsigned int* err_flags,
+                         const uint32_t* cand_count, unsigned int* cand_pre_total, unsigned int* ticket /* nullptr: the caller launches the compaction itself */) {
     ProjRec* recs = reinterpret_cast<ProjRec*>(proj);
+    const CompactArgs ca{fin_count, n_frames, markers, marker_cap, marker_total, err_flags, cand_count, cand_pre_total, few ? ticket : nullptr};
+    const CompactArgs none{nullptr, 0u, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (dbg > 0 || dbg == -1000) hipLaunchKernelGGL(k_projection, dim3(256), dim3(64), 0, st, fin_xy, work, work_count, S, recs);
     // Four waves sample a candidate: a candidate is a chain of round trips to the frame (19 of them for one wave: 65 us for a lone
     // candidate however idle the chip is, 33 us with four waves).  What follows the sampling runs on all four waves when the
@@ -1234,11 +1270,11 @@ hipError_t launch_decode(hipStream_t st, PixelSrc src, int W, int H, uint32_t fi
     few = tuning_knob("A3_DECODE_WIDE", few);   // (-DA3_TUNING builds only)
     if (few)
         hipLaunchKernelGGL((k_decode<256, 256>), dim3(grid_blocks), dim3(256), decode_lds_bytes(S, n, max_taps), st, src, W, H, first_frame, fin_xy, work, work_count,
-                           max_cand, S, n, max_taps, dict, n_codes, tau, filter, recs, wtab, reinterpret_cast<DecodeOut*>(outs), patches, patch_cap, per_frame, d);
+                           max_cand, S, n, max_taps, dict, n_codes, tau, filter, recs, wtab, reinterpret_cast<DecodeOut*>(outs), patches, patch_cap, per_frame, d, ca);
     else
         hipLaunchKernelGGL((k_decode<A3_D_THREADS, 64>), dim3(grid_blocks), dim3(A3_D_THREADS), decode_lds_bytes(S, n, max_taps), st, src, W, H, first_frame, fin_xy, work,
                            work_count, max_cand, S, n, max_taps, dict, n_codes, tau, filter, recs, wtab, reinterpret_cast<DecodeOut*>(outs), patches, patch_cap,
-                           per_frame, d);
+                           per_frame, d, none);
     return hipGetLastError();
 }
 

@@ -20,13 +20,12 @@ for part in $PARTS; do
   echo "== $part"
   case $part in
   bench)
-    timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 --frames-cache /tmp/c2frames > "$OUT/bench.json.log" 2> "$OUT/bench.err" || { tail -5 "$OUT/bench.err"; exit 1; }
+    timeout -k 10 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench.json.log" 2> "$OUT/bench.err" || { tail -5 "$OUT/bench.err"; exit 1; }
     python3 tools/show_bench.py "$OUT/bench.json.log" ;;
   stats)
-    [ -f /tmp/c2frames.c2.n256.r0.npz ] || timeout -k 10 300 python3 bench.py --steps 2 --warmup 1 --repeats 1 --frames-cache /tmp/c2frames --no-cpu-baseline --no-other-workloads > /dev/null 2>&1
     cd /tmp
-    timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o isolated -- python3 "$ROOT/bench.py" --gpus 1 --steps 20 --warmup 5 --no-pipeline --frames-cache /tmp/c2frames --no-cpu-baseline --no-other-workloads > "$OUT/isolated.log" 2>&1 || { tail -5 "$OUT/isolated.log"; exit 2; }
-    timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o overlapped -- python3 "$ROOT/bench.py" --gpus 1 --steps 20 --warmup 5 --frames-cache /tmp/c2frames --no-cpu-baseline --no-other-workloads > "$OUT/overlapped.log" 2>&1 || { tail -5 "$OUT/overlapped.log"; exit 2; }
+    timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o isolated -- python3 "$ROOT/bench.py" --gpus 1 --steps 20 --warmup 5 --no-pipeline --device-synth --min-timed-s 1.0 --no-cpu-baseline --no-other-workloads > "$OUT/isolated.log" 2>&1 || { tail -5 "$OUT/isolated.log"; exit 2; }
+    timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o overlapped -- python3 "$ROOT/bench.py" --gpus 1 --steps 20 --warmup 5 --device-synth --min-timed-s 1.0 --no-cpu-baseline --no-other-workloads > "$OUT/overlapped.log" 2>&1 || { tail -5 "$OUT/overlapped.log"; exit 2; }
     cd "$ROOT"
     for f in isolated overlapped; do grep '^{' "$OUT/$f.log" | tail -1 > "$OUT/$f.json.log"; python3 tools/show_bench.py "$OUT/$f.json.log" | head -2; done ;;
   pmc)
@@ -37,7 +36,7 @@ for part in $PARTS; do
     for b in readbench scatterbench valubench; do [ -x tools/micro/$b ] && timeout -k 5 200 ./tools/micro/$b > "$OUT/$b.txt" 2>&1; done
     timeout -k 10 200 python3 tools/k1_concurrency.py 256 10 2>&1 | grep -v amdgpu.ids > "$OUT/k1_concurrency.txt"; cat "$OUT/k1_concurrency.txt" ;;
   step)
-    timeout -k 10 400 python3 tools/ab_streams.py 256 48 5 shared:2:2:2,own:2:2:0,own:4:2:0,own:4:2:0:4,own:4:2:0:-1:0,own:4:2:0:-1:1,own:3:2:0:-1:1,own:5:2:0:-1:1 2>&1 | grep -v amdgpu.ids > "$OUT/ab_streams.txt"; cut -c1-120 "$OUT/ab_streams.txt"
+    timeout -k 10 400 python3 tools/ab_streams.py 256 48 5 shared:2:2:-1,own:2:2:-1,own:4:2:-1,own:4:2:-1:-1,own:4:2:-1:-1:0,own:4:2:2:-1,own:4:2:-1:4,own:3:2:-1:-1,own:5:2:-1:-1,own:4:2:-1:-1:1:same=1 2>&1 | grep -v amdgpu.ids > "$OUT/ab_streams.txt"; cut -c1-120 "$OUT/ab_streams.txt"
     timeout -k 10 600 python3 tools/spin_probe.py 256 40 2>&1 | grep -v amdgpu.ids > "$OUT/spin_probe.txt"; cut -c1-150 "$OUT/spin_probe.txt" ;;
   dist)
     timeout -k 10 400 python3 bench.py --gpus 2 --steps 20 --warmup 5 --backend gloo --device-synth --no-cpu-baseline > "$OUT/rehearsal_n2_gloo.log" 2> "$OUT/rehearsal_n2_gloo.err" || echo "c2 rehearsal failed"
