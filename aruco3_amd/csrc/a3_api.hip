@@ -420,16 +420,19 @@ int enqueue_back(a3_ctx* ctx, hipStream_t st, const BackArgs& b) {
     A3_HIP(launch_frame_candidates(st, ctx->cands.as<CandRec>(), ctx->cand_count, b.n, b.max_cand, b.min_corner_separation,
                                    ctx->pre_xy.as<uint16_t>(), ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(),
                                    ctx->work.as<uint32_t>(), d_work_count, b.S, ctx->proj.p));
-    // few frames (the one-frame call of the reference's callers, small batches): all four waves of a workgroup run the stages behind
-    // the sampling, and the launch's last workgroup gathers the markers itself (scratch word 5 is its ticket) -- a launch less
+    // few frames (small batches): all four waves of a workgroup run the stages behind the sampling.  One or two frames per call (the
+    // reference's own call shape, src/aruco.rs:52): the launch's last workgroup also gathers the markers (scratch word 5 is its
+    // ticket) -- a launch less.  Only there: every workgroup publishes its results with a fence and takes a ticket, and 4096 of those
+    // on one address cost a 32-frame batch 0.35 ms where the extra launch costs 5 us.
     const int few = b.n <= 64u ? 1 : 0;
+    const bool fused_compact = b.n <= 2u;
     A3_HIP(launch_decode(st, b.src, (int)b.W, (int)b.H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), d_work_count,
                          b.max_cand, b.S, ctx->mark_size, b.S, ctx->dict.as<uint64_t>(), ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors,
                          ctx->proj.p, ctx->wtab.as<float>(), ctx->outs.p, b.taps ? ctx->patches.as<uint8_t>() : nullptr, b.patch_cap, ctx->per_frame,
                          (int)std::min<uint32_t>(4096u, b.n * 128u) /* (grid-stride over the work list; 4096 workgroups that find nothing cost a one-frame call ~4 us) */, 0,
                          few, ctx->fin_count.as<uint32_t>(), b.n, ctx->markers_ptr, b.marker_cap, d_marker_total, d_err, ctx->cand_count, ctx->scratch_u32 + 2,
-                         ctx->scratch_u32 + 5));
-    if (!few)
+                         fused_compact ? ctx->scratch_u32 + 5 : nullptr));
+    if (!fused_compact)
         A3_HIP(launch_compact_markers(st, ctx->outs.p, ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(), b.n, 0, b.max_cand,
                                       ctx->markers_ptr, b.marker_cap, ctx->per_frame, d_marker_total, d_err, ctx->cand_count, ctx->scratch_u32 + 2));
     if (b.want_pose) {   // IPPE on the device-resident marker list (src/pose.rs:52-81), no extra round trip

@@ -177,7 +177,8 @@ template <int G>
 __global__ __launch_bounds__(64) void k_dart_count(const uint64_t* __restrict__ bits, int W, int H, uint32_t first_frame,
                                                    unsigned long long* __restrict__ frame_darts, uint32_t* __restrict__ tile_darts,
                                                    uint32_t* __restrict__ tile_darts_h1, unsigned long long* __restrict__ tile_mask) {
-    // tile_mask[(frame * tiles + tile) * kCountHalves + part]: bit r * 4 + jl = word jl of row r of this part owns darts.  A part
+    // tile_mask[(frame * tiles + tile) * kCountHalves + part]: bit jl * 16 + r = word jl of row r of this part owns darts (column by
+    // column: k_dart_assign numbers a tile's words, and with them its darts, in that order).  A part
     // is 16 rows x 4 words = the 64 words that one wave of k_dart_assign's phase 1 would look at: the mask lets that kernel
     // hand only the words that own darts to its lanes.
     static_assert(kCountLanes % kTileWords == 0, "a wave counts whole tiles");
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(64) void k_dart_count(const uint64_t* __restrict__ 
             const uint32_t src = (m >> 8) & 63u, r = (m >> 16) & 15u, sgl = src & (G - 1), sgrp = src / G;
             const uint32_t tile = (sgl - 1u) / kTileWords, jl = (sgl - 1u) & (kTileWords - 1);
             atomicAdd(&s_tile[sgrp][tile], ndw);
-            atomicOr(&s_mask[sgrp][tile], 1ull << (4u * r + jl));
+            atomicOr(&s_mask[sgrp][tile], 1ull << (16u * jl + r));
         }
     };
     auto wave_sync = []() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
@@ -475,19 +476,12 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
     // rl).  Consecutive darts then fill blocks about as tall as wide instead of strips 256 pixels wide and a few rows high, and
     // k_local_contract's tiles of consecutive darts have less than half the rim: fewer windows that freeze, fewer entries for the
     // global rounds, more short borders that close (and are finished with) inside a tile.  Matters on dense graphs only (noise-like
-    // frames: 16 k darts per tile); a clean frame's tile holds a few hundred darts.  k_dart_count's masks are row-major (bit
-    // r * 4 + jl of part p = word jl of row 16 p + r): every fourth bit of the four parts, compressed, is a column's 64 rows.
-    auto every_fourth = [](unsigned long long x) -> unsigned long long {   // bits 0, 4, 8 ... 60 -> bits 0 .. 15
-        x &= 0x1111111111111111ull;
-        x = (x | (x >> 3)) & 0x0303030303030303ull;
-        x = (x | (x >> 6)) & 0x000F000F000F000Full;
-        x = (x | (x >> 12)) & 0x000000FF000000FFull;
-        return (x | (x >> 24)) & 0xFFFFull;
-    };
+    // frames: 16 k darts per tile); a clean frame's tile holds a few hundred darts.  k_dart_count's masks come column by column (bit
+    // jl * 16 + r of part p = word jl of row 16 p + r): a column's 64 rows are 16 bits of each of the four parts.
     unsigned long long cm[4];
 #pragma unroll
     for (int c = 0; c < 4; c++)
-        cm[c] = every_fourth(tm[0] >> c) | (every_fourth(tm[1] >> c) << 16) | (every_fourth(tm[2] >> c) << 32) | (every_fourth(tm[3] >> c) << 48);
+        cm[c] = ((tm[0] >> (16 * c)) & 0xFFFFull) | (((tm[1] >> (16 * c)) & 0xFFFFull) << 16) | (((tm[2] >> (16 * c)) & 0xFFFFull) << 32) | (((tm[3] >> (16 * c)) & 0xFFFFull) << 48);
     const unsigned long long m0 = cm[0], m1 = cm[1], m2 = cm[2], m3 = cm[3];
     tile_stage(bits + (size_t)(first_frame + f) * wpr * H, W, H, s_t);
     s_nodes[threadIdx.x] = 0; s_c0[threadIdx.x] = 0; s_c1[threadIdx.x] = 0; s_c2[threadIdx.x] = 0; s_cnt[threadIdx.x] = 0;
@@ -849,16 +843,24 @@ __global__ __launch_bounds__(256, LT >= 2048 ? 4 : 8) void k_local_contract(uint
     // was tried: most windows of a clean frame only become final in the last rounds, and the extra flags made it 20 % slower.)
     constexpr int kLocalRounds = LT == 4096 ? 12 : (LT == 2048 ? 11 : (LT == 1024 ? 10 : 9));   // 2^rounds >= LT
     const int n_rounds = dbg == 0 ? kLocalRounds : (dbg < 0 ? 0 : dbg);
+    // Dense graphs (the global-rounds path: noise-like frames): most cycles are a handful of darts long and complete after three or
+    // four rounds.  A window that meets its own minimum again in the window it is joined with has wrapped its cycle (keys are
+    // unique: the same dart at two positions of the walk) -- its key and offset are final, it takes no further part (`done`), and
+    // a window that later joins it becomes complete in turn.  On clean frames most windows only complete in the last rounds and
+    // the test buys nothing (round 3: -20 %), so it is made on the dense path only.
+    const bool early = frame_entries == nullptr;
+    uint32_t done = 0;
     for (int round = 0; round < n_rounds; round++) {
         uint32_t upd = 0;   // bit u: window u was joined with its successor window in this round (a frozen one is not: its
                             // LDS copy stays as it is and need not be written again)
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             const uint32_t i = threadIdx.x + u * 256;
-            if (i < cnt) {
+            if (i < cnt && !((done >> u) & 1u)) {
                 const uint32_t t = np[u] - lo;          // unsigned: also catches ptr < lo
                 if (t < cnt) {
                     const Win w = s_win[t];
+                    if (early && w.key == nk[u]) done |= 1u << u;
                     if (w.key < nk[u]) { nk[u] = w.key; no[u] = nd[u] + (w.offdist & 0xFFFFu); }
                     nd[u] += w.offdist >> 16;
                     np[u] = w.ptr;
