@@ -1475,12 +1475,18 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
                                       ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p, ctx->stB.as<JumpState>(),
                                       ctx->leader_list.as<uint32_t>(), d_leader_count, 0, ctx->counters, nullptr, dbg ? dbg : 11, ctx->frame_base.as<uint32_t>(), nullptr, ctx->dbg_frames, 0,
                                       0u, nullptr));
-        } else if (kernel == 3) {   // dbg < 0: k_decode alone (variant -dbg), dbg >= 0: k_projection + k_decode
+        } else if (kernel == 3 || kernel == 4) {   // dbg < 0: k_decode alone (variant -dbg; -5: the whole kernel), dbg >= 0: k_projection + k_decode
+            if (kernel == 4) {   // COLD frames, as the pipeline meets them (1.6 GB went through the threshold kernel, the contour stage's buffers since):
+                                 // half a gigabyte of the pixel-base plane is overwritten first (garbage after a batch anyway), outside the timed span
+                const size_t sweep = std::min<size_t>(ctx->pix_base.cap & ~(size_t)15, (size_t)512 << 20);
+                if (sweep) A3_HIP(launch_zero(st, ctx->pix_base.p, sweep));
+                A3_HIP(hipEventRecord(e0, st));
+            }
             A3_HIP(launch_decode(st, ctx->dbg_src, (int)ctx->W, (int)ctx->H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), ctx->scratch_u32,
                                  ctx->max_cand, ctx->cfg.homography_sample_size, ctx->mark_size, ctx->cfg.homography_sample_size, ctx->dict.as<uint64_t>(),
                                  ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors, ctx->proj.p, ctx->wtab.as<float>(), ctx->outs.p, nullptr, 0u, nullptr, 4096,
                                  dbg == 0 ? -1000 : dbg, ctx->frames <= 64u ? 1 : 0, nullptr, 0u, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr));   // 0: k_projection + k_decode, < 0: k_decode alone (variant -dbg)
-        } else return fail(ctx, A3_ERR_INVALID, "kernel: 0 dart_count, 1 dart_assign, 2 local_contract, 3 decode");
+        } else return fail(ctx, A3_ERR_INVALID, "kernel: 0 dart_count, 1 dart_assign, 2 local_contract, 3 decode, 4 decode on cold frames");
         A3_HIP(hipEventRecord(e1, st));
         A3_HIP(hipStreamSynchronize(st));
         float ms = 0;

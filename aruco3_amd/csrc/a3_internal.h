@@ -13,7 +13,7 @@ extern "C" {
 #endif
 
 /* kernel-level timing for tuning (tools/kernel_probe.py): re-runs one kernel (0 dart_count, 1 dart_assign, 2 local_contract,
- * 3 decode) on the buffers of the last single-chunk batch, optionally truncated (dbg), and returns the average device time.
+ * 3 decode, 4 decode with the frames evicted from the caches before every run: bench.py's roofline_warp) on the buffers of the last single-chunk batch, optionally truncated (dbg), and returns the average device time.
  * The internal contour buffers hold garbage afterwards; results already returned are unaffected. */
 int  a3_debug_kernel_time(a3_ctx *ctx, int kernel, int dbg, int reps, float *avg_ms);
 

@@ -1041,7 +1041,14 @@ __global__ __launch_bounds__(256) void k_entry_jump(const EntryState* __restrict
         const uint32_t i = sp.slot(i0, cap);
         if (i == kNone) continue;
         EntryState s = in[i];
+        // An entry whose window met its own minimum again in the window it was joined with has wrapped its cycle (keys are unique): key
+        // and offset are final.  It is written once more (pad 1 -> 2: both ping-pong buffers then hold the final state) and takes
+        // no further part -- no scattered read of its partner, no write.  Noise-like frames: most cycles close within a few rounds,
+        // and the scattered 24-byte partner reads (a 128-byte line each) are what a round costs.
+        if (s.pad >= 2u) continue;
+        if (s.pad == 1u) { s.pad = 2u; out[i] = s; const_cast<EntryState*>(in)[i].pad = 2u; continue; }   // (nobody reads a partner's pad)
         const EntryState t = in[s.ptr];
+        if (t.key == s.key) s.pad = 1u;
         if (t.key < s.key) { s.key = t.key; s.off = s.dist + t.off; changed++; }
         s.dist += t.dist;
         s.ptr = t.ptr;

@@ -119,10 +119,12 @@ def main():
                     help="own (default): every context on a stream of its own -- the threshold kernels of consecutive batches serialise (each "
                          "fills the chip's register file), the contour / decode chains of the batches in flight overlap one another; "
                          "shared: all contexts enqueue on ONE stream (steps run in order; only the deferred decode stage overlaps)")
-    ap.add_argument("--gates", choices=("burst", "none"), default="burst",
-                    help="with --streams own: burst (default) = before each submit context k calls a3_order_after for the contexts k+1 .. N-1, so "
-                         "the threshold kernels of one rotation run back to back after the previous rotation's chains have drained; none = "
-                         "free-running rotation")
+    ap.add_argument("--gates", choices=("burst", "none"), default="none",
+                    help="with --streams own: none (default) = free-running rotation: batch i + N is submitted as soon as batch i is collected, the "
+                         "hardware interleaves threshold kernels and chains as they come (with a batch of its own per context this is the fastest "
+                         "arrangement measured, by 2 %%: profiles/r05_ab_streams.txt); burst = before each submit context k calls a3_order_after for the "
+                         "contexts k+1 .. N-1: the threshold kernels of one rotation run back to back after the previous rotation's chains have "
+                         "drained, the library holds the chains of all but the last member (the same process times it as `ab_burst_gates`)")
     ap.add_argument("--overlap", type=int, default=-1, help="measurement aid (a3_internal.h: a3_debug_set_overlap): force where the decode stage of "
                                                             "a submitted batch is released, 0 never deferred / 1 / 2, for every batch of the process; "
                                                             "-1 (default) = nothing is switched: the library decides per batch, as it does for any caller")
@@ -380,9 +382,11 @@ def main():
 
     gated = own_streams and args.gates == "burst" and n_ctx > 1
 
+    use_gates = [gated]
+
     def submit(cx):
         k = ctx_index[id(cx)]
-        if gated:   # bursts: this batch's threshold kernel starts once the previous rotation's chains (contexts k+1 ..) have drained
+        if use_gates[0]:   # bursts: this batch's threshold kernel starts once the previous rotation's chains (contexts k+1 ..) have drained
             for other in ctxs[k + 1:]:
                 cx.order_after(other)
         j = buf_for(k, gstep[0] // n_ctx)
@@ -457,8 +461,9 @@ def main():
     # retiring wave slots, which a lone launch -- sized to fill the chip in exactly one round -- cannot: the per-launch time here
     # is what the kernel costs inside a step, the isolated one above what it costs alone.
     k1_burst_ms = None
-    if gated and args.workload in WORKLOADS:
+    if own_streams and n_ctx > 1 and args.workload in WORKLOADS:
         spans = []
+        use_gates[0] = True
         for cx in ctxs:
             cx.set_profiling(_lib.PROFILE_THRESHOLD_ONLY)
         for rep in range(12):
@@ -480,6 +485,7 @@ def main():
                 spans.append(max(a for a, _ in per_ctx) / n_ctx)
         for cx in ctxs:
             cx.set_profiling(0)
+        use_gates[0] = gated
         spans = sorted(spans[2:])
         k1_burst_ms = spans[len(spans) // 2] if spans else None
 
@@ -551,7 +557,7 @@ def main():
 
     # ==== A/B block: other ways to step, same frames, same box, same minute.  Internal switches (a3_internal.h) may appear from here on;
     # ==== everything above this line calls the public header only (tests/test_bench_public_abi.py greps for it).
-    ab_shared, ab_r04_default = None, None
+    ab_shared, ab_r04_default, ab_gates = None, None, None
     internal_probes = []
     if not use_dist and own_streams and not args.no_other_workloads:
         def timed(fn, k=20):
@@ -595,10 +601,23 @@ def main():
         except Exception as e:   # a side measurement must not take the line down
             ab_shared = {"error": repr(e)}
         try:
+            # (1b) the other way to use a3_order_after (public calls only): the headline free-running -> burst gates + held chains, or vice versa
+            use_gates[0] = not gated
+            med, nr, r2 = timed(run_steps)
+            ab_gates = {"value": round(args.frames * args.steps / med, 2), "unit": "frames/s", "ms_per_step": round(med / args.steps * 1e3, 4), "regions": nr,
+                        "library_stepping_seen": [cx.stats()["stepping"] for cx in ctxs],
+                        "stepping": ("burst gates (a3_order_after before every submit: context k after the contexts k+1 .. N-1), chains held by the library"
+                                     if not gated else "free-running rotation, no gates")}
+        except Exception as e:
+            ab_gates = {"error": repr(e)}
+        finally:
+            use_gates[0] = gated
+        try:
             # (2) what a caller of the public header got until round 4: own streams + gates, but the library's process-wide default was
             # "decode deferred behind the next k_local_contract" and chains were never held (needs the internal switch now)
             assert L.a3_debug_set_overlap(2) == 0
             internal_probes.append("a3_debug_set_overlap(2) for ab_r04_library_default, reset to -1 afterwards")
+            use_gates[0] = True
             med, nr, r2 = timed(run_steps)
             ab_r04_default = {"value": round(args.frames * args.steps / med, 2), "unit": "frames/s", "ms_per_step": round(med / args.steps * 1e3, 4),
                               "regions": nr, "library_stepping_seen": [cx.stats()["stepping"] for cx in ctxs],
@@ -607,6 +626,7 @@ def main():
         except Exception as e:
             ab_r04_default = {"error": repr(e)}
         finally:
+            use_gates[0] = gated
             L.a3_debug_set_overlap(args.overlap if args.overlap >= 0 else -1)
     stats = ctx.stats()
 
@@ -620,8 +640,11 @@ def main():
         try:
             detect_sync(ctx, 0)
             n_cand = int(ctx.stats()["candidates"])
-            dec_ms = ctx.debug_kernel_time(3, -1, 10)          # k_decode alone (no k_projection: the product solves those in k_frame_candidates)
-            samp_ms = ctx.debug_kernel_time(3, -2, 10)         # the same launch stopped after the sampling loop
+            # k_decode alone (no k_projection: the product solves those in k_frame_candidates), the frames COLD as the pipeline meets them
+            # (kernel 4 overwrites half a gigabyte before every run, outside the timed span -- as scatterbench sweeps 512 MB)
+            dec_ms = ctx.debug_kernel_time(4, -5, 10)
+            samp_ms = ctx.debug_kernel_time(4, -2, 10)         # the same launch stopped after the sampling loop
+            dec_warm_ms = ctx.debug_kernel_time(3, -5, 10)     # (frames still in the caches from the run before: round 4's "71.5-74 us")
             internal_probes.append("a3_debug_kernel_time(decode) for roofline_warp")
             S = 49
             warp_bytes = (S * S * 4 + 32) * n_cand             # 9 604 B read upper bound + 32 B written per candidate
@@ -632,8 +655,9 @@ def main():
                 "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                 "achieved": round(warp_bytes / (dec_ms * 1e-3) / 1e9, 1), "frac": round(warp_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "bytes_per_candidate": S * S * 4 + 32, "candidates_per_launch": n_cand, "avg_launch_ms": round(dec_ms, 4),
-                "sampling_only_ms": round(samp_ms, 4), "dependent_tail_ms": round(dec_ms - samp_ms, 4),
-                "timed_how": "a3_debug_kernel_time: the kernel re-run alone, 10 times, on the work list of a synchronous batch of this run, HIP events around it",
+                "sampling_only_ms": round(samp_ms, 4), "dependent_tail_ms": round(dec_ms - samp_ms, 4), "avg_launch_ms_frames_warm": round(dec_warm_ms, 4),
+                "timed_how": "a3_debug_kernel_time: the kernel re-run alone, 10 times, on the work list of a synchronous batch of this run, HIP events around it; "
+                             "before every run 512 MB are overwritten so that the kernel finds the frames cold, as inside the pipeline",
                 "traffic": pmc_decode_traffic_bytes(),
                 # what the kernel is actually bound by: 64-byte sector requests of scattered 12-byte taps
                 "request_rate": None if ceil_us is None else {
@@ -732,16 +756,17 @@ def main():
         if args.no_pipeline:
             stepping = "one context, synchronous: every kernel runs alone"
         elif own_streams:
-            stepping = (f"{n_ctx} contexts, each on a stream of its own, used in rotation, {n_ctx} batches ahead of the host (batch i + {n_ctx} is submitted as "
-                        "soon as batch i is collected).  One threshold launch is 2048 waves of 256 VGPRs = every register of the chip: nothing co-runs "
-                        "with it, and one that arrives while other batches are in the middle of their contour / decode chains only slows those down.  "
-                        + ("The rotation therefore runs in BURSTS (a3_order_after: before each submit context k waits for the contexts k+1 .. N-1): the "
-                           f"{n_ctx} threshold kernels of a rotation run back to back once the previous rotation's chains have drained, then the {n_ctx} chains "
-                           "(latency-, LDS- and issue-bound, almost no HBM traffic) run together and overlap one another"
-                           if gated else "Free-running rotation: no gates, the hardware interleaves threshold kernels and chains as they come")
-                        + ".  The library holds the chain of every burst member but the last behind its threshold kernel and the last member's "
-                          "submit enqueues them all (a3_order_after in include/aruco3_hip.h: the library's behaviour, no switch; "
-                          "`library_stepping_seen` is a3_stats.stepping of the warm-up's last rotation)")
+            stepping = (f"{n_ctx} contexts, each on a stream of its own and stepping a batch of its own, used in rotation, {n_ctx} batches ahead of the host (batch i + "
+                        f"{n_ctx} is submitted as soon as batch i is collected).  One threshold launch is 2048 waves of 256 VGPRs = every register of the chip: nothing "
+                        "co-runs with it; the contour / decode chains of the batches in flight overlap one another.  "
+                        + ("BURSTS (a3_order_after: before each submit context k waits for the contexts k+1 .. N-1): the threshold kernels of a rotation run back to "
+                           "back once the previous rotation's chains have drained; the library holds the chain of every burst member but the last behind its "
+                           "threshold kernel and the last member's submit enqueues them all (the library's behaviour behind include/aruco3_hip.h, no switch)"
+                           if gated else
+                           "FREE-RUNNING rotation: no gates, no mode, nothing but submit and collect -- the hardware interleaves threshold kernels and chains as "
+                           "they come.  With four DIFFERENT batches in flight this is the fastest arrangement measured (burst gates: `ab_burst_gates`, 2 % "
+                           "slower; round 4's 437 k frames/s in bursts came from four contexts re-reading ONE batch out of the Infinity Cache)")
+                        + " (`library_stepping_seen` is a3_stats.stepping of every context's last batch)")
         else:
             stepping = (f"{n_ctx} contexts on ONE stream, {n_ctx} batches ahead: steps run in order; the decode stage of a submitted batch runs on the "
                         "device's decode stream, released behind the next batch's k_local_contract")
@@ -822,6 +847,8 @@ def main():
             out["roofline_warp"] = roofline_warp
         if ab_shared is not None:
             out["ab_shared_stream"] = ab_shared
+        if ab_gates is not None:
+            out["ab_burst_gates" if not gated else "ab_free_running"] = ab_gates
         if ab_r04_default is not None:
             out["ab_r04_library_default"] = ab_r04_default
         if gathered is not None:

@@ -206,7 +206,7 @@ def test_bench_config5_two_ranks_gloo_with_poses_in_the_gather():
     assert g["rank0_poses_bit_equal_after_gather"] is True
     assert g["pose_pairs_gathered"] >= 4 * g["batches_in_last_collective"] * 10 and g["max_markers_per_record"] >= 16
     assert g["record_bytes"] == 8 + g["max_markers_per_record"] * (56 + 104)
-    assert out["gates"].startswith("burst") and out["contexts"] == 4
+    assert out["gates"] == "none" and out["contexts"] == 4
 
 
 def test_bench_line_carries_parity_and_isolated_roofline():
@@ -222,8 +222,10 @@ def test_bench_line_carries_parity_and_isolated_roofline():
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["parity_in_run"]["summary"] == "32/32 frames" and out["parity_in_run"]["batches_covered"] == 4     # four distinct batches of 8 in flight
     assert out["config"]["distinct_batches_in_flight"] == 4 and out["library"]["internal_switches_used"] == []
-    assert out["library_stepping_seen"] == ["held_released_by_last"] * 3 + ["burst_last"]
+    assert out["library_stepping_seen"] == ["whole"] * 4 and out["gates"] == "none"                     # the headline: free-running rotation
+    assert out["ab_burst_gates"]["library_stepping_seen"] == ["held_released_by_last"] * 3 + ["burst_last"]   # the same calls + a3_order_after
     assert out["ab_r04_library_default"]["library_stepping_seen"] == ["decode_deferred"] * 4
+    assert out["roofline_warp"]["avg_launch_ms"] > out["roofline_warp"]["sampling_only_ms"] > 0
     assert out["roofline"]["launches_timed"] == 3 and out["roofline"]["avg_launch_ms"] > 0 and 0 < out["e2e_frac"] < 1
     assert out["ab_shared_stream"]["same_markers"] is True
     assert out["library"]["tuning_build"] is False

@@ -79,6 +79,18 @@ __global__ __launch_bounds__(64) void k_read(const uint8_t* __restrict__ base, s
                 if (((r + i) & 7) == 7 && lane < 8) reinterpret_cast<unsigned long long*>(bits + (size_t)gridDim.x * rows * 64)[(size_t)blockIdx.x * rows + r + i - 7 + lane] = acc;
                 if (((r + i) % 10) == 0) bits[((size_t)blockIdx.x * rows + r + i) * 64 + lane] = (uint16_t)acc;
             }
+            if (STORE >= 400) {   // the same bursts, destination wrapped into a 4 MB window: the stores hit in the L2s and nothing is written back
+                constexpr int PER = STORE - 400;
+                const int rr = r + i;
+                reinterpret_cast<uint16_t*>(lds)[(rr % PER) * 64 + lane] = (uint16_t)acc;
+                if (rr % PER == PER - 1 || rr == rows - 1) {
+                    const int first = rr - rr % PER, cnt = rr - first + 1;
+                    for (int q = 0; q < cnt; q += 8) {
+                        uint4 v = reinterpret_cast<const uint4*>(lds + (size_t)q * 128)[lane];
+                        reinterpret_cast<uint4*>(bits + ((((size_t)blockIdx.x * rows + first + q) * 64) & ((2u << 20) - 1u)))[lane] = v;
+                    }
+                }
+            } else
             if (STORE >= 100) {
                 constexpr int PER = STORE - 100;
                 const int rr = r + i;
@@ -143,7 +155,8 @@ __global__ void k_fill(uint32_t* p, size_t n) {
     }
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const bool quick = argc > 1;   // any argument: skip the store-width sweep, print the K1-shape lines only
     const int frames = 256, W = 1920, H = 1080;
     const size_t row_stride = (size_t)W * 3, bytes = row_stride * H * frames;
     uint8_t* d; uint32_t* out;
@@ -153,6 +166,7 @@ int main() {
     const double gb = (double)frames * H * 2 * 3072 / 1e9;
     printf("random data, %.2f GB requested per launch; ms per launch\n", gb);
     for (int occ : {2}) {
+        if (quick) break;
         const size_t lds = occ == 8 ? 0 : (occ == 4 ? 9000 : 19000);
         for (int sy : {4, 8}) {
             printf("occ %d strips_y %d: read-only %.3f | short x64 %.3f | dword x32 %.3f | dwordx2 x16 %.3f | dwordx4 x8 %.3f | 1 KB every 8 rows %.3f | 512 B every 4 rows %.3f | 1 KB every 64 rows %.3f | nt dword every 8 rows %.3f | nt 1 KB / 8 rows %.3f | sc1 1 KB / 8 rows %.3f | LDS-buffered, burst at wave end %.3f | sparse: flags/row + 10%% rows %.3f | sparse, flags per 8 rows %.3f | LDS flush every 32 rows %.3f | 64 rows %.3f | 96 rows %.3f | 136 rows %.3f\n", occ, sy,
@@ -174,6 +188,10 @@ int main() {
     printf("K1 shape (occ 2, strips_y 4): reads only %.3f | + 14 halo rows %.3f | + halo + stores in bursts of 128 rows %.3f | no halo, bursts of 128 rows %.3f\n",
            run<0, 3, 0, 0>(d, row_stride, frames, H, 4, 19000, out, 20), run<0, 3, 0, 0, 7>(d, row_stride, frames, H, 4, 19000, out, 20),
            run<0, 3, 0, 228, 7>(d, row_stride, frames, H, 4, 19000, out, 20), run<0, 3, 0, 228>(d, row_stride, frames, H, 4, 19000, out, 20));
+    // where does the price of the stores arise?  the same bursts into a 4 MB window (they stay in the L2s: no write-back traffic) against the real destination
+    printf("K1 shape, halo + bursts of 128 rows: to the 66 MB image %.3f | into a 4 MB window (L2-resident) %.3f | reads + halo only %.3f\n",
+           run<0, 3, 0, 228, 7>(d, row_stride, frames, H, 4, 19000, out, 20), run<0, 3, 0, 528, 7>(d, row_stride, frames, H, 4, 19000, out, 20),
+           run<0, 3, 0, 0, 7>(d, row_stride, frames, H, 4, 19000, out, 20));
     // more bytes in flight per SIMD: deeper load queues at two waves per SIMD, three waves per SIMD (LDS cap 13000: bursts of 64 rows)
     printf("K1 shape, halo + bursts of 128 rows, load queue depth 3 / 5 / 6 / 9 rows: %.3f | %.3f | %.3f | %.3f ; reads only, depth 5 / 9: %.3f | %.3f\n",
            run<0, 3, 0, 228, 7>(d, row_stride, frames, H, 4, 19000, out, 20), run<0, 5, 0, 228, 7>(d, row_stride, frames, H, 4, 19000, out, 20),
