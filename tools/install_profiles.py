@@ -5,7 +5,7 @@ microbenchmarks, the stepping A/B, the spinner probe, the two-rank rehearsals.  
 the PMC summary of the same run (bench.py read the previously committed summary when it ran).  Usage: python tools/install_profiles.py [tag]"""
 import csv, json, pathlib, shutil, subprocess, sys
 ROOT = pathlib.Path(__file__).resolve().parent.parent
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 prof, new = ROOT / "profiles", ROOT / "gpurun_out" / "refresh"
 
 
@@ -28,12 +28,14 @@ if (new / "bench.json.log").exists():
         print("traffic not patched:", e)
     (prof / f"{tag}_bench_c2.json.log").write_text(json.dumps(d) + "\n")
     print(d["value"], d["ms_per_step"], d["roofline"], d["stage_ms_per_step"], d.get("cpu_baseline", {}).get("value"), d.get("parity_in_run", {}).get("summary"))
-for name in ("readbench.txt", "scatterbench.txt", "valubench.txt", "k1_concurrency.txt", "ab_streams.txt", "spin_probe.txt", "pmc_issue.txt", "pmc_decode.txt"):
+for name in ("readbench.txt", "scatterbench.txt", "valubench.txt", "k1_concurrency.txt", "ab_streams.txt", "spin_probe.txt", "pmc_issue.txt", "pmc_decode.txt",
+             "rotation.txt", "pmc_chain.txt", "pmc_chain.json", "noise_prof.txt", "noise_c0_kernel_stats.csv", "noise_c4_kernel_stats.csv", "queue_probe_nccl16.txt"):
     if (new / name).exists() and (new / name).stat().st_size > 0:
         shutil.copy(new / name, prof / f"{tag}_{name}")
 for src, dst in (("rehearsal_n2_gloo.log", "rehearsal_n2_gloo.json.log"), ("rehearsal_c5_n2_gloo.log", "rehearsal_c5_n2_gloo.json.log"),
                  ("bench_c5.json.log", "bench_c5.json.log"), ("force_dist_nccl_1rank.log", "force_dist_nccl_1rank.json.log"),
-                 ("isolated.json.log", "bench_c2_isolated.json.log"), ("overlapped.json.log", "bench_c2_overlapped_profiled.json.log")):
+                 ("isolated.json.log", "bench_c2_isolated.json.log"), ("overlapped.json.log", "bench_c2_overlapped_profiled.json.log"),
+                 ("gather_guard_on.log", "gather_guard_on.json.log"), ("gather_guard_off.log", "gather_guard_off.json.log")):
     if (new / src).exists():
         try:
             (prof / f"{tag}_{dst}").write_text(json.dumps(line(new / src)) + "\n")
