@@ -165,6 +165,14 @@ def contours_by_darts(binary: np.ndarray, max_iter: int = 64, node_rule: str = "
 
     T = {c: min(ev)[0] for c, ev in events_of.items()}
     S = {c: min(ev)[1] for c, ev in events_of.items()}
+    T_natural = dict(T)
+    # static_fire (csrc/k_contours.hip): does a cycle's SMALLEST event fire whatever the other cycles do?  A W-event on a pixel that owns
+    # this one dart only; an E-event on a pixel without a W side.  Such a cycle starts at its natural start under every assignment --
+    # which is what lets k_local_contract finish with a short border without looking at its neighbours (kDead).
+    static_ok = {}
+    for c, evs in events_of.items():
+        key, d, q = min(evs)
+        static_ok[c] = (len(pix_darts[q]) == 1) if not (key & 1) else (q not in ev_w)
     iters = 0
     while True:
         iters += 1
@@ -197,5 +205,6 @@ def contours_by_darts(binary: np.ndarray, max_iter: int = 64, node_rule: str = "
         s = path.index(S[c])
         rot = path[s:] + path[:s]
         out.append([(dart_list[d][0], dart_list[d][1]) for d in rot])
-    stats = {"darts": n, "broken": broken, "cycles": len(cycles), "iters": iters, "chain_events": chain_has_event}
+    stats = {"darts": n, "broken": broken, "cycles": len(cycles), "iters": iters, "chain_events": chain_has_event,
+             "T_final": dict(T), "T_natural": T_natural, "static_ok": static_ok, "cycle_len": {c: len(cycles[c]) for c in events_of if cycles[c] is not None}}
     return out, stats
