@@ -35,7 +35,7 @@ SYMBOLS = [
     "a3_contour_count", "a3_download_contours", "a3_detection_record_bytes", "a3_pack_detections",
 ]
 # aruco3_amd/csrc/a3_internal.h: probes and single-stage hooks for this repository's tests and tools, not for bindings
-INTERNAL_SYMBOLS = ["a3_debug_set_overlap", "a3_debug_set_k1_waves", "a3_debug_set_partition", "a3_debug_build_flags", "a3_debug_spin", "a3_debug_set_mark_threshold", "a3_debug_set_hold", "a3_debug_launch_threshold", "a3_debug_stream_wait_threshold", "a3_debug_kernel_time", "a3_selftest_ieee", "a3_debug_clockwise", "a3_debug_rotate_bits", "a3_debug_discard_too_near"]
+INTERNAL_SYMBOLS = ["a3_debug_set_k1_stream", "a3_debug_set_overlap", "a3_debug_set_k1_waves", "a3_debug_set_partition", "a3_debug_build_flags", "a3_debug_spin", "a3_debug_set_mark_threshold", "a3_debug_set_hold", "a3_debug_launch_threshold", "a3_debug_stream_wait_threshold", "a3_debug_kernel_time", "a3_selftest_ieee", "a3_debug_clockwise", "a3_debug_rotate_bits", "a3_debug_discard_too_near"]
 
 
 class A3Error(RuntimeError):
@@ -164,6 +164,9 @@ def load():
     if hasattr(L, "a3_debug_set_overlap"):      # (older builds loaded through A3_HIP_LIB for A/B runs lack it)
         L.a3_debug_set_overlap.restype = C.c_int
         L.a3_debug_set_overlap.argtypes = [C.c_int]
+    if hasattr(L, "a3_debug_set_k1_stream"):
+        L.a3_debug_set_k1_stream.restype = C.c_int
+        L.a3_debug_set_k1_stream.argtypes = [C.c_int]
     if hasattr(L, "a3_debug_set_k1_waves"):
         L.a3_debug_set_k1_waves.restype = C.c_int
         L.a3_debug_set_k1_waves.argtypes = [C.c_int]

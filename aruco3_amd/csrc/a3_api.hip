@@ -333,6 +333,9 @@ bool g_decode_low_prio = false;   // (see a3_debug_set_overlap)
 // CU partition (a3_internal.h: a3_debug_set_partition): the threshold kernel of every batch on a device-wide stream restricted to
 // g_part_k1_cus compute units, everything else on streams restricted to the others.  0 = off.
 int g_part_k1_cus = 0, g_part_pattern = 0;
+// a3_debug_set_k1_stream (measurement aid): 0 off; 1 / 2: the threshold kernel of every batch on a device-wide stream of the LOWEST /
+// HIGHEST priority (no CU mask), ordered against the context's stream by two events
+int g_k1_stream_prio = 0;
 bool g_hold_rests = true;        // a3_debug_set_hold: bursts hold their chains back (see submit_common); 0 for A/B
 bool g_mark_threshold = false;   // a3_debug_set_mark_threshold: record an event behind every threshold kernel (costs ~2 % of a step: tools/spin_probe.py)
 enum { kStreamCopy = 0, kStreamDecode = 1, kStreamK1 = 2 };
@@ -364,7 +367,8 @@ hipError_t device_stream(int device, int kind, hipStream_t* out) {
     if (!st) {
         int lo = 0, hi = 0;
         hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (e == hipSuccess) e = create_stream(&st, kind == kStreamK1 ? 1 : 0, kind == kStreamDecode && g_decode_low_prio ? lo : 0);
+        const int prio = kind == kStreamDecode && g_decode_low_prio ? lo : (kind == kStreamK1 && g_k1_stream_prio == 1 ? lo : (kind == kStreamK1 && g_k1_stream_prio == 2 ? hi : 0));
+        if (e == hipSuccess) e = create_stream(&st, kind == kStreamK1 ? 1 : 0, prio);
         if (e != hipSuccess) { st = nullptr; return e; }
     }
     *out = st;
@@ -632,7 +636,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     prof = ctx->profiling == 1 && (ctx->batch_seq++ % (uint32_t)ctx->profile_every) != 0 ? 0 : ctx->profiling;
     ctx->front_prof = prof;
     hipStream_t k1st = st;
-    if (g_part_k1_cus > 0) {   // CU partition: the threshold kernel runs on the device's K1 stream, between two events
+    if (g_part_k1_cus > 0 || g_k1_stream_prio > 0) {   // CU partition / priority probe: the threshold kernel runs on the device's K1 stream, between two events
         A3_HIP(device_stream(ctx->device, kStreamK1, &k1st));
         A3_HIP(hipEventRecord(ctx->ev_k1_ready, st));
         A3_HIP(hipStreamWaitEvent(k1st, ctx->ev_k1_ready, 0));
@@ -1557,6 +1561,12 @@ int a3_debug_launch_threshold(a3_ctx* ctx, const void* pixels_device, int fmt, u
 }
 
 int a3_debug_set_mark_threshold(int on) { g_mark_threshold = on != 0; return A3_OK; }
+int a3_debug_set_k1_stream(int mode) {   // before the first context of the process is used (the device-wide stream is created once)
+    if (mode < 0 || mode > 2) return A3_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(g_streams_mu);
+    g_k1_stream_prio = mode;
+    return A3_OK;
+}
 int a3_debug_set_hold(int on) {
     std::lock_guard<std::mutex> lk(g_defer_mu);
     if (!g_held.empty()) return A3_ERR_INVALID;   // (chains held under the old setting: collect them first)

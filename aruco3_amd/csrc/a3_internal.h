@@ -37,6 +37,10 @@ int  a3_debug_spin(void *hip_stream, int workgroups, int threads, int usec);
  * batch -- which alone costs ~2 % of a step -- and a3_debug_stream_wait_threshold makes work enqueued on `hip_stream` afterwards
  * wait for the threshold kernel of ctx's batch in flight.  Company released there costs a step as much as company released at once. */
 int  a3_debug_set_mark_threshold(int on);
+/* priority probe (measured, not adopted: profiles/r05_k1_priority.txt): 1 / 2 = the threshold kernel of every batch on one device-wide
+ * stream of the lowest / highest priority, ordered against the context's stream by two events; 0 = on the context's stream (the
+ * product).  Call before any context is used. */
+int  a3_debug_set_k1_stream(int mode);
 int  a3_debug_stream_wait_threshold(a3_ctx *ctx, void *hip_stream);
 
 /* 0: contexts that declared burst gates (a3_order_after) enqueue their whole batch at submit, as round 3's library did; 1 (default):

@@ -43,6 +43,8 @@ def main():
     same_batch = [False]
     arg = lambda k: args_of[0] if same_batch[0] else args_of[k % len(args_of)]
     L = _lib.load()
+    if os.environ.get("A3_K1_STREAM", "0") != "0":     # 1 / 2: the threshold kernels on one device-wide stream of the lowest / highest priority
+        assert L.a3_debug_set_k1_stream(int(os.environ["A3_K1_STREAM"])) == 0
     if os.environ.get("A3_PARTITION", "0") != "0":     # "k1_cus[:pattern]": CU partition, set before any context exists
         pp = os.environ["A3_PARTITION"].split(":")
         assert L.a3_debug_set_partition(int(pp[0]), int(pp[1]) if len(pp) > 1 else 0) == 0
