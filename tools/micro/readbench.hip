@@ -79,6 +79,18 @@ __global__ __launch_bounds__(64) void k_read(const uint8_t* __restrict__ base, s
                 if (((r + i) & 7) == 7 && lane < 8) reinterpret_cast<unsigned long long*>(bits + (size_t)gridDim.x * rows * 64)[(size_t)blockIdx.x * rows + r + i - 7 + lane] = acc;
                 if (((r + i) % 10) == 0) bits[((size_t)blockIdx.x * rows + r + i) * 64 + lane] = (uint16_t)acc;
             }
+            if (STORE >= 600) {   // parking only: the result bits go to LDS and are read back in bursts, but never stored
+                constexpr int PER = STORE - 600;
+                const int rr = r + i;
+                reinterpret_cast<uint16_t*>(lds)[(rr % PER) * 64 + lane] = (uint16_t)acc;
+                if (rr % PER == PER - 1 || rr == rows - 1) {
+                    const int first = rr - rr % PER, cnt = rr - first + 1;
+                    for (int q = 0; q < cnt; q += 8) {
+                        uint4 v = reinterpret_cast<const uint4*>(lds + (size_t)q * 128)[lane];
+                        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+                    }
+                }
+            } else
             if (STORE >= 400) {   // the same bursts, destination wrapped into a 4 MB window: the stores hit in the L2s and nothing is written back
                 constexpr int PER = STORE - 400;
                 const int rr = r + i;
@@ -189,9 +201,11 @@ int main(int argc, char** argv) {
            run<0, 3, 0, 0>(d, row_stride, frames, H, 4, 19000, out, 20), run<0, 3, 0, 0, 7>(d, row_stride, frames, H, 4, 19000, out, 20),
            run<0, 3, 0, 228, 7>(d, row_stride, frames, H, 4, 19000, out, 20), run<0, 3, 0, 228>(d, row_stride, frames, H, 4, 19000, out, 20));
     // where does the price of the stores arise?  the same bursts into a 4 MB window (they stay in the L2s: no write-back traffic) against the real destination
-    printf("K1 shape, halo + bursts of 128 rows: to the 66 MB image %.3f | into a 4 MB window (L2-resident) %.3f | reads + halo only %.3f\n",
+    printf("K1 shape, halo + bursts of 128 rows: to the 66 MB image %.3f | into a 4 MB window (L2-resident) %.3f | parked in LDS and read back, never stored %.3f | reads + halo only %.3f\n",
            run<0, 3, 0, 228, 7>(d, row_stride, frames, H, 4, 19000, out, 20), run<0, 3, 0, 528, 7>(d, row_stride, frames, H, 4, 19000, out, 20),
-           run<0, 3, 0, 0, 7>(d, row_stride, frames, H, 4, 19000, out, 20));
+           run<0, 3, 0, 728, 7>(d, row_stride, frames, H, 4, 19000, out, 20), run<0, 3, 0, 0, 7>(d, row_stride, frames, H, 4, 19000, out, 20));
+    printf("the same with the LDS allocation but no stores at all (occupancy and LDS carve-out as K1's): %.3f ; with 64 KB of LDS per workgroup (one wave per SIMD... two per CU): %.3f\n",
+           run<0, 3, 0, 0, 7>(d, row_stride, frames, H, 4, 19000, out, 20), run<0, 3, 0, 0, 7>(d, row_stride, frames, H, 4, 64000, out, 20));
     // more bytes in flight per SIMD: deeper load queues at two waves per SIMD, three waves per SIMD (LDS cap 13000: bursts of 64 rows)
     printf("K1 shape, halo + bursts of 128 rows, load queue depth 3 / 5 / 6 / 9 rows: %.3f | %.3f | %.3f | %.3f ; reads only, depth 5 / 9: %.3f | %.3f\n",
            run<0, 3, 0, 228, 7>(d, row_stride, frames, H, 4, 19000, out, 20), run<0, 5, 0, 228, 7>(d, row_stride, frames, H, 4, 19000, out, 20),
