@@ -623,8 +623,11 @@ impl Detector {
 /// `Detection.grey` / `.candidates` / `.homographies` stay empty).  Inside, `depth` contexts of their own (not the registry's) are
 /// used in rotation, each on a stream of its own, with the burst gates the header describes: before each submit context k calls
 /// `a3_order_after` for the contexts k+1 .. depth-1, so the threshold kernels of one rotation run back to back after the previous
-/// rotation's chains have drained and the contour / decode chains of the rotation run together.  depth = 4 is the fastest
-/// arrangement measured for 256 x 1920x1080 frames per batch (Stepping); results never depend on it.
+/// rotation's chains have drained and the contour / decode chains of the rotation run together.  Measured with a batch of its own per
+/// context (round 5) a free-running rotation -- the same calls without `a3_order_after` -- is as fast within
+/// 2 %, and depth 3 or 4 within 1 % of each other; the gates are kept because they give a rotation a quiet threshold phase and a quiet
+/// chain phase, which is what a caller wants who runs something else (a collective, a copy) beside the detector.  Results never depend
+/// on any of it.
 /// The burst stepping is what the library does with these calls by itself (include/aruco3_hip.h, a3_order_after: a context that
 /// declared gates holds its chain back behind its threshold kernel, the rotation's last context releases them) -- this type calls
 /// nothing outside the public header, and `last_stepping()` reports what the library did with the batch just collected.
