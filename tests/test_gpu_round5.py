@@ -171,3 +171,74 @@ def test_gather_survives_a_lagging_collective():
     bad = _bench(["--no-gather-backpressure"])
     gb = bad["gathered"]
     assert gb["collectives_with_wrong_records"] > 0, "the race check cannot see an overwritten record"
+
+
+def test_borders_finished_early_are_counted_once_and_change_nothing(dicts, oracle):
+    """Dense graphs (noise-like frames) take the round-5 path on which short borders that close inside a tile and start unconditionally
+    are finished with in k_local_contract (kDead), windows that wrapped drop out of the doubling rounds, and the tighter length bound
+    prunes: a3_stats.contours_traced of the PRODUCT path -- borders finished early + borders listed -- must equal the number of borders
+    the reference follows (1-pixel specks aside), exactly as the tapped run (no early finish) counts them; candidates and markers
+    must be those of the oracle.  Uniform noise (the reference's bench recipe), denser and sparser noise (many column-0 starts, where
+    natural starts do not fire), and sigma-8 noise over rendered markers; small frames (one tile) up to 1080p (global entry rounds)."""
+    from aruco3_amd import synth
+
+    rng = np.random.default_rng(55)
+    d = dicts.new_from_named_dict("ARUCO")
+    det = _round5_detector(dicts)
+    cases = []
+    for (w, h, n), p in (((192, 160, 6), None), ((640, 360, 3), None), ((1920, 1080, 1), None), ((333, 217, 4), 0.62), ((256, 256, 4), 0.38)):
+        if p is None:
+            cases.append(rng.integers(0, 256, size=(n, h, w, 3), dtype=np.uint8))
+        else:   # grey levels arranged so that a fraction p of the pixels thresholds to foreground in blobs of a few pixels
+            a = (rng.random((n, h, w)) < p).astype(np.uint8) * 255
+            cases.append(np.repeat(a[..., None], 3, axis=3))
+    spec4, name4 = synth.config_spec(4)
+    d4 = dicts.new_from_named_dict(name4)
+    cases.append(np.stack([synth.render_frame(spec4, d4.code_list, d4.num_bits, synth.frame_seed(4, 100 + i))[0] for i in range(2)]))
+    for ci, frames in enumerate(cases):
+        dd = d4 if ci == len(cases) - 1 else d
+        detector = _round5_detector(dicts, name4) if ci == len(cases) - 1 else det
+        want_traced, want_markers = 0, []
+        for f in range(frames.shape[0]):
+            ref = oracle.detect(frames[f], dd.code_list, dd.num_bits, dd._tau)
+            cs, _, _ = oracle.find_contours(ref["thresholded"])
+            img = ref["thresholded"] > 0
+            want_traced += sum(1 for c in cs if not _speck(img, c))
+            want_markers.append([(m["id"], m["code"], tuple(v for c in m["corners"] for v in c)) for m in ref["markers"]])
+        got = {}
+        for taps in (False, True):
+            ctx = detector._context()
+            ctx.set_debug_taps(taps)
+            n, h, w, c = frames.shape
+            a = np.ascontiguousarray(frames)
+            m, per = ctx.detect_batch(a.ctypes.data, _lib_mod().MEM_HOST, _lib_mod().FMT_RGB8, w, h, w * c, h * w * c, n)
+            st = ctx.stats()
+            got[taps] = (st["contours_traced"], st["contours_materialised"], [(int(x["id"]), int(x["code"]), tuple(int(v) for v in x["corners"])) for x in m], per.tolist())
+        ctx.set_debug_taps(False)
+        assert got[False][0] == want_traced == got[True][0], (ci, got[False][0], got[True][0], want_traced)
+        assert got[True][1] == want_traced                                  # taps: every traced border is materialised
+        assert got[False][1] < got[True][1] or want_traced < 50             # the product path prunes
+        flat = [t for fr in want_markers for t in fr]
+        assert got[False][2] == flat == got[True][2], ci
+        assert got[False][3] == got[True][3] == [len(fr) for fr in want_markers]
+
+
+def _speck(img, c):
+    """a 1-point contour of a pixel without any foreground 8-neighbour (the kernels never build darts for those)"""
+    if len(c) != 1:
+        return False
+    x, y = (int(v) for v in c[0])
+    h, w = img.shape
+    return not any((dx or dy) and 0 <= x + dx < w and 0 <= y + dy < h and img[y + dy, x + dx] for dy in (-1, 0, 1) for dx in (-1, 0, 1))
+
+
+def _round5_detector(dicts, name="ARUCO"):
+    from aruco3_amd.aruco import Detector, DetectorConfig
+
+    return Detector(DetectorConfig(), dicts.new_from_named_dict(name))
+
+
+def _lib_mod():
+    from aruco3_amd import _lib
+
+    return _lib
