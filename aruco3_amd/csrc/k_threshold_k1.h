@@ -571,6 +571,8 @@ hipError_t launch_k1(hipStream_t st, const uint8_t* pixels, int fmt, size_t row_
     // = exactly one round of two waves per SIMD.
     const int strips_x = (W + T_OUT - 1) / T_OUT;
     const long long slots = (long long)g_k1_cus * 4 * g_k1_waves, cols = (long long)strips_x * n;
+    // (Strips of ONE row for a single small frame -- 480 waves of one 15-row block instead of 30 waves of two -- were tried in round 5:
+    // 23.0 us against 16.8 for one 640x480 frame; a wave's fixed costs outweigh the block saved.  The model stays at >= 16 rows.)
     int best_sy = 1; double best_cost = 1e300;
     for (int sy = 1; sy <= std::max(1, H / 16); sy++) {
         const int rows = (H + sy - 1) / sy;
