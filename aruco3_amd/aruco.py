@@ -175,3 +175,81 @@ class Detector:
         if stream is not None:
             ctx.set_stream(stream)
         return ctx.detect_batch(ptr, mem, fmt, w, h, rs, fs, n, out_cap)
+
+
+def _detections(markers, per) -> List[Detection]:
+    out, pos = [], 0
+    for f in range(len(per)):
+        det = Detection()
+        for m in markers[pos: pos + int(per[f])]:
+            c = m["corners"]
+            det.markers.append(Marker(int(m["id"]), int(m["code"]), [(int(c[2 * i]), int(c[2 * i + 1])) for i in range(4)], int(m["hamming_distance"])))
+        pos += int(per[f])
+        out.append(det)
+    return out
+
+
+class BatchQueue:
+    """Several batches in flight -- the Python twin of `BatchQueue` in integration/aruco3_hip.rs (additive API; public entry points of
+    include/aruco3_hip.h only).  `depth` contexts of its own are used in rotation, each on a stream of its own: `submit` hands a batch
+    over and returns at once, `collect` waits for the OLDEST batch in flight and returns its detections (markers only).
+
+    gates=False (default): a free-running rotation -- with a batch of its own per context the fastest arrangement measured (DESIGN.md
+    section 4.4).  gates=True: before each submit context k calls a3_order_after for the contexts k+1 .. depth-1 (bursts): the library
+    holds the chain of every member but the last behind its threshold kernel; `last_stepping` says what it did with the batch just
+    collected.  Results never depend on any of it.  Frames must stay valid and unmodified until their batch is collected (the queue
+    keeps a reference to what it was handed)."""
+
+    def __init__(self, detector: Detector, depth: int = 4, gates: bool = False):
+        if not 1 <= depth <= 8:
+            raise ValueError("depth must be in 1..8")
+        d = detector.dictionary
+        self._ctxs = [_lib.Context(detector.config._c(), d.code_list, d.num_bits, d._tau, detector.device) for _ in range(depth)]
+        self._keep = [None] * depth
+        self._gates = gates
+        self._head = self._in_flight = self._submitted = 0
+        self.last_stepping = None
+
+    def __len__(self) -> int:
+        return self._in_flight
+
+    @property
+    def full(self) -> bool:
+        return self._in_flight == len(self._ctxs)
+
+    def submit(self, images, out_cap: int = 0) -> None:
+        if self.full:
+            raise RuntimeError("BatchQueue is full: collect() the oldest batch first")
+        depth = len(self._ctxs)
+        k = self._submitted % depth
+        ctx = self._ctxs[k]
+        if self._gates:
+            for m in range(k + 1, depth):
+                ctx.order_after(self._ctxs[m])
+        ptr, mem, fmt, w, h, rs, fs, n, keep = _as_frames(images)
+        ctx.set_debug_taps(False)
+        ctx.submit(ptr, mem, fmt, w, h, rs, fs, n, out_cap=out_cap or n * 64)
+        self._keep[k] = keep
+        self._submitted += 1
+        self._in_flight += 1
+
+    def collect(self) -> List[Detection]:
+        if not self._in_flight:
+            raise RuntimeError("BatchQueue.collect with nothing in flight")
+        k = self._head
+        ctx = self._ctxs[k]
+        self._head = (self._head + 1) % len(self._ctxs)
+        self._in_flight -= 1
+        try:
+            markers, per = ctx.collect()
+        finally:
+            self._keep[k] = None
+        self.last_stepping = ctx.stats()["stepping"]
+        return _detections(markers, per)
+
+    def close(self) -> None:
+        while self._in_flight:
+            self.collect()
+        for c in self._ctxs:
+            c.close()
+        self._ctxs = []

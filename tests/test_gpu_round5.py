@@ -242,3 +242,41 @@ def _lib_mod():
     from aruco3_amd import _lib
 
     return _lib
+
+
+@pytest.mark.parametrize("gates", [False, True])
+def test_python_batch_queue_matches_detect_batch(dicts, gates):
+    """aruco3_amd.aruco.BatchQueue (the twin of the Rust shim's): batches of device tensors and of host arrays through a rotation of
+    four contexts, free-running and with burst gates: every batch equals Detector.detect_batch; the library reports the stepping"""
+    import torch
+
+    from aruco3_amd import synth
+    from aruco3_amd.aruco import BatchQueue, Detector, DetectorConfig
+
+    det = Detector(DetectorConfig(), dicts.new_from_named_dict("ARUCO_DEFAULT"))
+    batches = [synth.config_frames(1, 5, first=5 * j)[0] for j in range(6)]
+    want = [[[(m.id, m.code, tuple(m.corners), m.hamming_distance) for m in d.markers] for d in det.detect_batch(b)] for b in batches]
+    assert sum(len(f) for w in want for f in w) > 50
+    q = BatchQueue(det, depth=4, gates=gates)
+    inputs = [torch.from_numpy(b).cuda() if j % 2 == 0 else b for j, b in enumerate(batches)]     # device and host frames in turn
+    seen = []
+    for rep in range(3):
+        order = list(range(6))
+        submitted = []
+        for j in order:
+            if q.full:
+                k = submitted.pop(0)
+                got = q.collect()
+                seen.append(q.last_stepping)
+                assert [[(m.id, m.code, tuple(m.corners), m.hamming_distance) for m in d.markers] for d in got] == want[k], (rep, k)
+            q.submit(inputs[j]); submitted.append(j)
+        while len(q):
+            k = submitted.pop(0)
+            got = q.collect()
+            seen.append(q.last_stepping)
+            assert [[(m.id, m.code, tuple(m.corners), m.hamming_distance) for m in d.markers] for d in got] == want[k], (rep, k)
+    q.close()
+    if gates:
+        assert "held_released_by_last" in seen and "burst_last" in seen
+    else:
+        assert set(seen) == {"whole"}
