@@ -168,14 +168,17 @@ int  a3_detect_batch_pose_submit(a3_ctx *ctx, const void *pixels, int memory, in
 int  a3_detect_batch_pose_collect(a3_ctx *ctx, a3_marker *out, a3_pose *poses, size_t out_cap, uint32_t *per_frame_count,
                                   size_t *out_n);
 
-/* Several contexts in flight on one device ("bursts").  A context per batch in flight, each on a stream of its own, lets the
- * contour / decode chains of consecutive batches overlap one another (they are latency-, LDS- and issue-bound and leave most of
- * the chip idle); the threshold kernel does not take part in that -- one launch occupies every register of the chip -- and a
- * threshold kernel that arrives while other batches are in the middle of their chains only slows those down.  The fastest
- * arrangement measured (Stepping) therefore runs BURSTS: with N contexts used in rotation (batch j on context
- * j % N, batch j + N submitted as soon as batch j is collected), context k calls
+/* Several contexts in flight on one device.  A context per batch in flight, each on a stream of its own, used in rotation (batch j
+ * on context j % N, batch j + N submitted as soon as batch j is collected), lets the contour / decode chains of consecutive batches
+ * overlap one another (they are latency-, LDS- and issue-bound and leave most of the chip idle); the threshold kernel does not take
+ * part in that -- one launch occupies every register of the chip.  Nothing more is needed: with N = 3 or 4 and a batch of its own
+ * per context this FREE-RUNNING rotation is the fastest arrangement measured.
+ *
+ * BURSTS are the same rotation with phases: context k calls
  *     a3_order_after(ctx[k], ctx[m])   for every m in k+1 .. N-1
- * before each submit.  What the library does with that, always (there is no mode to select; since ABI 5):
+ * before each submit; the threshold kernels of one rotation then run back to back on an otherwise quiet GPU, and its chains
+ * together -- within 2 % of the free-running rotation, and the arrangement to choose when something else (a collective, a copy)
+ * should find the GPU in a known phase.  What the library does with these calls, always (there is no mode to select; since ABI 5):
  *   - the call itself: the next batch submitted on `ctx` starts on the device only after everything enqueued so far on `other`
  *     (its batch in flight included) has finished -- the batches of one rotation start once the previous rotation has drained;
  *   - a submit on a context that declared such gates since its previous submit enqueues the batch's THRESHOLD KERNEL ONLY and
@@ -189,7 +192,7 @@ int  a3_detect_batch_pose_collect(a3_ctx *ctx, a3_marker *out, a3_pose *poses, s
  * (frame count / size) on a context and to batches whose contour graph must be planned on the host (graphs that outgrow the
  * pools: uniform-noise frames), while a3_set_profiling(A3_PROFILE_STAGES) is on, and to contexts that share one stream: those
  * are in order already, a3_order_after between them is a no-op, and their decode stage is deferred behind the next batch's
- * contour stage instead (A3_STEP_DECODE_DEFERRED).  N = 4 for 256 x 1920x1080 frames per batch.  Scheduling only: results are
+ * contour stage instead (A3_STEP_DECODE_DEFERRED).  Scheduling only: results are
  * identical in every arrangement.
  *
  * Threading.  One context is never used from two threads at once.  DIFFERENT contexts may be driven from different threads, with
