@@ -50,6 +50,12 @@ __device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(
 #ifndef A3_T_ADD32
 #define A3_T_ADD32 1
 #endif
+// -DA3_T_WIDE_FLUSH=1 (round 5, measured): the parked result bits leave in 16-byte stores, eight rows per store
+// instruction (lanes 8j .. 8j+7 write row j's 124 bytes), instead of one 2-byte store per lane and row: 18 store instructions per
+// burst of 128 rows instead of 143.
+#ifndef A3_T_WIDE_FLUSH
+#define A3_T_WIDE_FLUSH 0
+#endif
 #ifndef A3_T_LUMA_GROUPS
 #define A3_T_LUMA_GROUPS 1
 #endif
@@ -384,6 +390,31 @@ __global__ __launch_bounds__(64, T_PF == A3_T_PF ? A3_T_WAVES : 1) void k_grey_t
     // the XCD's L2 instead of fetching them again from HBM.  The box filter is symmetric, so direction only changes
     // the order rows enter and leave the window.
     const int dir = (sy & 1) ? -1 : 1;
+    // the parked rows [0, nb) (row q is image row yb0 + dir * q) leave for the packed image
+    auto flush_parked = [&](int nb, int yb0) {
+#if A3_T_WIDE_FLUSH
+        if constexpr (sizeof(out_bits_t) == 2) {
+            // bytes of a row this strip owns: 2 per owner lane (lanes 1 .. 62 whose columns start inside the image)
+            const int first_x = sx * T_OUT, n_own = min(62, (W - first_x + T_LPX - 1) / T_LPX);
+            const int row_bytes = 2 * n_own, c = lane & 7, qo = lane >> 3;
+            typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+            uint8_t* const dst0 = bout + (first_x >> 3) + 16 * c;
+            const uint8_t* const src0 = reinterpret_cast<const uint8_t*>(s_out) + 16 * c;
+            for (int q0 = 0; q0 < nb; q0 += 8) {
+                const int q = q0 + qo;
+                if (q >= nb || 16 * c >= row_bytes) continue;
+                uint8_t* dst = dst0 + (size_t)(yb0 + dir * q) * bpr;
+                const uint8_t* src = src0 + (size_t)q * 128;
+                if (16 * c + 16 <= row_bytes) *reinterpret_cast<u32x4_a4*>(dst) = *reinterpret_cast<const u32x4_a4*>(src);
+                else for (int b = 0; 16 * c + b < row_bytes; b += 2) *reinterpret_cast<uint16_t*>(dst + b) = *reinterpret_cast<const uint16_t*>(src + b);
+            }
+            return;
+        }
+#endif
+        if (owner)
+            for (int q = 0; q < nb; q++)
+                *reinterpret_cast<out_bits_t*>(bout + (size_t)(yb0 + dir * q) * bpr + (x0 >> 3)) = s_out[q * 64 + lane];
+    };
     const int r_first = dir > 0 ? y_begin - R : y_end - 1 + R, n_rows = (y_end - y_begin) + 2 * R;
     RawRow<FMT> q[T_PF];
     // FAST: every load is unconditional (row and column clamped into the image) so that the loop body has no branch
@@ -524,21 +555,21 @@ __global__ __launch_bounds__(64, T_PF == A3_T_PF ? A3_T_WAVES : 1) void k_grey_t
                     *reinterpret_cast<out_bits_t*>(bout + (size_t)y * bpr + (x0 >> 3)) = (out_bits_t)outb;
             } else {
                 if (n_buf == 0) y_buf0 = y;
+#if A3_T_WIDE_FLUSH
+                s_out[n_buf * 64 + (sizeof(out_bits_t) == 2 ? ((lane + 63) & 63) : lane)] = (out_bits_t)outb;   // owners 1..62 at slots 0..61: a row's bytes as they lie in memory
+#else
                 s_out[n_buf * 64 + lane] = (out_bits_t)outb;
+#endif
                 n_buf++;
             }
         }
         // (checked once per block of UNROLL rows, outside the unrolled body: the buffer holds flush_rows + UNROLL rows)
         if (flush_rows > 0 && n_buf >= flush_rows) {   // wave-uniform
-            if (owner)
-                for (int q = 0; q < n_buf; q++)
-                    *reinterpret_cast<out_bits_t*>(bout + (size_t)(y_buf0 + dir * q) * bpr + (x0 >> 3)) = s_out[q * 64 + lane];
+            flush_parked(n_buf, y_buf0);
             n_buf = 0;
         }
     }
-    if (flush_rows > 0 && owner)
-        for (int q = 0; q < n_buf; q++)
-            *reinterpret_cast<out_bits_t*>(bout + (size_t)(y_buf0 + dir * q) * bpr + (x0 >> 3)) = s_out[q * 64 + lane];
+    if (flush_rows > 0) flush_parked(n_buf, y_buf0);
 #ifdef A3_TUNING
     if (g_k1_stamps && lane == 0) {   // 100 MHz timestamps of this wave's life + where it ran (HW_ID, XCC_ID)
         unsigned long long* o = g_k1_stamps + (size_t)blockIdx.x * 4;
