@@ -49,13 +49,13 @@ hipError_t launch_contour_quads(hipStream_t, const ContourRec*, const DeviceCoun
 // k_decode.hip
 size_t decode_out_bytes();
 hipError_t launch_frame_candidates(hipStream_t, const CandRec*, const uint32_t*, uint32_t, uint32_t, float, uint16_t*, uint16_t*, uint32_t*,
-                                   uint32_t*, unsigned int*, uint32_t, void*);
+                                   uint32_t*, unsigned int*, uint32_t, void*, float*);
+uint32_t frame_cand_lds_slots();
 size_t proj_rec_bytes();
 size_t weight_table_bytes();
 hipError_t launch_weight_table(hipStream_t, uint32_t, uint32_t, uint32_t, float*);
 hipError_t launch_decode(hipStream_t, PixelSrc, int, int, uint32_t, const uint16_t*, const uint32_t*, const unsigned int*, uint32_t,
-                         uint32_t, uint32_t, uint32_t, const uint64_t*, uint32_t, uint32_t, int, void*, const float*, void*, uint8_t*, uint32_t, uint32_t*, int, int, int,
-                         const uint32_t*, uint32_t, a3_marker*, uint32_t, unsigned int*, unsigned int*, const uint32_t*, unsigned int*, unsigned int*);
+                         uint32_t, uint32_t, uint32_t, const uint64_t*, uint32_t, uint32_t, int, void*, const float*, void*, uint8_t*, uint32_t, uint32_t*, int, int, int);
 hipError_t launch_compact_markers(hipStream_t, const void*, const uint16_t*, const uint32_t*, uint32_t, uint32_t, uint32_t, a3_marker*,
                                   uint32_t, uint32_t*, unsigned int*, unsigned int*, const uint32_t*, unsigned int*);
 hipError_t launch_pack_detections(hipStream_t, const a3_marker*, const a3_pose*, const uint32_t*, uint32_t, uint32_t, uint32_t, void*, unsigned int*);
@@ -80,9 +80,11 @@ namespace {
 thread_local std::string g_create_error;
 
 // Quad candidates kept per frame.  The reference is unbounded (src/aruco.rs:124-166 pushes into a Vec); here the tables start at
-// kMaxCandDefault per frame and a batch that overflows them is re-run with tables twice the size, up to kMaxCandLimit (the
-// per-frame ordering + discard_too_near kernel keeps a frame's candidates in LDS: 21 bytes each); beyond that: A3_ERR_LIMIT.
+// kMaxCandDefault per frame and a batch that overflows them is re-run with tables twice the size (1024, 2048, 4096, 6144 -- as far as the
+// per-frame ordering + discard_too_near kernel keeps a frame's candidates in LDS, 21 bytes each -- then 12 288 ... through memory), up
+// to kMaxCandLimit = 65 536, where a3_marker.candidate_index (16 bits) ends; beyond that: A3_ERR_LIMIT.
 constexpr uint32_t kMaxCandDefault = 1024, kMaxCandLimit = A3_MAX_CANDIDATES_PER_FRAME;
+static_assert(kMaxCandLimit == 65536, "a3_marker.candidate_index is a uint16_t");
 constexpr uint32_t kMaxContoursDefault = 1u << 20;
 constexpr uint64_t kMaxDartsDefault = 48ull << 20;
 constexpr uint64_t kMaxPointsDefault = 64ull << 20;
@@ -219,7 +221,7 @@ struct a3_ctx {
     DevBuf d_xy, d_succ, stA, stB, t_cur, t_next;
     DevBuf leader_list, leader_keep, entry_list, entry_pos, es_a, es_b;
     DevBuf contours, cyc_start_off, points;
-    DevBuf cands, pre_xy, fin_xy, fin_count, work, outs, proj, patches;
+    DevBuf cands, pre_xy, fin_xy, fin_count, work, outs, proj, patches, cand_big;
     // one allocation zeroed by one memset per batch and read back with one copy: [scratch 256 B | counters | per_frame | frame_cursor | cand_count]
     DevBuf zero_blk;
     a3_marker* markers_ptr = nullptr;                // the compacted marker list, right behind the read-back head in the zero block
@@ -423,22 +425,18 @@ int enqueue_back(a3_ctx* ctx, hipStream_t st, const BackArgs& b) {
     unsigned int* d_err = ctx->scratch_u32 + 4;
     A3_HIP(launch_frame_candidates(st, ctx->cands.as<CandRec>(), ctx->cand_count, b.n, b.max_cand, b.min_corner_separation,
                                    ctx->pre_xy.as<uint16_t>(), ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(),
-                                   ctx->work.as<uint32_t>(), d_work_count, b.S, ctx->proj.p));
-    // few frames (small batches): all four waves of a workgroup run the stages behind the sampling.  One or two frames per call (the
-    // reference's own call shape, src/aruco.rs:52): the launch's last workgroup also gathers the markers (scratch word 5 is its
-    // ticket) -- a launch less.  Only there: every workgroup publishes its results with a fence and takes a ticket, and 4096 of those
-    // on one address cost a 32-frame batch 0.35 ms where the extra launch costs 5 us.
+                                   ctx->work.as<uint32_t>(), d_work_count, b.S, ctx->proj.p, ctx->cand_big.as<float>()));
+    // few frames (small batches): all four waves of a workgroup run the stages behind the sampling.  (Round 5 tried folding the marker
+    // gather into k_decode for one-frame calls -- its last workgroup, found by a ticket -- to save a launch: the call got 5 us SLOWER,
+    // 166 against 161 us in alternating runs, a fence + ticket per workgroup and a serial tail costing more than the launch; removed.)
     const int few = b.n <= 64u ? 1 : 0;
-    const bool fused_compact = b.n <= 2u;
     A3_HIP(launch_decode(st, b.src, (int)b.W, (int)b.H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), d_work_count,
                          b.max_cand, b.S, ctx->mark_size, b.S, ctx->dict.as<uint64_t>(), ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors,
                          ctx->proj.p, ctx->wtab.as<float>(), ctx->outs.p, b.taps ? ctx->patches.as<uint8_t>() : nullptr, b.patch_cap, ctx->per_frame,
                          (int)std::min<uint32_t>(4096u, b.n * 128u) /* (grid-stride over the work list; 4096 workgroups that find nothing cost a one-frame call ~4 us) */, 0,
-                         few, ctx->fin_count.as<uint32_t>(), b.n, ctx->markers_ptr, b.marker_cap, d_marker_total, d_err, ctx->cand_count, ctx->scratch_u32 + 2,
-                         fused_compact ? ctx->scratch_u32 + 5 : nullptr));
-    if (!fused_compact)
-        A3_HIP(launch_compact_markers(st, ctx->outs.p, ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(), b.n, 0, b.max_cand,
-                                      ctx->markers_ptr, b.marker_cap, ctx->per_frame, d_marker_total, d_err, ctx->cand_count, ctx->scratch_u32 + 2));
+                         few));
+    A3_HIP(launch_compact_markers(st, ctx->outs.p, ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(), b.n, 0, b.max_cand,
+                                  ctx->markers_ptr, b.marker_cap, ctx->per_frame, d_marker_total, d_err, ctx->cand_count, ctx->scratch_u32 + 2));
     if (b.want_pose) {   // IPPE on the device-resident marker list (src/pose.rs:52-81), no extra round trip
         const a3_intrinsics& in = b.pose_intr;
         A3_HIP(launch_pose(st, reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(ctx->markers_ptr) + offsetof(a3_marker, corners)),
@@ -620,6 +618,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
     A3_HIP(ctx->fin_xy.ensure((size_t)n * kMaxCand * 16));
     A3_HIP(ctx->fin_count.ensure((size_t)n * 4));
     A3_HIP(ctx->work.ensure((size_t)n * kMaxCand * 4));
+    if (kMaxCand > frame_cand_lds_slots()) A3_HIP(ctx->cand_big.ensure((size_t)n * kMaxCand * 4));   // keys / perimeters of k_frame_candidates' through-memory form
     A3_HIP(ctx->outs.ensure((size_t)n * kMaxCand * decode_out_bytes()));
     A3_HIP(ctx->proj.ensure((size_t)n * kMaxCand * proj_rec_bytes()));
     const uint32_t marker_cap = marker_cap_of(ctx, n, out_cap);
@@ -957,8 +956,14 @@ int finish_batch(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_fram
     if (flags & kErrBrokenEvent) return fail(ctx, A3_ERR_INTERNAL, "contour graph: a start event lies on an open chain");
     if (flags & kErrResolve) return fail(ctx, A3_ERR_INTERNAL, "contour start resolution did not converge");
     if (flags & kErrCandTable) {   // a frame has more quad candidates than its table: twice the table and again
-        if (ctx->max_cand >= kMaxCandLimit) return fail(ctx, A3_ERR_LIMIT, "a frame holds more than 6144 quad candidates (A3_MAX_CANDIDATES_PER_FRAME)");
-        ctx->max_cand = std::min(kMaxCandLimit, ctx->max_cand * 2);
+        // straight to the table that holds the fullest frame (hs[5], from the marker gather): 2048, 4096, 6144 (the last that
+        // k_frame_candidates works in LDS), 12 288, 24 576, 49 152, 65 536
+        const uint32_t lds_slots = frame_cand_lds_slots(), need = std::max(hs[5], ctx->max_cand + 1u);
+        if (need > kMaxCandLimit) return fail(ctx, A3_ERR_LIMIT, "a frame holds more than 65536 quad candidates (A3_MAX_CANDIDATES_PER_FRAME)");
+        uint32_t next = ctx->max_cand;
+        while (next < need) next = next < lds_slots ? std::min(lds_slots, next * 2) : std::min(kMaxCandLimit, next * 2);
+        if ((uint64_t)n * next > 0xFFFFFFFFull) return fail(ctx, A3_ERR_LIMIT, "frames x candidate slots per frame exceeds 2^32: fewer frames per call");
+        ctx->max_cand = next;
         return 1;
     }
     if (flags & kErrMarkerCap) return fail(ctx, A3_ERR_CAPACITY, "out_cap is smaller than the number of markers found");
@@ -1138,7 +1143,7 @@ void a3_destroy(a3_ctx* ctx) {
                       &ctx->tile_darts, &ctx->d_xy, &ctx->d_succ, &ctx->stA, &ctx->stB, &ctx->t_cur, &ctx->t_next,
                       &ctx->leader_list, &ctx->leader_keep, &ctx->entry_list, &ctx->entry_pos, &ctx->es_a, &ctx->es_b,
                       &ctx->contours, &ctx->cyc_start_off, &ctx->points, &ctx->zero_blk, &ctx->cands,
-                      &ctx->pre_xy, &ctx->fin_xy, &ctx->fin_count, &ctx->work, &ctx->outs, &ctx->proj, &ctx->patches,
+                      &ctx->pre_xy, &ctx->fin_xy, &ctx->fin_count, &ctx->work, &ctx->outs, &ctx->proj, &ctx->patches, &ctx->cand_big,
                       &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_d, &ctx->hsum, &ctx->pose_buf, &ctx->wtab};
     for (DevBuf* b : bufs) b->release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -1489,7 +1494,7 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
             A3_HIP(launch_decode(st, ctx->dbg_src, (int)ctx->W, (int)ctx->H, 0, ctx->fin_xy.as<uint16_t>(), ctx->work.as<uint32_t>(), ctx->scratch_u32,
                                  ctx->max_cand, ctx->cfg.homography_sample_size, ctx->mark_size, ctx->cfg.homography_sample_size, ctx->dict.as<uint64_t>(),
                                  ctx->n_codes, ctx->tau, ctx->cfg.filter_high_bit_errors, ctx->proj.p, ctx->wtab.as<float>(), ctx->outs.p, nullptr, 0u, nullptr, 4096,
-                                 dbg == 0 ? -1000 : dbg, ctx->frames <= 64u ? 1 : 0, nullptr, 0u, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr));   // 0: k_projection + k_decode, < 0: k_decode alone (variant -dbg)
+                                 dbg == 0 ? -1000 : dbg, ctx->frames <= 64u ? 1 : 0));   // 0: k_projection + k_decode, < 0: k_decode alone (variant -dbg)
         } else return fail(ctx, A3_ERR_INVALID, "kernel: 0 dart_count, 1 dart_assign, 2 local_contract, 3 decode, 4 decode on cold frames");
         A3_HIP(hipEventRecord(e1, st));
         A3_HIP(hipStreamSynchronize(st));
@@ -1847,7 +1852,7 @@ int a3_debug_discard_too_near(a3_ctx* ctx, const uint32_t* quads_xy, size_t n, f
     A3_HIP(hipMemcpyAsync(small, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
     uint16_t* pre = ctx->tmp_b.as<uint16_t>(); uint16_t* fin = pre + kMaxCand * 8;
     A3_HIP(launch_frame_candidates(ctx->stream, ctx->tmp_a.as<CandRec>(), small, 1, kMaxCand, min_distance, pre, fin, small + 1,
-                                   ctx->tmp_c.as<uint32_t>(), small + 2, 0u, nullptr));
+                                   ctx->tmp_c.as<uint32_t>(), small + 2, 0u, nullptr, nullptr));
     uint32_t cnt = 0;
     A3_HIP(hipMemcpyAsync(&cnt, small + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
     A3_HIP(hipStreamSynchronize(ctx->stream));

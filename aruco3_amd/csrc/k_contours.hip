@@ -104,18 +104,11 @@ constexpr int kTileWords = 4, kTileRows = 64;
 __host__ __device__ inline uint32_t dart_tiles_x(uint32_t W) { return (words_per_row(W) + kTileWords - 1) / kTileWords; }
 __host__ __device__ inline uint32_t dart_tiles(uint32_t W, uint32_t H) { return dart_tiles_x(W) * ((H + kTileRows - 1) / kTileRows); }
 
-__device__ __forceinline__ bool tile_word(int W, int H, int* j, int* y) {
-    const int tx = blockIdx.x % dart_tiles_x((uint32_t)W), ty = blockIdx.x / dart_tiles_x((uint32_t)W);
-    *j = tx * kTileWords + (threadIdx.x & (kTileWords - 1));
-    *y = ty * kTileRows + (threadIdx.x >> 2);
-    return *j < (int)words_per_row((uint32_t)W) && *y < H;
-}
-
 // The tile's words plus a one-word / one-row apron are staged in LDS with row-contiguous loads (6 words per row,
 // 66 rows) instead of nine strided 8-byte loads per lane.
-__device__ __forceinline__ void tile_stage(const uint64_t* __restrict__ img, int W, int H, uint64_t (*s_t)[kTileWords + 2]) {
+__device__ __forceinline__ void tile_stage(const uint64_t* __restrict__ img, int W, int H, uint32_t tile, uint64_t (*s_t)[kTileWords + 2]) {
     const int wpr = (int)words_per_row((uint32_t)W);
-    const int tx = blockIdx.x % dart_tiles_x((uint32_t)W), ty = blockIdx.x / dart_tiles_x((uint32_t)W);
+    const int tx = tile % dart_tiles_x((uint32_t)W), ty = tile / dart_tiles_x((uint32_t)W);
     const int j0 = tx * kTileWords - 1, y0 = ty * kTileRows - 1;
     // both words of a lane are requested before either is stored (unconditional loads from clamped addresses, masked
     // afterwards: a load behind a bounds test is issued and waited for on its own)
@@ -443,7 +436,7 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
                                                      uint32_t* __restrict__ pix_base, const uint32_t* __restrict__ tile_darts,
                                                      uint64_t* __restrict__ d_rec, uint32_t* __restrict__ d_succ,
                                                      const uint32_t* __restrict__ n_live, int dbg,
-                                                     const unsigned long long* __restrict__ tile_mask) {
+                                                     const unsigned long long* __restrict__ tile_mask, uint32_t tiles, uint32_t n_frames) {
     // dbg (a3_debug_kernel_time only; 0 in the product path): stop after 1 = the empty-tile test, 2 = phase 1 and its scans,
     // 3 = the range allocation; 4 = run phase 2 without its global stores
     __shared__ uint32_t s_wave[4];
@@ -461,16 +454,23 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
     __shared__ uint16_t s_nbk[256];
     __shared__ uint8_t s_wofrank[256], s_rank[256], s_fr[256];
     const int wpr = (int)words_per_row((uint32_t)W);
-    const uint32_t f = blockIdx.y;
-    if (tile_darts[(size_t)(first_frame + f) * gridDim.x + blockIdx.x] == 0u) return;   // uniform for the workgroup
+    // XCD-aware workgroup -> tile mapping.  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one, and its L2).  A tile
+    // row of the packed image is 32 bytes of a 128-byte line, and with (tile, frame) = (blockIdx.x, blockIdx.y) on a 1920-pixel frame
+    // -- 8 tiles side by side -- XCD k got tile column k of EVERY frame: each XCD fetched every line of every frame, 251 MB from the
+    // fabric per 256 frames for an image of 66 MB.  Here XCD k works through one contiguous eighth of the (frame, tile) sequence in
+    // order: a line's tiles meet in one L2, and so do the apron rows that vertical neighbours share.
+    const uint32_t n_wg = tiles * n_frames, chunk = (n_wg + 7u) >> 3, g = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+    if (g >= n_wg) return;
+    const uint32_t f = g / tiles, tile = g - f * tiles;
+    if (tile_darts[(size_t)(first_frame + f) * tiles + tile] == 0u) return;   // uniform for the workgroup
     if (n_live && *n_live == 0u) return;   // device-side plan: the graph does not fit the pool, the host re-plans
-    const uint32_t dart0 = frame_base[f] + tile_off[(size_t)(first_frame + f) * gridDim.x + blockIdx.x];
+    const uint32_t dart0 = frame_base[f] + tile_off[(size_t)(first_frame + f) * tiles + tile];
     if (dbg == 1) return;
     // Phase 1 works on the words that own darts only (k_dart_count's masks say which: typically 60 of a tile's 256, so one wave
     // does what four did -- the kernel is bound by its instruction count), lane k taking the k-th of them; every word's entry
     // in the per-word arrays starts at zero.
     __shared__ uint32_t s_cnt[256];   // per word: darts (low 17 bits) | border pixels << 17
-    const unsigned long long* tm = tile_mask + ((size_t)(first_frame + f) * gridDim.x + blockIdx.x) * kCountHalves;
+    const unsigned long long* tm = tile_mask + ((size_t)(first_frame + f) * tiles + tile) * kCountHalves;
     static_assert(kCountHalves == 4 && kTileWords == 4 && kTileRows == 64, "four 64-bit word masks per tile, four word columns of 64 rows");
     // Words are NUMBERED -- and with them the tile's darts -- column by column: w = jl * 64 + rl (word column jl = 64 pixels wide, row
     // rl).  Consecutive darts then fill blocks about as tall as wide instead of strips 256 pixels wide and a few rows high, and
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
     for (int c = 0; c < 4; c++)
         cm[c] = ((tm[0] >> (16 * c)) & 0xFFFFull) | (((tm[1] >> (16 * c)) & 0xFFFFull) << 16) | (((tm[2] >> (16 * c)) & 0xFFFFull) << 32) | (((tm[3] >> (16 * c)) & 0xFFFFull) << 48);
     const unsigned long long m0 = cm[0], m1 = cm[1], m2 = cm[2], m3 = cm[3];
-    tile_stage(bits + (size_t)(first_frame + f) * wpr * H, W, H, s_t);
+    tile_stage(bits + (size_t)(first_frame + f) * wpr * H, W, H, tile, s_t);
     s_nodes[threadIdx.x] = 0; s_c0[threadIdx.x] = 0; s_c1[threadIdx.x] = 0; s_c2[threadIdx.x] = 0; s_cnt[threadIdx.x] = 0;
     s_mark[threadIdx.x] = 0; s_mark[256 + threadIdx.x] = 0;
     __syncthreads();
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
     if (dbg == 2) return;
     __syncthreads();
     if (dbg == 3) return;
-    const int tx = blockIdx.x % dart_tiles_x((uint32_t)W), ty = blockIdx.x / dart_tiles_x((uint32_t)W);
+    const int tx = tile % dart_tiles_x((uint32_t)W), ty = tile / dart_tiles_x((uint32_t)W);
     uint32_t* pbf = pix_base + (size_t)f * W * H;
     for (uint32_t n = threadIdx.x; n < total_n; n += 256) {
         // word holding the n-th border pixel of the tile: the segment's first word + the words that begin inside the segment at or
@@ -1728,8 +1728,9 @@ hipError_t launch_dart_count(hipStream_t st, const uint64_t* bits, int W, int H,
 hipError_t launch_dart_build(hipStream_t st, const uint64_t* bits, int W, int H, uint32_t first_frame, uint32_t n_frames,
                              const uint32_t* frame_base, const uint32_t* tile_off, uint32_t* pix_base, const uint32_t* tile_darts, uint64_t* d_rec,
                              uint32_t* d_succ, uint32_t n_darts, const uint32_t* n_live, int dbg, const unsigned long long* tile_mask) {
-    hipLaunchKernelGGL(k_dart_assign, dim3(dart_tiles((uint32_t)W, (uint32_t)H), n_frames), dim3(256), 0, st, bits, W, H, first_frame, frame_base, tile_off,
-                       pix_base, tile_darts, d_rec, d_succ, n_live, dbg, tile_mask);
+    const uint32_t tiles = dart_tiles((uint32_t)W, (uint32_t)H);
+    hipLaunchKernelGGL(k_dart_assign, dim3((tiles * n_frames + 7u) / 8u * 8u), dim3(256), 0, st, bits, W, H, first_frame, frame_base, tile_off,
+                       pix_base, tile_darts, d_rec, d_succ, n_live, dbg, tile_mask, tiles, n_frames);
     if (dbg && dbg != 5) return hipGetLastError();   // 5 = everything (the probe's reference point), others leave d_succ alone
     hipLaunchKernelGGL(k_dart_link, dim3(blocks_for(n_darts, 256, env_cap("A3_LINK_BLOCKS", 4096))), dim3(256), 0, st, W, H, first_frame, pix_base, bits, d_rec, d_succ, n_darts, n_live);
     return hipGetLastError();

@@ -35,28 +35,38 @@ __device__ bool solve_projection(const float* from, float S, float* inv_out);
 // one wave per frame.  cands: unordered CandRec[max_cand] per frame (as k_contour_quads appended them).
 // proj != nullptr: the wave also solves the projection of every surviving candidate (one lane each: the 8x8 system needs
 // ~200 VGPRs, affordable in a one-wave workgroup) into proj[work index], which saves the separate k_projection launch.
+// BIG (tables beyond kFrameCandLds slots per frame -- a frame tiled with thousands of small squares; no camera frame gets there): the
+// sorted quads live where they end up anyway (pre_xy), keys and perimeters in a scratch plane of the caller's, and only the dead flags
+// in LDS (a byte per slot: 64 KB at the format's limit of 65 536 -- a3_marker.candidate_index is 16 bits).  Same walk, same order,
+// every LDS access of the small form a trip to the L2 instead: correct, not fast (0.1 s for 7 000 quads, all of them far apart).
+constexpr uint32_t kFrameCandLds = 6144;   // 21 bytes of LDS per slot in the small form: 129 KB of the CU's 160
 #ifndef A3_FC_WAVES
 #define A3_FC_WAVES 1
 #endif
+template <bool BIG>
 __global__ __launch_bounds__(64, A3_FC_WAVES) void k_frame_candidates(const CandRec* __restrict__ cands, const uint32_t* __restrict__ cand_count,
-                                                         uint32_t max_cand, float min_distance, uint16_t* __restrict__ pre_xy,
+                                                         uint32_t max_cand, float min_distance, uint16_t* pre_xy,
                                                          uint16_t* __restrict__ fin_xy, uint32_t* __restrict__ fin_count,
                                                          uint32_t* __restrict__ work, unsigned int* __restrict__ work_count,
-                                                         uint32_t S, ProjRec* __restrict__ proj) {
+                                                         uint32_t S, ProjRec* __restrict__ proj, float* big_scratch /* BIG: frames x max_cand */) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint16_t* s_xy = reinterpret_cast<uint16_t*>(smem);                       // max_cand * 8
-    float* s_per = reinterpret_cast<float*>(smem + (size_t)max_cand * 16);    // max_cand
-    uint8_t* s_dead = smem + (size_t)max_cand * 20;                           // max_cand
+    uint16_t* s_xy = BIG ? pre_xy + (size_t)blockIdx.x * max_cand * 8 : reinterpret_cast<uint16_t*>(smem);                      // max_cand * 8
+    float* s_per = BIG ? big_scratch + (size_t)blockIdx.x * max_cand : reinterpret_cast<float*>(smem + (size_t)max_cand * 16);   // max_cand
+    uint8_t* s_dead = BIG ? smem : smem + (size_t)max_cand * 20;                                                                // max_cand
+    // (BIG: what one lane wrote to memory another reads after the barrier -- the fence makes the wave's stores visible and drops stale lines)
+#define FC_SYNC() do { if (BIG) __threadfence(); __syncthreads(); } while (0)
     const uint32_t f = blockIdx.x;
     const int lane = threadIdx.x;
-    const uint32_t c = min(cand_count[f], max_cand);
+    // a frame that overflowed its table: k_contour_quads has flagged it, the host re-runs the batch with larger tables and nothing of
+    // this pass is used -- no point in ordering the slots that did fit (seconds, at the large end of the through-memory form)
+    const uint32_t c = cand_count[f] > max_cand ? 0u : cand_count[f];
     const CandRec* src = cands + (size_t)f * max_cand;
     // rank sort by start key (keys are unique: one border starts per pixel visit).  The keys go to LDS first: ranking
     // straight from global memory was a chain of c dependent loads per lane (s_per doubles as the key buffer until the
     // perimeters are written).
     uint32_t* s_key = reinterpret_cast<uint32_t*>(s_per);
     for (uint32_t i = lane; i < c; i += 64) s_key[i] = src[i].start_key;
-    __syncthreads();
+    FC_SYNC();
     for (uint32_t i = lane; i < c; i += 64) {
         const uint32_t key = s_key[i];
         const CandRec r = src[i];   // in flight while the rank is counted
@@ -64,13 +74,13 @@ __global__ __launch_bounds__(64, A3_FC_WAVES) void k_frame_candidates(const Cand
         for (uint32_t j = 0; j < c; j++) rank += s_key[j] < key;
         for (int k = 0; k < 8; k++) s_xy[rank * 8 + k] = r.xy[k];
     }
-    __syncthreads();
+    FC_SYNC();
     for (uint32_t i = lane; i < c; i += 64) {
         s_per[i] = perimeter4(&s_xy[i * 8]);
         s_dead[i] = 0;
-        for (int k = 0; k < 8; k++) pre_xy[((size_t)f * max_cand + i) * 8 + k] = s_xy[i * 8 + k];
+        if (!BIG) for (int k = 0; k < 8; k++) pre_xy[((size_t)f * max_cand + i) * 8 + k] = s_xy[i * 8 + k];
     }
-    __syncthreads();
+    FC_SYNC();
     // discard_too_near, src/aruco.rs:187-232: i ascending; for j > i ascending, a close pair kills the smaller
     // perimeter; once i itself is dead the rest of its row is a no-op.
     if (c >= 2 && c <= 64) {
@@ -138,9 +148,9 @@ __global__ __launch_bounds__(64, A3_FC_WAVES) void k_frame_candidates(const Cand
             if ((kill >> lane) & 1ull) s_dead[j] = 1;
         }
         if (i_dead && lane == 0) s_dead[i] = 1;
-        __syncthreads();
+        FC_SYNC();
     }
-    __syncthreads();
+    FC_SYNC();
     // survivors, order preserved: count them, take a range of the work list, then write quads, work items and projections
     uint32_t total = 0;
     for (uint32_t i0 = 0; i0 < c; i0 += 64) {
@@ -171,6 +181,7 @@ __global__ __launch_bounds__(64, A3_FC_WAVES) void k_frame_candidates(const Cand
         }
         base += __popcll(m);
     }
+#undef FC_SYNC
 }
 
 // ---------------------------------------------------------------------------------------
@@ -496,11 +507,6 @@ __device__ __forceinline__ void wave_best_var_to63(double& var, int& best_t) {
 
 // gather the accepted markers of frame f, candidate order preserved, by ONE WAVE (per_frame[] holds the number of accepted candidates
 // of every frame: k_decode counted them; a frame's first output slot is the sum over the frames before it)
-struct CompactArgs {
-    const uint32_t* fin_count; uint32_t n_frames; a3_marker* markers; uint32_t marker_cap; unsigned int* marker_total;
-    unsigned int* err_flags; const uint32_t* cand_count; unsigned int* cand_pre_total;
-    unsigned int* ticket;   // != nullptr: the last workgroup of k_decode's launch does the compaction (small batches: a launch less)
-};
 __device__ __forceinline__ void compact_frame_wave(uint32_t f, int lane, const DecodeOut* __restrict__ outs, const uint16_t* __restrict__ fin_xy,
                                                    const uint32_t* __restrict__ fin_count, uint32_t n_frames, uint32_t max_cand,
                                                    a3_marker* __restrict__ markers, uint32_t marker_cap, const uint32_t* __restrict__ per_frame,
@@ -511,10 +517,10 @@ __device__ __forceinline__ void compact_frame_wave(uint32_t f, int lane, const D
     for (int o = 32; o > 0; o >>= 1) base += __shfl_xor(base, o);
     if (f + 1 == n_frames && lane == 0) *marker_total = base + per_frame[f];
     if (f + 1 == n_frames) {   // a3_stats.candidates_pre: quads after contours_to_candidates, summed over the batch
-        uint32_t pre = 0;
-        for (uint32_t g = lane; g < n_frames; g += 64) pre += min(cand_count[g], max_cand);
-        for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o);
-        if (lane == 0) *cand_pre_total = pre;
+        uint32_t pre = 0, most = 0;   // cand_pre_total[3]: the largest number of quads any frame produced (beyond its table's slots: what the host grows the tables to)
+        for (uint32_t g = lane; g < n_frames; g += 64) { pre += min(cand_count[g], max_cand); most = max(most, cand_count[g]); }
+        for (int o = 32; o > 0; o >>= 1) { pre += __shfl_xor(pre, o); most = max(most, (uint32_t)__shfl_xor(most, o)); }
+        if (lane == 0) { *cand_pre_total = pre; cand_pre_total[3] = most; }
     }
     const uint32_t c = fin_count[f];
     uint32_t pos = base;
@@ -557,8 +563,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? A3_D_WAVES : A3_D_WAVES256) void k_d
                                                 const unsigned int* __restrict__ work_count, uint32_t max_cand, uint32_t S, uint32_t n,
                                                 uint32_t max_taps, const uint64_t* __restrict__ dict, uint32_t n_codes, uint32_t tau,
                                                 int filter, const ProjRec* __restrict__ proj, const float* __restrict__ wtab, DecodeOut* __restrict__ outs,
-                                                uint8_t* __restrict__ patches /*nullable*/, uint32_t patch_cap, uint32_t* __restrict__ per_frame /*nullable*/, int dbg,
-                                                CompactArgs ca) {
+                                                uint8_t* __restrict__ patches /*nullable*/, uint32_t patch_cap, uint32_t* __restrict__ per_frame /*nullable*/, int dbg) {
     // dbg (a3_debug_kernel_time only, 0 in the product path): 1 = no sampling, 2 / 3 / 4 = stop after sampling / Otsu / bits
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* s_patch = smem;
@@ -861,22 +866,6 @@ __global__ __launch_bounds__(NT, NT == 64 ? A3_D_WAVES : A3_D_WAVES256) void k_d
         }
 #undef POST_SYNC
     }
-    // Small batches (the one-frame call of the reference's own callers): the LAST workgroup of the launch to get here gathers the
-    // markers, one wave per frame in turn -- what k_compact_markers_par's launch would do ~5 us later.  Every workgroup's results
-    // are published (fence) before it takes its ticket; the last one sees them all.
-    if (ca.ticket) {
-        __shared__ uint32_t s_last;
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) s_last = atomicAdd(ca.ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
-        __syncthreads();
-        if (s_last) {
-            __threadfence();
-            for (uint32_t f = (uint32_t)tid >> 6; f < ca.n_frames; f += NT / 64)
-                compact_frame_wave(f, tid & 63, outs, fin_xy, ca.fin_count, ca.n_frames, max_cand, ca.markers, ca.marker_cap, per_frame, ca.marker_total,
-                                   ca.err_flags, ca.cand_count, ca.cand_pre_total);
-        }
-    }
 }
 
 // gather the accepted markers, frame by frame, candidate order preserved: one wave per frame.  per_frame[] already holds
@@ -908,9 +897,10 @@ __global__ __launch_bounds__(256) void k_compact_markers(const DecodeOut* __rest
     const int tid = threadIdx.x;
     if (tid == 0) s_base = *marker_total;
     {
-        uint32_t pre = 0;
-        for (uint32_t g = tid; g < n_frames; g += 256) pre += min(cand_count[g], max_cand);
+        uint32_t pre = 0, most = 0;
+        for (uint32_t g = tid; g < n_frames; g += 256) { pre += min(cand_count[g], max_cand); most = max(most, cand_count[g]); }
         if (pre) atomicAdd(cand_pre_total, pre);
+        if (most) atomicMax(cand_pre_total + 3, most);
     }
     __syncthreads();
     for (uint32_t f0 = 0; f0 < n_frames; f0 += 256) {
@@ -1233,16 +1223,24 @@ size_t decode_lds_bytes(uint32_t S, uint32_t n, uint32_t max_taps) {
 
 hipError_t launch_frame_candidates(hipStream_t st, const CandRec* cands, const uint32_t* cand_count, uint32_t n_frames, uint32_t max_cand,
                                    float min_distance, uint16_t* pre_xy, uint16_t* fin_xy, uint32_t* fin_count, uint32_t* work,
-                                   unsigned int* work_count, uint32_t S, void* proj) {
-    const size_t lds = (size_t)max_cand * 21 + 16;
-    if (lds > 48 * 1024) {   // tables grown past the default (a3_api.hip: kMaxCandLimit keeps this under the CU's 160 KB)
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_frame_candidates), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                   unsigned int* work_count, uint32_t S, void* proj, float* big_scratch /* max_cand > frame_cand_lds_slots(): frames x max_cand floats */) {
+    const bool big = max_cand > kFrameCandLds;
+    if (big && !big_scratch) return hipErrorInvalidValue;
+    const size_t lds = big ? (size_t)max_cand + 16 : (size_t)max_cand * 21 + 16;
+    if (lds > 48 * 1024) {   // tables grown past the default
+        const hipError_t e = hipFuncSetAttribute(big ? reinterpret_cast<const void*>(k_frame_candidates<true>) : reinterpret_cast<const void*>(k_frame_candidates<false>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_frame_candidates, dim3(n_frames), dim3(64), lds, st, cands, cand_count, max_cand, min_distance, pre_xy, fin_xy,
-                       fin_count, work, work_count, S, reinterpret_cast<ProjRec*>(proj));
+    if (big)
+        hipLaunchKernelGGL(k_frame_candidates<true>, dim3(n_frames), dim3(64), lds, st, cands, cand_count, max_cand, min_distance, pre_xy, fin_xy,
+                           fin_count, work, work_count, S, reinterpret_cast<ProjRec*>(proj), big_scratch);
+    else
+        hipLaunchKernelGGL(k_frame_candidates<false>, dim3(n_frames), dim3(64), lds, st, cands, cand_count, max_cand, min_distance, pre_xy, fin_xy,
+                           fin_count, work, work_count, S, reinterpret_cast<ProjRec*>(proj), nullptr);
     return hipGetLastError();
 }
+uint32_t frame_cand_lds_slots() { return kFrameCandLds; }
 
 size_t proj_rec_bytes() { return sizeof(ProjRec); }
 size_t weight_table_bytes() { return kWeightTableBytes; }
@@ -1254,12 +1252,8 @@ hipError_t launch_weight_table(hipStream_t st, uint32_t S, uint32_t n, uint32_t 
 
 hipError_t launch_decode(hipStream_t st, PixelSrc src, int W, int H, uint32_t first_frame, const uint16_t* fin_xy, const uint32_t* work,
                          const unsigned int* work_count, uint32_t max_cand, uint32_t S, uint32_t n, uint32_t max_taps, const uint64_t* dict,
-                         uint32_t n_codes, uint32_t tau, int filter, void* proj, const float* wtab, void* outs, uint8_t* patches, uint32_t patch_cap, uint32_t* per_frame, int grid_blocks, int dbg, int few,
-                         const uint32_t* fin_count, uint32_t n_frames, a3_marker* markers, uint32_t marker_cap, unsigned int* marker_total, unsigned int* err_flags,
-                         const uint32_t* cand_count, unsigned int* cand_pre_total, unsigned int* ticket /* nullptr: the caller launches the compaction itself */) {
+                         uint32_t n_codes, uint32_t tau, int filter, void* proj, const float* wtab, void* outs, uint8_t* patches, uint32_t patch_cap, uint32_t* per_frame, int grid_blocks, int dbg, int few) {
     ProjRec* recs = reinterpret_cast<ProjRec*>(proj);
-    const CompactArgs ca{fin_count, n_frames, markers, marker_cap, marker_total, err_flags, cand_count, cand_pre_total, few ? ticket : nullptr};
-    const CompactArgs none{nullptr, 0u, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (dbg > 0 || dbg == -1000) hipLaunchKernelGGL(k_projection, dim3(256), dim3(64), 0, st, fin_xy, work, work_count, S, recs);
     // Four waves sample a candidate: a candidate is a chain of round trips to the frame (19 of them for one wave: 65 us for a lone
     // candidate however idle the chip is, 33 us with four waves).  What follows the sampling runs on all four waves when the
@@ -1270,11 +1264,11 @@ hipError_t launch_decode(hipStream_t st, PixelSrc src, int W, int H, uint32_t fi
     few = tuning_knob("A3_DECODE_WIDE", few);   // (-DA3_TUNING builds only)
     if (few)
         hipLaunchKernelGGL((k_decode<256, 256>), dim3(grid_blocks), dim3(256), decode_lds_bytes(S, n, max_taps), st, src, W, H, first_frame, fin_xy, work, work_count,
-                           max_cand, S, n, max_taps, dict, n_codes, tau, filter, recs, wtab, reinterpret_cast<DecodeOut*>(outs), patches, patch_cap, per_frame, d, ca);
+                           max_cand, S, n, max_taps, dict, n_codes, tau, filter, recs, wtab, reinterpret_cast<DecodeOut*>(outs), patches, patch_cap, per_frame, d);
     else
         hipLaunchKernelGGL((k_decode<A3_D_THREADS, 64>), dim3(grid_blocks), dim3(A3_D_THREADS), decode_lds_bytes(S, n, max_taps), st, src, W, H, first_frame, fin_xy, work,
                            work_count, max_cand, S, n, max_taps, dict, n_codes, tau, filter, recs, wtab, reinterpret_cast<DecodeOut*>(outs), patches, patch_cap,
-                           per_frame, d, none);
+                           per_frame, d);
     return hipGetLastError();
 }
 

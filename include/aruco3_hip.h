@@ -32,11 +32,14 @@ enum {
     A3_ERR_NO_DEVICE = -5,
     A3_ERR_LIMIT = -6       /* a fixed limit of this implementation, which no larger buffer of the caller's cures: more than
                              * A3_MAX_CANDIDATES_PER_FRAME quad candidates in one frame (the reference's lists are unbounded Vecs,
-                             * src/aruco.rs:128; here a frame's candidates are ordered and thinned (discard_too_near) in one
-                             * workgroup's LDS), or a frame whose contour graph needs more than 2^32 nodes.  Growing `out` and
-                             * calling again -- the cure for A3_ERR_CAPACITY -- does not help. */
+                             * src/aruco.rs:128; here a3_marker.candidate_index is 16 bits), frames x candidate slots per frame
+                             * beyond 2^32 in one call, or a frame whose contour graph needs more than 2^32 nodes.  Growing `out`
+                             * and calling again -- the cure for A3_ERR_CAPACITY -- does not help. */
 };
-#define A3_MAX_CANDIDATES_PER_FRAME 6144
+/* The per-frame candidate tables start at 1024 slots and grow with a re-run of the batch (2048, 4096, 6144: ordered and thinned --
+ * discard_too_near -- in one workgroup's LDS; 12 288 ... 65 536: the same walk through memory, correct but slow -- 0.1 s for a frame
+ * of 7 000 quads -- which only a frame tiled with thousands of small squares reaches). */
+#define A3_MAX_CANDIDATES_PER_FRAME 65536
 
 /* pixel layouts accepted where the reference takes an image::DynamicImage (src/aruco.rs:52,60) */
 enum { A3_FMT_RGB8 = 0, A3_FMT_RGBA8 = 1, A3_FMT_L8 = 2,

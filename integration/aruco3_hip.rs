@@ -48,7 +48,7 @@ pub const A3_OK: c_int = 0;
 pub const A3_ERR_INVALID: c_int = -1;
 pub const A3_ERR_HIP: c_int = -2;
 pub const A3_ERR_CAPACITY: c_int = -3;
-pub const A3_ERR_LIMIT: c_int = -6; // a fixed limit of the library (6144 candidates per frame): growing the output does not help
+pub const A3_ERR_LIMIT: c_int = -6; // a fixed limit of the library (65536 candidates per frame): growing the output does not help
 pub const A3_ERR_INTERNAL: c_int = -4;
 pub const A3_ERR_NO_DEVICE: c_int = -5;
 
@@ -509,10 +509,10 @@ fn fill_debug_outputs(ctx: &HipCtx, f: u32, width: u32, height: u32, sample: u32
 /// With `Detection.homographies` populated the library keeps one patch per candidate of the batch, up to 2^20 patches per call;
 /// a populated call therefore never carries more frames than this (larger batches are split).
 const MAX_TAPPED_FRAMES: usize = 1024;
-/// The library's candidate tables grow to 6144 quads per frame (beyond that a3_detect_batch reports A3_ERR_LIMIT, which no retry
+/// The library's candidate tables grow to 65536 quads per frame (beyond that a3_detect_batch reports A3_ERR_LIMIT, which no retry
 /// cures and which `check` turns into a panic at once): marker lists are grown and the batch re-run only on A3_ERR_CAPACITY, and at
 /// most up to that many markers per frame.
-const MAX_MARKERS_PER_FRAME: usize = 6144;
+const MAX_MARKERS_PER_FRAME: usize = 65536;
 
 impl Detector {
     /// src/aruco.rs:52-121, same signature.  One frame = a batch of one.

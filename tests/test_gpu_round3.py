@@ -260,12 +260,36 @@ def test_candidate_table_grows_past_1024_quads_per_frame(dicts, oracle):
     assert markers_of_hip(m) == markers_of_oracle(oracle.detect(f1[0], d.code_list, d.num_bits, d._tau))
 
 
+@pytest.mark.parametrize("w,h,side,pitch,factor,lo,hi", [(3200, 2400, 24, 32, 0.2, 6144, 12288), (3600, 3600, 12, 18, 0.004, 24576, 49152)])
+def test_candidate_table_grows_past_the_lds_form(dicts, oracle, w, h, side, pitch, factor, lo, hi):
+    """~7 000 and ~40 000 quads in one frame: past the 6144 slots that k_frame_candidates orders and thins in LDS (round 4's limit),
+    into its through-memory form (tables of 12 288 / 49 152): candidates, their order, what discard_too_near leaves and the markers
+    equal the oracle's."""
+    from tests.test_gpu_shard_taps import _detect_host
+
+    img = _grid_of_squares(w, h, side, pitch)
+    det = _detector(dicts, "ARUCO", min_side_length_factor=factor)
+    d = det.dictionary
+    cfg = oracle.Config.default()
+    cfg.min_side_length_factor = factor
+    res = oracle.detect(img, d.code_list, d.num_bits, d._tau, cfg)
+    assert lo < len(res["candidates_pre"]) <= hi
+    ctx, m0, per0 = _detect_host(det, np.ascontiguousarray(img[None, :, :, None]), taps=False)
+    st = ctx.stats()
+    assert st["candidates_pre"] == len(res["candidates_pre"]) and st["candidates"] == len(res["candidates"])
+    assert markers_of_hip(m0) == markers_of_oracle(res)
+    assert ctx.candidates(0, before_discard=True).tolist() == res["candidates_pre"].tolist()
+    assert ctx.candidates(0).tolist() == res["candidates"].tolist()
+
+
 def test_more_candidates_than_the_limit_is_an_error_not_a_clip(dicts):
+    """Beyond 65 536 quads in one frame (a3_marker.candidate_index is 16 bits) the call fails with A3_ERR_LIMIT -- after growing its
+    tables seven times -- instead of returning a clipped list."""
     from aruco3_amd import _lib
     from tests.test_gpu_shard_taps import _detect_host
 
-    img = _grid_of_squares(3200, 2400, 24, 32)          # ~ 7 000 quads: past the 6144-slot limit
-    det = _detector(dicts, "ARUCO")
+    img = _grid_of_squares(4800, 4800, 10, 16)          # ~ 89 000 squares
+    det = _detector(dicts, "ARUCO", min_side_length_factor=0.004)   # (the default, 0.2 x the shorter side, would dismiss borders this short)
     with pytest.raises(_lib.A3Error) as e:
         _detect_host(det, np.ascontiguousarray(img[None, :, :, None]), taps=False)
     assert e.value.code == _lib.ERR_LIMIT
