@@ -184,8 +184,8 @@ hipError_t launch_k1_r2(uint32_t radius, hipStream_t st, const uint8_t* pixels, 
 // threshold windows the register-resident kernel covers: radii 1..kFusedMaxRadius.  Beyond 7 the packed 16-bit arithmetic ends --
 // (2R+1)^2 * 256 no longer fits a u16 from R = 8 on (289 * 256 = 73 984), so window sums and the compare would need 32-bit lanes and a ring
 // of 2R+1 rows no register file holds.
-// Radii 8..15 have a fused kernel of their own (k_threshold_big.hip: the grey ring in registers + LDS, 32-bit sums); what is left for
-// the separable path -- which needs a grey plane and a plane of row sums -- is radius 0 and radii above 15.
+// Radii 8..31 have a fused kernel of their own (k_threshold_big.hip: the grey ring in registers + LDS, 32-bit sums); what is left for
+// the separable path -- which needs a grey plane and a plane of row sums -- is radius 0 and radii above 31.
 constexpr uint32_t kFusedMaxRadius = 7;
 bool ring_kernel_applies(uint32_t radius, const uint8_t* pixels, size_t row_stride, size_t frame_stride, int W);
 hipError_t launch_ring_threshold(uint32_t radius, hipStream_t st, const uint8_t* pixels, int fmt, size_t row_stride, size_t frame_stride, int W, int H,

@@ -1,4 +1,4 @@
-// k_threshold_big.hip -- threshold windows 8..15 (adaptive_threshold(&grey, R), src/aruco.rs:61 with DetectorConfig.threshold_window
+// k_threshold_big.hip -- threshold windows 8..31 (adaptive_threshold(&grey, R), src/aruco.rs:61 with DetectorConfig.threshold_window
 // above the default 7), fused like K1: pixels -> grey -> (2R+1)^2 box sums -> compare -> packed bits in one pass over the frames.
 //
 // k_grey_threshold7 (k_threshold_k1.h) keeps a ring of the last 2R+1 rows of horizontal sums in registers and adds packed u16 pairs;
@@ -14,6 +14,9 @@
 //     (0, 1) one half, v_dot2_i32_i16 with -1 subtracts: two chains (pixels 0 and 8) of R + 1 instructions to start and two per
 //     slide step; the 2R columns beside the lane's 16 come from the neighbouring lanes (wave shifts, as in K1);
 //   * compare per pixel in 32 bits: d = S - (L + 1) * area, the result bit is d's sign, shifted in with one v_alignbit.
+// Radii 16..31 (round 5) are the same kernel with TWO lanes of apron on either side of a wave (a window reaches 31 columns: 60 lanes
+// own output instead of 62), E[] 80 columns wide, and one wave per SIMD -- 31 grey rows in registers (the compiler parks part of them in
+// AGPRs) + 32 KB of ring per wave in LDS leave room for four waves per CU.
 // Lanes, strips (2048 waves of 270 rows for 256 frames of 1920x1080), directions, the load queue and the XCD mapping are K1's, and so
 // are its two ways of reading a row: FAST (16-byte aligned pointers and strides, W % 16 == 0: unconditional vector loads from clamped
 // addresses) and the per-pixel loads of any other layout (load_raw).
@@ -33,50 +36,56 @@ __device__ __forceinline__ uint32_t dot_signed(uint32_t e, uint32_t w, uint32_t 
     return (uint32_t)__builtin_amdgcn_sdot2(__builtin_bit_cast(a3_s2, e), __builtin_bit_cast(a3_s2, w), (int)acc, false);
 }
 
-// E[k] = columns 2k - 16 (low half) and 2k - 15 (high half), k = 0 .. 23: the neighbouring lanes' 16 columns each and the lane's own.
-// sum of the columns lo .. hi (inclusive, -16 <= lo <= hi <= 31) added to acc; every index is a compile-time constant
-template <int LO, int HI>
+// E[k] = columns 2k - EB (low half) and 2k - EB + 1 (high half): the neighbouring lanes' 16 columns each (EB = 16: one lane on either
+// side, 24 dwords; EB = 32: two, 40 dwords) and the lane's own.
+// sum of the columns lo .. hi (inclusive, -EB <= lo <= hi <= 15 + EB) added to acc; every index is a compile-time constant
+template <int EB, int LO, int HI>
 __device__ __forceinline__ uint32_t sum_cols(const uint32_t* E, uint32_t acc) {
 #pragma unroll
-    for (int k = (LO + 16) >> 1; k <= (HI + 16) >> 1; k++) {
-        const bool lo_in = 2 * k - 16 >= LO, hi_in = 2 * k - 15 <= HI;
+    for (int k = (LO + EB) >> 1; k <= (HI + EB) >> 1; k++) {
+        const bool lo_in = 2 * k - EB >= LO, hi_in = 2 * k - EB + 1 <= HI;
         acc = dot_add(E[k], (lo_in ? 1u : 0u) | (hi_in ? 0x10000u : 0u), acc);
     }
     return acc;
 }
 // one column of E: value of column c
-template <int C>
-__device__ __forceinline__ uint32_t plus_col(const uint32_t* E, uint32_t acc) { return dot_add(E[(C + 16) >> 1], ((C + 16) & 1) ? 0x10000u : 1u, acc); }
-template <int C>
-__device__ __forceinline__ uint32_t minus_col(const uint32_t* E, uint32_t acc) { return dot_signed(E[(C + 16) >> 1], ((C + 16) & 1) ? 0xFFFF0000u : 0xFFFFu, acc); }
+template <int EB, int C>
+__device__ __forceinline__ uint32_t plus_col(const uint32_t* E, uint32_t acc) { return dot_add(E[(C + EB) >> 1], ((C + EB) & 1) ? 0x10000u : 1u, acc); }
+template <int EB, int C>
+__device__ __forceinline__ uint32_t minus_col(const uint32_t* E, uint32_t acc) { return dot_signed(E[(C + EB) >> 1], ((C + EB) & 1) ? 0xFFFF0000u : 0xFFFFu, acc); }
 
-template <int R, int X>
+template <int EB, int R, int X>
 __device__ __forceinline__ void slide_chain(const uint32_t* E, uint32_t* S) {   // S[X + 1 .. X + 7] from S[X]
     if constexpr (X % 8 != 7) {
-        S[X + 1] = minus_col<X - R>(E, plus_col<X + R + 1>(E, S[X]));
-        slide_chain<R, X + 1>(E, S);
+        S[X + 1] = minus_col<EB, X - R>(E, plus_col<EB, X + R + 1>(E, S[X]));
+        slide_chain<EB, R, X + 1>(E, S);
     }
 }
 
+// apron lanes on either side of a wave and the output columns left to it
+constexpr int ring_halo_lanes(int R) { return R > 15 ? 2 : 1; }
+constexpr int ring_out_cols(int R) { return (64 - 2 * ring_halo_lanes(R)) * T_LPX; }
+
 // grid: 8 * ceil(frames / 8) * strips_x * strips_y workgroups of one wave; dynamic LDS: (R + 1) KB of ring + (flush_rows + T_PF) * 128 B
 template <int FMT, int R, bool FAST>
-__global__ __launch_bounds__(64, 2) void k_grey_threshold_ring(const uint8_t* __restrict__ pixels, size_t row_stride, size_t frame_stride, int W, int H,
+__global__ __launch_bounds__(64, R > 15 ? 1 : 2) void k_grey_threshold_ring(const uint8_t* __restrict__ pixels, size_t row_stride, size_t frame_stride, int W, int H,
                                                                 int rows_per_wave, int strips_y, int n_frames, uint8_t* __restrict__ grey,
                                                                 uint8_t* __restrict__ bits, int flush_rows, int aligned_in) {
-    static_assert(R >= 8 && R <= 15, "radii 8..15: the neighbouring lane's 16 columns cover the window's reach");
+    static_assert(R >= 8 && R <= 31, "radii 8..31: one (..15) or two neighbouring lanes' 16 columns cover the window's reach");
     constexpr int NB = R + 1, PF = A3_T_PF;   // NB: rows of the ring's second stage (LDS)
+    constexpr int HL = ring_halo_lanes(R), EB = 16 * HL, OUT = ring_out_cols(R);
     // LDS admits eight waves per CU; they must sit two on every SIMD.  Below 169 VGPRs a SIMD takes three, the eight are then
     // spread unevenly (3 + 3 + 2 + 0 at worst), and a kernel bound by its instruction issue runs at the pace of the fullest SIMD (radii 8..13
     // compile to 140 .. 166 VGPRs and took 1.4 x window 7 that way, 14 and 15 -- 170 and 175 -- 1.17 x): the clobber lifts the
     // allocation above the line for every radius.
-    asm volatile("" ::: "v176");
+    if constexpr (R <= 15) asm volatile("" ::: "v176");
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
     uint4* s_ring = reinterpret_cast<uint4*>(s_raw);                                   // [NB][64]
     uint16_t* s_out = reinterpret_cast<uint16_t*>(s_raw + (size_t)NB * 1024);          // [flush_rows + PF][64]
     const int lane = threadIdx.x;
     // every strip of a frame on one XCD, top to bottom (k_grey_threshold7's map_by_frame)
     const int xcd = blockIdx.x & 7, kb = blockIdx.x >> 3;
-    const int strips_x = (W + T_OUT - 1) / T_OUT, per_frame = strips_x * strips_y, idx = kb % per_frame;
+    const int strips_x = (W + OUT - 1) / OUT, per_frame = strips_x * strips_y, idx = kb % per_frame;
     const int f = (kb / per_frame) * 8 + xcd;
     if (f >= n_frames) return;
     const int sx = idx / strips_y, sy = idx % strips_y;
@@ -86,9 +95,9 @@ __global__ __launch_bounds__(64, 2) void k_grey_threshold_ring(const uint8_t* __
     const size_t bpr = (size_t)words_per_row((uint32_t)W) * 8;
     uint8_t* bout = bits + (size_t)f * bpr * H;
 
-    const int x0 = sx * T_OUT - T_LPX + T_LPX * lane;
+    const int x0 = sx * OUT - HL * T_LPX + T_LPX * lane;
     const int y_begin = sy * rows_per_wave, y_end = min(H, y_begin + rows_per_wave);
-    const bool owner = lane >= 1 && lane <= 62 && x0 < W;
+    const bool owner = lane >= HL && lane <= 63 - HL && x0 < W;
     const bool lane_in = x0 >= 0 && x0 + T_LPX <= W;   // (FAST, W % 16 == 0: a lane's columns are all inside or all outside)
 
     // clipped window widths of the lane's columns (0 outside the image: the comparison then fails), 8 bits each
@@ -178,26 +187,32 @@ __global__ __launch_bounds__(64, 2) void k_grey_threshold_ring(const uint8_t* __
 #pragma unroll
                 for (int j = 0; j < T_LPX; j++) area[j] = mul24((axp[j >> 2] >> (8 * (j & 3))) & 255u, ay);
             }
-            // E[]: the column sums of columns -16 .. 31 (only the dwords a window of this radius reaches are fetched)
-            uint32_t E[24];
-            constexpr int KLO = (16 - R) >> 1, KHI = (31 + R) >> 1;   // first and last dword of E any window touches
+            // E[]: the column sums of columns -EB .. 15 + EB (only the dwords a window of this radius reaches are fetched)
+            uint32_t E[8 + 16 * HL];
+            constexpr int KLO = (EB - R) >> 1, KHI = (EB + 15 + R) >> 1;   // first and last dword of E any window touches
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                E[8 + i] = V[i];
-                E[i] = i >= KLO ? wave_from_left(V[i]) : 0u;
-                E[16 + i] = 16 + i <= KHI ? wave_from_right(V[i]) : 0u;
+                E[8 * HL + i] = V[i];
+                const uint32_t l1 = 8 * (HL - 1) + i >= KLO ? wave_from_left(V[i]) : 0u;
+                const uint32_t r1 = 8 * (HL + 1) + i <= KHI ? wave_from_right(V[i]) : 0u;
+                E[8 * (HL - 1) + i] = l1;
+                E[8 * (HL + 1) + i] = r1;
+                if constexpr (HL == 2) {
+                    E[i] = i >= KLO ? wave_from_left(l1) : 0u;
+                    E[32 + i] = 32 + i <= KHI ? wave_from_right(r1) : 0u;
+                }
             }
             uint32_t S[T_LPX];
-            S[0] = sum_cols<-R, R>(E, 0u);
-            S[8] = sum_cols<8 - R, 8 + R>(E, 0u);
-            slide_chain<R, 0>(E, S);
-            slide_chain<R, 8>(E, S);
+            S[0] = sum_cols<EB, -R, R>(E, 0u);
+            S[8] = sum_cols<EB, 8 - R, 8 + R>(E, 0u);
+            slide_chain<EB, R, 0>(E, S);
+            slide_chain<EB, R, 8>(E, S);
             // white iff S < (L + 1) * area: the sign of S - (L * area + area), shifted in from column 15 down to column 0
             uint32_t acc = 0u;
 #pragma unroll
             for (int j = T_LPX - 1; j >= 0; j--) {
                 const uint32_t L = (gc[j >> 2] >> (8 * (j & 3))) & 255u;
-                const uint32_t d = S[j] - (__umul24(L, area[j]) + area[j]);        // < 2^18 either way: the sign bit is the borrow
+                const uint32_t d = S[j] - (__umul24(L, area[j]) + area[j]);        // < 2^21 either way (63 * 63 * 256): the sign bit is the borrow
                 acc = __builtin_amdgcn_alignbit(acc, d, 31);              // acc * 2 + (d >> 31)
             }
             if (flush_rows <= 0) {
@@ -221,14 +236,15 @@ __global__ __launch_bounds__(64, 2) void k_grey_threshold_ring(const uint8_t* __
 template <int R>
 hipError_t launch_ring(hipStream_t st, const uint8_t* pixels, int fmt, size_t row_stride, size_t frame_stride, int W, int H, uint32_t n, uint8_t* grey,
                        uint64_t* bits) {
-    constexpr int NB = R + 1, WPC = 8;   // waves per CU: two per SIMD (115 + 4 R VGPRs; (R + 1) KB of ring and at least 29 parked rows each)
+    constexpr int NB = R + 1, WPC = R > 15 ? 4 : 8;   // waves per CU: two per SIMD (115 + 4 R VGPRs; (R + 1) KB of ring and at least 29 parked rows each); radii 16..31: one
+    constexpr int OUT = ring_out_cols(R);
     uint8_t* bin = reinterpret_cast<uint8_t*>(bits);
     if (W % 64 != 0) {  // packed rows end in padding bits that no strip writes
         hipError_t e = hipMemsetAsync(bits, 0, (size_t)words_per_row((uint32_t)W) * 8 * H * n, st);
         if (e != hipSuccess) return e;
     }
     // strips: K1's model (time ~ rounds x (rows per strip + 2R))
-    const int strips_x = (W + T_OUT - 1) / T_OUT;
+    const int strips_x = (W + OUT - 1) / OUT;
     const long long slots = (long long)g_k1_cus * WPC, cols = (long long)strips_x * n;
     int best_sy = 1; double best_cost = 1e300;
     for (int sy = 1; sy <= std::max(1, H / 16); sy++) {
@@ -261,7 +277,7 @@ hipError_t launch_ring(hipStream_t st, const uint8_t* pixels, int fmt, size_t ro
 }
 
 // the radii this file covers (any frame layout)
-bool ring_kernel_applies(uint32_t radius, const uint8_t*, size_t, size_t, int) { return radius >= 8 && radius <= 15; }
+bool ring_kernel_applies(uint32_t radius, const uint8_t*, size_t, size_t, int) { return radius >= 8 && radius <= 31; }
 
 hipError_t launch_ring_threshold(uint32_t radius, hipStream_t st, const uint8_t* pixels, int fmt, size_t row_stride, size_t frame_stride, int W, int H,
                                  uint32_t n, uint8_t* grey, uint64_t* bits) {
@@ -274,6 +290,22 @@ hipError_t launch_ring_threshold(uint32_t radius, hipStream_t st, const uint8_t*
         case 13: return launch_ring<13>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
         case 14: return launch_ring<14>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
         case 15: return launch_ring<15>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
+        case 16: return launch_ring<16>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
+        case 17: return launch_ring<17>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
+        case 18: return launch_ring<18>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
+        case 19: return launch_ring<19>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
+        case 20: return launch_ring<20>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
+        case 21: return launch_ring<21>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
+        case 22: return launch_ring<22>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
+        case 23: return launch_ring<23>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
+        case 24: return launch_ring<24>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
+        case 25: return launch_ring<25>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
+        case 26: return launch_ring<26>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
+        case 27: return launch_ring<27>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
+        case 28: return launch_ring<28>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
+        case 29: return launch_ring<29>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
+        case 30: return launch_ring<30>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
+        case 31: return launch_ring<31>(st, pixels, fmt, row_stride, frame_stride, W, H, n, grey, bits);
         default: return hipErrorInvalidValue;
     }
 }

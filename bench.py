@@ -1189,13 +1189,13 @@ def other_workloads(device, with_cpu=True, budget_s=100.0):
             note="benches/detect_markers.rs:29-51 recipe: every channel of every pixel uniform random u8; no markers")
         del noise, noise_more
     # other threshold windows on config 2's batch (src/aruco.rs:35,61: the reference's cost does not depend on the radius; here radii 1..7
-    # run the register-resident kernel templated on the radius, 8..15 the fused ring kernel, larger ones a separable three-kernel path);
+    # run the register-resident kernel templated on the radius, 8..31 the fused ring kernel, larger ones a separable three-kernel path);
     # the headline's 256 frames, so that the rows compare with it
     spec2, name2 = synth.config_spec(2)
     d2 = ARDictionary.new_from_named_dict(name2)
     f2, t2 = synth.render_frames_device(spec2, d2.code_list, d2.num_bits, [synth.frame_seed(2, i) for i in range(256)], device=device)
     f2_more = [synth.render_frames_device(spec2, d2.code_list, d2.num_bits, [synth.frame_seed(2, 256 * j + i) for i in range(256)], device=device)[0] for j in (1, 2, 3)]
-    for wnd in (3, 11):
+    for wnd in (3, 11, 21):
         run(f"C2_threshold_window_{wnd}", f2, name2, truths=t2, window=wnd, more=f2_more,
             note=f"BASELINE config 2's frames with DetectorConfig.threshold_window = {wnd} ({2 * wnd + 1} x {2 * wnd + 1})")
     del f2, f2_more

@@ -20,8 +20,8 @@ DICTS = ("ARUCO", "ARUCO_MIP_16H3", "APRILTAG_16H5", "APRILTAG_25H9", "ARUCO_MIP
 
 def _case(rng, big_windows=False):
     """one random case -> (config dict, dictionary name, pixel format name, frames [n, h, w, c] in R,G,B(,A) order).
-    big_windows: threshold windows 8..16, every other case on a width that is a multiple of 16: the fused kernel of windows
-    8..15 (k_threshold_big.hip) with its vector loads and with its per-pixel loads; 16 goes through the separable path."""
+    big_windows: threshold windows 8..33, every other case on a width that is a multiple of 16: the fused kernel of windows
+    8..31 (k_threshold_big.hip) with its vector loads and with its per-pixel loads; 32 and 33 go through the separable path."""
     from aruco3_amd import synth
     from aruco3_amd.dictionaries import ARDictionary
 
@@ -38,7 +38,7 @@ def _case(rng, big_windows=False):
     fmt = ("RGB8", "RGB8", "RGBA8", "BGRA8", "L8")[int(rng.integers(0, 5))]
     w, h = int(rng.integers(200, 900)), int(rng.integers(160, 700))
     if big_windows:
-        cfg["threshold_window"] = int(rng.integers(8, 17))
+        cfg["threshold_window"] = int(rng.integers(8, 34))
         if rng.integers(0, 2):
             w = (w + 15) // 16 * 16
         if not rng.integers(0, 6):

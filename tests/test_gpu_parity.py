@@ -142,9 +142,10 @@ def test_other_threshold_window(dicts, oracle):
         assert np.array_equal(ctx.download_grey(0, 640, 480, thresholded=True), oracle.adaptive_threshold(grey, win))
 
 
-@pytest.mark.parametrize("radius", [8, 9, 10, 11, 12, 13, 14, 15])
-def test_threshold_windows_8_to_15(dicts, oracle, radius):
-    """The fused kernel of windows 8..15 (grey ring in registers + LDS, 32-bit sums: k_threshold_big.hip) with its vector loads
+@pytest.mark.parametrize("radius", [8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 19, 22, 25, 28, 30, 31])
+def test_threshold_windows_8_to_31(dicts, oracle, radius):
+    """The fused kernel of windows 8..31 (grey ring in registers + LDS, 32-bit sums: k_threshold_big.hip; from 16 on with two apron
+    lanes per side and 960 output columns per wave) with its vector loads
     (W % 16 == 0: one and two column strips, images lower and narrower than the window) and with its per-pixel loads (any other
     width), every pixel format, noise / ramps / flat: into_luma8 + adaptive_threshold(&grey, radius) bit for bit, with and
     without a grey plane."""
@@ -351,7 +352,7 @@ def test_detector_config_variants(dicts, oracle, cfg):
 @pytest.mark.parametrize("window,row_pad,off", [(7, 20, 3), (11, 32, 16), (11, 20, 3)])
 def test_strided_and_offset_input(hip, dicts, oracle, window, row_pad, off):
     """row_stride / frame_stride larger than the packed size and a base pointer that is not 16-byte aligned
-    (the kernel then takes its per-pixel path); results must not change.  Window 11: the fused kernel of windows 8..15 on padded
+    (the kernel then takes its per-pixel path); results must not change.  Window 11: the fused kernel of windows 8..31 on padded
     but aligned rows (vector loads) and on unaligned ones (per-pixel loads)."""
     import torch
 
