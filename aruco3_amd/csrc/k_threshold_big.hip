@@ -62,17 +62,28 @@ __device__ __forceinline__ void slide_chain(const uint32_t* E, uint32_t* S) {   
     }
 }
 
+// The ring's split.  RA rows (the youngest) in registers, NB = 2R + 1 - RA in LDS.  Two waves per SIMD -- eight per CU -- are worth a
+// factor 1.8 (measured: 0.41 against 0.72 ms for radius 16), and eight waves fit a CU's LDS with at most 19 KB of ring each: up to radius
+// 18 the split is R | R + 1; beyond, as long as the registers hold the rest without scratch (115 + 4 RA VGPRs for RGB with vector loads,
+// 12 more for four-byte pixels, 25 fewer for L8, ~40 more with per-pixel loads), the LDS part stays at 19 rows and the register part
+// grows (1.26-1.45 x of window 7); the largest radii fall back to R | R + 1 and one wave per SIMD (2.4-2.6 x).
+constexpr int kRingLdsRows8 = 19;
+constexpr int ring_reg_rows(int R, bool fast, int fmt) {   // (the limits: the largest radius whose instantiation needs no scratch)
+    const int last8 = !fast ? 19 : (fmt == A3_FMT_L8 ? 28 : (fmt == A3_FMT_RGB8 ? 26 : 24));
+    return R + 1 <= kRingLdsRows8 ? R : (R <= last8 ? 2 * R + 1 - kRingLdsRows8 : R);
+}
 // apron lanes on either side of a wave and the output columns left to it
 constexpr int ring_halo_lanes(int R) { return R > 15 ? 2 : 1; }
 constexpr int ring_out_cols(int R) { return (64 - 2 * ring_halo_lanes(R)) * T_LPX; }
 
 // grid: 8 * ceil(frames / 8) * strips_x * strips_y workgroups of one wave; dynamic LDS: (R + 1) KB of ring + (flush_rows + T_PF) * 128 B
 template <int FMT, int R, bool FAST>
-__global__ __launch_bounds__(64, R > 15 ? 1 : 2) void k_grey_threshold_ring(const uint8_t* __restrict__ pixels, size_t row_stride, size_t frame_stride, int W, int H,
+__global__ __launch_bounds__(64, 2 * R + 1 - ring_reg_rows(R, FAST, FMT) <= kRingLdsRows8 ? 2 : 1) void k_grey_threshold_ring(const uint8_t* __restrict__ pixels, size_t row_stride, size_t frame_stride, int W, int H,
                                                                 int rows_per_wave, int strips_y, int n_frames, uint8_t* __restrict__ grey,
                                                                 uint8_t* __restrict__ bits, int flush_rows, int aligned_in) {
     static_assert(R >= 8 && R <= 31, "radii 8..31: one (..15) or two neighbouring lanes' 16 columns cover the window's reach");
-    constexpr int NB = R + 1, PF = A3_T_PF;   // NB: rows of the ring's second stage (LDS)
+    constexpr int RA = ring_reg_rows(R, FAST, FMT), NB = 2 * R + 1 - RA, PF = A3_T_PF;   // RA / NB: rows of the ring's first (registers) and second stage (LDS)
+    static_assert(RA >= R && NB >= 1, "the window's centre row (R iterations old) is still in registers");
     constexpr int HL = ring_halo_lanes(R), EB = 16 * HL, OUT = ring_out_cols(R);
     // LDS admits eight waves per CU; they must sit two on every SIMD.  Below 169 VGPRs a SIMD takes three, the eight are then
     // spread unevenly (3 + 3 + 2 + 0 at worst), and a kernel bound by its instruction issue runs at the pace of the fullest SIMD (radii 8..13
@@ -115,9 +126,9 @@ __global__ __launch_bounds__(64, R > 15 ? 1 : 2) void k_grey_threshold_ring(cons
 #pragma unroll
     for (int i = 0; i < 8; i++) V[i] = 0u;
     for (int s = 0; s < NB; s++) s_ring[s * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
-    uint32_t A[R][T_NG];       // the ring's first stage: A[i] = the grey row i + 1 iterations old; A[R - 1] is the window's centre row
+    uint32_t A[RA][T_NG];      // the ring's first stage: A[i] = the grey row i + 1 iterations old; A[R - 1] is the window's centre row
 #pragma unroll
-    for (int i = 0; i < R; i++) {
+    for (int i = 0; i < RA; i++) {
 #pragma unroll
         for (int j = 0; j < T_NG; j++) A[i][j] = 0u;
     }
@@ -158,14 +169,14 @@ __global__ __launch_bounds__(64, R > 15 ? 1 : 2) void k_grey_threshold_ring(cons
                     for (int i = 0; i < T_LPX; i++) if (x0 + i < W) dst[i] = (uint8_t)(g[i >> 2] >> (8 * (i & 3)));
                 }
             }
-            // the ring: the centre row (R iterations old) leaves the registers for the LDS slot of the row that leaves the window
-            // (2R + 1 iterations old; zeros at first), the others move up by one
+            // the ring: the oldest register row (RA iterations old; the centre row when RA == R) leaves the registers for the LDS slot of
+            // the row that leaves the window (2R + 1 iterations old; zeros at first), the others move up by one
             const uint4 old = s_ring[slot * 64 + lane];
             const uint32_t gc[4] = {A[R - 1][0], A[R - 1][1], A[R - 1][2], A[R - 1][3]};
-            s_ring[slot * 64 + lane] = make_uint4(gc[0], gc[1], gc[2], gc[3]);
+            s_ring[slot * 64 + lane] = make_uint4(A[RA - 1][0], A[RA - 1][1], A[RA - 1][2], A[RA - 1][3]);
             slot = slot + 1 == NB ? 0 : slot + 1;
 #pragma unroll
-            for (int i = R - 1; i > 0; i--) {
+            for (int i = RA - 1; i > 0; i--) {
 #pragma unroll
                 for (int j = 0; j < T_NG; j++) A[i][j] = A[i - 1][j];
             }
@@ -236,13 +247,16 @@ __global__ __launch_bounds__(64, R > 15 ? 1 : 2) void k_grey_threshold_ring(cons
 template <int R>
 hipError_t launch_ring(hipStream_t st, const uint8_t* pixels, int fmt, size_t row_stride, size_t frame_stride, int W, int H, uint32_t n, uint8_t* grey,
                        uint64_t* bits) {
-    constexpr int NB = R + 1, WPC = R > 15 ? 4 : 8;   // waves per CU: two per SIMD (115 + 4 R VGPRs; (R + 1) KB of ring and at least 29 parked rows each); radii 16..31: one
     constexpr int OUT = ring_out_cols(R);
     uint8_t* bin = reinterpret_cast<uint8_t*>(bits);
     if (W % 64 != 0) {  // packed rows end in padding bits that no strip writes
         hipError_t e = hipMemsetAsync(bits, 0, (size_t)words_per_row((uint32_t)W) * 8 * H * n, st);
         if (e != hipSuccess) return e;
     }
+    const int aligned_in = ((uintptr_t)pixels % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0);
+    const bool fast = aligned_in && W % 16 == 0 && (uintptr_t)grey % 16 == 0;   // (as in launch_k1)
+    // waves per CU: two per SIMD while the ring's LDS part is at most 19 KB per wave (then at least 4 parked rows each), else one
+    const int NB = 2 * R + 1 - ring_reg_rows(R, fast, fmt), WPC = NB <= kRingLdsRows8 ? 8 : 4;
     // strips: K1's model (time ~ rounds x (rows per strip + 2R))
     const int strips_x = (W + OUT - 1) / OUT;
     const long long slots = (long long)g_k1_cus * WPC, cols = (long long)strips_x * n;
@@ -256,11 +270,10 @@ hipError_t launch_ring(hipStream_t st, const uint8_t* pixels, int fmt, size_t ro
     const int rows_per_wave = (H + best_sy - 1) / best_sy;
     const int strips_y = (H + rows_per_wave - 1) / rows_per_wave;
     const int per_wave = (160 * 1024) / WPC - 64;   // (the allocation granule)
-    const int flush_rows = std::min({128, rows_per_wave, (per_wave - NB * 1024) / 128 - A3_T_PF});
+    const int flush_rows = std::max(1, std::min({128, rows_per_wave, (per_wave - NB * 1024) / 128 - A3_T_PF}));
     const size_t lds_bytes = (size_t)NB * 1024 + (size_t)(flush_rows + A3_T_PF) * 128;
+    if ((per_wave - NB * 1024) / 128 - A3_T_PF < 1) return hipErrorInvalidValue;   // (cannot happen: 19 KB + 4 rows fit an eighth, 32 KB + 60 rows a quarter)
     dim3 grid(8 * (((int)n + 7) / 8) * strips_x * strips_y), block(64);
-    const int aligned_in = ((uintptr_t)pixels % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0);
-    const bool fast = aligned_in && W % 16 == 0 && (uintptr_t)grey % 16 == 0;   // (as in launch_k1)
 #define A3_LAUNCH_RING(F)                                                                                                              \
     {                                                                                                                                  \
         if (fast) hipLaunchKernelGGL((k_grey_threshold_ring<F, R, true>), grid, block, lds_bytes, st, pixels, row_stride, frame_stride, W, H, rows_per_wave, strips_y, \

@@ -51,7 +51,7 @@ enum { A3_MEM_HOST = 0, A3_MEM_DEVICE = 1 };
 typedef struct a3_config {
     uint32_t threshold_window;               /* 7.  The block radius of adaptive_threshold (src/aruco.rs:61): the window is 2r+1 wide.  Every value
                                                 * >= 1 gives the reference's result; 1..31 run fused one-pass kernels (1..7 at about the speed of 7,
-                                                * 8..15 at 1.1-1.2 x, 16..31 at 2.1-2.5 x), larger windows a separable three-pass path (8-9 x) */
+                                                * 8..26 at 1.1-1.35 x, 27..31 at 2.3-2.5 x), larger windows a separable three-pass path (8-9 x) */
     double   contour_simplification_epsilon; /* 0.05 */
     float    min_side_length_factor;         /* 0.2 */
     float    min_corner_separation_factor;   /* 0.1 */

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The threshold stage alone for every threshold_window (radius): BASELINE config 2's batch, synchronous calls, the stage between
 events (nothing else on the GPU).  Radii 1..7 run the register-resident kernel templated on the radius, 8..31 the fused ring kernel
-(k_threshold_big.hip: one wave per SIMD from 16 on), larger ones the separable path (grey plane + row sums + column sums).   python tools/window_probe.py [frames] [radii...]"""
+(k_threshold_big.hip: one wave per SIMD from 27 on), larger ones the separable path (grey plane + row sums + column sums).   python tools/window_probe.py [frames] [radii...]"""
 import sys
 from pathlib import Path
 
