@@ -747,8 +747,8 @@ __device__ __forceinline__ bool static_fire(uint64_t rec) {
 
 // Phase 1: 11 doubling rounds inside one tile, entirely in LDS.  A window stops growing ("freezes") when its end leaves
 // the tile; cycles that close inside the tile finish here.  Darts that some frozen window ends on become "entries".
-template <int LT>
-__global__ __launch_bounds__(256, LT >= 2048 ? 4 : 8) void k_local_contract(uint32_t n_darts, int W, const uint64_t* __restrict__ d_rec,
+template <int LT, bool DEAD /* the early finish of short borders (dense graphs) is compiled in: its LDS and registers cost the clean-frame instantiation a wave per SIMD */>
+__global__ __launch_bounds__(256, (LT >= 2048 || DEAD) ? 4 : 8) void k_local_contract(uint32_t n_darts, int W, const uint64_t* __restrict__ d_rec,
                                                         const uint32_t* __restrict__ d_succ,
                                                         JumpState* __restrict__ loc,
                                                         uint32_t* __restrict__ entry_list,
@@ -765,7 +765,12 @@ __global__ __launch_bounds__(256, LT >= 2048 ? 4 : 8) void k_local_contract(uint
     constexpr uint32_t kFrameWin = 64;               // frames a tile may span with block-aggregated counting (beyond: direct atomics)
     __shared__ uint32_t s_fcnt[kFrameWin], s_fbase[kFrameWin];
     __shared__ uint32_t s_new_count, s_new_base, s_f0, s_dead_n;
-    __shared__ __attribute__((aligned(4))) uint8_t s_dead[LT];   // per dart of the tile: it LEADS a dead cycle
+    __shared__ __attribute__((aligned(4))) uint8_t s_dead[DEAD ? LT : 4];   // per dart of the tile: bit 0 = it LEADS a dead cycle, bit 1 = its own start event passes static_fire
+    constexpr uint32_t kQCap = DEAD ? 1024 : 1;      // leaders whose border may be finished here, queued for the epilogue (a tile of noise holds ~200)
+    __shared__ uint32_t s_q[kQCap];
+    __shared__ uint32_t s_qn;
+    static_assert(LT <= 2048, "a queue entry holds two 11-bit tile indices");
+    if constexpr (!DEAD) dead_count = nullptr;
     if (n_live) n_darts = min(n_darts, *n_live);
     const uint32_t lo = blockIdx.x * LT;
     if (lo >= n_darts) return;   // the grid covers the pool's capacity, the graph may be smaller
@@ -774,10 +779,11 @@ __global__ __launch_bounds__(256, LT >= 2048 ? 4 : 8) void k_local_contract(uint
     // copy the other lanes read (per dart and round: one 16-byte read of the next window, one 16-byte write)
     constexpr int PER = LT / 256;
     uint64_t nk[PER]; uint32_t np[PER], no[PER], nd[PER], succ0[PER], frm[PER];
-    if (threadIdx.x == 0) { s_new_count = 0; s_dead_n = 0; }
+    if (threadIdx.x == 0) { s_new_count = 0; s_dead_n = 0; s_qn = 0; }
     if (threadIdx.x < kFrameWin) s_fcnt[threadIdx.x] = 0;
     if (dead_count) { for (uint32_t i4 = threadIdx.x; i4 < LT / 4; i4 += 256) reinterpret_cast<uint32_t*>(s_dead)[i4] = 0u; }
     uint32_t sfire = 0;                              // bit u: the start event of my dart u fires unconditionally (static_fire)
+    uint32_t ecand = 0, epix = 0;                    // bit u: an E-event on a pixel with a W side (fires iff a witness exists, below); epix: 4 bits per dart = my rank among the pixel's darts | (their number - 1) << 2
     // all 16 loads of a lane are issued before the first is used: unconditional, from a clamped index (behind an `if (i < cnt)`
     // the compiler issues them one at a time, each with its own wait: 16 round trips to memory instead of one)
     uint64_t recs[PER];
@@ -797,10 +803,22 @@ __global__ __launch_bounds__(256, LT >= 2048 ? 4 : 8) void k_local_contract(uint
         frm[u] = rec_frame(rec);   // kept, like succ0, for the entry registration (no second read)
         nk[u] = ((uint64_t)ek << 32) | (lo + i); np[u] = succ0[u]; no[u] = 0; nd[u] = 1;
         if (i < cnt) s_win[i] = Win{nk[u], np[u], 1u << 16};
-        if (dead_count && ek != kNoKey && static_fire(rec)) sfire |= 1u << u;
+        if (dead_count && ek != kNoKey) {
+            if (static_fire(rec)) sfire |= 1u << u;
+            else if (info & kInfoE) {   // (not static: the pixel has a W side, and with it a W-event on another of its darts)
+                const uint32_t P = pdart_mask(rec_F(rec));
+                ecand |= 1u << u;
+                epix |= ((uint32_t)__popc(P & ((1u << (info & 7u)) - 1u)) | ((uint32_t)(__popc(P) - 1) << 2)) << (4 * u);
+            }
+        }
     }
     if (threadIdx.x == 0) s_f0 = frm[0];   // darts are frame-major: the tile's frames are f0, f0+1, ...
     lds_barrier();
+    if (dead_count && sfire) {             // (after the barrier: s_dead was zeroed word-wise by other lanes; read only in the epilogue)
+#pragma unroll
+        for (int u = 0; u < PER; u++)
+            if (sfire & (1u << u)) s_dead[threadIdx.x + u * 256] = 2;
+    }
     // Entries.  The entries of the reduced list are exactly the successors that lie outside their predecessor's tile; succ is
     // injective, so each is registered once, by that predecessor, with no global dedupe.  Slots are counted per workgroup
     // (one global atomic per tile and frame) -- and counted HERE, before the doubling rounds, which need nothing of it: the
@@ -885,19 +903,54 @@ __global__ __launch_bounds__(256, LT >= 2048 ? 4 : 8) void k_local_contract(uint
     // (hops back to the leader + 1), here in LDS; too short for k_cycle_select's test and starting unconditionally, the border is
     // finished with: counted as traced, listed nowhere.  Noise-like frames: most of the millions of borders.
     if (dead_count) {
-        uint32_t my_dead = 0;
+        // The leaders in question are a few per wave and dart slot: they are QUEUED (tile index, successor's index, pixel info) and
+        // worked on with every lane busy -- evaluated in place, each of a lane's eight slots cost the wave a chain of LDS round trips
+        // for the two or three lanes that had a candidate there (+ 107 us on the reference's bench input with the witness test).
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             const uint32_t i = threadIdx.x + u * 256;
-            if (i >= cnt || !(sfire & (1u << u))) continue;
-            if ((uint32_t)nk[u] != lo + i || (np[u] - lo) >= cnt) continue;            // not the leader, or the window left the tile
             const uint32_t sl = succ0[u] - lo;
-            if (sl >= cnt || sl == i) continue;                                        // (a chain end: the normal path reports it)
-            const Win ws = s_win[sl];
+            const bool push = i < cnt && ((sfire | ecand) & (1u << u)) && (uint32_t)nk[u] == lo + i && (np[u] - lo) < cnt   // the leader, its window in the tile
+                              && sl < cnt && sl != i;                                                                          // (a chain end: the normal path reports it)
+            const unsigned long long m = __ballot(push);
+            if (m == 0ull) continue;   // wave-uniform
+            uint32_t base = 0;
+            if ((threadIdx.x & 63) == (uint32_t)(__ffsll((long long)m) - 1)) base = atomicAdd(&s_qn, (uint32_t)__popcll(m));   // one LDS atomic per wave and slot
+            base = __shfl(base, __ffsll((long long)m) - 1);
+            const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+            if (push && slot < kQCap) s_q[slot] = i | (sl << 11) | (((epix >> (4 * u)) & 15u) << 22) | (((sfire >> u) & 1u) << 26);
+        }
+        lds_barrier();
+        const uint32_t nq = min(s_qn, kQCap);
+        uint32_t my_dead = 0;
+        for (uint32_t k = threadIdx.x; k < nq; k += 256) {
+            const uint32_t e = s_q[k], i = e & 2047u, sl = (e >> 11) & 2047u;
+            const Win wi = s_win[i], ws = s_win[sl];
             if ((uint32_t)ws.key != lo + i) continue;                                  // the successor's window did not wrap to this leader
             const uint32_t n = (ws.offdist & 0xFFFFu) + 1u;                            // border length in points
             if (n >= 5u && (uint64_t)n * n >= 8ull * min_edge_length) continue;        // k_cycle_select's parity-safe test (the diagonal bound cannot bind in a tile)
-            s_dead[i] = 1; my_dead++;
+            if (!((e >> 26) & 1u)) {
+                // An E-event on pixel q fires iff not (q has a W side and its W-event fires), and that W-event fires iff every border
+                // through q starts at or after it (k_resolve_eval).  A WITNESS settles it: a border through q -- through one of the
+                // leader's neighbours in the dart order -- that certainly starts before 2q: its window closed in this tile (it holds
+                // the border's smallest event and its leader), that event lies before 2q and passes static_fire (bit 1 of s_dead: the
+                // border starts there under every assignment).  The W-event then cannot fire, the E-event does.  (tests/dart_model.py:
+                // 64 % of a noise frame's borders start certainly by static_fire alone, 91 % with witnesses.)
+                const uint32_t pi = (e >> 22) & 15u, rank = pi & 3u, others = pi >> 2, first = i - rank;
+                if (rank > i || first + others >= cnt) continue;                       // the pixel's darts straddle the tile
+                const uint32_t w2q = (uint32_t)(wi.key >> 32) - 1u;                    // the leader's key is 2q + 1
+                Win wj[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) wj[j] = s_win[first + min(j, others)];
+                bool witness = false;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) {
+                    const uint32_t lj = (uint32_t)wj[j].key - lo;
+                    if ((wj[j].ptr - lo) < cnt && (uint32_t)(wj[j].key >> 32) < w2q && lj < cnt && (s_dead[lj] & 2u)) witness = true;
+                }
+                if (!witness) continue;
+            }
+            s_dead[i] |= 1; my_dead++;
         }
         if (my_dead) atomicAdd(&s_dead_n, my_dead);
         lds_barrier();
@@ -910,7 +963,7 @@ __global__ __launch_bounds__(256, LT >= 2048 ? 4 : 8) void k_local_contract(uint
         const uint32_t e = np[u];
         const bool frozen = (e - lo) >= cnt;
         const uint32_t li = (uint32_t)nk[u] - lo;                                      // my window's minimum: in the tile when it did not freeze
-        const bool dead = dead_count != nullptr && !frozen && li < cnt && s_dead[li] != 0;
+        const bool dead = dead_count != nullptr && !frozen && li < cnt && (s_dead[li] & 1u) != 0;
         JumpState r;
         r.key = nk[u]; r.ptr = e; r.off = loc_pack(no[u], nd[u], frozen) | (dead ? kDead : 0u);
         loc[lo + i] = r;
@@ -1752,11 +1805,14 @@ hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uin
     // entry_count[16] and leader_count[16] arrive zeroed (the caller's per-batch / per-chunk memset)
     const uint32_t ecap = entry_shard_cap(n_darts);
     if (phase != 2) {
-        if (frame_entries)
-            hipLaunchKernelGGL(k_local_contract<kLTFrame>, dim3((n_darts + kLTFrame - 1) / kLTFrame), dim3(256), 0, st, n_darts, W, d_rec, d_succ, loc,
+        if (frame_entries && !dead_count)
+            hipLaunchKernelGGL((k_local_contract<kLTFrame, false>), dim3((n_darts + kLTFrame - 1) / kLTFrame), dim3(256), 0, st, n_darts, W, d_rec, d_succ, loc,
+                               entry_list, entry_pos, entry_count, ecap, frame_base, frame_entries, n_live, dbg, min_edge_length, dead_count);
+        else if (frame_entries)   // (a dense graph's first batch, before its entries overflow k_entry_frame and the global rounds take over)
+            hipLaunchKernelGGL((k_local_contract<kLTFrame, true>), dim3((n_darts + kLTFrame - 1) / kLTFrame), dim3(256), 0, st, n_darts, W, d_rec, d_succ, loc,
                                entry_list, entry_pos, entry_count, ecap, frame_base, frame_entries, n_live, dbg, min_edge_length, dead_count);
         else
-            hipLaunchKernelGGL(k_local_contract<kLT>, dim3((n_darts + kLT - 1) / kLT), dim3(256), 0, st, n_darts, W, d_rec, d_succ, loc,
+            hipLaunchKernelGGL((k_local_contract<kLT, true>), dim3((n_darts + kLT - 1) / kLT), dim3(256), 0, st, n_darts, W, d_rec, d_succ, loc,
                                entry_list, entry_pos, entry_count, ecap, frame_base, frame_entries, n_live, dbg, min_edge_length, dead_count);
     }
     if (dbg || phase == 1) return hipGetLastError();

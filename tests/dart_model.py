@@ -169,10 +169,17 @@ def contours_by_darts(binary: np.ndarray, max_iter: int = 64, node_rule: str = "
     # static_fire (csrc/k_contours.hip): does a cycle's SMALLEST event fire whatever the other cycles do?  A W-event on a pixel that owns
     # this one dart only; an E-event on a pixel without a W side.  Such a cycle starts at its natural start under every assignment --
     # which is what lets k_local_contract finish with a short border without looking at its neighbours (kDead).
-    static_ok = {}
+    # Round 5's extension (k_local_contract, E-events on pixels with a W side): the E-event fires iff the pixel's W-event does not,
+    # and that cannot fire when a WITNESS exists -- a border through the pixel whose smallest event lies before the W-event and passes
+    # the static test itself (it starts there under every assignment).
+    static_ok, static_ok_wide = {}, {}
     for c, evs in events_of.items():
         key, d, q = min(evs)
         static_ok[c] = (len(pix_darts[q]) == 1) if not (key & 1) else (q not in ev_w)
+    for c, evs in events_of.items():
+        key, d, q = min(evs)
+        static_ok_wide[c] = static_ok[c] or bool((key & 1) and any(T_natural.get(cyc[e], INF) < 2 * q and static_ok.get(cyc[e], False)
+                                                                    for e in pix_darts[q]))
     iters = 0
     while True:
         iters += 1
@@ -206,5 +213,5 @@ def contours_by_darts(binary: np.ndarray, max_iter: int = 64, node_rule: str = "
         rot = path[s:] + path[:s]
         out.append([(dart_list[d][0], dart_list[d][1]) for d in rot])
     stats = {"darts": n, "broken": broken, "cycles": len(cycles), "iters": iters, "chain_events": chain_has_event,
-             "T_final": dict(T), "T_natural": T_natural, "static_ok": static_ok, "cycle_len": {c: len(cycles[c]) for c in events_of if cycles[c] is not None}}
+             "T_final": dict(T), "T_natural": T_natural, "static_ok": static_ok, "static_ok_wide": static_ok_wide, "cycle_len": {c: len(cycles[c]) for c in events_of if cycles[c] is not None}}
     return out, stats
