@@ -35,7 +35,7 @@ size_t entry_slots(uint32_t);
 size_t leader_list_bytes(uint32_t);
 hipError_t launch_rank_cycles(hipStream_t, uint32_t, int, const uint64_t*, const uint32_t*, JumpState*,
                               uint32_t*, uint32_t*, unsigned int*, void*, void*, JumpState*, uint32_t*, unsigned int*, int, DeviceCounters*, const uint32_t*, int,
-                              const uint32_t*, uint32_t*, uint32_t, int, uint32_t, unsigned int*);
+                              const uint32_t*, uint32_t*, uint32_t, int, uint32_t, unsigned int*, int);
 hipError_t launch_resolve(hipStream_t, const JumpState*, uint32_t, int, const uint64_t*, const uint32_t*, const unsigned int*, uint64_t*, uint64_t*,
                           DeviceCounters*, int, const uint32_t*);
 hipError_t launch_select_scatter(hipStream_t, const JumpState*, uint32_t, const uint32_t*, const unsigned int*, const uint32_t*, const uint64_t*,
@@ -812,7 +812,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
         A3_HIP(launch_rank_cycles(st, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), ctx->stA.as<JumpState>(),
                                   ctx->entry_list.as<uint32_t>(), ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
                                   ctx->stA.as<JumpState>(), ctx->leader_list.as<uint32_t>(), d_leader_count, rounds, ctr, n_live, 0, fb,
-                                  frame_entries, cc.count, 1, min_edge_length, dead_ctr));
+                                  frame_entries, cc.count, 1, min_edge_length, dead_ctr, inline_resolve_W > 0 ? 1 : 0));
         if (rel_mode == 2) { if (int rc = release_waiting()) return rc; }   // waiting decode stages go out behind this k_local_contract
         ctx->dbg_nd = nd; ctx->dbg_frames = c.count; ctx->dbg_chunks = (uint32_t)chunks.size();
         // second half: entry resolution, final states (+ border selection), point scatter, quads -- on `s2`
@@ -820,7 +820,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
             A3_HIP(launch_rank_cycles(s2, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), ctx->stA.as<JumpState>(),
                                       ctx->entry_list.as<uint32_t>(), ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
                                       ctx->stA.as<JumpState>() /* final states in place */, ctx->leader_list.as<uint32_t>(), d_leader_count, rounds, ctr,
-                                      n_live, 0, fb, frame_entries, cc.count, 2, min_edge_length, dead_ctr));
+                                      n_live, 0, fb, frame_entries, cc.count, 2, min_edge_length, dead_ctr, inline_resolve_W > 0 ? 1 : 0));
             const JumpState* fin = ctx->stA.as<JumpState>();
             A3_HIP(launch_resolve(s2, fin, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->leader_list.as<uint32_t>(), d_leader_count,
                                   ctx->t_cur.as<uint64_t>(), ctx->t_next.as<uint64_t>(), ctr, resolve_iters, n_live));
@@ -1486,7 +1486,7 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
                                       ctx->entry_list.as<uint32_t>(),
                                       ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p, ctx->stB.as<JumpState>(),
                                       ctx->leader_list.as<uint32_t>(), d_leader_count, 0, ctx->counters, nullptr, dbg ? dbg : 11, ctx->frame_base.as<uint32_t>(), nullptr, ctx->dbg_frames, 0,
-                                      0u, nullptr));
+                                      0u, nullptr, 0));
         } else if (kernel == 3 || kernel == 4) {   // dbg < 0: k_decode alone (variant -dbg; -5: the whole kernel), dbg >= 0: k_projection + k_decode
             if (kernel == 4) {   // COLD frames, as the pipeline meets them (1.6 GB went through the threshold kernel, the contour stage's buffers since):
                                  // half a gigabyte of the pixel-base plane is overwritten first (garbage after a batch anyway), outside the timed span

@@ -755,7 +755,8 @@ __global__ __launch_bounds__(256, (LT >= 2048 || DEAD) ? 4 : 8) void k_local_con
                                                         uint32_t* __restrict__ entry_pos, unsigned int* __restrict__ entry_count, uint32_t ecap,
                                                         const uint32_t* __restrict__ frame_base, uint32_t* __restrict__ frame_entries,
                                                         const uint32_t* __restrict__ n_live, int dbg,
-                                                        uint32_t min_edge_length, unsigned int* __restrict__ dead_count /*[16]; nullptr: mark nothing dead*/) {
+                                                        uint32_t min_edge_length, unsigned int* __restrict__ dead_count /*[16]; nullptr: mark nothing dead*/,
+                                                        int trust_natural /* the launch sequence ends in k_cycle_select's inline check (no fixpoint passes): see the epilogue */) {
     // frame_entries != nullptr: entries get slots grouped by frame (slot = frame_base[f] + running count of the frame: a
     // frame has at most as many entries as darts), for k_entry_frame; else the 16-shard allocation of the global rounds
     // dbg (a3_debug_kernel_time only; 0 in the product path): n > 0 runs n doubling rounds instead of 11; -1 = none
@@ -783,7 +784,7 @@ __global__ __launch_bounds__(256, (LT >= 2048 || DEAD) ? 4 : 8) void k_local_con
     if (threadIdx.x < kFrameWin) s_fcnt[threadIdx.x] = 0;
     if (dead_count) { for (uint32_t i4 = threadIdx.x; i4 < LT / 4; i4 += 256) reinterpret_cast<uint32_t*>(s_dead)[i4] = 0u; }
     uint32_t sfire = 0;                              // bit u: the start event of my dart u fires unconditionally (static_fire)
-    uint32_t ecand = 0, epix = 0;                    // bit u: an E-event on a pixel with a W side (fires iff a witness exists, below); epix: 4 bits per dart = my rank among the pixel's darts | (their number - 1) << 2
+    uint32_t ecand = 0, epix = 0;                    // bit u: an event that is not static (a W-event on a pixel with several darts, an E-event on a pixel with a W side: the epilogue looks at the pixel's other darts); epix: 4 bits per dart = my rank among the pixel's darts | (their number - 1) << 2
     // all 16 loads of a lane are issued before the first is used: unconditional, from a clamped index (behind an `if (i < cnt)`
     // the compiler issues them one at a time, each with its own wait: 16 round trips to memory instead of one)
     uint64_t recs[PER];
@@ -805,7 +806,7 @@ __global__ __launch_bounds__(256, (LT >= 2048 || DEAD) ? 4 : 8) void k_local_con
         if (i < cnt) s_win[i] = Win{nk[u], np[u], 1u << 16};
         if (dead_count && ek != kNoKey) {
             if (static_fire(rec)) sfire |= 1u << u;
-            else if (info & kInfoE) {   // (not static: the pixel has a W side, and with it a W-event on another of its darts)
+            else {                      // (an E-event: the pixel has a W side, and with it a W-event on another of its darts; a W-event: other darts)
                 const uint32_t P = pdart_mask(rec_F(rec));
                 ecand |= 1u << u;
                 epix |= ((uint32_t)__popc(P & ((1u << (info & 7u)) - 1u)) | ((uint32_t)(__popc(P) - 1) << 2)) << (4 * u);
@@ -930,25 +931,36 @@ __global__ __launch_bounds__(256, (LT >= 2048 || DEAD) ? 4 : 8) void k_local_con
             const uint32_t n = (ws.offdist & 0xFFFFu) + 1u;                            // border length in points
             if (n >= 5u && (uint64_t)n * n >= 8ull * min_edge_length) continue;        // k_cycle_select's parity-safe test (the diagonal bound cannot bind in a tile)
             if (!((e >> 26) & 1u)) {
-                // An E-event on pixel q fires iff not (q has a W side and its W-event fires), and that W-event fires iff every border
-                // through q starts at or after it (k_resolve_eval).  A WITNESS settles it: a border through q -- through one of the
-                // leader's neighbours in the dart order -- that certainly starts before 2q: its window closed in this tile (it holds
-                // the border's smallest event and its leader), that event lies before 2q and passes static_fire (bit 1 of s_dead: the
-                // border starts there under every assignment).  The W-event then cannot fire, the E-event does.  (tests/dart_model.py:
-                // 64 % of a noise frame's borders start certainly by static_fire alone, 91 % with witnesses.)
+                // Not static: the pixel's other darts -- the leader's neighbours in the dart order -- decide (k_resolve_eval: the W-event
+                // of pixel q fires iff every border through q starts at or after it; its E-event fires iff not (q has a W side and the
+                // W-event fires)).  A window that did not freeze holds its border's smallest event and its leader.
+                //  * CERTAIN, whatever the other borders' starts turn out to be: an E-event with a WITNESS -- a border through q whose
+                //    smallest event lies before 2q and passes static_fire (bit 1 of s_dead: the border starts there under every
+                //    assignment): the W-event cannot fire, the E-event does.  (tests/dart_model.py: 64 % of a noise frame's borders start
+                //    certainly by static_fire alone, 91 % with witnesses.)
+                //  * UNDER THE NATURAL ASSIGNMENT (every border starts at its smallest event), when the launch sequence relies on it
+                //    (trust_natural: k_cycle_select checks the listed borders the same way, and if ANY border's natural start does not
+                //    fire the batch is re-run with the fixpoint passes and without this rule): all of the pixel's darts in this tile with
+                //    closed windows, and the event fires given their smallest events.  If every border passes -- here or there -- the
+                //    natural assignment is the fixpoint (k_resolve_fast's argument) and a short border that was finished with here was
+                //    rightly counted as traced.  One that does not pass stays listed, and k_cycle_select raises the re-run.
                 const uint32_t pi = (e >> 22) & 15u, rank = pi & 3u, others = pi >> 2, first = i - rank;
                 if (rank > i || first + others >= cnt) continue;                       // the pixel's darts straddle the tile
-                const uint32_t w2q = (uint32_t)(wi.key >> 32) - 1u;                    // the leader's key is 2q + 1
+                const uint32_t ek = (uint32_t)(wi.key >> 32), w2q = ek & ~1u;          // the leader's key: 2q (W-event) or 2q + 1 (E-event)
                 Win wj[4];
 #pragma unroll
                 for (uint32_t j = 0; j < 4; j++) wj[j] = s_win[first + min(j, others)];
-                bool witness = false;
+                bool witness = false, closed = true, wfires = true;
 #pragma unroll
                 for (uint32_t j = 0; j < 4; j++) {
                     const uint32_t lj = (uint32_t)wj[j].key - lo;
-                    if ((wj[j].ptr - lo) < cnt && (uint32_t)(wj[j].key >> 32) < w2q && lj < cnt && (s_dead[lj] & 2u)) witness = true;
+                    const bool in_tile = (wj[j].ptr - lo) < cnt, before = (uint32_t)(wj[j].key >> 32) < w2q;
+                    if (in_tile && before && lj < cnt && (s_dead[lj] & 2u)) witness = true;
+                    closed = closed && in_tile;
+                    wfires = wfires && !before;
                 }
-                if (!witness) continue;
+                const bool is_e = (ek & 1u) != 0u;
+                if (!((is_e && witness) || (trust_natural && closed && (is_e ? !wfires : wfires)))) continue;
             }
             s_dead[i] |= 1; my_dead++;
         }
@@ -1801,19 +1813,20 @@ hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uin
                               unsigned int* leader_count, int max_rounds, DeviceCounters* ctr, const uint32_t* n_live, int dbg,
                               const uint32_t* frame_base, uint32_t* frame_entries /*nullptr: global rounds*/, uint32_t n_frames,
                               int phase /* 0: everything, 1: k_local_contract only, 2: what follows it */,
-                              uint32_t min_edge_length, unsigned int* dead_count /* [16], nullptr: no border is dropped early (debug taps) */) {
+                              uint32_t min_edge_length, unsigned int* dead_count /* [16], nullptr: no border is dropped early (debug taps) */,
+                              int trust_natural /* no fixpoint passes follow: k_cycle_select checks the natural starts inline */) {
     // entry_count[16] and leader_count[16] arrive zeroed (the caller's per-batch / per-chunk memset)
     const uint32_t ecap = entry_shard_cap(n_darts);
     if (phase != 2) {
         if (frame_entries && !dead_count)
             hipLaunchKernelGGL((k_local_contract<kLTFrame, false>), dim3((n_darts + kLTFrame - 1) / kLTFrame), dim3(256), 0, st, n_darts, W, d_rec, d_succ, loc,
-                               entry_list, entry_pos, entry_count, ecap, frame_base, frame_entries, n_live, dbg, min_edge_length, dead_count);
+                               entry_list, entry_pos, entry_count, ecap, frame_base, frame_entries, n_live, dbg, min_edge_length, dead_count, trust_natural);
         else if (frame_entries)   // (a dense graph's first batch, before its entries overflow k_entry_frame and the global rounds take over)
             hipLaunchKernelGGL((k_local_contract<kLTFrame, true>), dim3((n_darts + kLTFrame - 1) / kLTFrame), dim3(256), 0, st, n_darts, W, d_rec, d_succ, loc,
-                               entry_list, entry_pos, entry_count, ecap, frame_base, frame_entries, n_live, dbg, min_edge_length, dead_count);
+                               entry_list, entry_pos, entry_count, ecap, frame_base, frame_entries, n_live, dbg, min_edge_length, dead_count, trust_natural);
         else
             hipLaunchKernelGGL((k_local_contract<kLT, true>), dim3((n_darts + kLT - 1) / kLT), dim3(256), 0, st, n_darts, W, d_rec, d_succ, loc,
-                               entry_list, entry_pos, entry_count, ecap, frame_base, frame_entries, n_live, dbg, min_edge_length, dead_count);
+                               entry_list, entry_pos, entry_count, ecap, frame_base, frame_entries, n_live, dbg, min_edge_length, dead_count, trust_natural);
     }
     if (dbg || phase == 1) return hipGetLastError();
     EntryState* a = reinterpret_cast<EntryState*>(es_a);

@@ -180,6 +180,13 @@ def contours_by_darts(binary: np.ndarray, max_iter: int = 64, node_rule: str = "
         key, d, q = min(evs)
         static_ok_wide[c] = static_ok[c] or bool((key & 1) and any(T_natural.get(cyc[e], INF) < 2 * q and static_ok.get(cyc[e], False)
                                                                     for e in pix_darts[q]))
+    # does every border's smallest event fire under the NATURAL assignment (each border starts at its smallest event)?  If so that
+    # assignment is the fixpoint -- what k_cycle_select's inline check and k_local_contract's trust_natural rule rely on.
+    natural_fires = {}
+    for c, evs in events_of.items():
+        key, d, q = min(evs)
+        wf = all(T_natural.get(cyc[e], INF) >= 2 * q for e in pix_darts[q])
+        natural_fires[c] = (not (q in ev_w and wf)) if (key & 1) else wf
     iters = 0
     while True:
         iters += 1
@@ -213,5 +220,5 @@ def contours_by_darts(binary: np.ndarray, max_iter: int = 64, node_rule: str = "
         rot = path[s:] + path[:s]
         out.append([(dart_list[d][0], dart_list[d][1]) for d in rot])
     stats = {"darts": n, "broken": broken, "cycles": len(cycles), "iters": iters, "chain_events": chain_has_event,
-             "T_final": dict(T), "T_natural": T_natural, "static_ok": static_ok, "static_ok_wide": static_ok_wide, "cycle_len": {c: len(cycles[c]) for c in events_of if cycles[c] is not None}}
+             "T_final": dict(T), "T_natural": T_natural, "natural_fires": natural_fires, "static_ok": static_ok, "static_ok_wide": static_ok_wide, "cycle_len": {c: len(cycles[c]) for c in events_of if cycles[c] is not None}}
     return out, stats

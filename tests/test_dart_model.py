@@ -93,3 +93,21 @@ def test_static_fire_cycles_start_at_their_natural_start():
             elif st["T_final"].get(c) != st["T_natural"][c]:
                 n_moved_elsewhere += 1          # (borders whose start moves -- the column-0 anomalies -- must all be among the others)
     assert n_static > 2000 and n_short_static > 1000 and n_wide_only > 500   # (E-events with a witness: round 5's extension)
+
+
+def test_natural_assignment_is_the_fixpoint_when_every_natural_start_fires():
+    """k_cycle_select's inline check and k_local_contract's trust_natural rule: evaluate every border's smallest event under the
+    assignment "every border starts at its smallest event"; if all of them fire, that assignment is the fixpoint of the start
+    resolution (and a short border finished with early was rightly counted as traced); if one does not, some start moves -- the
+    case the library answers with a re-run through the fixpoint passes."""
+    rng = np.random.default_rng(20261003)      # (the sample of test_dart_cycles_equal_sequential_border_following: it holds cases of both kinds)
+    n_all = n_some = 0
+    for img in _images(rng, 600):
+        _, st = contours_by_darts(img, node_rule="pdart")
+        if all(st["natural_fires"].values()):
+            n_all += 1
+            assert st["T_final"] == st["T_natural"]
+        else:
+            n_some += 1
+            assert st["T_final"] != st["T_natural"]
+    assert n_all > 100 and n_some > 0

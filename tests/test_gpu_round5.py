@@ -195,6 +195,18 @@ def test_borders_finished_early_are_counted_once_and_change_nothing(dicts, oracl
     spec4, name4 = synth.config_spec(4)
     d4 = dicts.new_from_named_dict(name4)
     cases.append(np.stack([synth.render_frame(spec4, d4.code_list, d4.num_bits, synth.frame_seed(4, 100 + i))[0] for i in range(2)]))
+    # ... and a DENSE graph that needs the fixpoint passes (found with tests/dart_model.py): a white frame -- one component, first pixel
+    # (0, 0) -- whose outer border has events only at two dark pixels touching column 0 diagonally, where its natural start does not fire,
+    # plus 7 % single dark pixels away from the frame's edge (0.3 darts per pixel: the dense path).  The batch is re-run through the
+    # fixpoint passes, on which k_local_contract must not trust the natural assignment.
+    anomaly = np.full((2, 96, 128), 255, np.uint8)
+    specks = rng.random((2, 96, 128)) < 0.07
+    specks[:, :10, :10] = False
+    specks[:, :2, :] = False; specks[:, -2:, :] = False; specks[:, :, :2] = False; specks[:, :, -2:] = False
+    anomaly[specks] = 0
+    anomaly[:, 3, 1] = 0; anomaly[:, 4, 0] = 0
+    cases.insert(1, np.repeat(anomaly[..., None], 3, axis=3))
+    resolved = []
     for ci, frames in enumerate(cases):
         dd = d4 if ci == len(cases) - 1 else d
         detector = _round5_detector(dicts, name4) if ci == len(cases) - 1 else det
@@ -214,6 +226,8 @@ def test_borders_finished_early_are_counted_once_and_change_nothing(dicts, oracl
             m, per = ctx.detect_batch(a.ctypes.data, _lib_mod().MEM_HOST, _lib_mod().FMT_RGB8, w, h, w * c, h * w * c, n)
             st = ctx.stats()
             got[taps] = (st["contours_traced"], st["contours_materialised"], [(int(x["id"]), int(x["code"]), tuple(int(v) for v in x["corners"])) for x in m], per.tolist())
+            if not taps:
+                resolved.append(st["resolve_iterations"])
         ctx.set_debug_taps(False)
         assert got[False][0] == want_traced == got[True][0], (ci, got[False][0], got[True][0], want_traced)
         assert got[True][1] == want_traced                                  # taps: every traced border is materialised
@@ -221,6 +235,7 @@ def test_borders_finished_early_are_counted_once_and_change_nothing(dicts, oracl
         flat = [t for fr in want_markers for t in fr]
         assert got[False][2] == flat == got[True][2], ci
         assert got[False][3] == got[True][3] == [len(fr) for fr in want_markers]
+    assert resolved[1] >= 1 and resolved[0] == 0, resolved      # the anomaly case went through the fixpoint passes, plain noise did not
 
 
 def _speck(img, c):
