@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Round-4 soak (GPU box): tests/test_gpu_config_fuzz.py's run_case as a driver over N random configuration x dictionary x format x
-size combinations -- every threshold_window 3..12 among them, i.e. the radius-templated threshold kernels and the separable path -- plus
+size combinations -- every threshold_window 3..12 and, in every third case, 8..33 among them, i.e. the radius-templated threshold kernels, the ring kernel in all its splits and the separable path -- plus
 tools/fuzz_soak.py's structured-frame seeds.  Prints a progress line every 100 cases.   python tools/soak_r4.py [cases] [seeds]"""
 import sys, time
 from pathlib import Path
