@@ -922,7 +922,7 @@ int finish_batch(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_fram
     unsigned int flags = hs[4];
     for (int sh = 0; sh < 16; sh++) ctx->stats.contours_traced += hs[48 + sh];   // borders finished inside k_local_contract (kDead)
 #ifdef A3_TUNING
-    if (getenv("A3_PRINT_DEAD")) { uint64_t dead = 0; for (int sh = 0; sh < 16; sh++) dead += hs[48 + sh]; fprintf(stderr, "[a3] borders finished in k_local_contract: %llu\n", (unsigned long long)dead); }
+    if (tuning_knob("A3_PRINT_DEAD", 0)) { uint64_t dead = 0; for (int sh = 0; sh < 16; sh++) dead += hs[48 + sh]; fprintf(stderr, "[a3] borders finished in k_local_contract: %llu\n", (unsigned long long)dead); }
 #endif
     uint64_t need_points = 0; uint32_t need_contours = 0;
     bool jump_short = false, resolve_needed = false, entry_overflow = false;
