@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 K1_BYTES_PER_PIXEL = 3.125         # what K1 has to move: 3 B RGB read + 1/8 B bit-packed binary written; NO grey plane is written
 K1_SURVEY_BYTES_PER_PIXEL = 5      # SURVEY.md section 8d's figure (3 B read + 1 B grey + 1 B byte-wide binary): reported separately
 E2E_BYTES_PER_PIXEL = 3.25         # what one step must move end to end: K1's 3.125 B/px + the 1/8 B/px re-read of the packed image
-PROFILE_TAGS = ("r05", "r04", "r03", "r02")   # profiles/<tag>_pmc_bench_c2.json holds the PMC passes of this same command (newest first)
+PROFILE_TAGS = ("r06", "r05", "r04", "r03", "r02")   # profiles/<tag>_pmc_bench_c2.json holds the PMC passes of this same command (newest first)
 
 # the workloads this file can step (BASELINE.json configs): c2 is the one the metric is quoted on and the default; c5 is the
 # 3840x2160 detect + estimate_pose configuration (BASELINE config 5: `--workload c5 --gpus 4`)
@@ -658,7 +658,8 @@ def main():
                 "sampling_only_ms": round(samp_ms, 4), "dependent_tail_ms": round(dec_ms - samp_ms, 4), "avg_launch_ms_frames_warm": round(dec_warm_ms, 4),
                 "timed_how": "a3_debug_kernel_time: the kernel re-run alone, 10 times, on the work list of a synchronous batch of this run, HIP events around it; "
                              "before every run 512 MB are overwritten so that the kernel finds the frames cold, as inside the pipeline",
-                "traffic": pmc_decode_traffic_bytes(),
+                "traffic": pmc_decode_traffic_bytes()[0],
+                "traffic_source": pmc_decode_traffic_bytes()[1] + " (committed PMC pass, not this run)",
                 # what the kernel is actually bound by: 64-byte sector requests of scattered 12-byte taps
                 "request_rate": None if ceil_us is None else {
                     "what": "the tap pattern's sector-request ceiling: tools/micro/scatterbench (same candidates per launch, same 8x8 sample "
@@ -804,7 +805,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic_bytes() if args.workload == "c2" and args.frames == 256 else None,
+                "traffic": pmc_traffic_bytes()[0] if args.workload == "c2" and args.frames == 256 else None,
+                "traffic_source": (pmc_traffic_bytes()[1] + " (committed PMC pass of this command, not this run)") if args.workload == "c2" and args.frames == 256 else None,
                 # 3.125 B/px: the frame is read once (3 B/px) and only the bit-packed binary image (1/8 B/px) is written; the
                 # grey plane of SURVEY's 5 B/px accounting is never materialised (the decode stage re-derives the grey levels
                 # it samples).  achieved / frac count the bytes that move; the 5 B/px figure is kept under its own name.
@@ -833,6 +835,7 @@ def main():
             # every stage alone (the isolated launches); their sum is longer than a step, which overlaps them
             "stage_ms_per_step": {"threshold": stage_ms.get("threshold"), "contour": stage_ms.get("contour"), "decode": stage_ms.get("decode")},
             "stepping": stepping,
+            "stepping_word": "synchronous" if args.no_pipeline else ("free-running" if own_streams and not gated else "burst-gates" if own_streams else "shared-stream"),
             "contexts": n_ctx,
             "streams": "one per context" if own_streams else "shared",
             "gates": "burst (a3_order_after)" if gated else "none",
@@ -866,9 +869,112 @@ def main():
                 out["other_workloads"] = other_workloads(local_rank, with_cpu=not args.no_cpu_baseline)
             except Exception as e:   # side measurements never take the line down
                 out["other_workloads"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+        emit(out)
     if use_dist:
         dist.destroy_process_group()
+
+
+LINE_BUDGET = 4096       # bytes the LAST stdout line may take (the driver keeps a bounded tail of stdout: round 5's 22 KB line was lost)
+
+
+def _short(v, n=96):
+    return v if not isinstance(v, str) or len(v) <= n else v[: n - 1].rstrip() + "~"
+
+
+def _pick(d, keys, n=96):
+    return {k: _short(d[k], n) for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(out, detail_path="bench_detail.json"):
+    """The driver-facing line: the contract's keys, `roofline`, `roofline_warp`, `cpu_baseline`, `parity_in_run`, one-word `stepping` /
+    `gates` and a few headline figures of the other BASELINE configurations -- everything else (per-region times, prose, A/B rows,
+    the other workloads' tables) stays in `out`, which goes to bench_detail.json.  Never longer than LINE_BUDGET bytes: optional
+    keys are dropped, least important first, until it fits."""
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "repeats", "timed_region_s_total",
+                       "higher_is_better", "scaling", "dtype"))
+    line["vs_baseline"] = out.get("vs_baseline")
+    line["data"] = "synthetic"
+    cfg = out.get("config", {})
+    line["config"] = dict(_pick(cfg, ("frames_per_gpu", "distinct_batches_in_flight", "resolution", "dictionary")),
+                          workload=_short(cfg.get("workload", ""), 110), sharding=_short(cfg.get("sharding", ""), 60))
+    rf = out.get("roofline") or {}
+    line["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "bytes_per_pixel", "bytes_per_launch",
+                                  "avg_launch_ms", "launches_timed", "avg_launch_ms_in_company"), 100)
+    line["roofline"]["kernel"] = _short(rf.get("kernel", ""), 60)
+    rw = out.get("roofline_warp")
+    if isinstance(rw, dict):
+        if "error" in rw:
+            line["roofline_warp"] = {"error": _short(rw["error"], 120)}
+        else:
+            line["roofline_warp"] = _pick(rw, ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_launch_ms",
+                                               "candidates_per_launch", "bytes_per_candidate"), 100)
+            line["roofline_warp"]["kernel"] = _short(rw.get("kernel", ""), 40)
+            rr = rw.get("request_rate") or {}
+            if rr:
+                line["roofline_warp"]["frac_of_request_ceiling"] = rr.get("frac_of_ceiling_whole_kernel")
+                line["roofline_warp"]["request_ceiling_us"] = rr.get("ceiling_us_per_launch")
+    for k in ("e2e_frac", "stage_ms_per_step", "contexts", "gates"):
+        if k in out:
+            line[k] = out[k]
+    line["stepping"] = out.get("stepping_word", "synchronous")
+    if "cpu_baseline" in out and out["cpu_baseline"]:
+        cb = out["cpu_baseline"]
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample", "host_cores_available"), 150)
+        if isinstance(cb.get("all_cores"), dict):
+            line["cpu_baseline"]["all_cores"] = _pick(cb["all_cores"], ("value", "cores"))
+    if out.get("parity_in_run"):
+        line["parity_in_run"] = _pick(out["parity_in_run"], ("frames_compared", "frames_equal", "batches_covered", "pose_max_abs_diff", "against"), 60)
+    line["frames_with_all_ids_correct"] = out.get("frames_with_all_ids_correct")
+    if isinstance(out.get("library"), dict):
+        line["library"] = _pick(out["library"], ("abi", "tuning_build", "internal_switches_used"))
+    if isinstance(out.get("gathered"), dict):
+        line["gathered"] = _pick(out["gathered"], ("frames", "global_frame_indices_in_order", "all_ranks_ids_correct", "collectives", "verified_collectives",
+                                                   "collectives_with_wrong_records", "rank0_poses_bit_equal_after_gather"))
+    if isinstance(out.get("dist"), dict):
+        line["dist"] = _pick(out["dist"], ("backend", "world_size", "launcher"), 60)
+    # the other BASELINE configurations: [synchronous frames/s, pipelined frames/s, frames equal to the oracle / frames compared]
+    ow = out.get("other_workloads")
+    if isinstance(ow, dict) and "error" not in ow:
+        brief = {}
+        for name, row in ow.items():
+            if isinstance(row, dict) and "value" in row:
+                par = row.get("parity_in_run") or {}
+                brief[name] = [row["value"], (row.get("pipelined") or {}).get("value"), f"{par.get('frames_equal')}/{par.get('frames_compared')}"]
+        c1 = ow.get("C1_single_frame_from_host") or {}
+        if isinstance(c1.get("markers_only_pinned"), dict):
+            brief["C1_one_frame_per_call_ms"] = c1["markers_only_pinned"].get("median_ms")
+            brief["C1_launches_per_call"] = c1.get("launches_per_call")
+        ing = (ow.get("C2_from_host_frames") or {}).get("pinned")
+        if isinstance(ing, dict):
+            brief["C2_from_pinned_host_fps"] = ing.get("value")
+        brief["columns"] = "frames/s synchronous, frames/s pipelined, frames equal to the oracle"
+        line["other_workloads"] = brief
+    elif isinstance(ow, dict):
+        line["other_workloads"] = {"error": _short(ow["error"], 120)}
+    for k in ("ab_shared_stream", "ab_burst_gates", "ab_free_running", "ab_r04_library_default"):
+        if isinstance(out.get(k), dict) and "value" in out[k]:
+            line.setdefault("ab_fps", {})[k[3:]] = out[k]["value"]
+    line["detail"] = detail_path
+    for drop in ("ab_fps", "library", "dist", "other_workloads", "frames_with_all_ids_correct", "gathered", "contexts", "stage_ms_per_step"):
+        if len(json.dumps(line)) <= LINE_BUDGET:
+            break
+        line.pop(drop, None)
+    assert len(json.dumps(line)) <= LINE_BUDGET, "bench line over budget"
+    return line
+
+
+def emit(out):
+    """stdout carries exactly ONE line, the compact one.  Everything else goes to bench_detail.json (under gpurun_out/ when that
+    exists, so that it travels back from a GPU box; A3_BENCH_DETAIL overrides the path) and, as one line that starts with
+    `bench_detail `, to stderr."""
+    path = Path(os.environ.get("A3_BENCH_DETAIL", "") or ((ROOT / "gpurun_out" if (ROOT / "gpurun_out").is_dir() else ROOT) / "bench_detail.json"))
+    try:
+        path.write_text(json.dumps(out, indent=1))
+        rel = str(path.relative_to(ROOT)) if path.is_relative_to(ROOT) else str(path)
+    except OSError:
+        rel = "stderr only (bench_detail.json could not be written)"
+    print("bench_detail " + json.dumps(out), file=sys.stderr, flush=True)
+    print(json.dumps(compact_line(out, rel)), flush=True)
 
 
 def launch_ranks(args):
@@ -940,10 +1046,10 @@ def pmc_traffic_bytes():
         try:
             pmc = json.loads((ROOT / "profiles" / f"{tag}_pmc_bench_c2.json").read_text())
             k1 = next(v for k, v in pmc.items() if "k_grey_threshold7" in k)
-            return int((2.0 * k1["FETCH_SIZE"] + k1["WRITE_SIZE"]) * 1024)
+            return int((2.0 * k1["FETCH_SIZE"] + k1["WRITE_SIZE"]) * 1024), f"profiles/{tag}_pmc_bench_c2.json"
         except Exception:
             continue
-    return None
+    return None, "no PMC summary under profiles/"
 
 
 def pmc_decode_traffic_bytes():
@@ -953,10 +1059,10 @@ def pmc_decode_traffic_bytes():
         try:
             pmc = json.loads((ROOT / "profiles" / f"{tag}_pmc_chain.json").read_text())
             k = next(v for name, v in pmc.items() if "k_decode" in name)
-            return int((k["read_MB_exact"] + k["write_MB_exact"]) * 1e6)
+            return int((k["read_MB_exact"] + k["write_MB_exact"]) * 1e6), f"profiles/{tag}_pmc_chain.json"
         except Exception:
             continue
-    return None
+    return None, "no PMC summary under profiles/"
 
 
 def scatter_ceiling_us(n_cand):

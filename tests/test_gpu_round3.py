@@ -12,7 +12,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from tests.util import assert_frame_parity, marker_tuples, markers_of_hip, markers_of_oracle
+from tests.util import assert_frame_parity, bench_output, marker_tuples, markers_of_hip, markers_of_oracle
 
 pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
@@ -46,10 +46,9 @@ def test_bench_front_door_starts_its_own_ranks():
            "--device-synth", "--repeats", "2", "--no-other-workloads", "--no-cpu-baseline", "--launch-timeout", "500"]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-4000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]      # ONE JSON line on stdout
-    out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 3
+    line, out = bench_output(p)                                                # ONE JSON line on stdout, within the driver's budget
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 3 and line["gathered"]["global_frame_indices_in_order"] is True
+    assert line["dist"]["world_size"] == 2
     g = out["gathered"]       # the last collective: one rotation of four batches of 16 frames from each of the two ranks
     assert g["frames"] == 2 * 16 * g["batches_in_last_collective"] and g["global_frame_indices_in_order"] is True
     assert g["all_ranks_ids_correct"] >= 0.8 * g["frames"]

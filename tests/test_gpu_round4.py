@@ -10,7 +10,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from tests.util import marker_tuples
+from tests.util import bench_output, marker_tuples
 
 pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
@@ -197,9 +197,8 @@ def test_bench_config5_two_ranks_gloo_with_poses_in_the_gather():
            "--device-synth", "--repeats", "2", "--no-other-workloads", "--no-cpu-baseline", "--isolated-launches", "2", "--launch-timeout", "500"]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-4000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]
-    out = json.loads(lines[0])
+    line, out = bench_output(p)
+    assert line["n_gpus"] == 2 and line["config"]["resolution"] == [3840, 2160] and line["gathered"]["rank0_poses_bit_equal_after_gather"] is True
     assert out["n_gpus"] == 2 and out["config"]["resolution"] == [3840, 2160] and "detect + estimate_pose" in out["metric"]
     g = out["gathered"]
     assert g["frames"] == 2 * 4 * g["batches_in_last_collective"] and g["global_frame_indices_in_order"] is True
@@ -219,7 +218,17 @@ def test_bench_line_carries_parity_and_isolated_roofline():
            "--synth-workers", "4"]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-4000:]
-    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    line, out = bench_output(p)
+    # what the driver parses: the contract's keys, both rooflines, the CPU baseline and the parity count, in at most 4 KB
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "roofline_warp", "cpu_baseline", "parity_in_run", "e2e_frac", "stage_ms_per_step", "stepping", "gates"):
+        assert k in line, k
+    assert line["value"] == out["value"] and line["ms_per_step"] == out["ms_per_step"] and line["stepping"] == "free-running"
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "bytes_per_launch", "avg_launch_ms", "launches_timed", "kernel"):
+        assert k in line["roofline"] or (k in ("traffic", "traffic_source") and out["roofline"][k] is None), k
+    assert line["roofline"]["frac"] == out["roofline"]["frac"] and line["roofline_warp"]["frac"] == out["roofline_warp"]["frac"]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"]) and line["cpu_baseline"]["kind"] == "port"
+    assert (line["parity_in_run"]["frames_equal"], line["parity_in_run"]["frames_compared"]) == (32, 32)
     assert out["parity_in_run"]["summary"] == "32/32 frames" and out["parity_in_run"]["batches_covered"] == 4     # four distinct batches of 8 in flight
     assert out["config"]["distinct_batches_in_flight"] == 4 and out["library"]["internal_switches_used"] == []
     assert out["library_stepping_seen"] == ["whole"] * 4 and out["gates"] == "none"                     # the headline: free-running rotation

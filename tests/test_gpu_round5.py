@@ -10,7 +10,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from tests.util import marker_tuples
+from tests.util import bench_output, marker_tuples
 
 pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
@@ -155,7 +155,9 @@ def _bench(extra, timeout=900):
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stderr[-4000:]
-    return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    line, out = bench_output(p)
+    assert line["gathered"]["collectives_with_wrong_records"] == out["gathered"]["collectives_with_wrong_records"]
+    return out
 
 
 def test_gather_survives_a_lagging_collective():

@@ -10,7 +10,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from tests.util import marker_tuples, markers_of_hip, markers_of_oracle
+from tests.util import bench_output, marker_tuples, markers_of_hip, markers_of_oracle
 
 pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
@@ -219,8 +219,8 @@ def test_two_rank_rehearsal_as_child_processes():
            "--backend", "gloo", "--device-synth", "--repeats", "1", "--no-other-workloads"]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-4000:]
-    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
-    out = json.loads(line)
+    line, out = bench_output(p)
+    assert line["n_gpus"] == 2 and line["frames_with_all_ids_correct"] == out["frames_with_all_ids_correct"]
     assert out["n_gpus"] == 2 and out["scaling"] == "weak"
     g = out["gathered"]       # the last collective: one rotation of up to four batches of 16 frames from each of the two ranks
     assert g["frames"] == 2 * 16 * g["batches_in_last_collective"] and g["global_frame_indices_in_order"] is True

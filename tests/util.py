@@ -38,3 +38,20 @@ def marker_tuples(m):
     """a3_marker records as plain tuples (field values only: the 4 padding bytes of the 56-byte record are not data)"""
     return [(int(r["frame"]), int(r["id"]), int(r["code"]), tuple(int(v) for v in r["corners"]), int(r["hamming_distance"]),
              int(r["rotation"]), int(r["candidate_index"])) for r in m]
+
+
+BENCH_LINE_BUDGET = 4096
+
+
+def bench_output(p):
+    """(line, detail) of a finished `bench.py` child: stdout must hold exactly ONE line -- the compact JSON line the driver parses,
+    at most BENCH_LINE_BUDGET bytes -- and stderr a `bench_detail {...}` line with everything else."""
+    import json
+
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]
+    assert len(lines[0].encode()) <= BENCH_LINE_BUDGET, len(lines[0])
+    line = json.loads(lines[0])
+    det = [ln for ln in p.stderr.splitlines() if ln.startswith("bench_detail ")]
+    assert len(det) == 1, p.stderr[-2000:]
+    return line, json.loads(det[0][len("bench_detail "):])
