@@ -49,9 +49,10 @@ def bench_output(p):
     import json
 
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]
-    assert len(lines[0].encode()) <= BENCH_LINE_BUDGET, len(lines[0])
-    line = json.loads(lines[0])
+    # (RCCL prints its version banner on stdout: lines of other libraries may precede ours, never a second JSON line, and ours is last)
+    assert len([ln for ln in lines if ln.startswith("{")]) == 1 and lines[-1].startswith("{"), p.stdout[-2000:]
+    assert len(lines[-1].encode()) <= BENCH_LINE_BUDGET, len(lines[-1])
+    line = json.loads(lines[-1])
     det = [ln for ln in p.stderr.splitlines() if ln.startswith("bench_detail ")]
     assert len(det) == 1, p.stderr[-2000:]
     return line, json.loads(det[0][len("bench_detail "):])
