@@ -35,7 +35,7 @@ SYMBOLS = [
     "a3_contour_count", "a3_download_contours", "a3_detection_record_bytes", "a3_pack_detections",
 ]
 # aruco3_amd/csrc/a3_internal.h: probes and single-stage hooks for this repository's tests and tools, not for bindings
-INTERNAL_SYMBOLS = ["a3_debug_set_k1_stream", "a3_debug_set_overlap", "a3_debug_set_k1_waves", "a3_debug_set_partition", "a3_debug_build_flags", "a3_debug_spin", "a3_debug_set_mark_threshold", "a3_debug_set_hold", "a3_debug_launch_threshold", "a3_debug_stream_wait_threshold", "a3_debug_kernel_time", "a3_selftest_ieee", "a3_debug_clockwise", "a3_debug_rotate_bits", "a3_debug_discard_too_near"]
+INTERNAL_SYMBOLS = ["a3_debug_set_k1_stream", "a3_debug_set_overlap", "a3_debug_set_k1_waves", "a3_debug_set_partition", "a3_debug_build_flags", "a3_debug_spin", "a3_debug_set_mark_threshold", "a3_debug_set_hold", "a3_debug_launch_threshold", "a3_debug_stream_wait_threshold", "a3_debug_kernel_time", "a3_selftest_ieee", "a3_debug_clockwise", "a3_debug_rotate_bits", "a3_debug_discard_too_near", "a3_debug_inject_candidates"]
 
 
 class A3Error(RuntimeError):
@@ -230,6 +230,8 @@ def load():
     L.a3_debug_clockwise.argtypes = [vp, C.POINTER(C.c_int32), C.c_size_t, C.POINTER(C.c_int32)]
     L.a3_debug_rotate_bits.restype = C.c_int
     L.a3_debug_rotate_bits.argtypes = [vp, u8p, C.c_uint32, C.c_uint32, u8p]
+    L.a3_debug_inject_candidates.restype = C.c_int
+    L.a3_debug_inject_candidates.argtypes = [vp, u32p, C.c_size_t]
     L.a3_debug_discard_too_near.restype = C.c_int
     L.a3_debug_discard_too_near.argtypes = [vp, u32p, C.c_size_t, C.c_float, u32p, C.POINTER(C.c_size_t)]
     _lib = L
@@ -483,6 +485,11 @@ class Context:
         out = np.zeros_like(b)
         check(load().a3_debug_rotate_bits(self.handle, _p(b, C.c_uint8), n, times, _p(out, C.c_uint8)), self.handle)
         return out
+
+    def debug_inject_candidates(self, quads: np.ndarray):
+        """the next one-frame batch decodes THESE quads (n x 4 x 2, in this order) instead of what its contour stage finds"""
+        q = np.ascontiguousarray(quads, dtype=np.uint32).reshape(-1, 8)
+        check(load().a3_debug_inject_candidates(self.handle, _p(q, C.c_uint32), q.shape[0]), self)
 
     def debug_discard_too_near(self, quads: np.ndarray, min_distance: float) -> np.ndarray:
         q = np.ascontiguousarray(quads, dtype=np.uint32).reshape(-1, 8)

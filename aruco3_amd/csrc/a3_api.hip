@@ -182,6 +182,11 @@ struct a3_ctx {
     int jump_rounds_hint = 10, resolve_iters_hint = 4;
     uint32_t dbg_nd = 0, dbg_frames = 0, dbg_chunks = 0;
     PixelSrc dbg_src{};
+    // a3_debug_inject_candidates (tests only): quads that replace frame 0's candidate list of the next batch, between the contour
+    // stage and k_frame_candidates (quirk Q4: a degenerate quad cannot come out of a convex hull)
+    std::vector<CandRec> inject;
+    bool inject_armed = false;
+    uint32_t inject_count = 0;
     Pending pending;
     bool pending_trivial = false;   // a submitted batch with no frames / empty images   // a3_debug_kernel_time: shape of the last batch's contour graph
     int resolve_full_ttl = 0;
@@ -423,6 +428,13 @@ int enqueue_back(a3_ctx* ctx, hipStream_t st, const BackArgs& b) {
     unsigned int* d_work_count = ctx->scratch_u32 + 0;
     unsigned int* d_marker_total = ctx->scratch_u32 + 1;
     unsigned int* d_err = ctx->scratch_u32 + 4;
+    if (ctx->inject_armed) {   // (test hook; never set by a caller of the public header)
+        ctx->inject_armed = false;
+        const uint32_t cnt = (uint32_t)ctx->inject.size();
+        if (cnt) A3_HIP(hipMemcpyAsync(ctx->cands.p, ctx->inject.data(), cnt * sizeof(CandRec), hipMemcpyHostToDevice, st));
+        ctx->inject_count = cnt;
+        A3_HIP(hipMemcpyAsync(ctx->cand_count, &ctx->inject_count, 4, hipMemcpyHostToDevice, st));
+    }
     A3_HIP(launch_frame_candidates(st, ctx->cands.as<CandRec>(), ctx->cand_count, b.n, b.max_cand, b.min_corner_separation,
                                    ctx->pre_xy.as<uint16_t>(), ctx->fin_xy.as<uint16_t>(), ctx->fin_count.as<uint32_t>(),
                                    ctx->work.as<uint32_t>(), d_work_count, b.S, ctx->proj.p, ctx->cand_big.as<float>()));
@@ -1863,6 +1875,22 @@ int a3_debug_discard_too_near(a3_ctx* ctx, const uint32_t* quads_xy, size_t n, f
     if (cnt) A3_HIP(hipMemcpy(o.data(), fin, o.size() * 2, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < o.size(); i++) out_xy[i] = o[i];
     *n_out = cnt;
+    return A3_OK;
+}
+
+int a3_debug_inject_candidates(a3_ctx* ctx, const uint32_t* quads_xy, size_t n) {
+    if (!ctx || (!quads_xy && n)) return A3_ERR_INVALID;
+    if (ctx->pending.active || ctx->pending_trivial) return fail(ctx, A3_ERR_INVALID, "a3_debug_inject_candidates: a submitted batch has not been collected");
+    if (n > kMaxCandDefault) return fail(ctx, A3_ERR_CAPACITY, "a3_debug_inject_candidates: at most 1024 quads");
+    ctx->inject.resize(n);
+    for (size_t i = 0; i < n; i++) {
+        ctx->inject[i].start_key = (uint32_t)i;   // the given order
+        for (int k = 0; k < 8; k++) {
+            if (quads_xy[8 * i + k] > 65535u) return fail(ctx, A3_ERR_INVALID, "coordinates above 65535");
+            ctx->inject[i].xy[k] = (uint16_t)quads_xy[8 * i + k];
+        }
+    }
+    ctx->inject_armed = true;
     return A3_OK;
 }
 

@@ -73,6 +73,13 @@ int  a3_selftest_ieee(a3_ctx *ctx, const double *a, const double *b, size_t n, d
  *   discard_too_near          (src/aruco.rs:187-232)  -> k_frame_candidates on one frame whose candidates are `quads_xy` in order */
 int  a3_debug_clockwise(a3_ctx *ctx, const int32_t *quads_xy, size_t n, int32_t *out_xy);
 int  a3_debug_rotate_bits(a3_ctx *ctx, const uint8_t *bits, uint32_t n, uint32_t times, uint8_t *out);
+/* Quirk Q4 (src/aruco.rs:255-257: a failed projection -> 1 x 1 black patch -> code 0 looked up): the quads given here REPLACE the
+ * candidate list of frame 0 of the NEXT batch of this context (a synchronous a3_detect_batch of one frame), in the given order,
+ * between the contour stage and k_frame_candidates -- the place of the list enforce_clockwise_corners leaves behind
+ * (src/aruco.rs:68).  A convex hull never yields the collinear / repeated-corner quad that makes the 8 x 8 solve fail; this is
+ * the only way to lead one through discard_too_near, the solve, k_decode's 1 x 1 stand-in and the accept test on the device.
+ * One shot: the batch after that runs unchanged. */
+int  a3_debug_inject_candidates(a3_ctx *ctx, const uint32_t *quads_xy, size_t n);
 int  a3_debug_discard_too_near(a3_ctx *ctx, const uint32_t *quads_xy, size_t n, float min_distance, uint32_t *out_xy, size_t *n_out);
 
 #ifdef __cplusplus

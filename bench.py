@@ -141,6 +141,8 @@ def main():
     ap.add_argument("--max-markers", type=int, default=0, help="N > 1: markers per frame a gather record holds; 0 = calibrated on the first batch "
                                                                "(2 x the largest count on any rank, at least 8); a frame that holds more later is an error, never a clip")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="N > 1 started without a launcher: seconds the parent waits for its ranks")
+    ap.add_argument("--fail-rank", type=int, default=-1, help="test aid: this rank exits with code 3 once the process group is up (a rank that dies under "
+                                                               "its peers: the launcher must end the launch with a non-zero code, not hang)")
     ap.add_argument("--frames-cache", default="", help="npz path: reuse rendered frames between runs (profiling runs use it so that "
                                                         "nothing forks under the profiler)")
     args = ap.parse_args()
@@ -207,6 +209,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+        if args.fail_rank == rank:
+            os._exit(3)
 
     # The stepping below is what the LIBRARY does behind include/aruco3_hip.h: contexts on streams of their own + a3_order_after
     # gates -> bursts with held chains; contexts on one shared stream -> deferred decode.  No process-wide switch is set for the

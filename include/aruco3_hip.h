@@ -157,10 +157,13 @@ int  a3_detect_batch_pose(a3_ctx *ctx, const void *pixels, int memory, int fmt, 
  * against the caller's stream only through events recorded at submit; and the decode stage samples the FRAMES themselves (no grey plane is kept), so
  * a frame overwritten before collect changes what is read.  Pageable host frames have been read when submit returns.
  *
- * Hardware queues: the HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and two
- * streams that share a queue run in order whatever their events say.  A process that keeps four contexts on their own streams
- * plus the library's decode / copy streams in flight should export GPU_MAX_HW_QUEUES=8 before the runtime starts (bench.py
- * does); with fewer queues results are the same and the batches merely overlap less. */
+ * Hardware queues: the HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default), handed
+ * out in the order the streams are first used, and two streams that share a queue run in order whatever their events say -- a
+ * stream that merely waits (a collective waiting for its peers) holds up the others of its queue.  A process that keeps four
+ * contexts on their own streams plus the library's decode / copy streams in flight should export GPU_MAX_HW_QUEUES before the
+ * runtime starts: 8 when nothing else of the process uses streams; 16 when it also runs collectives or copies on streams of its
+ * own (bench.py sets 16: with 8 its collective's side stream landed on a context's queue and every collective stalled that
+ * context).  With fewer queues results are the same and the batches merely overlap less. */
 int  a3_detect_batch_submit(a3_ctx *ctx, const void *pixels, int memory, int fmt, uint32_t width, uint32_t height,
                             size_t row_stride, size_t frame_stride, uint32_t n_frames, size_t out_cap);
 int  a3_detect_batch_collect(a3_ctx *ctx, a3_marker *out, size_t out_cap, uint32_t *per_frame_count, size_t *out_n);

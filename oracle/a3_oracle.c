@@ -622,10 +622,12 @@ int a3o_homography_to_code_permutations(const uint8_t *patch, uint32_t pw, uint3
     return ok;
 }
 
-/* src/aruco.rs:52-121 */
-int a3o_detect(const a3o_config *cfg, const uint64_t *codes, size_t n_codes, uint8_t num_bits, uint8_t tau,
-               const uint8_t *px, int fmt, uint32_t w, uint32_t h, size_t row_stride, int keep_debug,
-               a3o_detection *out) {
+/* src/aruco.rs:52-121.  `inject` (test aid, NULL in a3o_detect): n_inject quads of 4 (x, y) pairs that REPLACE what
+ * contours_to_candidates + enforce_clockwise_corners (src/aruco.rs:65-68) delivered, in the given order -- the only way to lead a
+ * degenerate quad into extract_homographies' failure branch (src/aruco.rs:255-257, quirk Q4): a convex hull of four points never is. */
+static int detect_impl(const a3o_config *cfg, const uint64_t *codes, size_t n_codes, uint8_t num_bits, uint8_t tau,
+                       const uint8_t *px, int fmt, uint32_t w, uint32_t h, size_t row_stride, int keep_debug,
+                       const uint32_t *inject, size_t n_inject, a3o_detection *out) {
     memset(out, 0, sizeof(*out));
     out->width = w; out->height = h;
     uint32_t minwh = w < h ? w : h;
@@ -670,6 +672,14 @@ int a3o_detect(const a3o_config *cfg, const uint64_t *codes, size_t n_codes, uin
     free(edges);
     size_t nc = cand.n / 8;
     a3o_enforce_clockwise_corners(cand.v, nc);
+    if (inject) {
+        cand.n = 0; cand_start.n = 0;
+        for (size_t i = 0; i < n_inject; i++) {
+            for (int k = 0; k < 8; k++) u32vec_push(&cand, inject[8 * i + k]);
+            u32vec_push(&cand_start, (uint32_t)i);
+        }
+        nc = n_inject;
+    }
     out->n_candidates_pre = (uint32_t)nc;
     if (keep_debug) {
         out->candidates_pre = (uint32_t *)malloc((nc ? nc : 1) * 8 * sizeof(uint32_t));
@@ -741,6 +751,20 @@ int a3o_detect(const a3o_config *cfg, const uint64_t *codes, size_t n_codes, uin
     if (keep_debug) { out->grey = grey; out->thresholded = thr; }
     else { free(grey); free(thr); }
     return 0;
+}
+
+int a3o_detect(const a3o_config *cfg, const uint64_t *codes, size_t n_codes, uint8_t num_bits, uint8_t tau,
+               const uint8_t *px, int fmt, uint32_t w, uint32_t h, size_t row_stride, int keep_debug,
+               a3o_detection *out) {
+    return detect_impl(cfg, codes, n_codes, num_bits, tau, px, fmt, w, h, row_stride, keep_debug, NULL, 0, out);
+}
+
+/* a3o_detect with the candidate list handed in (see detect_impl) */
+int a3o_detect_quads(const a3o_config *cfg, const uint64_t *codes, size_t n_codes, uint8_t num_bits, uint8_t tau,
+                     const uint8_t *px, int fmt, uint32_t w, uint32_t h, size_t row_stride, int keep_debug,
+                     const uint32_t *quads, size_t n_quads, a3o_detection *out) {
+    static const uint32_t none[8] = {0};
+    return detect_impl(cfg, codes, n_codes, num_bits, tau, px, fmt, w, h, row_stride, keep_debug, quads ? quads : none, n_quads, out);
 }
 
 void a3o_free_detection(a3o_detection *d) {

@@ -115,6 +115,10 @@ int    a3o_homography_to_code_permutations(const uint8_t *patch, uint32_t pw, ui
 int  a3o_detect(const a3o_config *cfg, const uint64_t *codes, size_t n_codes, uint8_t num_bits, uint8_t tau,
                 const uint8_t *px, int fmt, uint32_t w, uint32_t h, size_t row_stride, int keep_debug,
                 a3o_detection *out);
+/* a3o_detect with the candidate list (after enforce_clockwise_corners, before discard_too_near) handed in: test aid for quirk Q4 */
+int  a3o_detect_quads(const a3o_config *cfg, const uint64_t *codes, size_t n_codes, uint8_t num_bits, uint8_t tau,
+                      const uint8_t *px, int fmt, uint32_t w, uint32_t h, size_t row_stride, int keep_debug,
+                      const uint32_t *quads, size_t n_quads, a3o_detection *out);
 void a3o_free_detection(a3o_detection *d);
 
 /* ---- L3: pose ---- */

@@ -140,6 +140,9 @@ def lib():
         L.a3o_detect.restype = C.c_int
         L.a3o_detect.argtypes = [C.POINTER(Config), u64p, C.c_size_t, C.c_uint8, C.c_uint8, u8p, C.c_int, C.c_uint32, C.c_uint32,
                                  C.c_size_t, C.c_int, C.POINTER(Detection)]
+        L.a3o_detect_quads.restype = C.c_int
+        L.a3o_detect_quads.argtypes = [C.POINTER(Config), u64p, C.c_size_t, C.c_uint8, C.c_uint8, u8p, C.c_int, C.c_uint32, C.c_uint32,
+                                       C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(Detection)]
         L.a3o_free_detection.restype = None
         L.a3o_free_detection.argtypes = [C.POINTER(Detection)]
         L.a3o_make_marker_square.restype = None
@@ -310,15 +313,21 @@ def homography_to_code_permutations(patch: np.ndarray, mark_size_: int):
     return (codes if ok else None)
 
 
-def detect(img: np.ndarray, codes: np.ndarray, num_bits: int, tau: int, config: Config = None, keep_debug: bool = True) -> dict:
-    """Run the whole restated Detector::detect and return every stage as numpy data."""
+def detect(img: np.ndarray, codes: np.ndarray, num_bits: int, tau: int, config: Config = None, keep_debug: bool = True, quads=None) -> dict:
+    """Run the whole restated Detector::detect and return every stage as numpy data.  `quads` (test aid, n x 4 x 2): the candidate
+    list handed to discard_too_near / extract_homographies INSTEAD of what the contour stage found (quirk Q4's degenerate quads)."""
     cfg = config or Config.default()
     img = _u8(img)
     h, w = img.shape[:2]
     codes = np.ascontiguousarray(codes, dtype=np.uint64)
     d = Detection()
-    rc = lib().a3o_detect(C.byref(cfg), _p(codes, C.c_uint64), codes.size, num_bits, tau, _p(img, C.c_uint8), _fmt_of(img), w, h,
-                          img.strides[0], int(keep_debug), C.byref(d))
+    if quads is None:
+        rc = lib().a3o_detect(C.byref(cfg), _p(codes, C.c_uint64), codes.size, num_bits, tau, _p(img, C.c_uint8), _fmt_of(img), w, h,
+                              img.strides[0], int(keep_debug), C.byref(d))
+    else:
+        q = np.ascontiguousarray(quads, dtype=np.uint32).reshape(-1, 8)
+        rc = lib().a3o_detect_quads(C.byref(cfg), _p(codes, C.c_uint64), codes.size, num_bits, tau, _p(img, C.c_uint8), _fmt_of(img), w, h,
+                                    img.strides[0], int(keep_debug), _p(q, C.c_uint32), q.shape[0], C.byref(d))
     assert rc == 0
     S = d.sample
     nc, npre, nm = d.n_candidates, d.n_candidates_pre, d.n_markers

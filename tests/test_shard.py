@@ -73,7 +73,7 @@ def _worker(rank, world, port, q):
         d = shard.broadcast_dictionary(d0, "cpu", 0)
         ref = ARDictionary.new_from_named_dict("APRILTAG_36H11")
         ok = d.num_bits == 36 and d._tau == 11 and np.array_equal(d.code_list, ref.code_list)
-        total = 13   # not a multiple of the world size: the shorter block is padded for the all-gather
+        total = 13 if world == 2 else 8 * 5 + 3   # not a multiple of the world size: the shorter blocks are padded for the all-gather
         lo, hi = shard.partition(total, world, rank)
         rows = max(b - a for a, b in (shard.partition(total, world, r) for r in range(world)))
         m, per = _fake_markers(rank, hi - lo)
@@ -102,6 +102,44 @@ def test_broadcast_and_gather_world2_gloo():
     for p in procs:
         p.join(60)
     assert res == [(0, True), (1, True)]
+
+
+def test_broadcast_and_gather_world8_gloo():
+    """BASELINE config 3's world size as eight PROCESSES (not eight slices of one): dictionary broadcast, the contiguous split with
+    unequal blocks (43 frames: three ranks hold six, five hold five), padded records, one all-gather, global frame order"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(r, True) for r in range(8)]
+
+
+def test_bench_launcher_with_eight_ranks_and_no_gpu_ends_the_launch():
+    """`python bench.py --gpus 8` as the driver types it, on a box without a GPU: eight children, all of them fail at the first device
+    call; the parent names a rank, exits non-zero within its timeout, prints no JSON line and leaves no child running"""
+    import subprocess
+    import sys
+    import time
+    from pathlib import Path
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "8", "--backend", "gloo", "--frames", "2", "--steps", "1", "--warmup", "0",
+                        "--device-synth", "--repeats", "1", "--no-other-workloads", "--no-cpu-baseline", "--launch-timeout", "240"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=400)
+    assert p.returncode != 0 and time.time() - t0 < 300
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert "rank" in p.stderr and "exited with" in p.stderr
 
 
 def test_bench_launcher_without_a_gpu_fails_loudly_and_cleanly():
