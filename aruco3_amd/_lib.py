@@ -22,8 +22,8 @@ MEM_HOST, MEM_DEVICE = 0, 1
 PROFILE_OFF, PROFILE_STAGES, PROFILE_THRESHOLD_ONLY, PROFILE_THRESHOLD_SAMPLED = 0, 1, 2, 3
 STAGE_THRESHOLD, STAGE_CONTOUR, STAGE_DECODE = 0, 1, 2
 # a3_stats.stepping & 0xFF (include/aruco3_hip.h A3_STEP_*)
-STEP_WHOLE, STEP_DECODE_DEFERRED, STEP_HELD_RELEASED_BY_LAST, STEP_HELD_RELEASED_EARLY, STEP_BURST_LAST = 0, 1, 2, 3, 4
-STEP_NAMES = {0: "whole", 1: "decode_deferred", 2: "held_released_by_last", 3: "held_released_early", 4: "burst_last"}
+STEP_WHOLE, STEP_DECODE_DEFERRED, STEP_HELD_RELEASED_BY_LAST, STEP_HELD_RELEASED_EARLY, STEP_BURST_LAST, STEP_HELD = 0, 1, 2, 3, 4, 5
+STEP_NAMES = {0: "whole", 1: "decode_deferred", 2: "held_released_by_last", 3: "held_released_early", 4: "burst_last", 5: "held"}
 
 # every symbol include/aruco3_hip.h declares
 SYMBOLS = [

@@ -165,7 +165,7 @@ struct a3_ctx {
     int back_rc = 0;                 // a failed launch of the deferred half, whoever enqueued it (guarded by g_defer_mu): collect reports it
     bool allow_defer = false;        // set by the submit entry points for the batch being enqueued
     int batch_mode = 0;              // where the decode stage of the batch being submitted is released (batch_mode_of, fixed at submit)
-    uint32_t stepping = 0;           // A3_STEP_* of the batch in flight / last finished (a3_stats.stepping)
+    std::atomic<uint32_t> stepping{0};   // A3_STEP_* of the batch in flight / last finished (a3_stats.stepping); another thread's submit may release this context's held chain
     uint32_t released_others = 0;    // held chains of other contexts this batch's submit released (the burst's last member)
     uint32_t reruns = 0;             // synchronous re-runs the device asked for while the last call's batch was produced (pool growth, more passes, host plan)
     BackArgs back;
@@ -497,7 +497,10 @@ int need_stream(a3_ctx* ctx) {
         A3_HIP(hipSetDevice(ctx->device));
         A3_HIP(create_stream(&ctx->own_stream, 0, 0));
     }
-    ctx->stream = ctx->own_stream;
+    {   // (batch_mode_of reads every live context's stream under this lock, possibly from another thread's submit)
+        std::lock_guard<std::mutex> lk(g_streams_mu);
+        ctx->stream = ctx->own_stream;
+    }
     return A3_OK;
 }
 
@@ -978,6 +981,15 @@ int finish_batch(a3_ctx* ctx, a3_marker* out, size_t out_cap, uint32_t* per_fram
         uint32_t next = ctx->max_cand;
         while (next < need) next = next < lds_slots ? std::min(lds_slots, next * 2) : std::min(kMaxCandLimit, next * 2);
         if ((uint64_t)n * next > 0xFFFFFFFFull) return fail(ctx, A3_ERR_LIMIT, "frames x candidate slots per frame exceeds 2^32: fewer frames per call");
+        {   // Every frame of the batch gets the table of the fullest one: what that costs is known before anything is allocated, and a
+            // batch whose tables cannot fit is a limit of this implementation (fewer frames per call cure it), not a HIP failure.
+            const size_t per_slot = sizeof(CandRec) + 16 + 16 + 4 + (next > lds_slots ? 4 : 0) + decode_out_bytes() + proj_rec_bytes();
+            const size_t had = ctx->cands.cap + ctx->pre_xy.cap + ctx->fin_xy.cap + ctx->work.cap + ctx->cand_big.cap + ctx->outs.cap + ctx->proj.cap;
+            const size_t want = (size_t)n * next * per_slot;
+            size_t free_b = 0, total_b = 0;
+            if (want > had && hipMemGetInfo(&free_b, &total_b) == hipSuccess && want - had > free_b)
+                return fail(ctx, A3_ERR_LIMIT, "candidate tables of this batch do not fit the device (every frame gets the fullest frame's table): fewer frames per call");
+        }
         ctx->max_cand = next;
         return 1;
     }
@@ -1180,7 +1192,10 @@ int a3_set_stream(a3_ctx* ctx, void* hip_stream) {
         std::lock_guard<std::mutex> lk(g_defer_mu);
         if (ctx->rest_held) (void)flush_held_locked(ctx, nullptr);
     }
-    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;   // (may be null until first needed)
+    {   // (batch_mode_of reads every live context's stream under this lock, possibly from another thread's submit)
+        std::lock_guard<std::mutex> lk(g_streams_mu);
+        ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;   // (may be null until first needed)
+    }
     return A3_OK;
 }
 
@@ -1346,8 +1361,11 @@ static int submit_common(a3_ctx* ctx, const void* pixels, int memory, int fmt, u
     // threshold kernel.  This is the library's behaviour behind the public header -- no switch selects it.  Exceptions, all of
     // them "enqueue the whole batch now": every stage is being timed (the stage times are those of stages that run alone); the
     // batch needs a host-side plan (first batch of a shape, or a graph that outgrew the previous plan: the plan waits for the
-    // device, and a chain enqueued later by another thread must not); the context runs on a caller's stream (its batches are
-    // in order there anyway, a3_order_after is a no-op); a forced mode 1 / 2 (a3_debug_set_overlap: round 4's default, for A/B).
+    // device, and a chain enqueued later by another thread must not); the context SHARES its stream with another context
+    // (batch_mode_of != 0: they are in order there anyway, a3_order_after is a no-op, the decode stage is deferred instead);
+    // a forced mode 1 / 2 (a3_debug_set_overlap: round 4's default, for A/B).  A context alone on a caller's stream IS held like
+    // one on a stream of its own: its chain then lands on that stream behind whatever the caller queued after the submit
+    // (stated in the header).
     const bool gated = ctx->gates_declared;
     ctx->gates_declared = false;
     ctx->batch_mode = batch_mode_of(ctx);
@@ -1361,6 +1379,7 @@ static int submit_common(a3_ctx* ctx, const void* pixels, int memory, int fmt, u
         std::lock_guard<std::mutex> lk(g_defer_mu);
         pd.active = true;
         ctx->rest_held = true; ctx->held_rc = 0;
+        ctx->stepping = A3_STEP_HELD;   // (until the chain goes out: flush_held_locked says how)
         g_held.push_back(ctx);
         return A3_OK;
     }

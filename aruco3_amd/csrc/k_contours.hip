@@ -722,6 +722,8 @@ constexpr uint32_t kFinal = 0x40000000u;
 // borders through shared pixels reads it (a traced border labels its pixels however short it is).  Only in states whose window
 // did not freeze (kFinal and kDead never meet: k_jump_finalize rewrites frozen windows only).
 constexpr uint32_t kDead = 0x20000000u;
+// (readers test both bits: in a kFinal word bit 29 belongs to the hop count -- a dart 2^29 or more hops from its leader is not a dead one)
+__device__ __forceinline__ bool is_dead(uint32_t off_word) { return (off_word & (kFinal | kDead)) == kDead; }
 __device__ __forceinline__ uint32_t fin_off(uint32_t w) { return (w & kFinal) ? (w & 0x3FFFFFFFu) : (w & 0xFFFu); }
 __device__ __forceinline__ uint32_t loc_dist(uint32_t w) { return (w >> 12) & 0x1FFFu; }
 
@@ -1170,7 +1172,7 @@ __global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const J
             const bool better = (od[u] & kFrozen) && g[u].key < s[u].key;
             if (better) { s[u].key = g[u].key; s[u].off = (loc_dist(od[u]) + g[u].off) | kFinal; }
             if (better || fin != loc) fin[d] = s[u];
-            if ((uint32_t)s[u].key == d && (uint32_t)(s[u].key >> 32) != kNoKey && !(s[u].off & kDead)) mask |= 1u << (it + u);
+            if ((uint32_t)s[u].key == d && (uint32_t)(s[u].key >> 32) != kNoKey && !is_dead(s[u].off)) mask |= 1u << (it + u);
         }
     }
     // one global atomic per workgroup: leaders are counted in a block scan first
@@ -1493,7 +1495,7 @@ __global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restr
 #pragma unroll
         for (int u = 0; u < B; u++) {
             live[u] = d0 + (uint32_t)u * stride < n_darts && (uint32_t)(s[u].key >> 32) != kNoKey &&   // else: no start event on this cycle
-                      !(s[u].off & kDead);                                                               // ... or a dead one (k_local_contract)
+                      !is_dead(s[u].off);                                                                // ... or a dead one (k_local_contract)
             const uint32_t leader = live[u] ? (uint32_t)s[u].key : 0u;
             ls[u] = st[leader];    // key: is the leader's window intact; ptr: its border slot (k_cycle_select)
             c[u] = ls[u].ptr;

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64, A3_FC_WAVES) void k_frame_candidates(const Cand
             if ((kill >> lane) & 1ull) s_dead[j] = 1;
         }
         if (i_dead && lane == 0) s_dead[i] = 1;
-        FC_SYNC();
+        __syncthreads();   // (only s_dead changes inside this loop, and s_dead lives in LDS in both forms: no memory fence per row)
     }
     FC_SYNC();
     // survivors, order preserved: count them, take a range of the work list, then write quads, work items and projections

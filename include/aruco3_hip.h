@@ -106,7 +106,9 @@ enum {
     A3_STEP_HELD_RELEASED_BY_LAST = 2,  /* burst member: chain held at submit, enqueued by the submit of the burst's last member */
     A3_STEP_HELD_RELEASED_EARLY = 3,    /* burst member whose chain went out before a last member came: at collect, at a gate on it,
                                          * at a3_set_stream */
-    A3_STEP_BURST_LAST = 4              /* the burst's last member: released the others' chains behind its threshold kernel */
+    A3_STEP_BURST_LAST = 4,             /* the burst's last member: released the others' chains behind its threshold kernel */
+    A3_STEP_HELD = 5                    /* only ever seen BETWEEN submit and collect of a burst member: its chain is still held; the
+                                         * collected batch reports 2 or 3 */
 };
 
 typedef struct a3_ctx a3_ctx;
@@ -194,6 +196,9 @@ int  a3_detect_batch_pose_collect(a3_ctx *ctx, a3_marker *out, a3_pose *poses, s
  *     threshold kernels back to back followed by N chains side by side, with no host in between;
  *   - a held chain nobody released goes out when its batch is collected, when another context declares a gate on it, or when
  *     a3_set_stream moves its context.  a3_stats.stepping of the collected batch says which of these happened.
+ * A context that runs on a CALLER's stream of its own (a3_set_stream; no other context on it) is stepped the same way: with gates
+ * declared its chain is held and enqueued LATER on that stream -- by whichever thread releases it -- and so lands behind any work
+ * the caller queued on the stream after the submit.
  * The hold does not apply -- the whole batch is enqueued at submit, gates still ordering it -- to the first batch of a shape
  * (frame count / size) on a context and to batches whose contour graph must be planned on the host (graphs that outgrow the
  * pools: uniform-noise frames), while a3_set_profiling(A3_PROFILE_STAGES) is on, and to contexts that share one stream: those

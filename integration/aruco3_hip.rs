@@ -128,7 +128,7 @@ pub struct A3Stats {
     pub jump_rounds: u32,
     pub chunks: u32,
     /// bits 0-7: A3_STEP_* (how the library scheduled the batch: 0 whole, 1 decode deferred, 2 chain held and released by the burst's
-    /// last member, 3 chain held and released early, 4 the burst's last member); bits 8-15: other contexts' chains this submit released;
+    /// last member, 3 chain held and released early, 4 the burst's last member, 5 chain still held: between submit and collect only); bits 8-15: other contexts' chains this submit released;
     /// bits 16-23: synchronous re-runs of the batch the device asked for
     pub stepping: u32,
 }

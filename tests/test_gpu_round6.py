@@ -154,3 +154,36 @@ def test_bench_front_door_ends_the_launch_when_a_rank_dies():
     assert p.returncode != 0 and time.time() - t0 < 400
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert "rank 3 exited with 3" in p.stderr
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# what a3_get_stats says between the submit and the collect of a held batch
+# ------------------------------------------------------------------------------------------------------------------
+def test_a_held_chain_reports_held_until_it_goes_out(dicts):
+    """a gated submit holds its chain: a3_stats.stepping reads A3_STEP_HELD (5) until somebody releases it -- here collect -- and the
+    collected batch then says how it went out; a context alone on a CALLER's stream is held the same way (header, a3_order_after)"""
+    import torch
+
+    from aruco3_amd import _lib, synth
+    from aruco3_amd.aruco import Detector, DetectorConfig
+
+    fa, _ = synth.config_frames(1, 3)
+    da = torch.from_numpy(fa).cuda()
+    n, h, w, c = fa.shape
+    aa = (da.data_ptr(), _lib.MEM_DEVICE, _lib.FMT_RGB8, w, h, w * c, h * w * c, n)
+    c0, c1 = (Detector(DetectorConfig(), dicts.new_from_named_dict("ARUCO_DEFAULT"))._context() for _ in range(2))
+    want = c0.detect_batch(*aa); c0.detect_batch(*aa); c1.detect_batch(*aa); c1.detect_batch(*aa)
+    for own_stream in (True, False):
+        s0 = torch.cuda.Stream()
+        if not own_stream:
+            c0.set_stream(s0.cuda_stream)
+        c0.order_after(c1); c0.submit(*aa)
+        assert c0.stats()["stepping"] == "held"
+        got = c0.collect()
+        assert c0.stats()["stepping"] == "held_released_early"
+        assert markers_of_hip(got[0]) == markers_of_hip(want[0])
+        c0.order_after(c1); c0.submit(*aa)
+        assert c0.stats()["stepping"] == "held"
+        c1.submit(*aa)                                  # the burst's last member releases it
+        assert c0.stats()["stepping"] == "held_released_by_last"
+        assert markers_of_hip(c0.collect()[0]) == markers_of_hip(want[0]) and markers_of_hip(c1.collect()[0]) == markers_of_hip(want[0])
