@@ -391,7 +391,7 @@ std::vector<a3_ctx*> g_deferred;
 // 0: no deferral; 1: release a waiting decode stage behind the next batch's threshold kernel; 2 (default): behind the next batch's
 // k_local_contract -- the kernels that follow it (entry resolution, finalize, scatter, quads) are latency-bound like the decode
 // stage and share the chip with it, whereas the dart kernels before it are bound by VALU and LDS throughput and only get slower
-// in company.  Measured in one process (tools/ab_overlap.py, BASELINE config 2, two contexts): 0.820 / 0.769 / 0.762 ms per step
+// in company.  Measured in one process (tools/attic/ab_overlap.py, BASELINE config 2, two contexts): 0.820 / 0.769 / 0.762 ms per step
 // for modes 0 / 1 / 2 (0.794 / 0.744 / 0.741 on another box); smaller decode grids (2048 ... 512 workgroups) only lose.  Deferring the second half of the contour stage as well (entry resolution ... quads, released with the
 // decode stage behind the next threshold kernel) was built and measured: 0.777 with two contexts, 0.821 with three -- dropped.
 // (a3_debug_set_overlap in a3_internal.h switches modes for the A/B measurements of tools/.)

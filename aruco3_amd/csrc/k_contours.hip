@@ -1746,7 +1746,7 @@ __global__ void k_unpack_bits(const uint64_t* __restrict__ bits, int W, int H, u
 // ---------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------
-// grid caps of the per-dart sweeps, overridable for tuning (tools/sweep_grids.sh)
+// grid caps of the per-dart sweeps, overridable for tuning (tools/attic/sweep_grids.sh)
 static inline int env_cap(const char* name, int dflt) { const int v = tuning_knob(name, dflt); return v > 0 ? v : dflt; }   // grid caps: constants unless -DA3_TUNING
 static inline int blocks_for(uint64_t n, int per_block, int cap) {
     uint64_t b = (n + per_block - 1) / per_block;

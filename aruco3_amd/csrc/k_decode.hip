@@ -554,7 +554,7 @@ __device__ __forceinline__ void compact_frame_wave(uint32_t f, int lane, const D
 }
 
 // NT threads sample one candidate, PT of them (64, or all) run the stages after the sampling.  History of the shape, on the
-// 2.5 k candidates of BASELINE config 2 (tools/tune_decode.sh): 256 threads throughout, 4 samples "in flight" per lane, row-major
+// 2.5 k candidates of BASELINE config 2 (tools/attic/tune_decode.sh): 256 threads throughout, 4 samples "in flight" per lane, row-major
 // sample order (round 1): 116 us; 64 threads, 8 x 8 blocked order: 98 us; 256 threads sampling, the first wave doing the rest:
 // 94 us -- and 7 us less than the 64-thread version inside the pipeline, where the frames are not in any cache.
 template <int NT, int PT>

@@ -30,7 +30,7 @@ static __device__ unsigned long long* g_k1_stamps = nullptr;   // per translatio
 // Pixels per lane and row.  16 (the default): 256 VGPRs (the ring of row sums alone is 120), two waves per SIMD.  8: every
 // per-lane array halves, 144 VGPRs, three waves per SIMD -- built to see whether occupancy was what kept the kernel (stores off)
 // 0.025 ms above the bare reads of tools/micro/readbench.hip.  It was not: 0.293 ms against 0.286 with stores off, 0.343 against
-// 0.324 with them (tools/tune_k1.sh); the difference to the microbenchmark is the 5 % of halo rows and the feeder lanes.
+// 0.324 with them (tools/attic/tune_k1.sh); the difference to the microbenchmark is the 5 % of halo rows and the feeder lanes.
 constexpr int T_LPX = A3_T_LPX;
 static_assert(T_LPX == 8 || T_LPX == 16, "a lane owns 8 or 16 consecutive pixels");
 constexpr int T_NG = T_LPX / 4;      // grey dwords per lane and row
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(64, T_PF == A3_T_PF ? A3_T_WAVES : 1) void k_grey_t
     } else { pair = (k / strips_y) * 8 + xcd; sy = k % strips_y; }
     if (pair >= n_pairs) return;
 #ifdef A3_TUNING
-    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();   // (tools/k1_wave_times.py: when a launch's waves start and end)
+    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();   // (tools/attic/k1_wave_times.py: when a launch's waves start and end)
 #endif
     const int sx = pair % strips_x;
     const uint32_t f = pair / strips_x;
