@@ -234,6 +234,61 @@ fn dump_one(name: &str, w: u32, h: u32, channels: u32, dict_name: &str, raw: Vec
     println!("{}: {} contours, {} candidates, {} markers -> {}", name, contours.len(), n, m, path.display());
 }
 
+/// Quirk Q4 (src/aruco.rs:255-257): quads no convex hull can deliver, on which `Projection::from_control_points` has no solution, and
+/// what the rest of `homography_to_code_permutations` (src/aruco.rs:264-292) makes of the 1 x 1 black image the crate then pushes.
+/// The same quads as tests/test_gpu_round6.py (_DEGENERATE), plus two ordinary ones that must solve.  Records (q = quads):
+///     q4_quads            u32[q][4][2]
+///     q4_projection_ok    u8[q]          from_control_points(quad -> 49 x 49 square) returned Some
+///     q4_standin_otsu     u8[1]          otsu_level(&GrayImage::new(1, 1))
+///     q4_standin_binary   u8[1]          threshold(.., otsu, Binary) of that image
+///     q4_standin_resized  u8[4][10][10]  imageops::resize(.., ms, ms, Triangle) of it for ms = 6, 7, 8, 10 (top-left ms x ms filled)
+fn dump_q4(out_dir: &PathBuf) {
+    let quads: Vec<[(u32, u32); 4]> = vec![
+        [(10, 10), (50, 50), (90, 90), (130, 130)],
+        [(300, 300), (300, 300), (340, 300), (340, 340)],
+        [(200, 20), (260, 20), (260, 20), (200, 20)],
+        [(77, 401), (77, 401), (77, 401), (77, 401)],
+        [(500, 100), (560, 100), (620, 100), (560, 160)],
+        [(100, 100), (200, 110), (190, 210), (95, 200)],
+        [(400, 50), (470, 120), (400, 190), (330, 120)],
+    ];
+    let mut fx = Fx::new();
+    let mut flat = vec![];
+    let mut ok = vec![];
+    let hf = 49f32;
+    for q in quads.iter() {
+        for p in q.iter() {
+            flat.push(p.0);
+            flat.push(p.1);
+        }
+        let projection = Projection::from_control_points(
+            [(q[0].0 as f32, q[0].1 as f32), (q[1].0 as f32, q[1].1 as f32), (q[2].0 as f32, q[2].1 as f32), (q[3].0 as f32, q[3].1 as f32)],
+            [(0f32, 0f32), (hf, 0f32), (hf, hf), (0f32, hf)],
+        );
+        ok.push(if projection.is_some() { 1u8 } else { 0u8 });
+    }
+    fx.u32s("q4_quads", &[quads.len(), 4, 2], &flat);
+    fx.u8s("q4_projection_ok", &[quads.len()], &ok);
+    let standin = GrayImage::new(1, 1);                                                                              // src/aruco.rs:256
+    let level = imageproc::contrast::otsu_level(&standin);                                                           // :264
+    let binarized = imageproc::contrast::threshold(&standin, level, imageproc::contrast::ThresholdType::Binary);     // :265
+    fx.u8s("q4_standin_otsu", &[1], &[level]);
+    fx.u8s("q4_standin_binary", &[1], binarized.as_raw());
+    let mut resized = vec![0u8; 4 * 10 * 10];
+    for (k, ms) in [6u32, 7, 8, 10].iter().enumerate() {
+        let reduced = image::imageops::resize(&binarized, *ms, *ms, image::imageops::FilterType::Triangle);          // :273
+        for y in 0..*ms {
+            for x in 0..*ms {
+                resized[k * 100 + (y * 10 + x) as usize] = reduced.get_pixel(x, y).0[0];
+            }
+        }
+    }
+    fx.u8s("q4_standin_resized", &[4, 10, 10], &resized);
+    let path = out_dir.join("q4_degenerate.a3fx");
+    fs::File::create(&path).expect("create").write_all(&fx.buf).expect("write");
+    println!("q4_degenerate: {:?} -> {}", ok, path.display());
+}
+
 #[test]
 fn dump_fixtures() {
     let inputs = PathBuf::from(std::env::var("A3_FIXTURE_INPUTS").expect("A3_FIXTURE_INPUTS=<repo>/tests/fixtures/inputs"));
@@ -249,4 +304,5 @@ fn dump_fixtures() {
         assert_eq!(raw.len(), (w * h * c) as usize);
         dump_one(name, w, h, c, dict, raw, &out_dir);
     }
+    dump_q4(&out_dir);
 }

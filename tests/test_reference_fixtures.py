@@ -178,3 +178,40 @@ def test_reader_and_comparison_are_not_vacuous(oracle, dicts, tmp_path):
         flat = broken[stage].reshape(-1)
         flat[flat.size // 2] ^= 1
         assert [k for k, _ in compare(broken, got)] == [stage]
+
+
+# ---- quirk Q4 (src/aruco.rs:255-257): the degenerate quads of tests/test_gpu_round6.py, as integration/dump_fixtures.rs::dump_q4 writes them ----
+Q4_QUADS = np.array([
+    [[10, 10], [50, 50], [90, 90], [130, 130]], [[300, 300], [300, 300], [340, 300], [340, 340]], [[200, 20], [260, 20], [260, 20], [200, 20]],
+    [[77, 401], [77, 401], [77, 401], [77, 401]], [[500, 100], [560, 100], [620, 100], [560, 160]],
+    [[100, 100], [200, 110], [190, 210], [95, 200]], [[400, 50], [470, 120], [400, 190], [330, 120]]], dtype=np.uint32)
+
+
+def oracle_q4(oracle):
+    S = 49
+    to = np.array([0, 0, S, 0, S, S, 0, S], np.float32)
+    ok = np.array([oracle.from_control_points(q.reshape(8).astype(np.float32), to)[0] for q in Q4_QUADS], dtype=np.uint8)
+    one = np.zeros((1, 1), np.uint8)                        # GrayImage::new(1, 1)
+    level = oracle.otsu_level(one)
+    binary = ((one > level) * 255).astype(np.uint8)         # threshold(.., Binary)
+    resized = np.zeros((4, 10, 10), np.uint8)
+    for k, ms in enumerate((6, 7, 8, 10)):
+        resized[k, :ms, :ms] = oracle.resize_triangle(binary, ms, ms)
+    return {"q4_quads": Q4_QUADS, "q4_projection_ok": ok, "q4_standin_otsu": np.array([level], np.uint8), "q4_standin_binary": binary.reshape(1),
+            "q4_standin_resized": resized}
+
+
+def test_oracle_q4_branch_is_what_the_tests_assume(oracle):
+    """the five degenerate quads fail, the two ordinary ones solve; one black pixel stays black through Otsu / threshold / resize"""
+    got = oracle_q4(oracle)
+    assert got["q4_projection_ok"].tolist() == [0, 0, 0, 0, 0, 1, 1]
+    assert int(got["q4_standin_otsu"][0]) == 0 and int(got["q4_standin_binary"][0]) == 0 and not got["q4_standin_resized"].any()
+
+
+def test_oracle_against_reference_q4_fixture(oracle):
+    path = FIX / "q4_degenerate.a3fx"
+    if not path.exists():
+        pytest.skip(f"{path.name} absent: produce it with integration/dump_fixtures.rs where cargo exists (INTEGRATION.md)")
+    ref, got = read_a3fx(path), oracle_q4(oracle)
+    for k, v in got.items():
+        assert k in ref and np.array_equal(np.asarray(ref[k]).reshape(-1), np.asarray(v).reshape(-1)), k
