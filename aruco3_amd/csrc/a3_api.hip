@@ -34,7 +34,7 @@ size_t entry_state_bytes();
 size_t entry_slots(uint32_t);
 size_t leader_list_bytes(uint32_t);
 hipError_t launch_rank_cycles(hipStream_t, uint32_t, int, const uint64_t*, const uint32_t*, JumpState*,
-                              uint32_t*, uint32_t*, unsigned int*, void*, void*, JumpState*, uint32_t*, unsigned int*, int, DeviceCounters*, const uint32_t*, int,
+                              uint32_t*, unsigned int*, void*, void*, JumpState*, uint32_t*, unsigned int*, int, DeviceCounters*, const uint32_t*, int,
                               const uint32_t*, uint32_t*, uint32_t, int, uint32_t, unsigned int*, int);
 hipError_t launch_resolve(hipStream_t, const JumpState*, uint32_t, int, const uint64_t*, const uint32_t*, const unsigned int*, uint64_t*, uint64_t*,
                           DeviceCounters*, int, const uint32_t*);
@@ -224,7 +224,7 @@ struct a3_ctx {
 
     DevBuf dict, in, grey, bin, frame_darts, frame_darts_dev, frame_base, pix_base, tile_darts;
     DevBuf d_xy, d_succ, stA, stB, t_cur, t_next;
-    DevBuf leader_list, leader_keep, entry_list, entry_pos, es_a, es_b;
+    DevBuf leader_list, leader_keep, entry_list, es_a, es_b;
     DevBuf contours, cyc_start_off, points;
     DevBuf cands, pre_xy, fin_xy, fin_count, work, outs, proj, patches, cand_big;
     // one allocation zeroed by one memset per batch and read back with one copy: [scratch 256 B | counters | per_frame | frame_cursor | cand_count]
@@ -319,7 +319,6 @@ int ensure_dart_pool(a3_ctx* ctx, uint64_t darts) {
     A3_HIP(ctx->leader_keep.ensure(leader_list_bytes((uint32_t)darts)));   // k_cycle_select: pass-1 verdict per leader slot
     const size_t eslots = entry_slots((uint32_t)darts);   // sharded slot space: darts + at most 16 tiles of padding
     A3_HIP(ctx->entry_list.ensure(eslots * 4));
-    A3_HIP(ctx->entry_pos.ensure(darts * 4));
     // entries are darts whose predecessor lies in another 2048-dart tile; the bound darts is never reached in practice,
     // but an adversarial image can come close, so size for it
     A3_HIP(ctx->es_a.ensure(eslots * entry_state_bytes()));
@@ -825,7 +824,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
         const Chunk cc = c;
         // first half: the doubling rounds inside LDS tiles
         A3_HIP(launch_rank_cycles(st, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), ctx->stA.as<JumpState>(),
-                                  ctx->entry_list.as<uint32_t>(), ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
+                                  ctx->entry_list.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
                                   ctx->stA.as<JumpState>(), ctx->leader_list.as<uint32_t>(), d_leader_count, rounds, ctr, n_live, 0, fb,
                                   frame_entries, cc.count, 1, min_edge_length, dead_ctr, inline_resolve_W > 0 ? 1 : 0));
         if (rel_mode == 2) { if (int rc = release_waiting()) return rc; }   // waiting decode stages go out behind this k_local_contract
@@ -833,7 +832,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
         // second half: entry resolution, final states (+ border selection), point scatter, quads -- on `s2`
         auto chunk_back = [=](hipStream_t s2) -> int {
             A3_HIP(launch_rank_cycles(s2, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), ctx->stA.as<JumpState>(),
-                                      ctx->entry_list.as<uint32_t>(), ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
+                                      ctx->entry_list.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
                                       ctx->stA.as<JumpState>() /* final states in place */, ctx->leader_list.as<uint32_t>(), d_leader_count, rounds, ctr,
                                       n_live, 0, fb, frame_entries, cc.count, 2, min_edge_length, dead_ctr, inline_resolve_W > 0 ? 1 : 0));
             const JumpState* fin = ctx->stA.as<JumpState>();
@@ -1168,7 +1167,7 @@ void a3_destroy(a3_ctx* ctx) {
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     DevBuf* bufs[] = {&ctx->dict, &ctx->in, &ctx->grey, &ctx->bin, &ctx->frame_darts, &ctx->frame_darts_dev, &ctx->frame_base, &ctx->pix_base,
                       &ctx->tile_darts, &ctx->d_xy, &ctx->d_succ, &ctx->stA, &ctx->stB, &ctx->t_cur, &ctx->t_next,
-                      &ctx->leader_list, &ctx->leader_keep, &ctx->entry_list, &ctx->entry_pos, &ctx->es_a, &ctx->es_b,
+                      &ctx->leader_list, &ctx->leader_keep, &ctx->entry_list, &ctx->es_a, &ctx->es_b,
                       &ctx->contours, &ctx->cyc_start_off, &ctx->points, &ctx->zero_blk, &ctx->cands,
                       &ctx->pre_xy, &ctx->fin_xy, &ctx->fin_count, &ctx->work, &ctx->outs, &ctx->proj, &ctx->patches, &ctx->cand_big,
                       &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_d, &ctx->hsum, &ctx->pose_buf, &ctx->wtab};
@@ -1515,7 +1514,7 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
         } else if (kernel == 2) {
             A3_HIP(launch_rank_cycles(st, ctx->dbg_nd, (int)ctx->W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), ctx->stA.as<JumpState>(),
                                       ctx->entry_list.as<uint32_t>(),
-                                      ctx->entry_pos.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p, ctx->stB.as<JumpState>(),
+                                      d_entry_count, ctx->es_a.p, ctx->es_b.p, ctx->stB.as<JumpState>(),
                                       ctx->leader_list.as<uint32_t>(), d_leader_count, 0, ctx->counters, nullptr, dbg ? dbg : 11, ctx->frame_base.as<uint32_t>(), nullptr, ctx->dbg_frames, 0,
                                       0u, nullptr, 0));
         } else if (kernel == 3 || kernel == 4) {   // dbg < 0: k_decode alone (variant -dbg; -5: the whole kernel), dbg >= 0: k_projection + k_decode

@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256, (LT >= 2048 || DEAD) ? 4 : 8) void k_local_con
                                                         const uint32_t* __restrict__ d_succ,
                                                         JumpState* __restrict__ loc,
                                                         uint32_t* __restrict__ entry_list,
-                                                        uint32_t* __restrict__ entry_pos, unsigned int* __restrict__ entry_count, uint32_t ecap,
+                                                        unsigned int* __restrict__ entry_count, uint32_t ecap,
                                                         const uint32_t* __restrict__ frame_base, uint32_t* __restrict__ frame_entries,
                                                         const uint32_t* __restrict__ n_live, int dbg,
                                                         uint32_t min_edge_length, unsigned int* __restrict__ dead_count /*[16]; nullptr: mark nothing dead*/,
@@ -804,7 +804,10 @@ __global__ __launch_bounds__(256, (LT >= 2048 || DEAD) ? 4 : 8) void k_local_con
         const uint32_t q = (xy >> 16) * (uint32_t)W + (xy & 0xFFFF);
         const uint32_t ek = (info & kInfoW) ? 2u * q : ((info & kInfoE) ? 2u * q + 1u : kNoKey);
         frm[u] = rec_frame(rec);   // kept, like succ0, for the entry registration (no second read)
-        nk[u] = ((uint64_t)ek << 32) | (lo + i); np[u] = succ0[u]; no[u] = 0; nd[u] = 1;
+        // A successor outside the tile freezes the window at once; its pointer then names the dart INSIDE the tile that the window
+        // ends on -- lo + LT + i: outside [lo, lo + cnt) whatever the arithmetic wraps to -- because that dart's lane knows the slot
+        // the successor is registered under as an entry (below), which is what everybody downstream wants from a frozen window.
+        nk[u] = ((uint64_t)ek << 32) | (lo + i); np[u] = (succ0[u] - lo) < cnt ? succ0[u] : lo + (uint32_t)LT + i; no[u] = 0; nd[u] = 1;
         if (i < cnt) s_win[i] = Win{nk[u], np[u], 1u << 16};
         if (dead_count && ek != kNoKey) {
             if (static_fire(rec)) sfire |= 1u << u;
@@ -829,6 +832,7 @@ __global__ __launch_bounds__(256, (LT >= 2048 || DEAD) ? 4 : 8) void k_local_con
     // of every workgroup's life.
     const uint32_t f0 = frame_entries ? s_f0 : 0u;
     uint32_t my_slot[PER];
+    uint32_t direct = 0;   // bit u: my_slot[u] is the slot itself, not a rank inside (tile, frame)
 #pragma unroll
     for (int u = 0; u < PER; u++) {
         const uint32_t i = threadIdx.x + u * 256;
@@ -840,9 +844,8 @@ __global__ __launch_bounds__(256, (LT >= 2048 || DEAD) ? 4 : 8) void k_local_con
                 const uint32_t f = frm[u];
                 if (f - f0 < kFrameWin) my_slot[u] = atomicAdd(&s_fcnt[f - f0], 1u);          // rank inside (tile, frame)
                 else {                                                                           // a tile over > 64 tiny frames
-                    const uint32_t slot = frame_base[f] + atomicAdd(&frame_entries[f], 1u);
-                    entry_list[slot] = s0;
-                    entry_pos[s0] = slot;
+                    my_slot[u] = frame_base[f] + atomicAdd(&frame_entries[f], 1u);
+                    direct |= 1u << u;
                 }
             } else my_slot[u] = atomicAdd(&s_new_count, 1u);
         }
@@ -895,13 +898,20 @@ __global__ __launch_bounds__(256, (LT >= 2048 || DEAD) ? 4 : 8) void k_local_con
             const uint32_t i = threadIdx.x + u * 256;
             if (upd & (1u << u)) s_win[i] = Win{nk[u], np[u], no[u] | (nd[u] << 16)};
         }
+        if (round == n_rounds - 1) {   // the entry slots' bases ride on the last round's barrier (the atomics have long returned)
+            if (frame_entries) { if (threadIdx.x < kFrameWin) s_fbase[threadIdx.x] = slot_a + slot_b; }
+            else if (threadIdx.x == 0) s_new_base = slot_a + slot_b;
+        }
         lds_barrier();
     }
     // (Leaving the loop as soon as no window of the tile grew any more -- all frozen, wrapped round their cycle, or run into a
     // dead end -- was tried as well: most tiles of a clean frame hold a chain that needs all eleven rounds.)
     // results
-    if (frame_entries) { if (threadIdx.x < kFrameWin) s_fbase[threadIdx.x] = slot_a + slot_b; }
-    else if (threadIdx.x == 0) s_new_base = slot_a + slot_b;
+    if (n_rounds <= 0) {   // (the probe's "no rounds" form)
+        if (frame_entries) { if (threadIdx.x < kFrameWin) s_fbase[threadIdx.x] = slot_a + slot_b; }
+        else if (threadIdx.x == 0) s_new_base = slot_a + slot_b;
+        lds_barrier();
+    }
     // Dead cycles (kDead): a leader whose window wrapped inside the tile knows its border's length from its successor's window
     // (hops back to the leader + 1), here in LDS; too short for k_cycle_select's test and starting unconditionally, the border is
     // finished with: counted as traced, listed nowhere.  Noise-like frames: most of the millions of borders.
@@ -970,6 +980,20 @@ __global__ __launch_bounds__(256, (LT >= 2048 || DEAD) ? 4 : 8) void k_local_con
         lds_barrier();
         if (threadIdx.x == 0 && s_dead_n) atomicAdd(&dead_count[blockIdx.x & 15u], s_dead_n);
     }
+    // Entries get their slots; the slot of dart i's successor is left in LDS under i (the windows are not needed any more), where
+    // the windows that froze on i find it: a frozen window's state carries the SLOT of the entry it ends on.  (Until round 5 it
+    // carried the entry's dart index and every reader went through an entry_pos[] array: a scattered 4-byte read per frozen dart in
+    // k_jump_finalize -- three dependent loads where two do -- and an array of 4 bytes per dart of the pool.)
+    // (behind the last round's barrier -- or the epilogue's -- s_fbase / s_new_base are in place and nobody reads s_win any more)
+    uint32_t* s_slot = reinterpret_cast<uint32_t*>(s_win);
+#pragma unroll
+    for (int u = 0; u < PER; u++)
+        if (my_slot[u] != kNone) {
+            const uint32_t slot = (direct & (1u << u)) ? my_slot[u] : (frame_entries ? s_fbase[frm[u] - f0] : s_new_base) + my_slot[u];
+            s_slot[threadIdx.x + u * 256] = slot;
+            entry_list[slot] = succ0[u];
+        }
+    lds_barrier();
 #pragma unroll
     for (int u = 0; u < PER; u++) {
         const uint32_t i = threadIdx.x + u * 256;
@@ -979,17 +1003,9 @@ __global__ __launch_bounds__(256, (LT >= 2048 || DEAD) ? 4 : 8) void k_local_con
         const uint32_t li = (uint32_t)nk[u] - lo;                                      // my window's minimum: in the tile when it did not freeze
         const bool dead = dead_count != nullptr && !frozen && li < cnt && (s_dead[li] & 1u) != 0;
         JumpState r;
-        r.key = nk[u]; r.ptr = e; r.off = loc_pack(no[u], nd[u], frozen) | (dead ? kDead : 0u);
+        r.key = nk[u]; r.ptr = frozen ? s_slot[(e - lo - (uint32_t)LT) & (uint32_t)(LT - 1)] : e; r.off = loc_pack(no[u], nd[u], frozen) | (dead ? kDead : 0u);
         loc[lo + i] = r;
     }
-    lds_barrier();
-#pragma unroll
-    for (int u = 0; u < PER; u++)
-        if (my_slot[u] != kNone) {
-            const uint32_t slot = (frame_entries ? s_fbase[frm[u] - f0] : s_new_base) + my_slot[u];
-            entry_list[slot] = succ0[u];
-            entry_pos[succ0[u]] = slot;
-        }
 }
 
 struct __attribute__((aligned(8))) EntryState { uint64_t key; uint32_t ptr; uint32_t off; uint32_t dist; uint32_t pad; };
@@ -1001,7 +1017,6 @@ struct __attribute__((aligned(8))) EntryState { uint64_t key; uint32_t ptr; uint
 constexpr uint32_t kEntryLdsCap = 2048;
 __global__ __launch_bounds__(256) void k_entry_frame(const uint32_t* __restrict__ entry_list, const uint32_t* __restrict__ frame_entries,
                                                      const uint32_t* __restrict__ frame_base, const JumpState* __restrict__ loc,
-                                                     const uint32_t* __restrict__ entry_pos,
                                                      EntryState* __restrict__ es, DeviceCounters* __restrict__ ctr) {
     // one 16-byte record per entry (a single ds_read_b128 fetches the window an entry is joined with) + its length
     struct __attribute__((aligned(16))) Rec { uint64_t key; uint32_t ptr; uint32_t off; };
@@ -1015,8 +1030,8 @@ __global__ __launch_bounds__(256) void k_entry_frame(const uint32_t* __restrict_
     // copy the other lanes read
     constexpr int PER = kEntryLdsCap / 256;
     uint64_t nk[PER]; uint32_t np[PER], no[PER], nd[PER];
-    // the three dependent loads (entry -> its local state -> slot of the entry it froze at) for four entries per lane at a time:
-    // a clean frame has several hundred entries, i.e. one trip of this loop
+    // the two dependent loads (entry -> its local state, which names the slot of the entry it froze at) for four entries per lane at
+    // a time: a clean frame has several hundred entries, i.e. one trip of this loop
     constexpr int EB = 4;
     static_assert(PER % EB == 0, "whole batches");
 #pragma unroll
@@ -1029,9 +1044,9 @@ __global__ __launch_bounds__(256) void k_entry_frame(const uint32_t* __restrict_
 #pragma unroll
         for (int u = 0; u < EB; u++) l[u] = loc[e[u]];
 #pragma unroll
-        for (int u = 0; u < EB; u++) pos[u] = entry_pos[l[u].ptr];   // (some dart, and ignored, when the window did not freeze)
+        for (int u = 0; u < EB; u++) pos[u] = l[u].ptr;   // (some dart, and ignored, when the window did not freeze)
         // (the values are "used" here so that the compiler cannot sink the later entries' loads into the `i < cnt` test below,
-        // which would turn overlapped chains of three round trips into chains in a row)
+        // which would turn overlapped chains of round trips into chains in a row)
 #pragma unroll
         for (int u = 0; u < EB; u++) asm volatile("" : "+v"(pos[u]), "+v"(l[u].key), "+v"(l[u].off));
 #pragma unroll
@@ -1081,8 +1096,7 @@ __global__ __launch_bounds__(256) void k_entry_frame(const uint32_t* __restrict_
 // Phase 2 set-up: the reduced list over entries.  An entry's local window always freezes (its predecessor lies in another
 // tile, so it cannot sit on a tile-local cycle) unless its chain dead-ends inside the tile; then it points at itself.
 __global__ void k_entry_init(const uint32_t* __restrict__ entry_list, const unsigned int* __restrict__ entry_count,
-                             const JumpState* __restrict__ loc,
-                             const uint32_t* __restrict__ entry_pos, EntryState* __restrict__ es, uint32_t cap) {
+                             const JumpState* __restrict__ loc, EntryState* __restrict__ es, uint32_t cap) {
     const EntrySpace sp(entry_count);
     for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < sp.total; i0 += gridDim.x * blockDim.x) {
         const uint32_t i = sp.slot(i0, cap);
@@ -1091,7 +1105,7 @@ __global__ void k_entry_init(const uint32_t* __restrict__ entry_list, const unsi
         const JumpState l = loc[e];
         EntryState s;
         s.key = l.key; s.off = loc_off(l.off); s.dist = loc_dist(l.off); s.pad = 0;
-        s.ptr = (l.off & kFrozen) ? entry_pos[l.ptr] : i;
+        s.ptr = (l.off & kFrozen) ? l.ptr : i;
         es[i] = s;
     }
 }
@@ -1133,7 +1147,7 @@ __host__ __device__ inline uint32_t leader_shard_cap(uint32_t n_darts) { return 
 // ... and the leaders of cycles that carry at least one start event are collected (one atomic per wave) for the
 // per-border kernels that follow.
 __global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const JumpState* loc,
-                                                       const uint32_t* __restrict__ entry_pos, const EntryState* __restrict__ es,
+                                                       const EntryState* __restrict__ es,
                                                        JumpState* fin /* may be loc: only the states that change are then written */,
                                                        uint32_t* __restrict__ leader_list,
                                                        unsigned int* __restrict__ leader_count /*[kLeaderShards]*/, uint32_t shard_cap,
@@ -1147,10 +1161,11 @@ __global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const J
     const uint32_t shard = blockIdx.x & (kLeaderShards - 1);   // spread the slot counter over 16 addresses
     const uint32_t stride = gridDim.x * blockDim.x;            // the launcher keeps ceil(n_darts / stride) <= 32
     uint32_t mask = 0;                                          // bit i: my i-th dart leads a cycle that has a start event
-    // B darts per lane at a time, each of the three dependent loads (local state -> slot of the entry the window froze at ->
-    // that entry's state) issued for all of them before the first is used: the kernel is a chain of round trips to memory, and
-    // one dart at a time it is three of them per dart.  Loads are unconditional from clamped indices (slot 0 for windows that
-    // did not freeze: a cached line); behind an `if` the compiler would issue them one at a time again.
+    // B darts per lane at a time, each of the two dependent loads (local state, which names the slot of the entry the window froze
+    // at -> that entry's state) issued for all of them before the first is used: the kernel is a chain of round trips to memory.
+    // Loads are unconditional from clamped indices (slot 0 for windows that did not freeze: a cached line); behind an `if` the
+    // compiler would issue them one at a time again.  (Round 6: the slot comes with the state; rounds 2-5 fetched it from an
+    // entry_pos[] array in between, a third dependent, scattered load.)
     constexpr int B = A3_FIN_B;
     int it = 0;
     for (uint32_t d0 = blockIdx.x * blockDim.x + threadIdx.x; d0 < n_darts; d0 += B * stride, it += B) {
@@ -1160,9 +1175,9 @@ __global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const J
 #pragma unroll
         for (int u = 0; u < B; u++) s[u] = loc[min(d0 + (uint32_t)u * stride, n_darts - 1u)];
 #pragma unroll
-        for (int u = 0; u < B; u++) { od[u] = s[u].off; pos[u] = entry_pos[(od[u] & kFrozen) ? s[u].ptr : 0u]; }
+        for (int u = 0; u < B; u++) { od[u] = s[u].off; pos[u] = (od[u] & kFrozen) ? s[u].ptr : 0u; }
 #pragma unroll
-        for (int u = 0; u < B; u++) g[u] = es[(od[u] & kFrozen) ? pos[u] : 0u];
+        for (int u = 0; u < B; u++) g[u] = es[pos[u]];
 #pragma unroll
         for (int u = 0; u < B; u++) {
             const uint32_t d = d0 + (uint32_t)u * stride;
@@ -1810,7 +1825,7 @@ size_t leader_list_bytes(uint32_t n_darts) { return (size_t)leader_shard_cap(n_d
 // leaders + ranks for every dart of the chunk.  loc/fin: JumpState[n_darts]; es_a/es_b: EntryState[n_darts] (upper bound);
 // entry_count[16] and leader_count[16] arrive zeroed.
 hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uint64_t* d_rec, const uint32_t* d_succ,
-                              JumpState* loc, uint32_t* entry_list, uint32_t* entry_pos,
+                              JumpState* loc, uint32_t* entry_list,
                               unsigned int* entry_count, void* es_a, void* es_b, JumpState* fin, uint32_t* leader_list,
                               unsigned int* leader_count, int max_rounds, DeviceCounters* ctr, const uint32_t* n_live, int dbg,
                               const uint32_t* frame_base, uint32_t* frame_entries /*nullptr: global rounds*/, uint32_t n_frames,
@@ -1822,32 +1837,32 @@ hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uin
     if (phase != 2) {
         if (frame_entries && !dead_count)
             hipLaunchKernelGGL((k_local_contract<kLTFrame, false>), dim3((n_darts + kLTFrame - 1) / kLTFrame), dim3(256), 0, st, n_darts, W, d_rec, d_succ, loc,
-                               entry_list, entry_pos, entry_count, ecap, frame_base, frame_entries, n_live, dbg, min_edge_length, dead_count, trust_natural);
+                               entry_list, entry_count, ecap, frame_base, frame_entries, n_live, dbg, min_edge_length, dead_count, trust_natural);
         else if (frame_entries)   // (a dense graph's first batch, before its entries overflow k_entry_frame and the global rounds take over)
             hipLaunchKernelGGL((k_local_contract<kLTFrame, true>), dim3((n_darts + kLTFrame - 1) / kLTFrame), dim3(256), 0, st, n_darts, W, d_rec, d_succ, loc,
-                               entry_list, entry_pos, entry_count, ecap, frame_base, frame_entries, n_live, dbg, min_edge_length, dead_count, trust_natural);
+                               entry_list, entry_count, ecap, frame_base, frame_entries, n_live, dbg, min_edge_length, dead_count, trust_natural);
         else
             hipLaunchKernelGGL((k_local_contract<kLT, true>), dim3((n_darts + kLT - 1) / kLT), dim3(256), 0, st, n_darts, W, d_rec, d_succ, loc,
-                               entry_list, entry_pos, entry_count, ecap, frame_base, frame_entries, n_live, dbg, min_edge_length, dead_count, trust_natural);
+                               entry_list, entry_count, ecap, frame_base, frame_entries, n_live, dbg, min_edge_length, dead_count, trust_natural);
     }
     if (dbg || phase == 1) return hipGetLastError();
     EntryState* a = reinterpret_cast<EntryState*>(es_a);
     EntryState* b = reinterpret_cast<EntryState*>(es_b);
     if (frame_entries) {   // clean frames: every frame's entry list fits LDS, one launch instead of ~9
-        hipLaunchKernelGGL(k_entry_frame, dim3(n_frames), dim3(256), 0, st, entry_list, frame_entries, frame_base, loc, entry_pos, a, ctr);
+        hipLaunchKernelGGL(k_entry_frame, dim3(n_frames), dim3(256), 0, st, entry_list, frame_entries, frame_base, loc, a, ctr);
         const int fin_blocks = std::max(blocks_for(n_darts, 256, env_cap("A3_FIN_BLOCKS", 1536)), (int)(((uint64_t)n_darts + 256ull * 32 - 1) / (256ull * 32)));
-        hipLaunchKernelGGL(k_jump_finalize, dim3(fin_blocks), dim3(256), 0, st, n_darts, loc, entry_pos, a, fin,
+        hipLaunchKernelGGL(k_jump_finalize, dim3(fin_blocks), dim3(256), 0, st, n_darts, loc, a, fin,
                            leader_list, leader_count, leader_shard_cap(n_darts), n_live, ctr);
         return hipGetLastError();
     }
     const dim3 grid(blocks_for(n_darts / 16 + 1, 256, 1024)), block(256);   // entries are a few % of the darts on clean frames
-    hipLaunchKernelGGL(k_entry_init, grid, block, 0, st, entry_list, entry_count, loc, entry_pos, a, ecap);
+    hipLaunchKernelGGL(k_entry_init, grid, block, 0, st, entry_list, entry_count, loc, a, ecap);
     for (int r = 0; r < max_rounds; r++) {
         hipLaunchKernelGGL(k_entry_jump, grid, block, 0, st, a, b, entry_count, ecap, r, ctr);
         EntryState* t = a; a = b; b = t;
     }
     const int fin_blocks = std::max(blocks_for(n_darts, 256, env_cap("A3_FIN_BLOCKS", 1536)), (int)(((uint64_t)n_darts + 256ull * 32 - 1) / (256ull * 32)));
-    hipLaunchKernelGGL(k_jump_finalize, dim3(fin_blocks), block, 0, st, n_darts, loc, entry_pos, a, fin,
+    hipLaunchKernelGGL(k_jump_finalize, dim3(fin_blocks), block, 0, st, n_darts, loc, a, fin,
                        leader_list, leader_count, leader_shard_cap(n_darts), n_live, ctr);
     return hipGetLastError();
 }
