@@ -41,10 +41,11 @@
 #include "a3_common.h"
 
 // Darts per lane and trip in the per-dart sweeps (build knobs, swept on BASELINE config 2).  k_jump_finalize: 2 / 4 / 6 / 8 darts
-// -> 53 / 48 / 44.5 / 45 us: its three dependent loads want company.  k_scatter_points: 1 / 2 / 3 / 4 -> 34.5 / 37 / 37.5 / 41 us
+// -> 53 / 48 / 44.5 / 45 us with its three dependent loads of rounds 2-5; with two (round 6: the entry's slot comes with the state)
+// 4 / 6 / 8 / 10 -> 44.7 / 41.9 / 39.0 / 165 us (10 spills).  k_scatter_points: 1 / 2 / 3 / 4 -> 34.5 / 37 / 37.5 / 41 us
 // (on 8192 workgroups): its loads of one dart already come two and three at a time, and more threads beat more darts per thread.
 #ifndef A3_FIN_B
-#define A3_FIN_B 6
+#define A3_FIN_B 8
 #endif
 #ifndef A3_SCAT_B
 #define A3_SCAT_B 1

@@ -187,3 +187,21 @@ def test_a_held_chain_reports_held_until_it_goes_out(dicts):
         c1.submit(*aa)                                  # the burst's last member releases it
         assert c0.stats()["stepping"] == "held_released_by_last"
         assert markers_of_hip(c0.collect()[0]) == markers_of_hip(want[0]) and markers_of_hip(c1.collect()[0]) == markers_of_hip(want[0])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round 6: a frozen window carries its entry's slot -- the path of a contraction tile that spans more than 64 tiny frames
+# ------------------------------------------------------------------------------------------------------------------
+def test_thousands_of_tiny_frames_share_contraction_tiles(dicts, oracle):
+    """3000 frames of 5 x 4 pixels of noise in one batch: a frame owns a dozen darts, a 1024-dart tile of k_local_contract spans
+    some eighty frames -- more than the 64 whose entries it counts in LDS, so the entries of the frame that straddles the tile's end
+    take their slots one by one (k_local_contract's `direct` path).  find_contours itself (count, order, start, type, every point)
+    against the oracle, frame by frame."""
+    from tests.test_gpu_shard_taps import _compare_contours, _detector
+
+    rng = np.random.default_rng(606)
+    frames = rng.integers(0, 256, size=(3000, 4, 5), dtype=np.uint8)
+    det = _detector(dicts, "ARUCO_DEFAULT")
+    ctx, n = _compare_contours(det, oracle, frames)
+    st = ctx.stats()
+    assert n > 3000 and st["darts"] > 20000 and st["darts"] / 3000 < 15.5, st    # fewer than 16 darts a frame: > 64 frames per 1024-dart tile
