@@ -456,9 +456,6 @@ __device__ __forceinline__ void rotated_source(uint32_t r, uint32_t n, uint32_t 
 #ifndef A3_D_KU
 #define A3_D_KU 2
 #endif
-#ifndef A3_D_KU_FEW
-#define A3_D_KU_FEW A3_D_KU
-#endif
 #ifndef A3_D_WAVES
 #define A3_D_WAVES 5
 #endif
@@ -625,8 +622,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? A3_D_WAVES : A3_D_WAVES256) void k_d
                         t7 = s_inv[7], t8 = s_inv[8];
             // kU samples per lane per trip: all their row reads (one 12-byte load per row and sample: the two taps of a row
             // are adjacent) are in flight before the first is converted
-            // (PT == NT: the small-batch form -- few candidates, every round trip of a candidate's sampling shows)
-            constexpr int kU = PT == NT ? A3_D_KU_FEW : A3_D_KU;
+            constexpr int kU = A3_D_KU;
             // Sample order: blocks of 8 x 8 output pixels, one block per wave instruction (lane = 8 * (y & 7) + (x & 7)).  Taps
             // of a block lie in a compact patch of the frame whatever the marker's rotation, so the 64 lanes of a load touch
             // a few dozen cache lines; a row-major order puts the 64 samples of an instruction on a slanted line that crosses
