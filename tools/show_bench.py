@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """One bench run, condensed: python tools/show_bench.py <name>.json.log   (the compact stdout line; <name>.detail.json beside it --
 A3_BENCH_DETAIL, tools/refresh_r06.sh -- is read for everything the line does not carry; a bench_detail.json may be given directly)"""
-import json, sys
+import json, signal, sys
 from pathlib import Path
+
+signal.signal(signal.SIGPIPE, signal.SIG_DFL)   # `| head` is not an error
 
 p = Path(sys.argv[1])
 text = p.read_text().strip()
