@@ -947,7 +947,6 @@ def compact_line(out, detail_path="bench_detail.json"):
         c1 = ow.get("C1_single_frame_from_host") or {}
         if isinstance(c1.get("markers_only_pinned"), dict):
             brief["C1_one_frame_per_call_ms"] = c1["markers_only_pinned"].get("median_ms")
-            brief["C1_launches_per_call"] = c1.get("launches_per_call")
         ing = (ow.get("C2_from_host_frames") or {}).get("pinned")
         if isinstance(ing, dict):
             brief["C2_from_pinned_host_fps"] = ing.get("value")
