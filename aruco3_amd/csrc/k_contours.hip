@@ -454,6 +454,7 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
     __shared__ uint32_t s_mark[512];
     __shared__ uint16_t s_nbk[256];
     __shared__ uint8_t s_wofrank[256], s_rank[256], s_fr[256];
+    __shared__ uint32_t s_multi;   // some pixel of the tile owns more than one dart
     const int wpr = (int)words_per_row((uint32_t)W);
     // XCD-aware workgroup -> tile mapping.  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one, and its L2).  A tile
     // row of the packed image is 32 bytes of a 128-byte line, and with (tile, frame) = (blockIdx.x, blockIdx.y) on a 1920-pixel frame
@@ -485,8 +486,10 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
         cm[c] = ((tm[0] >> (16 * c)) & 0xFFFFull) | (((tm[1] >> (16 * c)) & 0xFFFFull) << 16) | (((tm[2] >> (16 * c)) & 0xFFFFull) << 32) | (((tm[3] >> (16 * c)) & 0xFFFFull) << 48);
     const unsigned long long m0 = cm[0], m1 = cm[1], m2 = cm[2], m3 = cm[3];
     tile_stage(bits + (size_t)(first_frame + f) * wpr * H, W, H, tile, s_t);
-    s_nodes[threadIdx.x] = 0; s_c0[threadIdx.x] = 0; s_c1[threadIdx.x] = 0; s_c2[threadIdx.x] = 0; s_cnt[threadIdx.x] = 0;
+    // (s_nodes / s_c0..2 are read for words that own darts only, and phase 1 writes those: nothing to zero there)
+    s_cnt[threadIdx.x] = 0;
     s_mark[threadIdx.x] = 0; s_mark[256 + threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_multi = 0;
     __syncthreads();
     const uint32_t a0 = (uint32_t)__popcll(m0), a1 = a0 + (uint32_t)__popcll(m1), a2 = a1 + (uint32_t)__popcll(m2), n_act = a2 + (uint32_t)__popcll(m3);
     for (uint32_t k = threadIdx.x; k < n_act; k += 256) {
@@ -507,7 +510,9 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
         const uint64_t k4 = (s1 & s2) | (s3 & (s1 ^ s2));
         const uint64_t t = k1 ^ k2 ^ k3, q1 = (k1 & k2) | (k3 & (k1 ^ k2));
         s_nodes[w] = nodes;
-        s_c0[w] = s1 ^ s2 ^ s3; s_c1[w] = t ^ k4; s_c2[w] = q1 | (t & k4);
+        const uint64_t c1 = t ^ k4, c2 = q1 | (t & k4);
+        s_c0[w] = s1 ^ s2 ^ s3; s_c1[w] = c1; s_c2[w] = c2;
+        if ((c1 | c2) != 0ull) s_multi = 1u;   // (a plain store of the same value from whoever sees it)
         s_cnt[w] = nd | ((uint32_t)__popcll(nodes) << 17);
         s_wofrank[k] = (uint8_t)w; s_rank[w] = (uint8_t)k;
     }
@@ -532,6 +537,10 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
     if (dbg == 3) return;
     const int tx = tile % dart_tiles_x((uint32_t)W), ty = tile / dart_tiles_x((uint32_t)W);
     uint32_t* pbf = pix_base + (size_t)f * W * H;
+    // No pixel of the tile owns more than one dart -- on clean frames 999 border pixels in a thousand own exactly one, so most tiles
+    // qualify: a pixel's darts before it in its word are then the border pixels before it (one popcount of the node mask that is in
+    // hand anyway) instead of the sum over three bit planes, for the pixel itself and for its successor's pixel.
+    const bool single = __builtin_amdgcn_readfirstlane((int)s_multi) == 0;
     for (uint32_t n = threadIdx.x; n < total_n; n += 256) {
         // word holding the n-th border pixel of the tile: the segment's first word + the words that begin inside the segment at or
         // before this pixel (n = threadIdx.x + 256 t: a wave's lanes are the 64 pixels of segment n >> 6, lane = n & 63)
@@ -547,7 +556,8 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
         uint32_t P = pdart_mask(F);
         const uint64_t below = (1ull << i) - 1ull;
         // darts of the word's earlier border pixels
-        const uint32_t off = (uint32_t)__popcll(s_c0[w] & below) + 2u * (uint32_t)__popcll(s_c1[w] & below) + 4u * (uint32_t)__popcll(s_c2[w] & below);
+        const uint32_t off = single ? (uint32_t)__popcll(m & below)
+                                    : (uint32_t)__popcll(s_c0[w] & below) + 2u * (uint32_t)__popcll(s_c1[w] & below) + 4u * (uint32_t)__popcll(s_c2[w] & below);
         const int x = 64 * wj + i;
         uint32_t cur = dart0 + s_dbase[w] + off;
         // only pixels on the rim of the tile can be the target of a successor pointer from another tile
@@ -577,8 +587,9 @@ __global__ __launch_bounds__(256) void k_dart_assign(const uint64_t* __restrict_
                 succ = cur;   // chain end unless the target dart exists
                 if ((P2 >> kin) & 1u) {
                     const uint64_t below2 = (1ull << i2) - 1ull;
-                    const uint32_t off2 = (uint32_t)__popcll(s_c0[w2] & below2) + 2u * (uint32_t)__popcll(s_c1[w2] & below2) +
-                                          4u * (uint32_t)__popcll(s_c2[w2] & below2);
+                    const uint32_t off2 = single ? (uint32_t)__popcll(s_nodes[w2] & below2)
+                                                 : (uint32_t)__popcll(s_c0[w2] & below2) + 2u * (uint32_t)__popcll(s_c1[w2] & below2) +
+                                                   4u * (uint32_t)__popcll(s_c2[w2] & below2);
                     succ = dart0 + s_dbase[w2] + off2 + (uint32_t)__popc(P2 & ((1u << kin) - 1u));
                 }
             } else {
