@@ -31,14 +31,15 @@ hipError_t launch_dart_build(hipStream_t, const uint64_t*, int, int, uint32_t, u
                              uint64_t*, uint32_t*, uint32_t, const uint32_t*, int, const unsigned long long*);
 hipError_t launch_zero(hipStream_t, void*, size_t);
 size_t entry_state_bytes();
+size_t fin_state_bytes();
 size_t entry_slots(uint32_t);
 size_t leader_list_bytes(uint32_t);
 hipError_t launch_rank_cycles(hipStream_t, uint32_t, int, const uint64_t*, const uint32_t*, JumpState*,
-                              uint32_t*, unsigned int*, void*, void*, JumpState*, uint32_t*, unsigned int*, int, DeviceCounters*, const uint32_t*, int,
+                              uint32_t*, unsigned int*, void*, void*, void*, uint32_t*, unsigned int*, int, DeviceCounters*, const uint32_t*, int,
                               const uint32_t*, uint32_t*, uint32_t, int, uint32_t, unsigned int*, int);
-hipError_t launch_resolve(hipStream_t, const JumpState*, uint32_t, int, const uint64_t*, const uint32_t*, const unsigned int*, uint64_t*, uint64_t*,
+hipError_t launch_resolve(hipStream_t, const JumpState*, const void*, uint32_t, int, const uint64_t*, const uint32_t*, const unsigned int*, uint64_t*, uint64_t*,
                           DeviceCounters*, int, const uint32_t*);
-hipError_t launch_select_scatter(hipStream_t, const JumpState*, uint32_t, const uint32_t*, const unsigned int*, const uint32_t*, const uint64_t*,
+hipError_t launch_select_scatter(hipStream_t, const JumpState*, const void*, uint32_t, const uint32_t*, const unsigned int*, const uint32_t*, const uint64_t*,
                                  const uint32_t*, uint32_t, uint32_t,
                                  uint32_t, double, double, ContourRec*, uint32_t*, uint32_t, uint64_t, DeviceCounters*,
                                  const uint64_t*, uint32_t*, const uint32_t*, int, uint32_t*, int);
@@ -312,7 +313,7 @@ int ensure_dart_pool(a3_ctx* ctx, uint64_t darts) {
     A3_HIP(ctx->d_xy.ensure(darts * 8));   // dart records (dart_rec)
     A3_HIP(ctx->d_succ.ensure(darts * 4));
     A3_HIP(ctx->stA.ensure(darts * sizeof(JumpState)));
-    A3_HIP(ctx->stB.ensure(darts * sizeof(JumpState)));
+    A3_HIP(ctx->stB.ensure(darts * fin_state_bytes()));   // the 8-byte final states (leader, hops | flags) of k_jump_finalize
     A3_HIP(ctx->t_cur.ensure(darts * 8));
     A3_HIP(ctx->t_next.ensure(darts * 8));
     A3_HIP(ctx->leader_list.ensure(leader_list_bytes((uint32_t)darts)));   // leaders of cycles with a start event, 16 shards
@@ -825,7 +826,7 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
         // first half: the doubling rounds inside LDS tiles
         A3_HIP(launch_rank_cycles(st, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), ctx->stA.as<JumpState>(),
                                   ctx->entry_list.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
-                                  ctx->stA.as<JumpState>(), ctx->leader_list.as<uint32_t>(), d_leader_count, rounds, ctr, n_live, 0, fb,
+                                  ctx->stB.p, ctx->leader_list.as<uint32_t>(), d_leader_count, rounds, ctr, n_live, 0, fb,
                                   frame_entries, cc.count, 1, min_edge_length, dead_ctr, inline_resolve_W > 0 ? 1 : 0));
         if (rel_mode == 2) { if (int rc = release_waiting()) return rc; }   // waiting decode stages go out behind this k_local_contract
         ctx->dbg_nd = nd; ctx->dbg_frames = c.count; ctx->dbg_chunks = (uint32_t)chunks.size();
@@ -833,12 +834,13 @@ int enqueue_batch(a3_ctx* ctx, const uint8_t* pixels, int fmt, uint32_t W, uint3
         auto chunk_back = [=](hipStream_t s2) -> int {
             A3_HIP(launch_rank_cycles(s2, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), ctx->stA.as<JumpState>(),
                                       ctx->entry_list.as<uint32_t>(), d_entry_count, ctx->es_a.p, ctx->es_b.p,
-                                      ctx->stA.as<JumpState>() /* final states in place */, ctx->leader_list.as<uint32_t>(), d_leader_count, rounds, ctr,
+                                      ctx->stB.p /* the 8-byte final states */, ctx->leader_list.as<uint32_t>(), d_leader_count, rounds, ctr,
                                       n_live, 0, fb, frame_entries, cc.count, 2, min_edge_length, dead_ctr, inline_resolve_W > 0 ? 1 : 0));
-            const JumpState* fin = ctx->stA.as<JumpState>();
-            A3_HIP(launch_resolve(s2, fin, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->leader_list.as<uint32_t>(), d_leader_count,
+            const JumpState* loc = ctx->stA.as<JumpState>();
+            const void* fin = ctx->stB.p;
+            A3_HIP(launch_resolve(s2, loc, fin, nd, (int)W, ctx->d_xy.as<uint64_t>(), ctx->leader_list.as<uint32_t>(), d_leader_count,
                                   ctx->t_cur.as<uint64_t>(), ctx->t_next.as<uint64_t>(), ctr, resolve_iters, n_live));
-            A3_HIP(launch_select_scatter(s2, fin, nd, ctx->leader_list.as<uint32_t>(), d_leader_count, ctx->d_succ.as<uint32_t>(), ctx->t_cur.as<uint64_t>(), fb,
+            A3_HIP(launch_select_scatter(s2, loc, fin, nd, ctx->leader_list.as<uint32_t>(), d_leader_count, ctx->d_succ.as<uint32_t>(), ctx->t_cur.as<uint64_t>(), fb,
                                          cc.count, cc.first, min_edge_length, eps_factor, image_diag,
                                          ctx->contours.as<ContourRec>(), ctx->cyc_start_off.as<uint32_t>(), max_contours, max_points, ctr,
                                          ctx->d_xy.as<uint64_t>(), ctx->points.as<uint32_t>(), n_live, inline_resolve_W, ctx->leader_keep.as<uint32_t>(),
@@ -1514,7 +1516,7 @@ int a3_debug_kernel_time(a3_ctx* ctx, int kernel, int dbg, int reps, float* avg_
         } else if (kernel == 2) {
             A3_HIP(launch_rank_cycles(st, ctx->dbg_nd, (int)ctx->W, ctx->d_xy.as<uint64_t>(), ctx->d_succ.as<uint32_t>(), ctx->stA.as<JumpState>(),
                                       ctx->entry_list.as<uint32_t>(),
-                                      d_entry_count, ctx->es_a.p, ctx->es_b.p, ctx->stB.as<JumpState>(),
+                                      d_entry_count, ctx->es_a.p, ctx->es_b.p, ctx->stB.p,
                                       ctx->leader_list.as<uint32_t>(), d_leader_count, 0, ctx->counters, nullptr, dbg ? dbg : 11, ctx->frame_base.as<uint32_t>(), nullptr, ctx->dbg_frames, 0,
                                       0u, nullptr, 0));
         } else if (kernel == 3 || kernel == 4) {   // dbg < 0: k_decode alone (variant -dbg; -5: the whole kernel), dbg >= 0: k_projection + k_decode

@@ -761,6 +761,17 @@ constexpr uint32_t kDead = 0x20000000u;
 __device__ __forceinline__ bool is_dead(uint32_t off_word) { return (off_word & (kFinal | kDead)) == kDead; }
 __device__ __forceinline__ uint32_t fin_off(uint32_t w) { return (w & kFinal) ? (w & 0x3FFFFFFFu) : (w & 0xFFFu); }
 __device__ __forceinline__ uint32_t loc_dist(uint32_t w) { return (w >> 12) & 0x1FFFu; }
+// What every dart knows once k_jump_finalize has run, in 8 bytes: its cycle's leader and its hop distance to it, plus whether the
+// cycle carries a start event and whether it is a dead one (k_local_contract).  Round 6: the sweeps that need the final answer per dart
+// (k_scatter_points, the fixpoint passes) read this array, and k_jump_finalize writes it front to back instead of patching a third
+// of the 16-byte local states in place (93 MB of scattered line write-backs per 256 frames, and 98 MB for k_scatter_points to read).
+// The 16-byte LOCAL states stay as k_local_contract left them; a LEADER's local key is already final (its own key is the smallest
+// of its cycle, hence of every window that holds it).  k_cycle_select parks a listed leader's border slot in the hops field of the
+// leader's OWN FinState (a leader is 0 hops from itself; kFinHops = no slot): k_scatter_points then finds "does my leader lead" and
+// "where do its points go" in one 8-byte load -- and the test is made on FINAL states: in a run that has not converged (too few
+// global rounds: the batch is re-run) a dart may name a leader that does not hold its own key, and nothing of such a dart is used.
+struct __attribute__((aligned(8))) FinState { uint32_t leader; uint32_t w; };
+constexpr uint32_t kFinEvent = 0x80000000u, kFinDead = 0x40000000u, kFinHops = 0x3FFFFFFFu;
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global load, store and returning
 // atomic the wave has in flight (s_waitcnt vmcnt(0)); where the barrier only hands LDS data between waves that wait would
@@ -1181,9 +1192,9 @@ __host__ __device__ inline uint32_t leader_shard_cap(uint32_t n_darts) { return 
 
 // ... and the leaders of cycles that carry at least one start event are collected (one atomic per wave) for the
 // per-border kernels that follow.
-__global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const JumpState* loc,
+__global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const JumpState* __restrict__ loc,
                                                        const EntryState* __restrict__ es,
-                                                       JumpState* fin /* may be loc: only the states that change are then written */,
+                                                       FinState* __restrict__ fin,
                                                        uint32_t* __restrict__ leader_list,
                                                        unsigned int* __restrict__ leader_count /*[kLeaderShards]*/, uint32_t shard_cap,
                                                        const uint32_t* __restrict__ n_live, const DeviceCounters* __restrict__ ctr) {
@@ -1218,11 +1229,12 @@ __global__ __launch_bounds__(256) void k_jump_finalize(uint32_t n_darts, const J
             const uint32_t d = d0 + (uint32_t)u * stride;
             if (d >= n_darts) break;
             // a window that was final inside its tile -- wrapped, or frozen at an entry whose own cycle minimum is not smaller --
-            // keeps its state as it is (fin_off reads the packed word); two thirds of the states are not written again
+            // keeps its local answer; the others take the entry's
             const bool better = (od[u] & kFrozen) && g[u].key < s[u].key;
             if (better) { s[u].key = g[u].key; s[u].off = (loc_dist(od[u]) + g[u].off) | kFinal; }
-            if (better || fin != loc) fin[d] = s[u];
-            if ((uint32_t)s[u].key == d && (uint32_t)(s[u].key >> 32) != kNoKey && !is_dead(s[u].off)) mask |= 1u << (it + u);
+            const bool event = (uint32_t)(s[u].key >> 32) != kNoKey, dead = is_dead(s[u].off);
+            fin[d] = FinState{(uint32_t)s[u].key, fin_off(s[u].off) | (event ? kFinEvent : 0u) | (dead ? kFinDead : 0u)};
+            if ((uint32_t)s[u].key == d && event && !dead) mask |= 1u << (it + u);
         }
     }
     // one global atomic per workgroup: leaders are counted in a block scan first
@@ -1249,8 +1261,8 @@ constexpr uint64_t kInf64 = ~0ull;
 // passes over all darts below are skipped; this is the case unless a component's first pixel lies in column 0.
 // T0 is written for the listed leaders only -- the only slots k_cycle_select reads.
 // does the smallest event of the border led by dart d (key0 = st[d].key) fire under the natural assignment?
-__device__ __forceinline__ bool natural_start_fires(uint32_t d, uint64_t key0, const JumpState* __restrict__ st, const uint64_t* __restrict__ d_rec,
-                                                    int W) {
+__device__ __forceinline__ bool natural_start_fires(uint32_t d, uint64_t key0, const JumpState* __restrict__ st, const FinState* __restrict__ fin,
+                                                    const uint64_t* __restrict__ d_rec, int W) {
     const uint64_t rec = d_rec[d];
     if (static_fire(rec)) return true;   // (the leader's key is its own event's: no look at the neighbours' states needed)
     const uint32_t info = rec_info(rec);
@@ -1262,19 +1274,19 @@ __device__ __forceinline__ bool natural_start_fires(uint32_t d, uint64_t key0, c
     const uint32_t base = d - __popc(P & ((1u << k) - 1u));
     const int cnt = __popc(P);
     bool wfires = true;
-    // a pixel owns at most four darts: their keys, then their leaders' keys, each as one batch of loads (clamped indices) rather
-    // than a chain of up to eight round trips with an early exit
-    uint64_t kj[4], lk[4];
+    // a pixel owns at most four darts: their leaders, then the leaders' own keys (a leader's local state is final), each as one batch
+    // of loads (clamped indices) rather than a chain of up to eight round trips with an early exit
+    uint32_t lj[4];
+    uint64_t lk[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) kj[j] = st[base + (uint32_t)min(j, cnt - 1)].key;
+    for (int j = 0; j < 4; j++) lj[j] = fin[base + (uint32_t)min(j, cnt - 1)].leader;
 #pragma unroll
-    for (int j = 0; j < 4; j++) lk[j] = st[(uint32_t)kj[j]].key;
+    for (int j = 0; j < 4; j++) lk[j] = st[lj[j]].key;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const uint32_t leader = (uint32_t)kj[j];
-        // T0 of the border through this dart: its key, provided the dart sits on an intact cycle with an event
-        uint32_t t = (uint32_t)(kj[j] >> 32);
-        if (leader != d && (uint32_t)lk[j] != leader) t = kNoKey;
+        // T0 of the border through this dart: its leader's event key, provided the dart sits on an intact cycle with an event
+        uint32_t t = (uint32_t)(lk[j] >> 32);
+        if (lj[j] != d && (uint32_t)lk[j] != lj[j]) t = kNoKey;
         if (j < cnt && t < 2u * q) wfires = false;
     }
     const bool has_w = x > 0 && !(F & 1u);
@@ -1285,7 +1297,7 @@ __device__ __forceinline__ bool natural_start_fires(uint32_t d, uint64_t key0, c
 }
 
 // (Launched only when the full passes below are in the launch sequence; otherwise k_cycle_select does this check itself.)
-__global__ __launch_bounds__(256) void k_resolve_fast(const JumpState* __restrict__ st, const uint32_t* __restrict__ leader_list,
+__global__ __launch_bounds__(256) void k_resolve_fast(const JumpState* __restrict__ st, const FinState* __restrict__ fin, const uint32_t* __restrict__ leader_list,
                                                       const unsigned int* __restrict__ leader_count, uint32_t shard_cap, int W,
                                                       const uint64_t* __restrict__ d_rec, uint64_t* __restrict__ t_cur,
                                                       DeviceCounters* __restrict__ ctr) {
@@ -1300,20 +1312,20 @@ __global__ __launch_bounds__(256) void k_resolve_fast(const JumpState* __restric
         const uint32_t d = leader_list[(size_t)sh * shard_cap + i];
         const uint64_t key0 = st[d].key;            // (smallest event key << 32) | d
         t_cur[d] = key0;
-        if (!natural_start_fires(d, key0, st, d_rec, W)) moved = true;
+        if (!natural_start_fires(d, key0, st, fin, d_rec, W)) moved = true;
     }
     if (moved) ctr->resolve_needed = 1u;
 }
 
 // leaders get their natural start (their own key: the smallest event on the cycle); every other slot is "never"
-__global__ void k_resolve_init(const JumpState* __restrict__ st, uint32_t n_darts, uint64_t* __restrict__ t_cur,
+__global__ void k_resolve_init(const JumpState* __restrict__ st, const FinState* __restrict__ fin, uint32_t n_darts, uint64_t* __restrict__ t_cur,
                                uint64_t* __restrict__ t_next, const DeviceCounters* __restrict__ ctr, const uint32_t* __restrict__ n_live) {
     if (!ctr->resolve_needed) return;
     if (n_live) n_darts = min(n_darts, *n_live);
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
-        const uint64_t key = st[d].key;
-        const bool natural = (uint32_t)key == d && (uint32_t)(key >> 32) != kNoKey;
-        t_cur[d] = natural ? key : kInf64;
+        const FinState fs = fin[d];
+        const bool natural = fs.leader == d && (fs.w & kFinEvent) != 0u;
+        t_cur[d] = natural ? st[d].key : kInf64;   // (a leader's local key is its own: final)
         t_next[d] = kInf64;
     }
 }
@@ -1323,7 +1335,7 @@ __global__ void k_resolve_init(const JumpState* __restrict__ st, uint32_t n_dart
 //   W-event(q) fires iff Wfires(q); E-event(q) fires iff not (hasW(q) and Wfires(q))
 //                                                           (reference: the `else if`, label(q) > 0)
 // and propose T'(cycle) = min key of its firing events.
-__global__ __launch_bounds__(256) void k_resolve_eval(const JumpState* __restrict__ st, uint32_t n_darts, int W,
+__global__ __launch_bounds__(256) void k_resolve_eval(const FinState* __restrict__ fin, uint32_t n_darts, int W,
                                                       const uint64_t* __restrict__ d_rec, const uint64_t* __restrict__ t_cur,
                                                       uint64_t* __restrict__ t_next, int iter, DeviceCounters* __restrict__ ctr,
                                                       const uint32_t* __restrict__ n_live) {
@@ -1334,8 +1346,8 @@ __global__ __launch_bounds__(256) void k_resolve_eval(const JumpState* __restric
         const uint32_t info = rec_info(rec);
         if (!(info & (kInfoW | kInfoE))) continue;
         // an event dart must sit on an intact cycle, whose leader is its own leader (open chains never carry events)
-        const uint32_t my_leader = (uint32_t)st[d].key;
-        if ((uint32_t)st[my_leader].key != my_leader) { atomicOr(&ctr->err_flags, kErrBrokenEvent); continue; }
+        const uint32_t my_leader = fin[d].leader;
+        if (fin[my_leader].leader != my_leader) { atomicOr(&ctr->err_flags, kErrBrokenEvent); continue; }
         const uint32_t xy = rec_xy(rec);
         const uint32_t x = xy & 0xFFFF, y = xy >> 16;
         const uint32_t q = y * (uint32_t)W + x;
@@ -1345,7 +1357,7 @@ __global__ __launch_bounds__(256) void k_resolve_eval(const JumpState* __restric
         const int cnt = __popc(P);
         bool wfires = true;
         for (int i = 0; i < cnt; i++) {
-            const uint32_t leader = (uint32_t)st[base + i].key;
+            const uint32_t leader = fin[base + i].leader;
             const uint32_t t = (uint32_t)(t_cur[leader] >> 32);
             if (t < 2u * q) { wfires = false; break; }
         }
@@ -1359,14 +1371,14 @@ __global__ __launch_bounds__(256) void k_resolve_eval(const JumpState* __restric
 }
 
 // adopt T' as T, count the cycles whose start moved (into this pass's slot), clear T' for the next pass
-__global__ void k_resolve_commit(const JumpState* __restrict__ st, uint32_t n_darts, uint64_t* __restrict__ t_cur,
+__global__ void k_resolve_commit(const FinState* __restrict__ fin, uint32_t n_darts, uint64_t* __restrict__ t_cur,
                                  uint64_t* __restrict__ t_next, int iter, int last, DeviceCounters* __restrict__ ctr,
                                  const uint32_t* __restrict__ n_live) {
     if (!ctr->resolve_needed || (iter > 0 && ctr->resolve_changed[iter - 1] == 0)) return;
     if (n_live) n_darts = min(n_darts, *n_live);
     uint32_t changed = 0;
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < n_darts; d += gridDim.x * blockDim.x) {
-        if ((uint32_t)st[d].key != d) continue;
+        if (fin[d].leader != d) continue;
         const uint64_t a = t_cur[d], b = t_next[d];
         if (a != b) { changed++; t_cur[d] = b; }
         t_next[d] = kInf64;
@@ -1381,11 +1393,11 @@ __global__ void k_resolve_commit(const JumpState* __restrict__ st, uint32_t n_da
 // ---------------------------------------------------------------------------------------
 // select the borders worth materialising, then write their points in traversal order
 // ---------------------------------------------------------------------------------------
-// The border slot of a listed leader (kNone: not materialised) is written into the `ptr` word of the leader's OWN state -- nothing
-// reads that word after k_jump_finalize -- so that k_scatter_points finds "is my leader's window intact" and "where do its points
-// go" in one 16-byte load per dart instead of two scattered ones (on noise-like frames, 50 M darts, the scattered loads are the
-// kernel).
-__global__ __launch_bounds__(256) void k_cycle_select(JumpState* st, const uint32_t* __restrict__ leader_list,
+// The border slot of a listed leader (kFinHops: not materialised) is written into the hops field of the leader's OWN FinState -- a
+// leader is 0 hops from itself, and every reader of that field special-cases the leader -- so that k_scatter_points finds "does my
+// leader lead itself" and "where do its points go" in one 8-byte load per dart instead of two scattered ones (on noise-like frames,
+// 50 M darts, the scattered loads are the kernel).
+__global__ __launch_bounds__(256) void k_cycle_select(const JumpState* __restrict__ st, FinState* fin, const uint32_t* __restrict__ leader_list,
                                                       const unsigned int* __restrict__ leader_count, const uint32_t* __restrict__ d_succ,
                                                       const uint64_t* __restrict__ t_cur, const uint32_t* __restrict__ frame_base,
                                                       uint32_t n_frames, uint32_t first_frame, uint32_t min_edge_length, double eps_factor,
@@ -1420,8 +1432,9 @@ __global__ __launch_bounds__(256) void k_cycle_select(JumpState* st, const uint3
         if (!e.traced) return e;
         // the successor's window must have wrapped around to this leader, else this is a chain, not a cycle
         const uint32_t sl = d_succ[e.d];
-        if (sl == e.d || (uint32_t)st[sl].key != e.d) { e.broken = true; return e; }
-        e.n = fin_off(st[sl].off) + 1u;
+        const FinState fsl = fin[sl];
+        if (sl == e.d || fsl.leader != e.d) { e.broken = true; return e; }
+        e.n = (fsl.w & kFinHops) + 1u;
         // Parity-safe pruning (src/aruco.rs:133-158):
         //  (1) a candidate keeps 4 border points in convex position whose hull edges are all >= sqrt(min_edge_length) long
         //      (src/aruco.rs:149-159).  The closed border visits the four in some order; between two of them it needs at least
@@ -1451,7 +1464,7 @@ __global__ __launch_bounds__(256) void k_cycle_select(JumpState* st, const uint3
         if (e.valid) { const uint32_t sh = i0 / span; keep_tmp[(size_t)sh * shard_cap + (i0 - sh * span)] = e.keep ? 1u : 0u; }
         // the k_resolve_fast test, folded in: if some border's smallest event does not fire the batch is re-run with the
         // fixpoint passes (what is selected below is then discarded)
-        if (W > 0 && e.valid && !natural_start_fires(e.d, e.t, st, d_rec, W)) moved = true;
+        if (W > 0 && e.valid && !natural_start_fires(e.d, e.t, st, fin, d_rec, W)) moved = true;
     }
     if (moved) ctr->resolve_needed = 1u;
     if (broken) atomicOr(&ctr->err_flags, kErrBrokenEvent);
@@ -1494,13 +1507,13 @@ __global__ __launch_bounds__(256) void k_cycle_select(JumpState* st, const uint3
         {
             const uint32_t sh = i0 / span, i = i0 - sh * span;
             if (i >= leader_count[sh]) continue;
-            if (!keep_tmp[(size_t)sh * shard_cap + i]) { st[leader_list[(size_t)sh * shard_cap + i]].ptr = kNone; continue; }
+            if (!keep_tmp[(size_t)sh * shard_cap + i]) { fin[leader_list[(size_t)sh * shard_cap + i]].w = kFinEvent | kFinHops; continue; }
         }
         const Eval e = eval(i0);
         if (!e.valid) continue;
         uint32_t slot = kNone;
         if (e.keep) {
-            if (c >= max_contours) atomicOr(&ctr->err_flags, kErrContourTable);
+            if (c >= max_contours || c >= kFinHops) atomicOr(&ctr->err_flags, kErrContourTable);   // (a slot must fit the 30-bit field)
             else if (pb + e.n > max_points) atomicOr(&ctr->err_flags, kErrPointPool);
             else {
                 uint32_t lo = 0, hi = n_frames;  // frame of this dart: binary search in frame_base
@@ -1511,16 +1524,16 @@ __global__ __launch_bounds__(256) void k_cycle_select(JumpState* st, const uint3
                 r.point_base = (uint32_t)pb;
                 r.n = e.n;
                 contours[c] = r;
-                cyc_start_off[c] = fin_off(st[(uint32_t)e.t].off);
+                cyc_start_off[c] = (uint32_t)e.t == e.d ? 0u : fin[(uint32_t)e.t].w & kFinHops;   // (the leader's own hops field is about to hold its slot)
                 slot = c;
             }
             c++; pb += e.n;
         }
-        st[e.d].ptr = slot;
+        fin[e.d].w = kFinEvent | (slot == kNone ? kFinHops : slot);   // (listed leaders carry an event and are not dead)
     }
 }
 
-__global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restrict__ st, uint32_t n_darts, const uint64_t* __restrict__ d_rec,
+__global__ __launch_bounds__(256) void k_scatter_points(const FinState* __restrict__ fin, uint32_t n_darts, const uint64_t* __restrict__ d_rec,
                                                         const ContourRec* __restrict__ contours,
                                                         const uint32_t* __restrict__ cyc_start_off, uint32_t* __restrict__ points,
                                                         const uint32_t* __restrict__ n_live, const DeviceCounters* __restrict__ ctr) {
@@ -1531,24 +1544,24 @@ __global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restr
     constexpr int B = A3_SCAT_B;
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t d0 = blockIdx.x * blockDim.x + threadIdx.x; d0 < n_darts; d0 += B * stride) {
-        JumpState s[B];
+        FinState s[B];
         uint64_t rec[B];
         uint32_t c[B], so[B];
-        JumpState ls[B];
+        FinState ls[B];
         ContourRec r[B];
         bool live[B];
 #pragma unroll
         for (int u = 0; u < B; u++) {
             const uint32_t d = min(d0 + (uint32_t)u * stride, n_darts - 1u);
-            s[u] = st[d];
+            s[u] = fin[d];
         }
 #pragma unroll
         for (int u = 0; u < B; u++) {
-            live[u] = d0 + (uint32_t)u * stride < n_darts && (uint32_t)(s[u].key >> 32) != kNoKey &&   // else: no start event on this cycle
-                      !is_dead(s[u].off);                                                                // ... or a dead one (k_local_contract)
-            const uint32_t leader = live[u] ? (uint32_t)s[u].key : 0u;
-            ls[u] = st[leader];    // key: is the leader's window intact; ptr: its border slot (k_cycle_select)
-            c[u] = ls[u].ptr;
+            live[u] = d0 + (uint32_t)u * stride < n_darts && (s[u].w & kFinEvent) != 0u &&   // else: no start event on this cycle
+                      (s[u].w & kFinDead) == 0u;                                              // ... or a dead one (k_local_contract)
+            const uint32_t leader = live[u] ? s[u].leader : 0u;
+            ls[u] = fin[leader];   // the leader's own final state -- leader: does it lead itself; hops field: its border slot (k_cycle_select)
+            c[u] = ls[u].w & kFinHops;
             // the dart's record travels with the second round of loads, and only for darts that may be written out (on noise-like
             // frames nine darts in ten are not: a third of the kernel's bytes)
             rec[u] = live[u] ? d_rec[min(d0 + (uint32_t)u * stride, n_darts - 1u)] : 0ull;
@@ -1557,7 +1570,7 @@ __global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restr
         for (int u = 0; u < B; u++) {
             // a leader that does not hold its own key: an open chain, or states of a run that has not converged (the batch is
             // then re-run) -- its slot was never written this batch
-            live[u] = live[u] && (uint32_t)ls[u].key == (uint32_t)s[u].key && c[u] != kNone;
+            live[u] = live[u] && ls[u].leader == s[u].leader && c[u] != kFinHops;
             r[u] = contours[live[u] ? c[u] : 0u];
             so[u] = cyc_start_off[live[u] ? c[u] : 0u];
         }
@@ -1565,7 +1578,7 @@ __global__ __launch_bounds__(256) void k_scatter_points(const JumpState* __restr
         for (int u = 0; u < B; u++) {
             if (!live[u]) continue;
             // off = hops forward to the leader; position along the border counted from the start dart
-            const uint32_t off = fin_off(s[u].off);
+            const uint32_t off = s[u].leader == d0 + (uint32_t)u * stride ? 0u : s[u].w & kFinHops;   // (the leader's own hops field holds its slot)
             const uint32_t rank = so[u] >= off ? so[u] - off : so[u] + r[u].n - off;
             points[r[u].point_base + rank] = rec_xy(rec[u]);
         }
@@ -1854,6 +1867,7 @@ hipError_t launch_dart_build(hipStream_t st, const uint64_t* bits, int W, int H,
 }
 
 size_t entry_state_bytes() { return sizeof(EntryState); }
+size_t fin_state_bytes() { return sizeof(FinState); }
 size_t entry_slots(uint32_t n_darts) { return (size_t)entry_shard_cap(n_darts) * kEntryShards; }
 size_t leader_list_bytes(uint32_t n_darts) { return (size_t)leader_shard_cap(n_darts) * kLeaderShards * 4; }
 
@@ -1861,7 +1875,7 @@ size_t leader_list_bytes(uint32_t n_darts) { return (size_t)leader_shard_cap(n_d
 // entry_count[16] and leader_count[16] arrive zeroed.
 hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uint64_t* d_rec, const uint32_t* d_succ,
                               JumpState* loc, uint32_t* entry_list,
-                              unsigned int* entry_count, void* es_a, void* es_b, JumpState* fin, uint32_t* leader_list,
+                              unsigned int* entry_count, void* es_a, void* es_b, void* fin /* FinState[n_darts] */, uint32_t* leader_list,
                               unsigned int* leader_count, int max_rounds, DeviceCounters* ctr, const uint32_t* n_live, int dbg,
                               const uint32_t* frame_base, uint32_t* frame_entries /*nullptr: global rounds*/, uint32_t n_frames,
                               int phase /* 0: everything, 1: k_local_contract only, 2: what follows it */,
@@ -1886,7 +1900,7 @@ hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uin
     if (frame_entries) {   // clean frames: every frame's entry list fits LDS, one launch instead of ~9
         hipLaunchKernelGGL(k_entry_frame, dim3(n_frames), dim3(256), 0, st, entry_list, frame_entries, frame_base, loc, a, ctr);
         const int fin_blocks = std::max(blocks_for(n_darts, 256, env_cap("A3_FIN_BLOCKS", 1536)), (int)(((uint64_t)n_darts + 256ull * 32 - 1) / (256ull * 32)));
-        hipLaunchKernelGGL(k_jump_finalize, dim3(fin_blocks), dim3(256), 0, st, n_darts, loc, a, fin,
+        hipLaunchKernelGGL(k_jump_finalize, dim3(fin_blocks), dim3(256), 0, st, n_darts, loc, a, reinterpret_cast<FinState*>(fin),
                            leader_list, leader_count, leader_shard_cap(n_darts), n_live, ctr);
         return hipGetLastError();
     }
@@ -1897,19 +1911,20 @@ hipError_t launch_rank_cycles(hipStream_t st, uint32_t n_darts, int W, const uin
         EntryState* t = a; a = b; b = t;
     }
     const int fin_blocks = std::max(blocks_for(n_darts, 256, env_cap("A3_FIN_BLOCKS", 1536)), (int)(((uint64_t)n_darts + 256ull * 32 - 1) / (256ull * 32)));
-    hipLaunchKernelGGL(k_jump_finalize, dim3(fin_blocks), block, 0, st, n_darts, loc, a, fin,
+    hipLaunchKernelGGL(k_jump_finalize, dim3(fin_blocks), block, 0, st, n_darts, loc, a, reinterpret_cast<FinState*>(fin),
                        leader_list, leader_count, leader_shard_cap(n_darts), n_live, ctr);
     return hipGetLastError();
 }
 
-hipError_t launch_resolve(hipStream_t st, const JumpState* fin, uint32_t n_darts, int W, const uint64_t* d_rec, const uint32_t* leader_list,
+hipError_t launch_resolve(hipStream_t st, const JumpState* loc, const void* fin8, uint32_t n_darts, int W, const uint64_t* d_rec, const uint32_t* leader_list,
                           const unsigned int* leader_count, uint64_t* t_cur, uint64_t* t_next, DeviceCounters* ctr, int max_iters,
                           const uint32_t* n_live) {
+    const FinState* fin = reinterpret_cast<const FinState*>(fin8);
     if (max_iters <= 0) return hipSuccess;   // k_cycle_select checks the natural starts itself; the caller re-runs the batch if they do not hold
     const dim3 grid(blocks_for(n_darts, 256, 4096)), block(256);
-    hipLaunchKernelGGL(k_resolve_fast, dim3(blocks_for(n_darts / 16 + 1, 256, 1024)), block, 0, st, fin, leader_list, leader_count,
+    hipLaunchKernelGGL(k_resolve_fast, dim3(blocks_for(n_darts / 16 + 1, 256, 1024)), block, 0, st, loc, fin, leader_list, leader_count,
                        leader_shard_cap(n_darts), W, d_rec, t_cur, ctr);
-    hipLaunchKernelGGL(k_resolve_init, grid, block, 0, st, fin, n_darts, t_cur, t_next, ctr, n_live);
+    hipLaunchKernelGGL(k_resolve_init, grid, block, 0, st, loc, fin, n_darts, t_cur, t_next, ctr, n_live);
     for (int it = 0; it < max_iters; it++) {
         hipLaunchKernelGGL(k_resolve_eval, grid, block, 0, st, fin, n_darts, W, d_rec, t_cur, t_next, it, ctr, n_live);
         hipLaunchKernelGGL(k_resolve_commit, grid, block, 0, st, fin, n_darts, t_cur, t_next, it, it == max_iters - 1 ? 1 : 0, ctr, n_live);
@@ -1917,7 +1932,7 @@ hipError_t launch_resolve(hipStream_t st, const JumpState* fin, uint32_t n_darts
     return hipGetLastError();
 }
 
-hipError_t launch_select_scatter(hipStream_t st, const JumpState* fin, uint32_t n_darts, const uint32_t* leader_list,
+hipError_t launch_select_scatter(hipStream_t st, const JumpState* loc, const void* fin8, uint32_t n_darts, const uint32_t* leader_list,
                                  const unsigned int* leader_count, const uint32_t* d_succ, const uint64_t* t_cur,
                                  const uint32_t* frame_base, uint32_t n_frames, uint32_t first_frame, uint32_t min_edge_length,
                                  double eps_factor, double image_diag, ContourRec* contours, uint32_t* cyc_start_off,
@@ -1925,11 +1940,11 @@ hipError_t launch_select_scatter(hipStream_t st, const JumpState* fin, uint32_t 
                                  const uint32_t* n_live, int inline_resolve_W, uint32_t* keep_tmp, int keep_all) {
     // 8192 workgroups for the graphs of clean frames (6-8 M darts), more for the tens of millions of darts of noise-like ones
     const dim3 grid(blocks_for(n_darts, 256, env_cap("A3_SCATTER_BLOCKS", (int)std::min<uint32_t>(65536u, std::max<uint32_t>(8192u, n_darts / 1024u))))), block(256);
-    hipLaunchKernelGGL(k_cycle_select, dim3(blocks_for(n_darts / 64 + 1, 256, env_cap("A3_SELECT_BLOCKS", 1024))), block, 0, st, const_cast<JumpState*>(fin), leader_list, leader_count, d_succ, t_cur,
+    hipLaunchKernelGGL(k_cycle_select, dim3(blocks_for(n_darts / 64 + 1, 256, env_cap("A3_SELECT_BLOCKS", 1024))), block, 0, st, loc, reinterpret_cast<FinState*>(const_cast<void*>(fin8)), leader_list, leader_count, d_succ, t_cur,
                        frame_base, n_frames, first_frame, min_edge_length,
                        eps_factor, image_diag, contours, cyc_start_off, max_contours, max_points, ctr, leader_shard_cap(n_darts), d_rec,
                        inline_resolve_W, keep_tmp, keep_all);
-    hipLaunchKernelGGL(k_scatter_points, grid, block, 0, st, fin, n_darts, d_rec, contours, cyc_start_off, points, n_live, ctr);
+    hipLaunchKernelGGL(k_scatter_points, grid, block, 0, st, reinterpret_cast<const FinState*>(fin8), n_darts, d_rec, contours, cyc_start_off, points, n_live, ctr);
     return hipGetLastError();
 }
 
